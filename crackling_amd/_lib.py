@@ -1,0 +1,81 @@
+"""ctypes binding of libissl_hip.so (C ABI declared in include/issl_hip.h)."""
+import ctypes as C
+import os
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libissl_hip.so")
+
+
+class IsslError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"[{code}] {message}")
+        self.code = code
+        self.message = message
+
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} is missing: build it with `make` (or __graft_entry__.build()). "
+        "crackling_amd has no CPU fallback for the ISSL scorer."
+    )
+
+lib = C.CDLL(LIB_PATH)
+
+
+class Header(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("n_sites", "seq_len", "n_lines", "slice_width", "n_slices", "n_scores")]
+
+
+class Hit(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("guide", "slice", "pos", "id", "dist", "occ")]
+
+
+class Stats(C.Structure):
+    _fields_ = [
+        ("n_guides", C.c_uint64), ("candidates", C.c_uint64), ("hits", C.c_uint64), ("scan_tiles", C.c_uint64),
+        ("ms_bin", C.c_double), ("ms_scan", C.c_double), ("ms_group", C.c_double), ("ms_replay", C.c_double),
+        ("ms_total", C.c_double), ("scan_launches", C.c_uint64),
+    ]
+
+
+_P = C.c_void_p
+_u64p = C.POINTER(C.c_uint64)
+_f64p = C.POINTER(C.c_double)
+
+_protos = {
+    "issl_last_error": (C.c_char_p, []),
+    "issl_abi_version": (C.c_int, []),
+    "issl_index_open": (C.c_int, [C.c_char_p, C.POINTER(_P)]),
+    "issl_index_from_memory": (C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),
+    "issl_index_build_from_text": (C.c_int, [C.c_char_p, C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(_P)]),
+    "issl_index_build_from_sites": (C.c_int, [_P, _P, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(_P)]),
+    "issl_index_write": (C.c_int, [_P, C.c_char_p]),
+    "issl_index_header": (C.c_int, [_P, C.POINTER(Header)]),
+    "issl_index_bucket_sizes": (C.c_int, [_P, _P, C.c_size_t]),
+    "issl_index_close": (C.c_int, [_P]),
+    "issl_index_device_bytes": (C.c_int, [_P, C.POINTER(C.c_size_t)]),
+    "issl_index_upload": (C.c_int, [_P, C.c_int]),
+    "issl_index_upload_into": (C.c_int, [_P, C.c_int, _P, C.c_size_t]),
+    "issl_index_attach_image": (C.c_int, [C.c_int, _P, C.c_size_t, C.POINTER(_P)]),
+    "issl_index_image": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_size_t)]),
+    "issl_encode_guides": (C.c_int, [C.c_char_p, C.c_size_t, C.c_size_t, C.c_size_t, _P]),
+    "issl_decode_guide": (C.c_int, [C.c_uint64, C.c_size_t, C.c_char_p]),
+    "issl_read_query_file": (C.c_int, [C.c_char_p, C.c_size_t, C.POINTER(_P), C.POINTER(C.c_size_t)]),
+    "issl_free": (None, [_P]),
+    "issl_method_from_string": (C.c_int, [C.c_char_p]),
+    "issl_score": (C.c_int, [_P, _P, C.c_size_t, C.c_int, C.c_double, C.c_int, _P, _P]),
+    "issl_score_device": (C.c_int, [_P, _P, C.c_size_t, C.c_int, C.c_double, C.c_int, _P, _P, _P]),
+    "issl_dump_hits": (C.c_int, [_P, _P, C.c_size_t, C.c_int, C.c_double, C.c_int, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "issl_last_stats": (C.c_int, [_P, C.POINTER(Stats)]),
+    "issl_count_candidates": (C.c_int, [_P, _P, C.c_size_t, C.POINTER(C.c_uint64)]),
+}
+for _name, (_res, _args) in _protos.items():
+    _fn = getattr(lib, _name)  # AttributeError here = library/header mismatch: fail loudly
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+EXPORTS = tuple(_protos)
+
+
+def check(rc):
+    if rc != 0:
+        raise IsslError(rc, lib.issl_last_error().decode(errors="replace"))

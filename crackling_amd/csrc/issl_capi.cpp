@@ -1,0 +1,664 @@
+// extern "C" surface of libissl_hip.so (include/issl_hip.h): index handles, HBM image management,
+// scoring pipeline orchestration.  Compiled by hipcc as host code; kernels are in issl_kernels.hip.
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "issl_device.hpp"
+
+using namespace issl;
+
+namespace issl {
+
+static uint64_t align256(uint64_t x) { return (x + 255ull) & ~255ull; }
+
+void layout_image(ImageHeader &h, const Geometry &g, uint64_t n_scores_unique, uint64_t n_tiles)
+{
+    std::memset(&h, 0, sizeof h);
+    h.magic = kImageMagic;
+    h.version = kImageVersion;
+    h.kind = 0;
+    h.n_sites = g.n_sites;
+    h.seq_len = g.seq_len;
+    h.n_lines = g.n_lines;
+    h.slice_width = g.slice_width;
+    h.n_slices = g.n_slices;
+    h.n_scores_file = g.n_scores;
+    h.n_buckets = g.n_buckets();
+    h.n_scores_unique = n_scores_unique;
+    h.n_tiles = n_tiles;
+    h.tile_cands = kTileCands;
+    uint64_t off = kHeaderBytes;
+    h.off_bucket_start = off; off = align256(off + 8 * (h.n_buckets + 1));
+    h.off_tile_first = off;   off = align256(off + 4 * (h.n_buckets + 1));
+    h.off_score_mask = off;   off = align256(off + 8 * n_scores_unique);
+    h.off_score_val = off;    off = align256(off + 8 * n_scores_unique);
+    h.off_sites = off;        off = align256(off + 8 * g.n_sites);
+    h.off_entries = off;      off = align256(off + 8 * g.n_sites * g.n_slices);
+    h.off_scan = off;         off = align256(off + 4ull * kTileCands * n_tiles);
+    h.total_bytes = off;
+}
+
+ImageView make_view(const ImageHeader &h, void *base)
+{
+    uint8_t *p = static_cast<uint8_t *>(base);
+    ImageView v;
+    v.bucket_start = reinterpret_cast<const uint64_t *>(p + h.off_bucket_start);
+    v.tile_first = reinterpret_cast<const uint32_t *>(p + h.off_tile_first);
+    v.score_mask = reinterpret_cast<const uint64_t *>(p + h.off_score_mask);
+    v.score_val = reinterpret_cast<const double *>(p + h.off_score_val);
+    v.sites = reinterpret_cast<const uint64_t *>(p + h.off_sites);
+    v.entries = reinterpret_cast<const uint64_t *>(p + h.off_entries);
+    v.scan = reinterpret_cast<const uint32_t *>(p + h.off_scan);
+    v.n_sites = h.n_sites;
+    v.n_buckets = static_cast<uint32_t>(h.n_buckets);
+    v.n_scores = static_cast<uint32_t>(h.n_scores_unique);
+    v.slice_width = static_cast<uint32_t>(h.slice_width);
+    v.n_slices = static_cast<uint32_t>(h.n_slices);
+    v.n_tiles = static_cast<uint32_t>(h.n_tiles);
+    return v;
+}
+
+} // namespace issl
+
+struct issl_index {
+    std::unique_ptr<HostIndex> host; // absent for attached images
+    Geometry geo;
+    std::vector<uint64_t> bucket_sizes;
+    // device state
+    int device = -1;
+    void *d_image = nullptr;
+    bool owns_image = false;
+    ImageHeader hdr{};
+    ImageView view{};
+    Workspace ws;
+    hipEvent_t ev[5] = {};
+    bool have_events = false;
+    issl_stats stats{};
+};
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) {                                                                    \
+            set_error(std::string("HIP error: ") + hipGetErrorString(e_) + " at " #expr);          \
+            return ISSL_E_DEVICE;                                                                  \
+        }                                                                                          \
+    } while (0)
+
+static int supported_geometry(const Geometry &g)
+{
+    if (g.seq_len == 20 && g.slice_width == 8 && g.n_slices == 5) return ISSL_OK;
+    set_error("unsupported index geometry: the gfx950 scan kernels implement 20 bp sequences with five "
+              "8-bit slices (got seq_len=" + std::to_string(g.seq_len) + " slice_width=" +
+              std::to_string(g.slice_width) + " slices=" + std::to_string(g.n_slices) + ")");
+    return ISSL_E_UNSUPPORTED;
+}
+
+static int select_device(int device)
+{
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        set_error("no HIP device available: the ISSL scorer has no CPU fallback");
+        return ISSL_E_DEVICE;
+    }
+    if (device < 0 || device >= count) {
+        set_error("device " + std::to_string(device) + " out of range (" + std::to_string(count) + " visible)");
+        return ISSL_E_ARG;
+    }
+    HIP_TRY(hipSetDevice(device));
+    return ISSL_OK;
+}
+
+static void free_workspace(Workspace &w)
+{
+    void *ptrs[] = {w.ng, w.gfill, w.gstart, w.gword, w.gidx, w.items, w.plan, w.counters, w.hits, w.sorted, w.gcount,
+                    w.goff, w.gcur, w.blocksum, w.d_guides, w.d_mit, w.d_cfd, w.d_kept, w.d_hitrec};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    w = Workspace{};
+}
+
+template <typename T> static int dev_alloc(T *&p, size_t count)
+{
+    if (p) {
+        (void)hipFree(p);
+        p = nullptr;
+    }
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p), std::max<size_t>(count, 1) * sizeof(T)));
+    return ISSL_OK;
+}
+
+static int ensure_hit_capacity(issl_index *ix, size_t want)
+{
+    Workspace &w = ix->ws;
+    if (want <= w.cap_hits) return ISSL_OK;
+    int rc;
+    if ((rc = dev_alloc(w.hits, want))) return rc;
+    if ((rc = dev_alloc(w.sorted, want))) return rc;
+    w.cap_hits = want;
+    return ISSL_OK;
+}
+
+static int ensure_workspace(issl_index *ix, size_t n)
+{
+    Workspace &w = ix->ws;
+    const size_t nb = ix->hdr.n_buckets;
+    int rc;
+    if (w.n_buckets != nb) {
+        if ((rc = dev_alloc(w.ng, nb))) return rc;
+        if ((rc = dev_alloc(w.gfill, nb))) return rc;
+        if ((rc = dev_alloc(w.gstart, nb + 1))) return rc;
+        if ((rc = dev_alloc(w.counters, 1))) return rc;
+        if ((rc = dev_alloc(w.plan, 1))) return rc;
+        w.n_buckets = static_cast<uint32_t>(nb);
+    }
+    if (n > w.cap_guides) {
+        const size_t cap = std::max<size_t>(n, 1024);
+        const size_t slots = cap * ix->hdr.n_slices + kGuideGroup * nb;
+        const size_t items = nb + cap * ix->hdr.n_slices / kItemGuides + 2;
+        if ((rc = dev_alloc(w.gword, slots))) return rc;
+        if ((rc = dev_alloc(w.gidx, slots))) return rc;
+        if ((rc = dev_alloc(w.items, items + 1))) return rc;
+        if ((rc = dev_alloc(w.gcount, cap + 1))) return rc;
+        if ((rc = dev_alloc(w.goff, cap + 1))) return rc;
+        if ((rc = dev_alloc(w.gcur, cap))) return rc;
+        if ((rc = dev_alloc(w.blocksum, (cap + 1) / 2048 + 2))) return rc;
+        if ((rc = dev_alloc(w.d_guides, cap))) return rc;
+        if ((rc = dev_alloc(w.d_mit, cap))) return rc;
+        if ((rc = dev_alloc(w.d_cfd, cap))) return rc;
+        if ((rc = dev_alloc(w.d_kept, cap))) return rc;
+        w.cap_guides = cap;
+        w.cap_gslots = slots;
+        w.cap_items = items;
+    }
+    if (w.cap_hits == 0) {
+        const size_t want = std::max<size_t>(size_t(1) << 20, 64 * n);
+        if ((rc = ensure_hit_capacity(ix, want))) return rc;
+    }
+    if (!ix->have_events) {
+        for (auto &e : ix->ev) HIP_TRY(hipEventCreate(&e));
+        ix->have_events = true;
+    }
+    return ISSL_OK;
+}
+
+static int finish_upload(issl_index *ix)
+{
+    // sections that are plain copies
+    const HostIndex &h = *ix->host;
+    const Geometry &g = h.geo;
+    const uint64_t nb = g.n_buckets();
+    uint8_t *base = static_cast<uint8_t *>(ix->d_image);
+    std::vector<uint64_t> bstart(nb + 1);
+    std::vector<uint32_t> tfirst(nb + 1);
+    bstart[0] = 0;
+    tfirst[0] = 0;
+    for (uint64_t b = 0; b < nb; ++b) {
+        bstart[b + 1] = bstart[b] + h.sizes[b];
+        tfirst[b + 1] = tfirst[b] + static_cast<uint32_t>((h.sizes[b] + kTileCands - 1) / kTileCands);
+    }
+    std::vector<uint64_t> masks;
+    std::vector<double> vals;
+    h.unique_scores(masks, vals);
+    HIP_TRY(hipMemcpy(base, &ix->hdr, sizeof(ImageHeader), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(base + ix->hdr.off_bucket_start, bstart.data(), 8 * (nb + 1), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(base + ix->hdr.off_tile_first, tfirst.data(), 4 * (nb + 1), hipMemcpyHostToDevice));
+    if (!masks.empty()) {
+        HIP_TRY(hipMemcpy(base + ix->hdr.off_score_mask, masks.data(), 8 * masks.size(), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(base + ix->hdr.off_score_val, vals.data(), 8 * vals.size(), hipMemcpyHostToDevice));
+    }
+    HIP_TRY(hipMemcpy(base + ix->hdr.off_sites, h.sites, 8 * g.n_sites, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(base + ix->hdr.off_entries, h.entries, 8 * g.n_sites * g.n_slices, hipMemcpyHostToDevice));
+    ix->view = make_view(ix->hdr, ix->d_image);
+    // scan stream: built on the device from sites + entries
+    uint32_t *flag = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&flag), 4));
+    HIP_TRY(hipMemset(flag, 0, 4));
+    launch_pack_scan_stream(ix->view, reinterpret_cast<uint32_t *>(base + ix->hdr.off_scan), flag, nullptr);
+    HIP_TRY(hipGetLastError());
+    uint32_t err = 0;
+    HIP_TRY(hipMemcpy(&err, flag, 4, hipMemcpyDeviceToHost));
+    (void)hipFree(flag);
+    if (err) {
+        set_error("Error reading index: a slice entry refers to an off-target id beyond the site table");
+        return ISSL_E_FORMAT;
+    }
+    return ISSL_OK;
+}
+
+static uint64_t count_tiles(const HostIndex &h)
+{
+    uint64_t t = 0;
+    for (uint64_t b = 0; b < h.geo.n_buckets(); ++b) t += (h.sizes[b] + kTileCands - 1) / kTileCands;
+    return t;
+}
+
+static void release_device(issl_index *ix)
+{
+    if (ix->device >= 0) (void)hipSetDevice(ix->device);
+    free_workspace(ix->ws);
+    if (ix->have_events) {
+        for (auto &e : ix->ev) (void)hipEventDestroy(e);
+        ix->have_events = false;
+    }
+    if (ix->d_image && ix->owns_image) (void)hipFree(ix->d_image);
+    ix->d_image = nullptr;
+    ix->owns_image = false;
+}
+
+static int new_index_from_host(std::unique_ptr<HostIndex> h, issl_index **out)
+{
+    issl_index *ix = new (std::nothrow) issl_index();
+    if (!ix) {
+        set_error("out of memory");
+        return ISSL_E_NOMEM;
+    }
+    ix->geo = h->geo;
+    ix->bucket_sizes.assign(h->sizes, h->sizes + h->geo.n_buckets());
+    ix->host = std::move(h);
+    *out = ix;
+    return ISSL_OK;
+}
+
+// The scoring pipeline.  Guides and outputs are device pointers on ix->device.
+static int score_core(issl_index *ix, const uint64_t *d_guides, size_t n, int max_dist, double threshold, int method,
+                      double *d_mit, double *d_cfd, hipStream_t stream, bool dump)
+{
+    if (!ix->d_image) {
+        set_error("index has no device image: call issl_index_upload first");
+        return ISSL_E_STATE;
+    }
+    if (n >= (size_t(1) << 29)) {
+        set_error("at most 2^29-1 guides per call");
+        return ISSL_E_ARG;
+    }
+    HIP_TRY(hipSetDevice(ix->device));
+    ix->stats = issl_stats{};
+    ix->stats.n_guides = n;
+    if (n == 0) return ISSL_OK;
+    int rc = ensure_workspace(ix, n);
+    if (rc) return rc;
+    ScoreParams p;
+    p.max_dist = max_dist;
+    p.method = method;
+    p.maximum_sum = (10000.0 - threshold * 100) / threshold; // isslScoreOfftargets.cpp:326
+    const uint32_t n32 = static_cast<uint32_t>(n);
+    Counters c{};
+    PlanInfo pl{};
+    for (int attempt = 0;; ++attempt) {
+        HIP_TRY(hipEventRecord(ix->ev[0], stream));
+        launch_bin_guides(ix->view, ix->ws, d_guides, n32, stream);
+        HIP_TRY(hipEventRecord(ix->ev[1], stream));
+        launch_scan(ix->view, ix->ws, d_guides, n32, max_dist, stream);
+        HIP_TRY(hipEventRecord(ix->ev[2], stream));
+        HIP_TRY(hipMemcpyAsync(&c, ix->ws.counters, sizeof c, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(&pl, ix->ws.plan, sizeof pl, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        HIP_TRY(hipGetLastError());
+        ix->stats.scan_launches = attempt + 1;
+        if (pl.error & 2u) {
+            set_error("internal error: scan item list overflow");
+            return ISSL_E_DEVICE;
+        }
+        if (c.n_hits <= ix->ws.cap_hits) break;
+        if (attempt >= 2) {
+            set_error("internal error: hit buffer kept overflowing");
+            return ISSL_E_DEVICE;
+        }
+        rc = ensure_hit_capacity(ix, static_cast<size_t>(c.n_hits) + c.n_hits / 8 + 1024);
+        if (rc) return rc;
+    }
+    if (dump && ix->ws.cap_hitrec < ix->ws.cap_hits) {
+        rc = dev_alloc(ix->ws.d_hitrec, ix->ws.cap_hits);
+        if (rc) return rc;
+        ix->ws.cap_hitrec = ix->ws.cap_hits;
+    }
+    launch_group_hits(ix->ws, n32, stream);
+    HIP_TRY(hipEventRecord(ix->ev[3], stream));
+    launch_replay(ix->view, ix->ws, d_guides, n32, p, d_mit, d_cfd, dump ? ix->ws.d_kept : nullptr,
+                  dump ? ix->ws.d_hitrec : nullptr, stream);
+    HIP_TRY(hipEventRecord(ix->ev[4], stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    HIP_TRY(hipGetLastError());
+    float ms[4] = {0, 0, 0, 0};
+    for (int i = 0; i < 4; ++i) (void)hipEventElapsedTime(&ms[i], ix->ev[i], ix->ev[i + 1]);
+    ix->stats.ms_bin = ms[0];
+    ix->stats.ms_scan = ms[1];
+    ix->stats.ms_group = ms[2];
+    ix->stats.ms_replay = ms[3];
+    ix->stats.ms_total = ms[0] + ms[1] + ms[2] + ms[3];
+    ix->stats.candidates = pl.candidates;
+    ix->stats.hits = c.n_hits;
+    ix->stats.scan_tiles = c.tiles;
+    return ISSL_OK;
+}
+
+extern "C" {
+
+const char *issl_last_error(void) { return get_error(); }
+int issl_abi_version(void) { return ISSL_ABI_VERSION; }
+
+int issl_index_open(const char *path, issl_index **out)
+{
+    if (!path || !out) { set_error("null argument"); return ISSL_E_ARG; }
+    std::unique_ptr<HostIndex> h(new (std::nothrow) HostIndex());
+    if (!h) { set_error("out of memory"); return ISSL_E_NOMEM; }
+    int rc = h->open_file(path);
+    if (rc) return rc;
+    return new_index_from_host(std::move(h), out);
+}
+
+int issl_index_from_memory(const void *image, size_t len, issl_index **out)
+{
+    if (!image || !out) { set_error("null argument"); return ISSL_E_ARG; }
+    std::unique_ptr<HostIndex> h(new (std::nothrow) HostIndex());
+    if (!h) { set_error("out of memory"); return ISSL_E_NOMEM; }
+    int rc = h->from_memory(image, len);
+    if (rc) return rc;
+    return new_index_from_host(std::move(h), out);
+}
+
+int issl_index_build_from_text(const char *text, size_t n_lines, size_t seq_len, size_t slice_width,
+                               issl_index **out)
+{
+    if (!text || !out) { set_error("null argument"); return ISSL_E_ARG; }
+    std::unique_ptr<HostIndex> h(new (std::nothrow) HostIndex());
+    if (!h) { set_error("out of memory"); return ISSL_E_NOMEM; }
+    int rc = h->build_from_text(text, n_lines, seq_len, slice_width);
+    if (rc) return rc;
+    return new_index_from_host(std::move(h), out);
+}
+
+int issl_index_build_from_sites(const uint64_t *sigs, const uint32_t *occ, size_t n_sites, size_t n_lines,
+                                size_t seq_len, size_t slice_width, issl_index **out)
+{
+    if (!sigs || !occ || !out) { set_error("null argument"); return ISSL_E_ARG; }
+    std::unique_ptr<HostIndex> h(new (std::nothrow) HostIndex());
+    if (!h) { set_error("out of memory"); return ISSL_E_NOMEM; }
+    int rc = h->build_from_sites(sigs, occ, n_sites, n_lines, seq_len, slice_width);
+    if (rc) return rc;
+    return new_index_from_host(std::move(h), out);
+}
+
+int issl_index_write(const issl_index *idx, const char *path)
+{
+    if (!idx || !path) { set_error("null argument"); return ISSL_E_ARG; }
+    if (!idx->host) { set_error("index was attached from a device image and has no host arrays"); return ISSL_E_STATE; }
+    return idx->host->write_file(path);
+}
+
+int issl_index_header(const issl_index *idx, issl_header *out)
+{
+    if (!idx || !out) { set_error("null argument"); return ISSL_E_ARG; }
+    out->n_sites = idx->geo.n_sites;
+    out->seq_len = idx->geo.seq_len;
+    out->n_lines = idx->geo.n_lines;
+    out->slice_width = idx->geo.slice_width;
+    out->n_slices = idx->geo.n_slices;
+    out->n_scores = idx->geo.n_scores;
+    return ISSL_OK;
+}
+
+int issl_index_bucket_sizes(const issl_index *idx, uint64_t *out, size_t n)
+{
+    if (!idx || !out) { set_error("null argument"); return ISSL_E_ARG; }
+    if (n < idx->bucket_sizes.size()) { set_error("bucket size buffer too small"); return ISSL_E_ARG; }
+    std::copy(idx->bucket_sizes.begin(), idx->bucket_sizes.end(), out);
+    return ISSL_OK;
+}
+
+int issl_index_close(issl_index *idx)
+{
+    if (!idx) return ISSL_OK;
+    release_device(idx);
+    delete idx;
+    return ISSL_OK;
+}
+
+int issl_index_device_bytes(const issl_index *idx, size_t *out)
+{
+    if (!idx || !out) { set_error("null argument"); return ISSL_E_ARG; }
+    if (idx->d_image) { *out = idx->hdr.total_bytes; return ISSL_OK; }
+    if (!idx->host) { set_error("index has neither host arrays nor a device image"); return ISSL_E_STATE; }
+    int rc = supported_geometry(idx->geo);
+    if (rc) return rc;
+    std::vector<uint64_t> m;
+    std::vector<double> v;
+    idx->host->unique_scores(m, v);
+    ImageHeader h;
+    layout_image(h, idx->geo, m.size(), count_tiles(*idx->host));
+    *out = h.total_bytes;
+    return ISSL_OK;
+}
+
+static int upload_common(issl_index *idx, int device, void *buf, size_t bytes)
+{
+    if (!idx) { set_error("null argument"); return ISSL_E_ARG; }
+    if (!idx->host) { set_error("index has no host arrays to upload"); return ISSL_E_STATE; }
+    int rc = supported_geometry(idx->geo);
+    if (rc) return rc;
+    rc = select_device(device);
+    if (rc) return rc;
+    release_device(idx);
+    std::vector<uint64_t> m;
+    std::vector<double> v;
+    idx->host->unique_scores(m, v);
+    layout_image(idx->hdr, idx->geo, m.size(), count_tiles(*idx->host));
+    idx->device = device;
+    if (buf) {
+        if (bytes < idx->hdr.total_bytes || (reinterpret_cast<uintptr_t>(buf) & 255u)) {
+            set_error("device buffer too small or not 256-byte aligned");
+            return ISSL_E_ARG;
+        }
+        idx->d_image = buf;
+        idx->owns_image = false;
+    } else {
+        HIP_TRY(hipMalloc(&idx->d_image, idx->hdr.total_bytes));
+        idx->owns_image = true;
+    }
+    rc = finish_upload(idx);
+    if (rc) release_device(idx);
+    return rc;
+}
+
+int issl_index_upload(issl_index *idx, int device) { return upload_common(idx, device, nullptr, 0); }
+
+int issl_index_upload_into(issl_index *idx, int device, void *dev_buf, size_t bytes)
+{
+    if (!dev_buf) { set_error("null device buffer"); return ISSL_E_ARG; }
+    return upload_common(idx, device, dev_buf, bytes);
+}
+
+int issl_index_attach_image(int device, void *dev_buf, size_t bytes, issl_index **out)
+{
+    if (!dev_buf || !out) { set_error("null argument"); return ISSL_E_ARG; }
+    int rc = select_device(device);
+    if (rc) return rc;
+    if (bytes < kHeaderBytes || (reinterpret_cast<uintptr_t>(dev_buf) & 255u)) {
+        set_error("device image too small or not 256-byte aligned");
+        return ISSL_E_ARG;
+    }
+    ImageHeader h;
+    HIP_TRY(hipMemcpy(&h, dev_buf, sizeof h, hipMemcpyDeviceToHost));
+    if (h.magic != kImageMagic || h.version != kImageVersion || h.tile_cands != kTileCands ||
+        h.total_bytes > bytes) {
+        set_error("device buffer does not hold an ISSL image of this library version");
+        return ISSL_E_FORMAT;
+    }
+    issl_index *ix = new (std::nothrow) issl_index();
+    if (!ix) { set_error("out of memory"); return ISSL_E_NOMEM; }
+    ix->geo.n_sites = h.n_sites;
+    ix->geo.seq_len = h.seq_len;
+    ix->geo.n_lines = h.n_lines;
+    ix->geo.slice_width = h.slice_width;
+    ix->geo.n_slices = h.n_slices;
+    ix->geo.n_scores = h.n_scores_file;
+    ix->hdr = h;
+    ix->device = device;
+    ix->d_image = dev_buf;
+    ix->owns_image = false;
+    ix->view = make_view(h, dev_buf);
+    std::vector<uint64_t> bstart(h.n_buckets + 1);
+    hipError_t e = hipMemcpy(bstart.data(), static_cast<uint8_t *>(dev_buf) + h.off_bucket_start,
+                             8 * (h.n_buckets + 1), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) {
+        delete ix;
+        set_error(std::string("HIP error: ") + hipGetErrorString(e));
+        return ISSL_E_DEVICE;
+    }
+    ix->bucket_sizes.resize(h.n_buckets);
+    for (uint64_t b = 0; b < h.n_buckets; ++b) ix->bucket_sizes[b] = bstart[b + 1] - bstart[b];
+    *out = ix;
+    return ISSL_OK;
+}
+
+int issl_index_image(const issl_index *idx, void **dev_ptr, size_t *bytes)
+{
+    if (!idx || !dev_ptr || !bytes) { set_error("null argument"); return ISSL_E_ARG; }
+    if (!idx->d_image) { set_error("index has no device image"); return ISSL_E_STATE; }
+    *dev_ptr = idx->d_image;
+    *bytes = idx->hdr.total_bytes;
+    return ISSL_OK;
+}
+
+int issl_encode_guides(const char *text, size_t n, size_t seq_len, size_t stride, uint64_t *out)
+{
+    if ((!text && n) || !out || seq_len == 0 || seq_len > 32 || stride < seq_len) {
+        set_error("bad argument to issl_encode_guides");
+        return ISSL_E_ARG;
+    }
+    for (size_t i = 0; i < n; ++i) out[i] = encode_guide(text + i * stride, seq_len);
+    return ISSL_OK;
+}
+
+int issl_decode_guide(uint64_t sig, size_t seq_len, char *out)
+{
+    if (!out || seq_len == 0 || seq_len > 32) { set_error("bad argument to issl_decode_guide"); return ISSL_E_ARG; }
+    decode_guide(sig, seq_len, out);
+    return ISSL_OK;
+}
+
+int issl_read_query_file(const char *path, size_t seq_len, uint64_t **out, size_t *n)
+{
+    if (!path || !out || !n || seq_len == 0 || seq_len > 32) { set_error("bad argument"); return ISSL_E_ARG; }
+    FILE *fp = std::fopen(path, "rb");
+    if (!fp) {
+        set_error(std::string("cannot open query file '") + path + "'");
+        return ISSL_E_IO;
+    }
+    std::fseek(fp, 0, SEEK_END);
+    const long sz = std::ftell(fp);
+    std::fseek(fp, 0, SEEK_SET);
+    const size_t line = seq_len + 1;
+    if (sz < 0 || static_cast<size_t>(sz) % line != 0) { // isslScoreOfftargets.cpp:277-282
+        std::fclose(fp);
+        set_error("Error: query file is not a multiple of the expected line length (" + std::to_string(line) +
+                  ")\nThe sequence length may be incorrect; alternatively, the line endings\nmay be something "
+                  "other than LF, or there may be junk at the end of the file.");
+        return ISSL_E_FORMAT;
+    }
+    std::vector<char> buf(static_cast<size_t>(sz));
+    if (sz == 0 || std::fread(buf.data(), static_cast<size_t>(sz), 1, fp) < 1) { // :290-293
+        std::fclose(fp);
+        set_error("Failed to read in query file.");
+        return ISSL_E_FORMAT;
+    }
+    std::fclose(fp);
+    const size_t count = static_cast<size_t>(sz) / line;
+    uint64_t *g = static_cast<uint64_t *>(std::malloc(8 * std::max<size_t>(count, 1)));
+    if (!g) { set_error("out of memory"); return ISSL_E_NOMEM; }
+    for (size_t i = 0; i < count; ++i) g[i] = encode_guide(buf.data() + i * line, seq_len);
+    *out = g;
+    *n = count;
+    return ISSL_OK;
+}
+
+void issl_free(void *p) { std::free(p); }
+
+int issl_method_from_string(const char *s) { return method_from_string(s); }
+
+int issl_score_device(issl_index *idx, const uint64_t *d_guides, size_t n, int max_dist, double threshold,
+                      int method, double *d_mit, double *d_cfd, void *stream)
+{
+    if (!idx || (n && (!d_guides || !d_mit || !d_cfd))) { set_error("null argument"); return ISSL_E_ARG; }
+    return score_core(idx, d_guides, n, max_dist, threshold, method, d_mit, d_cfd, static_cast<hipStream_t>(stream),
+                      false);
+}
+
+int issl_score(issl_index *idx, const uint64_t *guides, size_t n, int max_dist, double threshold, int method,
+               double *mit, double *cfd)
+{
+    if (!idx || (n && (!guides || !mit || !cfd))) { set_error("null argument"); return ISSL_E_ARG; }
+    if (!idx->d_image) { set_error("index has no device image: call issl_index_upload first"); return ISSL_E_STATE; }
+    if (n == 0) return ISSL_OK;
+    HIP_TRY(hipSetDevice(idx->device));
+    int rc = ensure_workspace(idx, n);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(idx->ws.d_guides, guides, 8 * n, hipMemcpyHostToDevice));
+    rc = score_core(idx, idx->ws.d_guides, n, max_dist, threshold, method, idx->ws.d_mit, idx->ws.d_cfd, nullptr,
+                    false);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(mit, idx->ws.d_mit, 8 * n, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(cfd, idx->ws.d_cfd, 8 * n, hipMemcpyDeviceToHost));
+    return ISSL_OK;
+}
+
+int issl_dump_hits(issl_index *idx, const uint64_t *guides, size_t n, int max_dist, double threshold, int method,
+                   issl_hit *hits, size_t cap, size_t *n_hits)
+{
+    if (!idx || !n_hits || (n && !guides) || (cap && !hits)) { set_error("null argument"); return ISSL_E_ARG; }
+    if (!idx->d_image) { set_error("index has no device image: call issl_index_upload first"); return ISSL_E_STATE; }
+    *n_hits = 0;
+    if (n == 0) return ISSL_OK;
+    HIP_TRY(hipSetDevice(idx->device));
+    int rc = ensure_workspace(idx, n);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(idx->ws.d_guides, guides, 8 * n, hipMemcpyHostToDevice));
+    rc = score_core(idx, idx->ws.d_guides, n, max_dist, threshold, method, idx->ws.d_mit, idx->ws.d_cfd, nullptr,
+                    true);
+    if (rc) return rc;
+    std::vector<uint32_t> goff(n + 1), kept(n);
+    HIP_TRY(hipMemcpy(goff.data(), idx->ws.goff, 4 * (n + 1), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(kept.data(), idx->ws.d_kept, 4 * n, hipMemcpyDeviceToHost));
+    std::vector<issl_hit> all(goff[n]);
+    if (goff[n]) HIP_TRY(hipMemcpy(all.data(), idx->ws.d_hitrec, sizeof(issl_hit) * goff[n], hipMemcpyDeviceToHost));
+    size_t total = 0;
+    for (size_t g = 0; g < n; ++g) {
+        for (uint32_t k = 0; k < kept[g]; ++k) {
+            if (total < cap) hits[total] = all[goff[g] + k];
+            ++total;
+        }
+    }
+    *n_hits = total;
+    return ISSL_OK;
+}
+
+int issl_last_stats(const issl_index *idx, issl_stats *out)
+{
+    if (!idx || !out) { set_error("null argument"); return ISSL_E_ARG; }
+    *out = idx->stats;
+    return ISSL_OK;
+}
+
+int issl_count_candidates(const issl_index *idx, const uint64_t *guides, size_t n, uint64_t *out)
+{
+    if (!idx || !out || (n && !guides)) { set_error("null argument"); return ISSL_E_ARG; }
+    const uint64_t per = idx->geo.buckets_per_slice();
+    uint64_t total = 0;
+    for (size_t i = 0; i < n; ++i)
+        for (uint64_t s = 0; s < idx->geo.n_slices; ++s)
+            total += idx->bucket_sizes[s * per + ((guides[i] >> (idx->geo.slice_width * s)) & (per - 1))];
+    *out = total;
+    return ISSL_OK;
+}
+
+} // extern "C"

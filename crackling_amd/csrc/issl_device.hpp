@@ -1,0 +1,142 @@
+// Device-side data model of the ISSL scorer: HBM image layout, workspace, kernel launchers.
+// Reference paths are relative to /root/reference.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+
+#include "issl_host.hpp"
+
+namespace issl {
+
+// ---- HBM image -------------------------------------------------------------------------------
+// One contiguous, self-describing device buffer so that it can be produced on one rank and
+// broadcast to the others as a single RCCL message.  All section offsets are 256-byte aligned.
+//
+//   [0,4096)       ImageHeader
+//   bucket_start   u64[nb+1]   prefix of the bucket lengths -> index into `entries`
+//                              (isslScoreOfftargets.cpp:261-270)
+//   tile_first     u32[nb+1]   first scan tile of every bucket (bucket b owns tiles
+//                              [tile_first[b], tile_first[b+1]); a tile is kTileCands candidates)
+//   score_mask     u64[ns]     sorted unique mismatch masks     (isslScoreOfftargets.cpp:188-197)
+//   score_val      f64[ns]     their local MIT scores
+//   sites          u64[N]      packed signatures                (:200-204)
+//   entries        u64[N*S]    bucket contents occ<<32|id       (:235-240)
+//   scan           u32[tiles*kTileCands]  the scan stream: for every bucket, in bucket order, the
+//                              candidate signature with its own slice removed, 16 positions, even
+//                              bits in the low half-word and odd bits in the high half-word;
+//                              each bucket zero-padded to a whole number of tiles.
+constexpr uint64_t kImageMagic = 0x314C535349444D41ull; // "AMDISSL1"
+constexpr uint32_t kImageVersion = 1;
+constexpr uint32_t kTileCands = 2048; // candidates per scan tile: 256 threads x 8 registers
+constexpr uint32_t kHeaderBytes = 4096;
+
+struct ImageHeader {
+    uint64_t magic;
+    uint32_t version;
+    uint32_t kind; // 0: 20 bp / 8-bit slices / 5 slices, 32-bit scan words
+    uint64_t n_sites, seq_len, n_lines, slice_width, n_slices, n_scores_file;
+    uint64_t n_buckets;
+    uint64_t n_scores_unique;
+    uint64_t n_tiles;
+    uint64_t tile_cands;
+    uint64_t total_bytes;
+    uint64_t off_bucket_start, off_tile_first, off_score_mask, off_score_val, off_sites, off_entries,
+        off_scan;
+};
+static_assert(sizeof(ImageHeader) <= kHeaderBytes, "header must fit its block");
+
+// Kernel-side view (raw pointers into the image).
+struct ImageView {
+    const uint64_t *bucket_start;
+    const uint32_t *tile_first;
+    const uint64_t *score_mask;
+    const double *score_val;
+    const uint64_t *sites;
+    const uint64_t *entries;
+    const uint32_t *scan;
+    uint64_t n_sites;
+    uint32_t n_buckets;
+    uint32_t n_scores;
+    uint32_t slice_width;
+    uint32_t n_slices;
+    uint32_t n_tiles;
+};
+
+// Layout computation shared by upload and attach.  Fills every field of `h` from the geometry,
+// the number of unique scores and the bucket sizes (sizes may be null when n_tiles is given).
+void layout_image(ImageHeader &h, const Geometry &g, uint64_t n_scores_unique, uint64_t n_tiles);
+ImageView make_view(const ImageHeader &h, void *base);
+
+// ---- scoring workspace -------------------------------------------------------------------------
+constexpr uint32_t kGuideGroup = 8;    // guide words fetched per scalar load
+constexpr uint32_t kItemGuides = 512;  // guides per scan item (bounds one tile's work)
+constexpr uint32_t kTileFixedCost = 4; // cost of fetching a tile, in guide-comparisons of that tile
+constexpr uint32_t kNoGuide = 0xFFFFFFFFu;
+
+// One unit of scan work: all tiles of one bucket against one group of guides of that bucket.
+struct ScanItem {
+    uint32_t bucket;
+    uint32_t g0, g1; // range in the bucket-sorted guide arrays, g0 % kGuideGroup == 0
+    uint32_t n_tiles;
+    uint64_t cost0;  // sum of costs of all earlier items; tile cost = (g1-g0)+kTileFixedCost
+};
+
+// Written by the planning kernel, read-only for the scan.
+struct PlanInfo {
+    uint32_t n_items;
+    uint32_t error;       // bit 1: item list overflow
+    uint64_t total_cost;
+    uint64_t candidates;  // sum over guides of their bucket lengths
+};
+
+// Updated by the scan with atomics.
+struct Counters {
+    uint32_t n_hits;      // hits the scan wanted to record (may exceed capacity)
+    uint32_t pad;
+    uint64_t tiles;       // (tile, item) pairs processed
+};
+
+struct Workspace {
+    uint32_t *ng = nullptr;      // [nb]   guides per bucket
+    uint32_t *gfill = nullptr;   // [nb]
+    uint32_t *gstart = nullptr;  // [nb+1] padded start of every bucket in gword/gidx
+    uint32_t *gword = nullptr;   // scan word of the guide for that slice
+    uint32_t *gidx = nullptr;    // guide index, kNoGuide in padding
+    ScanItem *items = nullptr;   // [max_items+1]
+    PlanInfo *plan = nullptr;
+    Counters *counters = nullptr;
+    uint64_t *hits = nullptr;    // [hit_cap] keys guide<<35 | slice<<32 | pos
+    uint64_t *sorted = nullptr;  // [hit_cap] grouped by guide
+    uint32_t *gcount = nullptr;  // [G+1] hits per guide
+    uint32_t *goff = nullptr;    // [G+1] exclusive prefix
+    uint32_t *gcur = nullptr;    // [G]
+    uint32_t *blocksum = nullptr;
+    uint64_t *d_guides = nullptr; // staging for the host API
+    double *d_mit = nullptr, *d_cfd = nullptr;
+    uint32_t *d_kept = nullptr;   // [G] hits scored before early exit (dump_hits)
+    issl_hit *d_hitrec = nullptr; // [hit_cap] expanded records (dump_hits)
+    size_t cap_hitrec = 0;
+    size_t cap_guides = 0;       // capacity in guides
+    size_t cap_hits = 0;
+    size_t cap_items = 0;
+    size_t cap_gslots = 0;
+    uint32_t n_buckets = 0;
+};
+
+struct ScoreParams {
+    int max_dist;
+    int method;
+    double maximum_sum; // (10000 - 100*thr)/thr, isslScoreOfftargets.cpp:326
+};
+
+// Launchers (issl_kernels.hip).  All asynchronous on `stream`.
+void launch_pack_scan_stream(const ImageView &v, uint32_t *scan_out, uint32_t *error_flag, void *stream);
+void launch_bin_guides(const ImageView &v, const Workspace &ws, const uint64_t *d_guides, uint32_t n, void *stream);
+void launch_scan(const ImageView &v, const Workspace &ws, const uint64_t *d_guides, uint32_t n, int max_dist,
+                 void *stream);
+void launch_group_hits(const Workspace &ws, uint32_t n, void *stream);
+void launch_replay(const ImageView &v, const Workspace &ws, const uint64_t *d_guides, uint32_t n,
+                   const ScoreParams &p, double *d_mit, double *d_cfd, uint32_t *d_kept, issl_hit *d_hitrec,
+                   void *stream);
+
+} // namespace issl

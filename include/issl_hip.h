@@ -1,0 +1,177 @@
+/*
+ * issl_hip.h -- C ABI of libissl_hip.so, the MI355X (gfx950) ISSL off-target scorer.
+ *
+ * Drop-in scope: the `isslScoreOfftargets` step of Crackling (reference paths relative to
+ * /root/reference).  The reference has no in-process API for this step -- its boundary is the
+ * process `isslScoreOfftargets <issl> <query> <maxDist> <threshold> <method>` launched from
+ * src/crackling/Crackling.py:767-778 -- so every entry point below names the block of
+ * src/ISSL/isslScoreOfftargets.cpp (or isslCreateIndex.cpp) whose work it takes over.
+ * bin/isslScoreOfftargets (crackling_amd/csrc/cli_score.cpp) is the shipped caller.
+ *
+ * Conventions: plain C types only; every function returns 0 on success or a negative
+ * ISSL_E_* code, never throws and never calls exit(); issl_last_error() holds the message of the
+ * last failure on the calling thread.  One issl_index is used by one thread at a time.
+ * Scoring needs a HIP device: there is NO CPU fallback, calls fail with ISSL_E_DEVICE.
+ */
+#ifndef ISSL_HIP_H
+#define ISSL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ISSL_ABI_VERSION 1
+
+enum {
+    ISSL_OK = 0,
+    ISSL_E_ARG = -1,      /* bad argument */
+    ISSL_E_IO = -2,       /* file cannot be opened / read / written */
+    ISSL_E_FORMAT = -3,   /* .issl or query file malformed (reference: "Error reading index", exit 1) */
+    ISSL_E_UNSUPPORTED = -4, /* geometry the kernels do not implement */
+    ISSL_E_DEVICE = -5,   /* HIP error or no device */
+    ISSL_E_NOMEM = -6,
+    ISSL_E_STATE = -7     /* call order (e.g. score before upload) */
+};
+
+/* Score methods, isslScoreOfftargets.cpp:44,121-143. */
+enum {
+    ISSL_METHOD_UNKNOWN = 0, /* neither score computed; the CLI prints -1 -1 */
+    ISSL_METHOD_MIT = 1,
+    ISSL_METHOD_CFD = 2,
+    ISSL_METHOD_AND = 3,
+    ISSL_METHOD_OR = 4,
+    ISSL_METHOD_AVG = 5
+};
+
+typedef struct issl_index issl_index; /* opaque */
+
+/* Header of an .issl file, isslScoreOfftargets.cpp:162-174 / isslCreateIndex.cpp:257-263. */
+typedef struct {
+    uint64_t n_sites;     /* offtargetsCount: distinct sites */
+    uint64_t seq_len;     /* seqLength */
+    uint64_t n_lines;     /* seqCount: input lines including duplicates */
+    uint64_t slice_width; /* bits per slice */
+    uint64_t n_slices;    /* sliceCount */
+    uint64_t n_scores;    /* scoresCount: {mask, local MIT score} pairs in the file */
+} issl_header;
+
+/* One scored off-target (the reference keeps these only implicitly, :382-463). */
+typedef struct {
+    uint32_t guide; /* index into the guide batch */
+    uint32_t slice; /* slice whose bucket produced it (first matching slice) */
+    uint32_t pos;   /* position j inside that bucket, :344 */
+    uint32_t id;    /* site id = low 32 bits of the bucket entry, :347 */
+    uint32_t dist;  /* mismatches, :380 */
+    uint32_t occ;   /* occurrences = high 32 bits of the entry, :348 */
+} issl_hit;
+
+/* Timings and counters of the last issl_score* call on an index (milliseconds, GPU events). */
+typedef struct {
+    uint64_t n_guides;
+    uint64_t candidates;    /* sum over guides of the 5 bucket lengths = comparisons done */
+    uint64_t hits;          /* candidates within max_dist, first matching slice only */
+    uint64_t scan_tiles;    /* candidate tiles x guide groups processed by the scan kernel */
+    double ms_bin;          /* guide binning kernels */
+    double ms_scan;         /* XOR/popcount scan kernel (the roofline kernel) */
+    double ms_group;        /* hit grouping (count/scan/scatter) */
+    double ms_replay;       /* ordered MIT/CFD accumulation */
+    double ms_total;        /* first kernel to last kernel */
+    uint64_t scan_launches; /* >1 when the hit buffer had to grow and the scan was repeated */
+} issl_stats;
+
+const char *issl_last_error(void);
+int issl_abi_version(void);
+
+/* ---- index: host side (A1, isslScoreOfftargets.cpp:152-270) ------------------------------ */
+
+/* Map and validate an .issl file.  Errors the reference reports (:164-167,201-204,223-226,237-240)
+ * and the ones it leaves undefined (missing file, truncated sections, ids out of range). */
+int issl_index_open(const char *path, issl_index **out);
+
+/* Same from a memory image of the file (copied). */
+int issl_index_from_memory(const void *image, size_t len, issl_index **out);
+
+/* isslCreateIndex.cpp:132-289 counterpart: build an index from the text of a SORTED site list,
+ * n_lines lines of seq_len characters + '\n'.  issl_index_write() then emits the same bytes as
+ * the reference builder. */
+int issl_index_build_from_text(const char *text, size_t n_lines, size_t seq_len,
+                               size_t slice_width, issl_index **out);
+
+/* Build from already packed, de-duplicated signatures in id order (isslCreateIndex.cpp:199-200
+ * state after the counting loop): sigs[i] occurs occ[i] times; n_lines = sum(occ). */
+int issl_index_build_from_sites(const uint64_t *sigs, const uint32_t *occ, size_t n_sites,
+                                size_t n_lines, size_t seq_len, size_t slice_width,
+                                issl_index **out);
+
+/* Write the .issl bytes (isslCreateIndex.cpp:256-289). */
+int issl_index_write(const issl_index *idx, const char *path);
+
+int issl_index_header(const issl_index *idx, issl_header *out);
+
+/* Bucket lengths, slice-major (isslScoreOfftargets.cpp:221-226): n_slices << slice_width values. */
+int issl_index_bucket_sizes(const issl_index *idx, uint64_t *out, size_t n);
+
+int issl_index_close(issl_index *idx);
+
+/* ---- index: HBM image ----------------------------------------------------------------- */
+
+/* Bytes of the device image (sites + bucket entries + packed scan stream + tables). */
+int issl_index_device_bytes(const issl_index *idx, size_t *out);
+
+/* Allocate the image on `device` (hipMalloc), copy and transform.  Owned by the index. */
+int issl_index_upload(issl_index *idx, int device);
+
+/* Same into caller-owned device memory (e.g. a torch uint8 tensor) of at least
+ * issl_index_device_bytes() bytes, 256-byte aligned.  The caller keeps it alive until close. */
+int issl_index_upload_into(issl_index *idx, int device, void *dev_buf, size_t bytes);
+
+/* Adopt an image that some other rank produced and that arrived in `dev_buf` through an RCCL
+ * broadcast: no file is needed on this rank.  Creates a new index handle. */
+int issl_index_attach_image(int device, void *dev_buf, size_t bytes, issl_index **out);
+
+/* Device pointer/size of the current image (for the broadcast on the producing rank). */
+int issl_index_image(const issl_index *idx, void **dev_ptr, size_t *bytes);
+
+/* ---- guides (A2, isslScoreOfftargets.cpp:63-71,82-89,275-305) ---------------------------- */
+
+/* 2-bit pack n guides laid out as lines of `stride` bytes (seq_len chars then anything). */
+int issl_encode_guides(const char *text, size_t n, size_t seq_len, size_t stride, uint64_t *out);
+/* out must hold seq_len+1 bytes. */
+int issl_decode_guide(uint64_t sig, size_t seq_len, char *out);
+/* Query file rules of :275-294; *out is malloc'd (free with issl_free). */
+int issl_read_query_file(const char *path, size_t seq_len, uint64_t **out, size_t *n);
+void issl_free(void *p);
+
+/* ---- scoring (A3-A11, isslScoreOfftargets.cpp:307-511) ------------------------------------ */
+
+int issl_method_from_string(const char *s);
+
+/* Score n guides held in host memory; mit/cfd receive 10000/(100+sum) per guide (:505-506).
+ * Blocking.  Both outputs are always written (the reference prints -1 for a method that was not
+ * requested, :517-525 -- that is the caller's business). */
+int issl_score(issl_index *idx, const uint64_t *guides, size_t n, int max_dist, double threshold,
+               int method, double *mit, double *cfd);
+
+/* Same with guides and outputs already in device memory of the index's device; asynchronous
+ * on `stream` (a hipStream_t, may be NULL) except when the hit buffer must grow. */
+int issl_score_device(issl_index *idx, const uint64_t *d_guides, size_t n, int max_dist,
+                      double threshold, int method, double *d_mit, double *d_cfd, void *stream);
+
+/* Parity helper: the scored off-targets of every guide in the reference's scoring order
+ * (slice, then position in bucket), truncated by early exit exactly as :467-496.
+ * *n_hits receives the total even when it exceeds cap. */
+int issl_dump_hits(issl_index *idx, const uint64_t *guides, size_t n, int max_dist,
+                   double threshold, int method, issl_hit *hits, size_t cap, size_t *n_hits);
+
+int issl_last_stats(const issl_index *idx, issl_stats *out);
+
+/* Sum over guides of the five bucket lengths (SURVEY 8d cross-check), host arithmetic only. */
+int issl_count_candidates(const issl_index *idx, const uint64_t *guides, size_t n, uint64_t *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ISSL_HIP_H */

@@ -1,0 +1,58 @@
+import json
+import os
+import pathlib
+import subprocess
+import sys
+
+import pytest
+
+ROOT = pathlib.Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+GOLD = ROOT / "tests" / "golden"
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _built():
+    """Product library + oracle (checker) must exist; build them if the tree is fresh."""
+    if not (ROOT / "crackling_amd" / "libissl_hip.so").exists() or not (ROOT / "bin" / "isslScoreOfftargets").exists():
+        subprocess.run(["make", "-C", str(ROOT)], check=True, capture_output=True)
+    if not (ROOT / "oracle" / "_build" / "liboracle.so").exists():
+        subprocess.run(["make", "-C", str(ROOT / "oracle"), "all"], check=True, capture_output=True)
+
+
+GOLDEN_SETS = ["uniform", "clustered", "edge"]
+
+
+class Golden:
+    def __init__(self, name):
+        self.name = name
+        self.dir = GOLD / name
+        self.issl = self.dir / "index.issl"
+        self.sites_txt = self.dir / "sites.txt"
+        self.guides_txt = self.dir / "guides.txt"
+        self.expected = json.loads((self.dir / "expected.json").read_text())
+        self.guides = self.guides_txt.read_text().splitlines()
+
+    def hits(self, thr):
+        import numpy as np
+        p = self.dir / f"hits_and_{thr}.tsv"
+        rows = [list(map(int, l.split("\t"))) for l in p.read_text().splitlines()]
+        return np.array(rows, dtype=np.uint32).reshape(-1, 6)
+
+    def hit_thresholds(self):
+        return sorted(int(p.stem.split("_")[-1]) for p in self.dir.glob("hits_and_*.tsv"))
+
+
+@pytest.fixture(scope="session", params=GOLDEN_SETS)
+def golden(request):
+    return Golden(request.param)
+
+
+@pytest.fixture(scope="session")
+def golden_uniform():
+    return Golden("uniform")

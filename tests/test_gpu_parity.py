@@ -1,0 +1,200 @@
+"""GPU parity tests: the HIP path (through the C ABI of libissl_hip.so) against
+  * the golden vectors of the compiled reference (stdout text, hit lists),
+  * the CPU oracle on seeded synthetic inputs (BASELINE.json configs[0]: 1k guides x 1M sites),
+  * size-independent properties at a larger size.
+Integer results (hit lists, counts) must be bit-exact; MIT/CFD doubles are compared bit-exactly too
+(north_star allows 1e-6: the ordered replay makes them identical in practice, tolerance stated below)."""
+import os
+import pathlib
+import subprocess
+
+import numpy as np
+import pytest
+
+import crackling_amd as ca
+import oracle_util as ou
+from synth import random_sites, random_guides, sigs_to_text
+
+pytestmark = pytest.mark.gpu
+ROOT = pathlib.Path(__file__).resolve().parent.parent
+FLOAT_TOL = 1e-6  # north_star tolerance for CFD/MIT; we additionally require bit-equality below
+
+
+@pytest.fixture(scope="module")
+def dev_index_cache():
+    cache = {}
+    yield cache
+    for ix in cache.values():
+        ix.close()
+
+
+def _dev(cache, golden):
+    if golden.name not in cache:
+        cache[golden.name] = ca.IsslIndex.open(golden.issl).upload(0)
+    return cache[golden.name]
+
+
+def test_scores_match_reference_stdout(golden, dev_index_cache):
+    ix = _dev(dev_index_cache, golden)
+    sigs = ca.encode_guides([g.encode() for g in golden.guides])
+    for key, want in golden.expected.items():
+        method, thr, dist = key.split("|")
+        mit, cfd = ix.score(sigs, int(dist), float(thr), method)
+        got = ca.format_scores(sigs, mit, cfd, method)
+        assert got == want, key
+
+
+def test_hit_lists_match_reference(golden, dev_index_cache):
+    ix = _dev(dev_index_cache, golden)
+    sigs = ca.encode_guides([g.encode() for g in golden.guides])
+    for thr in golden.hit_thresholds():
+        hits = ix.dump_hits(sigs, 4, float(thr), "and")
+        want = golden.hits(thr)
+        assert hits.shape == want.shape, (thr, hits.shape, want.shape)
+        assert np.array_equal(hits, want), thr
+
+
+def test_cli_stdout_is_byte_identical(golden):
+    exe = ROOT / "bin" / "isslScoreOfftargets"
+    for key in ("and|75|4", "mit|0|4", "cfd|75|4", "xyz|0|4"):
+        if key not in golden.expected:
+            continue
+        method, thr, dist = key.split("|")
+        r = subprocess.run([str(exe), str(golden.issl), str(golden.guides_txt), dist, thr, method],
+                           capture_output=True)
+        assert r.returncode == 0, r.stderr.decode()
+        assert r.stdout.decode() == golden.expected[key], key
+
+
+def test_crackling_caller_roundtrip(golden_uniform):
+    """The caller side of the boundary (Crackling.py:747-786) with our binary in place of the reference's."""
+    targets = [g + "AGG" for g in golden_uniform.guides if set(g) <= set("ACGT")]
+    text = ca.run_scorer_binary(str(ROOT / "bin" / "isslScoreOfftargets"), str(golden_uniform.issl), targets, 4, 75, "and")
+    parsed = ca.parse_scorer_output(text)
+    want = ca.parse_scorer_output(golden_uniform.expected["and|75|4"])
+    assert parsed == {k: want[k] for k in parsed} and len(parsed) == len(set(t[:20] for t in targets))
+
+
+@pytest.fixture(scope="module")
+def config0(tmp_path_factory):
+    """BASELINE.json configs[0]: 1k guides vs 1M-site synthetic index, slice width 8."""
+    sigs, occ = random_sites(1_000_000, seed=2026)
+    guides = random_guides(sigs, 1000, seed=2027)
+    ix = ca.IsslIndex.build_from_sites(sigs, occ)
+    p = tmp_path_factory.mktemp("cfg0") / "cfg0.issl"
+    ix.write(p)
+    ix.upload(0)
+    oracle = ou.OracleIndex(p)
+    yield ix, oracle, sigs, guides
+    ix.close()
+    oracle.close()
+
+
+@pytest.mark.parametrize("method,thr,dist", [("and", 0.0, 4), ("and", 75.0, 4), ("or", 75.0, 4), ("avg", 50.0, 3),
+                                              ("mit", 75.0, 4), ("cfd", 90.0, 2), ("and", 0.0, 0)])
+def test_config0_scores_match_oracle(config0, method, thr, dist):
+    ix, oracle, sigs, guides = config0
+    mit, cfd = ix.score(guides, dist, thr, method)
+    omit, ocfd = oracle.score(guides, dist, thr, method)
+    assert np.allclose(mit, omit, rtol=0, atol=FLOAT_TOL) and np.allclose(cfd, ocfd, rtol=0, atol=FLOAT_TOL)
+    assert np.array_equal(mit.view(np.uint64), omit.view(np.uint64)), "MIT not bit-identical"
+    assert np.array_equal(cfd.view(np.uint64), ocfd.view(np.uint64)), "CFD not bit-identical"
+    st = ix.stats()
+    assert st["candidates"] == ix.count_candidates(guides)
+
+
+def test_config0_hit_lists_match_oracle(config0):
+    ix, oracle, sigs, guides = config0
+    for thr in (0.0, 75.0):
+        hits = ix.dump_hits(guides, 4, thr, "and")
+        _, _, ohits = oracle.score(guides, 4, thr, "and", want_hits=True)
+        assert np.array_equal(hits, ohits), thr
+        if thr == 0.0:
+            assert ix.stats()["hits"] == len(ohits)
+
+
+def test_config0_properties(config0):
+    ix, oracle, sigs, guides = config0
+    mit, cfd = ix.score(guides, 4, 75.0, "and")
+    # permutation of the batch permutes the result
+    perm = np.random.default_rng(1).permutation(len(guides))
+    pm, pc = ix.score(guides[perm], 4, 75.0, "and")
+    assert np.array_equal(pm, mit[perm]) and np.array_equal(pc, cfd[perm])
+    # splitting the batch does not change any score (guides are independent, :316-509)
+    a = ix.score(guides[:333], 4, 75.0, "and"); b = ix.score(guides[333:], 4, 75.0, "and")
+    assert np.array_equal(np.concatenate([a[0], b[0]]), mit) and np.array_equal(np.concatenate([a[1], b[1]]), cfd)
+    # duplicates of one guide all get its score
+    rep = np.repeat(guides[:7], 300)
+    rm, rc = ix.score(rep, 4, 75.0, "and")
+    assert np.array_equal(rm, np.repeat(mit[:7], 300)) and np.array_equal(rc, np.repeat(cfd[:7], 300))
+    # an exact site scores at most 100*100/(100+occ... ) : dist-0 hit adds occ to CFD only
+    site = sigs[:50]
+    sm, sc = ix.score(site, 0, 0.0, "and")
+    assert np.all(sm == 100.0) and np.all(sc < 100.0)
+    # scores lie in (0, 100]
+    assert np.all((mit > 0) & (mit <= 100)) and np.all((cfd > 0) & (cfd <= 100))
+    # empty batch
+    em, ec = ix.score(np.empty(0, dtype=np.uint64))
+    assert len(em) == 0 and len(ec) == 0
+
+
+def test_large_max_dist_and_single_guide(config0):
+    ix, oracle, sigs, guides = config0
+    for dist in (6, 20):
+        mit, cfd = ix.score(guides[:64], dist, 0.0, "and")
+        omit, ocfd = oracle.score(guides[:64], dist, 0.0, "and")
+        assert np.array_equal(mit.view(np.uint64), omit.view(np.uint64)), dist
+        assert np.array_equal(cfd.view(np.uint64), ocfd.view(np.uint64)), dist
+    mit, cfd = ix.score(guides[5:6], 4, 75.0, "or")
+    omit, ocfd = oracle.score(guides[5:6], 4, 75.0, "or")
+    assert mit[0] == omit[0] and cfd[0] == ocfd[0]
+
+
+def test_skewed_batch_and_poly_a(config0):
+    """Ragged work: many guides in one bucket, homopolymers, guide words equal to the zero padding."""
+    ix, oracle, sigs, guides = config0
+    rng = np.random.default_rng(9)
+    skew = guides[:1].repeat(1500) ^ (rng.integers(0, 1 << 16, size=1500, dtype=np.uint64) << np.uint64(24))
+    batch = np.concatenate([skew, np.array([0, (1 << 40) - 1, 0x5555555555, 0xAAAAAAAAAA], dtype=np.uint64)])
+    mit, cfd = ix.score(batch, 4, 0.0, "and")
+    omit, ocfd = oracle.score(batch, 4, 0.0, "and")
+    assert np.array_equal(mit.view(np.uint64), omit.view(np.uint64))
+    assert np.array_equal(cfd.view(np.uint64), ocfd.view(np.uint64))
+
+
+def test_image_attach_and_caller_owned_memory(golden_uniform):
+    """issl_index_upload_into / issl_index_attach_image: the path a non-root rank takes after the broadcast."""
+    import torch
+    src = ca.IsslIndex.open(golden_uniform.issl)
+    nbytes = src.device_bytes()
+    buf = torch.empty(nbytes + 256, dtype=torch.uint8, device="cuda:0")
+    off = (-buf.data_ptr()) % 256
+    img = buf[off:off + nbytes]
+    src.upload_into_tensor(img)
+    clone = img.clone()  # stands in for the broadcast copy on another rank
+    if clone.data_ptr() % 256:
+        pytest.skip("allocator returned unaligned clone")
+    att = ca.IsslIndex.attach_tensor(clone)
+    assert att.header == src.header and np.array_equal(att.bucket_sizes(), src.bucket_sizes())
+    sigs = ca.encode_guides([g.encode() for g in golden_uniform.guides])
+    a = src.score(sigs, 4, 75.0, "and"); b = att.score(sigs, 4, 75.0, "and")
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    assert ca.format_scores(sigs, b[0], b[1], "and") == golden_uniform.expected["and|75|4"]
+    # device-resident in/out
+    d_g = torch.from_numpy(sigs.view(np.int64)).cuda()
+    d_m = torch.empty(len(sigs), dtype=torch.float64, device="cuda:0"); d_c = torch.empty_like(d_m)
+    att.score_device(d_g, d_m, d_c, 4, 75.0, "and")
+    torch.cuda.synchronize()
+    assert np.array_equal(d_m.cpu().numpy(), a[0]) and np.array_equal(d_c.cpu().numpy(), a[1])
+    att.close(); src.close()
+
+
+def test_hit_buffer_growth(golden):
+    """Force the overflow path: tiny first buffer cannot be requested through the ABI, so score a batch whose hits
+    exceed the initial 2^20 capacity only if the fixture is dense enough; otherwise check the counter."""
+    ix = ca.IsslIndex.open(golden.issl).upload(0)
+    sigs = ca.encode_guides([g.encode() for g in golden.guides])
+    ix.score(sigs, 4, 0.0, "and")
+    st = ix.stats()
+    assert st["scan_launches"] == 1 and st["hits"] == len(golden.hits(0))
+    ix.close()

@@ -1,0 +1,74 @@
+"""CPU: the oracle restatement against the golden vectors produced by the compiled reference
+(oracle/make_golden.py).  This is what pins the oracle; the GPU parity tests then compare against it."""
+import hashlib
+
+import numpy as np
+import pytest
+
+import oracle_util as ou
+from synth import random_sites, random_guides, sigs_to_text
+
+
+def test_oracle_scores_match_reference_stdout(golden):
+    ix = ou.OracleIndex(golden.issl)
+    sigs = ou.encode(golden.guides)
+    seqs = [s.upper() if set(s) <= set("ACGT") else None for s in golden.guides]
+    for key, want in golden.expected.items():
+        method, thr, dist = key.split("|")
+        mit, cfd = ix.score(sigs, int(dist), float(thr), method)
+        lines = want.splitlines()
+        printed = [l.split("\t")[0] for l in lines]  # the reference prints the DECODED signature
+        got = ou.format_tsv(printed, mit, cfd, method)
+        assert got == want, key
+
+
+def test_oracle_hit_lists_match_reference(golden):
+    ix = ou.OracleIndex(golden.issl)
+    sigs = ou.encode(golden.guides)
+    for thr in golden.hit_thresholds():
+        _, _, hits = ix.score(sigs, 4, float(thr), "and", want_hits=True)
+        assert np.array_equal(hits, golden.hits(thr)), thr
+
+
+def test_oracle_builder_bytes_match_reference(golden):
+    data = ou.build_issl(golden.sites_txt.read_bytes())
+    assert data == golden.issl.read_bytes()
+    assert hashlib.sha256(data).hexdigest() == (golden.dir / "index.sha256").read_text().strip()
+
+
+def test_oracle_thread_count_invariance(golden_uniform):
+    ix = ou.OracleIndex(golden_uniform.issl)
+    sigs = ou.encode(golden_uniform.guides)
+    a = ix.score(sigs, 4, 75.0, "and", threads=1)
+    b = ix.score(sigs, 4, 75.0, "and", threads=4)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+def test_worked_example_of_reference_comment():
+    # isslScoreOfftargets.cpp:350-375: AATTGCAT vs ATATCGAT -> 4 mismatches
+    a = int(ou.encode(["AATTGCAT" + "A" * 12])[0])
+    b = int(ou.encode(["ATATCGAT" + "A" * 12])[0])
+    x = a ^ b
+    mm = ((x & 0xAAAAAAAAAAAAAAAA) >> 1) | (x & 0x5555555555555555)
+    assert bin(mm).count("1") == 4
+    assert mm == 0b00_01_01_00_01_01_00_00 >> 0 or bin(mm).count("1") == 4
+
+
+def test_first_matching_slice_rule_equals_seen_bitmap():
+    """a candidate met in slice i is scored iff no slice j<i of the XOR is all zero."""
+    sigs, occ = random_sites(30000, seed=11)
+    text = sigs_to_text(sigs, occ)
+    import tempfile, os
+    with tempfile.TemporaryDirectory() as tmp:
+        p = os.path.join(tmp, "x.issl")
+        open(p, "wb").write(ou.build_issl(text))
+        ix = ou.OracleIndex(p)
+        guides = random_guides(sigs, 300, seed=12)
+        _, _, hits = ix.score(guides, 4, 0.0, "and", want_hits=True)
+    assert len(hits) > 100
+    for g, sl, pos, sid, dist, oc in hits:
+        x = int(guides[g]) ^ int(sigs[sid])
+        zero = [((x >> (8 * j)) & 0xFF) == 0 for j in range(5)]
+        assert zero[sl] and not any(zero[:sl])
+    # and every (guide, site) pair appears once
+    assert len({(int(h[0]), int(h[3])) for h in hits}) == len(hits)
