@@ -18,6 +18,28 @@ if not os.path.exists(LIB_PATH):
         "crackling_amd has no CPU fallback for the ISSL scorer."
     )
 
+
+
+def _preload_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64/libhsa-runtime64 (same
+    SONAME as /opt/rocm's).  If libissl_hip.so pulled in /opt/rocm's copy first, a later `import torch` would bring
+    a second runtime into the process and that one finds no GPU.  So when torch is installed, its libamdhip64 is
+    loaded first (without importing torch); libissl_hip.so's DT_NEEDED libamdhip64.so.7 then binds to it by SONAME.
+    The standalone executables in bin/ do not go through here and use /opt/rocm's runtime."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec and spec.submodule_search_locations:
+        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+            return cand
+    return None
+
+
+HIP_RUNTIME = _preload_hip_runtime()
 lib = C.CDLL(LIB_PATH)
 
 

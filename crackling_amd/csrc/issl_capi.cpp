@@ -124,6 +124,7 @@ static void free_workspace(Workspace &w)
                     w.goff, w.gcur, w.blocksum, w.d_guides, w.d_mit, w.d_cfd, w.d_kept, w.d_hitrec};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
+    if (w.raw) (void)hipFree(w.raw);
     w = Workspace{};
 }
 
@@ -148,6 +149,16 @@ static int ensure_hit_capacity(issl_index *ix, size_t want)
     return ISSL_OK;
 }
 
+static int ensure_raw_capacity(issl_index *ix, size_t chunks)
+{
+    Workspace &w = ix->ws;
+    if (chunks <= w.cap_chunks) return ISSL_OK;
+    int rc = dev_alloc(w.raw, (chunks + 1) * kChunkRecs); // +1: spare chunk that absorbs writes after exhaustion
+    if (rc) return rc;
+    w.cap_chunks = chunks;
+    return ISSL_OK;
+}
+
 static int ensure_workspace(issl_index *ix, size_t n)
 {
     Workspace &w = ix->ws;
@@ -159,6 +170,7 @@ static int ensure_workspace(issl_index *ix, size_t n)
         if ((rc = dev_alloc(w.gstart, nb + 1))) return rc;
         if ((rc = dev_alloc(w.counters, 1))) return rc;
         if ((rc = dev_alloc(w.plan, 1))) return rc;
+
         w.n_buckets = static_cast<uint32_t>(nb);
     }
     if (n > w.cap_guides) {
@@ -183,6 +195,11 @@ static int ensure_workspace(issl_index *ix, size_t n)
     if (w.cap_hits == 0) {
         const size_t want = std::max<size_t>(size_t(1) << 20, 64 * n);
         if ((rc = ensure_hit_capacity(ix, want))) return rc;
+    }
+    if (w.cap_chunks == 0) {
+        // every scan wave may hold one partly filled chunk; beyond that ~1 record per 50k comparisons
+        const size_t want = std::max<size_t>(size_t(kScanGridBlocks) * 4 * 4, n);
+        if ((rc = ensure_raw_capacity(ix, want))) return rc;
     }
     if (!ix->have_events) {
         for (auto &e : ix->ev) HIP_TRY(hipEventCreate(&e));
@@ -300,6 +317,7 @@ static int score_core(issl_index *ix, const uint64_t *d_guides, size_t n, int ma
         HIP_TRY(hipEventRecord(ix->ev[1], stream));
         launch_scan(ix->view, ix->ws, d_guides, n32, max_dist, stream);
         HIP_TRY(hipEventRecord(ix->ev[2], stream));
+        launch_verify(ix->view, ix->ws, d_guides, max_dist, stream);
         HIP_TRY(hipMemcpyAsync(&c, ix->ws.counters, sizeof c, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipMemcpyAsync(&pl, ix->ws.plan, sizeof pl, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
@@ -309,13 +327,19 @@ static int score_core(issl_index *ix, const uint64_t *d_guides, size_t n, int ma
             set_error("internal error: scan item list overflow");
             return ISSL_E_DEVICE;
         }
-        if (c.n_hits <= ix->ws.cap_hits) break;
-        if (attempt >= 2) {
-            set_error("internal error: hit buffer kept overflowing");
+        if (c.n_hits <= ix->ws.cap_hits && !c.raw_overflow) break;
+        if (attempt >= 6) {
+            set_error("internal error: hit buffers kept overflowing");
             return ISSL_E_DEVICE;
         }
-        rc = ensure_hit_capacity(ix, static_cast<size_t>(c.n_hits) + c.n_hits / 8 + 1024);
-        if (rc) return rc;
+        if (c.raw_overflow) { // raw_chunks counts every request, so it is the exact need of this batch
+            rc = ensure_raw_capacity(ix, static_cast<size_t>(c.raw_chunks) + c.raw_chunks / 8 + 1024);
+            if (rc) return rc;
+        }
+        if (c.n_hits > ix->ws.cap_hits) {
+            rc = ensure_hit_capacity(ix, static_cast<size_t>(c.n_hits) + c.n_hits / 8 + 1024);
+            if (rc) return rc;
+        }
     }
     if (dump && ix->ws.cap_hitrec < ix->ws.cap_hits) {
         rc = dev_alloc(ix->ws.d_hitrec, ix->ws.cap_hits);

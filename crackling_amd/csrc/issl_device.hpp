@@ -27,7 +27,7 @@ namespace issl {
 //                              each bucket zero-padded to a whole number of tiles.
 constexpr uint64_t kImageMagic = 0x314C535349444D41ull; // "AMDISSL1"
 constexpr uint32_t kImageVersion = 1;
-constexpr uint32_t kTileCands = 2048; // candidates per scan tile: 256 threads x 8 registers
+constexpr uint32_t kTileCands = 2048; // candidates per scan tile: one wave, 64 lanes x 32 registers
 constexpr uint32_t kHeaderBytes = 4096;
 
 struct ImageHeader {
@@ -72,6 +72,9 @@ constexpr uint32_t kGuideGroup = 8;    // guide words fetched per scalar load
 constexpr uint32_t kItemGuides = 512;  // guides per scan item (bounds one tile's work)
 constexpr uint32_t kTileFixedCost = 4; // cost of fetching a tile, in guide-comparisons of that tile
 constexpr uint32_t kNoGuide = 0xFFFFFFFFu;
+constexpr uint32_t kScanGridBlocks = 256u * 8u; // scan launch: 256 CUs x 8 workgroups of 4 independent waves
+constexpr uint32_t kScanRangesPerWave = 4;      // upper bound of cost ranges = waves x this
+constexpr uint32_t kChunkRecs = 128;            // raw-record chunk: 1 KiB, slot 0 is the fill count
 
 // One unit of scan work: all tiles of one bucket against one group of guides of that bucket.
 struct ScanItem {
@@ -85,6 +88,8 @@ struct ScanItem {
 struct PlanInfo {
     uint32_t n_items;
     uint32_t error;       // bit 1: item list overflow
+    uint32_t n_ranges;    // equal-cost ranges the scan's waves work through
+    uint32_t pad;
     uint64_t total_cost;
     uint64_t candidates;  // sum over guides of their bucket lengths
 };
@@ -92,7 +97,9 @@ struct PlanInfo {
 // Updated by the scan with atomics.
 struct Counters {
     uint32_t n_hits;      // hits the scan wanted to record (may exceed capacity)
-    uint32_t pad;
+    uint32_t next_range;  // ticket counter of the scan's dynamic range assignment
+    uint32_t raw_chunks;  // chunks of the raw record buffer handed out
+    uint32_t raw_overflow; // set when the raw buffer was too small
     uint64_t tiles;       // (tile, item) pairs processed
 };
 
@@ -104,6 +111,8 @@ struct Workspace {
     uint32_t *gidx = nullptr;    // guide index, kNoGuide in padding
     ScanItem *items = nullptr;   // [max_items+1]
     PlanInfo *plan = nullptr;
+    uint64_t *raw = nullptr;     // [(cap_chunks+1) * kChunkRecs] raw records of the scan, chunked
+    size_t cap_chunks = 0;
     Counters *counters = nullptr;
     uint64_t *hits = nullptr;    // [hit_cap] keys guide<<35 | slice<<32 | pos
     uint64_t *sorted = nullptr;  // [hit_cap] grouped by guide
@@ -134,6 +143,7 @@ void launch_pack_scan_stream(const ImageView &v, uint32_t *scan_out, uint32_t *e
 void launch_bin_guides(const ImageView &v, const Workspace &ws, const uint64_t *d_guides, uint32_t n, void *stream);
 void launch_scan(const ImageView &v, const Workspace &ws, const uint64_t *d_guides, uint32_t n, int max_dist,
                  void *stream);
+void launch_verify(const ImageView &v, const Workspace &ws, const uint64_t *d_guides, int max_dist, void *stream);
 void launch_group_hits(const Workspace &ws, uint32_t n, void *stream);
 void launch_replay(const ImageView &v, const Workspace &ws, const uint64_t *d_guides, uint32_t n,
                    const ScoreParams &p, double *d_mit, double *d_cfd, uint32_t *d_kept, issl_hit *d_hitrec,

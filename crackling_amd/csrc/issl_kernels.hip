@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void k_plan(ImageView v, const uint32_t *__res
     const uint32_t b0 = threadIdx.x * per;
     const uint32_t b1 = (b0 + per < nb) ? b0 + per : nb;
 
-    uint64_t slots = 0, n_it = 0, cost = 0, cand = 0;
+    uint64_t slots = 0, n_it = 0, cost = 0, cand = 0, wtiles = 0;
     for (uint32_t b = b0; b < b1; ++b) {
         const uint32_t g = ng[b];
         const uint32_t nt = v.tile_first[b + 1] - v.tile_first[b];
@@ -175,13 +175,15 @@ __global__ __launch_bounds__(256) void k_plan(ImageView v, const uint32_t *__res
             n_it += k;
             cost += static_cast<uint64_t>(nt) * (static_cast<uint64_t>(g) + static_cast<uint64_t>(k) * kTileFixedCost);
             cand += (v.bucket_start[b + 1] - v.bucket_start[b]) * g;
+            wtiles += static_cast<uint64_t>(nt) * k;
         }
     }
-    uint64_t tot_slots, tot_items, tot_cost, tot_cand;
+    uint64_t tot_slots, tot_items, tot_cost, tot_cand, tot_tiles;
     uint64_t slot_at = block_exclusive_scan(slots, lds, &tot_slots);
     uint64_t item_at = block_exclusive_scan(n_it, lds, &tot_items);
     uint64_t cost_at = block_exclusive_scan(cost, lds, &tot_cost);
     (void)block_exclusive_scan(cand, lds, &tot_cand);
+    (void)block_exclusive_scan(wtiles, lds, &tot_tiles);
 
     const bool overflow = tot_items > cap_items;
     for (uint32_t b = b0; b < b1; ++b) {
@@ -213,6 +215,9 @@ __global__ __launch_bounds__(256) void k_plan(ImageView v, const uint32_t *__res
         plan->n_items = overflow ? 0u : static_cast<uint32_t>(tot_items);
         plan->total_cost = overflow ? 0ull : tot_cost;
         plan->candidates = tot_cand;
+        // one range per tile while that keeps the ticket traffic low, else cost-balanced ranges
+        const uint64_t max_ranges = static_cast<uint64_t>(kScanGridBlocks) * 4u * kScanRangesPerWave;
+        plan->n_ranges = overflow ? 0u : static_cast<uint32_t>(tot_tiles < max_ranges ? tot_tiles : max_ranges);
         plan->error = overflow ? 2u : 0u;
     }
 }
@@ -284,40 +289,262 @@ void launch_bin_guides(const ImageView &v, const Workspace &ws, const uint64_t *
 // scan
 // ------------------------------------------------------------------------------------------------
 
-struct alignas(32) GuideGroup {
+struct alignas(4 * kGuideGroup) GuideGroup {
     uint32_t w[kGuideGroup];
 };
 
-constexpr int kRegs = kTileCands / 256; // candidates per thread
+constexpr int kRegs = kTileCands / 64; // candidates per lane: one wave owns a whole tile
 
-// Rare path, entered by a whole wave when any lane saw a candidate within max_dist of guide slot
-// `g`: re-test the lane's candidates exactly on the full signatures and append the keys.
-__device__ __forceinline__ void record_hits(const ImageView &v, const Workspace &ws,
-                                            const uint64_t *__restrict__ guides, const uint32_t (&c)[kRegs],
-                                            uint32_t g, uint32_t bucket, uint32_t tile_in_bucket, int max_dist)
+// Position inside the tile of register r of lane `lane` (tiles are read as 16-byte vectors, lane-major).
+__device__ __forceinline__ uint32_t tile_offset(int r, uint32_t lane)
 {
-    const uint32_t guide = ws.gidx[g];
-    if (guide == kNoGuide) return;
-    const uint32_t gw = ws.gword[g];
-    const uint64_t gsig = guides[guide];
-    const uint32_t slice = bucket >> v.slice_width;
-    const uint64_t start = v.bucket_start[bucket];
-    const uint64_t len = v.bucket_start[bucket + 1] - start;
-    const uint64_t low = (1ull << v.slice_width) - 1ull;
+    return (static_cast<uint32_t>(r >> 2) * 64u + lane) * 4u + static_cast<uint32_t>(r & 3);
+}
+
+// min over the lane's candidates of the mismatches against guide word gw, folded into `best`.
+// Written in blocks of 8 candidates, stage by stage, so that no instruction consumes the result of
+// the one right before it (the sub-dword OR needs a wait state before its result is read).
+template <bool SDWA>
+__device__ __forceinline__ uint32_t closest(const uint32_t (&c)[kRegs], uint32_t gw, uint32_t best)
+{
+#pragma unroll
+    for (int r0 = 0; r0 < kRegs; r0 += 8) {
+        uint32_t y[8], o[8], d[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) y[i] = c[r0 + i] ^ gw;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (SDWA) o[i] = fold_halves(y[i]);
+            else o[i] = (y[i] | (y[i] >> 16)) & 0xFFFFu;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) d[i] = __builtin_popcount(o[i]);
+#pragma unroll
+        for (int i = 0; i < 8; i += 2) {
+            const uint32_t m = d[i] < d[i + 1] ? d[i] : d[i + 1];
+            best = m < best ? m : best;
+        }
+    }
+    return best;
+}
+
+// ---- raw records ------------------------------------------------------------------------------
+// A candidate that the scan finds within max_dist of a guide is only NOTED by the scan kernel, as an
+// 8-byte record (guide slot, tile, offset in tile), with plain stores into a chunk of the raw buffer
+// that the wave owns -- no dependent load, no returning atomic on the hot path (one hit per ~50k
+// comparisons is frequent enough that a latency chain per hit would dominate the kernel).
+// k_verify then checks every record exactly, applies the first-matching-slice rule and appends the
+// final keys.  Chunk = kChunkRecs slots of 8 bytes, slot 0 = number of used slots (header included).
+__device__ __forceinline__ uint64_t raw_record(uint32_t gslot, uint32_t tile, uint32_t offset)
+{
+    return (static_cast<uint64_t>(gslot) << 37) | (static_cast<uint64_t>(tile) << 11) | offset;
+}
+
+struct RawWriter {
+    uint64_t *chunk; // current chunk of this wave (wave-uniform)
+    uint32_t fill;   // used slots of the current chunk, header included
+};
+
+__device__ __forceinline__ void raw_retire(const RawWriter &w, uint32_t lane)
+{
+    if (lane == 0) w.chunk[0] = w.fill;
+}
+
+__device__ __forceinline__ void raw_acquire(RawWriter &w, uint64_t *raw, uint32_t max_chunks, Counters *counters,
+                                            uint32_t lane)
+{
+    uint32_t idx = 0;
+    if (lane == 0) idx = atomicAdd(&counters->raw_chunks, 1u);
+    idx = __builtin_amdgcn_readfirstlane(idx);
+    if (idx >= max_chunks) { // buffer exhausted: write into the spare chunk, the host grows the buffer and re-runs
+        idx = max_chunks;
+        if (lane == 0) counters->raw_overflow = 1u;
+    }
+    w.chunk = raw + static_cast<uint64_t>(idx) * kChunkRecs;
+    w.fill = 1;
+}
+
+// Cold block of the scan: the wave knows that SOME lane has a candidate within thr of guide word gw.
+// Find them and note them.  Register r of lane l sits at tile offset tile_offset(r, l).
+template <bool SDWA>
+__device__ __forceinline__ void note_candidates(const uint32_t (&c)[kRegs], uint32_t gw, uint32_t thr, uint32_t gslot,
+                                                uint32_t tile, uint32_t lane, RawWriter &w, uint64_t *raw,
+                                                uint32_t max_chunks, Counters *counters)
+{
 #pragma unroll
     for (int r = 0; r < kRegs; ++r) {
         const uint32_t y = c[r] ^ gw;
         const uint32_t d = __builtin_popcount((y | (y >> 16)) & 0xFFFFu);
-        if (d > static_cast<uint32_t>(max_dist)) continue;
-        const uint64_t pos = static_cast<uint64_t>(tile_in_bucket) * kTileCands +
-                             (static_cast<uint32_t>(r >> 2) * 256u + threadIdx.x) * 4u + static_cast<uint32_t>(r & 3);
+        const bool near = d <= thr;
+        const uint64_t who = __ballot(near);
+        if (who != 0ull) {
+            const uint32_t n = static_cast<uint32_t>(__builtin_popcountll(who));
+            if (w.fill + n > kChunkRecs) {
+                raw_retire(w, lane);
+                raw_acquire(w, raw, max_chunks, counters, lane);
+            }
+            if (near) {
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(who >> 32),
+                                                                __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(who), 0u));
+                w.chunk[w.fill + rank] = raw_record(gslot, tile, tile_offset(r, lane));
+            }
+            w.fill += n;
+        }
+    }
+}
+
+// Scan kernel.  Every WAVE is an independent worker: it takes ranges of the cost axis (the first one
+// by its global wave number, further ones from an atomic ticket), and for every tile of the range
+// keeps the tile's 2048 scan words in registers (32 per lane) while the guide words of the item
+// stream through scalar registers, 8 per scalar load.
+// The streams the hot loop reads (scan words, tile table, items, guide words, plan) are separate
+// `const __restrict__` kernel arguments: they are never written by this kernel, which lets the
+// compiler fetch the wave-uniform ones through the scalar cache.
+template <bool SDWA>
+__global__ __launch_bounds__(256, 8) void k_scan(const uint32_t *__restrict__ scan_stream,
+                                                 const uint32_t *__restrict__ tile_first,
+                                                 const ScanItem *__restrict__ items,
+                                                 const PlanInfo *__restrict__ plan,
+                                                 const uint32_t *__restrict__ gword_stream, uint64_t *raw,
+                                                 uint32_t max_chunks, Counters *counters, int max_dist)
+{
+    const uint32_t n_items = plan->n_items;
+    const uint64_t total = plan->total_cost;
+    const uint32_t n_ranges = plan->n_ranges;
+    if (n_items == 0 || total == 0 || n_ranges == 0) return;
+    const uint32_t thr = static_cast<uint32_t>(max_dist);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
+    uint32_t range = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    uint32_t tiles_done = 0;
+    RawWriter w;
+    w.chunk = raw + static_cast<uint64_t>(max_chunks) * kChunkRecs; // spare chunk until the first real one
+    w.fill = kChunkRecs;                                             // "full": first note acquires a chunk
+    bool own_chunk = false;
+
+    while (range < n_ranges) {
+        // Ranges cut the cost axis into equal parts; a tile belongs to the range that holds its
+        // start cost.  No 128-bit intermediate: total < 2^50 and n_ranges <= 2^15.
+        const uint64_t lo = total / n_ranges * range + (total % n_ranges) * range / n_ranges;
+        const uint64_t hi = (range + 1 == n_ranges)
+                                ? total
+                                : total / n_ranges * (range + 1) + (total % n_ranges) * (range + 1) / n_ranges;
+        if (hi > lo) {
+            // item holding `lo`: last i with items[i].cost0 <= lo
+            uint32_t a = 0, z = n_items;
+            while (z - a > 1) {
+                const uint32_t mid = (a + z) >> 1;
+                if (items[mid].cost0 <= lo) a = mid; else z = mid;
+            }
+            uint32_t it = a;
+            ScanItem cur = items[it];
+            uint64_t tile_cost = static_cast<uint64_t>(cur.g1 - cur.g0) + kTileFixedCost;
+            uint64_t k = (lo - cur.cost0 + tile_cost - 1) / tile_cost; // first tile starting at or after lo
+            while (true) {
+                if (k >= cur.n_tiles) {
+                    ++it;
+                    if (it >= n_items) break;
+                    cur = items[it];
+                    tile_cost = static_cast<uint64_t>(cur.g1 - cur.g0) + kTileFixedCost;
+                    k = 0;
+                }
+                if (cur.cost0 + k * tile_cost >= hi) break;
+
+                // ---- one tile: 2048 candidates of bucket cur.bucket, tile k ---------------------
+                const uint32_t tile = tile_first[cur.bucket] + static_cast<uint32_t>(k);
+                const uint4 *__restrict__ src =
+                    reinterpret_cast<const uint4 *>(scan_stream + static_cast<uint64_t>(tile) * kTileCands);
+                uint32_t c[kRegs];
+#pragma unroll
+                for (int q = 0; q < kRegs / 4; ++q) {
+                    const uint4 t4 = src[q * 64 + lane];
+                    c[4 * q + 0] = t4.x; c[4 * q + 1] = t4.y; c[4 * q + 2] = t4.z; c[4 * q + 3] = t4.w;
+                }
+                const uint32_t g_full = cur.g0 + ((cur.g1 - cur.g0) & ~(kGuideGroup - 1u));
+                uint32_t g = cur.g0;
+                for (; g < g_full; g += kGuideGroup) {
+                    const GuideGroup gg = *reinterpret_cast<const GuideGroup *>(gword_stream + g);
+                    uint32_t flagged = 0; // bit u: a lane has a candidate within thr of guide g+u
+#pragma unroll
+                    for (uint32_t u = 0; u < kGuideGroup; ++u) {
+                        const uint32_t best = closest<SDWA>(c, gg.w[u], 64u);
+                        if (__ballot(best <= thr) != 0ull) flagged |= 1u << u;
+                    }
+                    while (flagged) { // ~4 % of the guide-tile pairs on random data
+                        const uint32_t u = static_cast<uint32_t>(__builtin_ctz(flagged));
+                        flagged &= flagged - 1u;
+                        note_candidates<SDWA>(c, gword_stream[g + u], thr, g + u, tile, lane, w, raw, max_chunks, counters);
+                        own_chunk = true;
+                    }
+                }
+                if (g < cur.g1) { // last, partial group: padding words are not compared
+                    const GuideGroup gg = *reinterpret_cast<const GuideGroup *>(gword_stream + g);
+                    uint32_t flagged = 0;
+#pragma unroll
+                    for (uint32_t u = 0; u < kGuideGroup - 1u; ++u) {
+                        if (g + u < cur.g1) {
+                            const uint32_t best = closest<SDWA>(c, gg.w[u], 64u);
+                            if (__ballot(best <= thr) != 0ull) flagged |= 1u << u;
+                        }
+                    }
+                    while (flagged) {
+                        const uint32_t u = static_cast<uint32_t>(__builtin_ctz(flagged));
+                        flagged &= flagged - 1u;
+                        note_candidates<SDWA>(c, gword_stream[g + u], thr, g + u, tile, lane, w, raw, max_chunks, counters);
+                        own_chunk = true;
+                    }
+                }
+                ++tiles_done;
+                ++k;
+            }
+        }
+        // next range: the ticket counter continues after the statically assigned first round
+        uint32_t ticket = 0;
+        if (lane == 0) ticket = atomicAdd(&counters->next_range, 1u);
+        range = n_waves + __builtin_amdgcn_readfirstlane(ticket);
+    }
+    if (own_chunk) raw_retire(w, lane);
+    if (lane == 0 && tiles_done)
+        atomicAdd(reinterpret_cast<unsigned long long *>(&counters->tiles), static_cast<unsigned long long>(tiles_done));
+}
+
+// Exact check of the raw records: one thread per record, one chunk per 128-thread workgroup.
+__global__ __launch_bounds__(kChunkRecs) void k_verify(ImageView v, Workspace ws, const uint64_t *__restrict__ guides,
+                                                       int max_dist)
+{
+    uint32_t n_chunks = ws.counters->raw_chunks;
+    if (n_chunks > ws.cap_chunks) n_chunks = static_cast<uint32_t>(ws.cap_chunks);
+    const uint64_t low = (1ull << v.slice_width) - 1ull;
+    for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+        const uint64_t *recs = ws.raw + static_cast<uint64_t>(chunk) * kChunkRecs;
+        const uint32_t used = static_cast<uint32_t>(recs[0]);
+        const uint32_t t = threadIdx.x + 1u;
+        if (t >= used || t >= kChunkRecs) continue;
+        const uint64_t rec = recs[t];
+        const uint32_t offset = static_cast<uint32_t>(rec) & (kTileCands - 1u);
+        const uint32_t tile = static_cast<uint32_t>(rec >> 11) & 0x3FFFFFFu;
+        const uint32_t gslot = static_cast<uint32_t>(rec >> 37);
+        const uint32_t guide = ws.gidx[gslot];
+        if (guide == kNoGuide) continue;
+        // bucket of the tile: last b with tile_first[b] <= tile
+        uint32_t lo = 0, hi = v.n_buckets;
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (v.tile_first[mid] <= tile) lo = mid; else hi = mid;
+        }
+        const uint32_t bucket = lo;
+        const uint32_t slice = bucket >> v.slice_width;
+        const uint64_t start = v.bucket_start[bucket];
+        const uint64_t len = v.bucket_start[bucket + 1] - start;
+        const uint64_t pos = static_cast<uint64_t>(tile - v.tile_first[bucket]) * kTileCands + offset;
         if (pos >= len) continue; // zero padding of the bucket's last tile
-        const uint64_t e = v.entries[start + pos];
-        const uint64_t ot = v.sites[e & 0xFFFFFFFFull];
-        const uint64_t x = gsig ^ ot;
-        if (__builtin_popcountll(mismatch_mask(gsig, ot)) > max_dist) continue; // exact, full signatures
+        const uint64_t gsig = guides[guide];
+        const uint64_t entry = v.entries[start + pos];
+        const uint64_t ot = v.sites[entry & 0xFFFFFFFFull];
+        if (__builtin_popcountll(mismatch_mask(gsig, ot)) > max_dist) continue; // exact, full signatures (:376-382)
         // First-matching-slice rule (equivalent of the seen bitmap, isslScoreOfftargets.cpp:385-390,463):
         // the site was already met iff an earlier slice of the XOR is all zero.
+        const uint64_t x = gsig ^ ot;
         bool earlier = false;
         for (uint32_t j = 0; j < slice; ++j)
             if (((x >> (v.slice_width * j)) & low) == 0) earlier = true;
@@ -329,147 +556,31 @@ __device__ __forceinline__ void record_hits(const ImageView &v, const Workspace 
     }
 }
 
-// The streams the hot loop reads (scan words, tile table, items, guide words, plan) are separate
-// `const __restrict__` kernel arguments: they are never written by this kernel, which lets the
-// compiler fetch the wave-uniform ones through the scalar cache.
-template <bool SDWA>
-__global__ __launch_bounds__(256) void k_scan(const uint32_t *__restrict__ scan_stream,
-                                              const uint32_t *__restrict__ tile_first,
-                                              const ScanItem *__restrict__ items,
-                                              const PlanInfo *__restrict__ plan,
-                                              const uint32_t *__restrict__ gword_stream, ImageView v, Workspace ws,
-                                              const uint64_t *__restrict__ guides, int max_dist, uint32_t n_ranges)
-{
-    const uint32_t n_items = plan->n_items;
-    const uint64_t total = plan->total_cost;
-    if (n_items == 0 || total == 0) return;
-    const uint32_t thr = static_cast<uint32_t>(max_dist);
-    uint64_t tiles_done = 0;
-
-    for (uint32_t range = blockIdx.x; range < n_ranges; range += gridDim.x) {
-        // Ranges cut the cost axis into equal parts; a tile belongs to the range that holds its
-        // start cost.  128-bit intermediate avoided: total < 2^50 and n_ranges <= 2^14.
-        const uint64_t lo = total / n_ranges * range + (total % n_ranges) * range / n_ranges;
-        const uint64_t hi = (range + 1 == n_ranges)
-                                ? total
-                                : total / n_ranges * (range + 1) + (total % n_ranges) * (range + 1) / n_ranges;
-        if (hi <= lo) continue;
-        // item holding `lo`: last i with items[i].cost0 <= lo
-        uint32_t a = 0, z = n_items;
-        while (z - a > 1) {
-            const uint32_t mid = (a + z) >> 1;
-            if (items[mid].cost0 <= lo) a = mid; else z = mid;
-        }
-        uint32_t it = a;
-        ScanItem cur = items[it];
-        uint64_t tile_cost = static_cast<uint64_t>(cur.g1 - cur.g0) + kTileFixedCost;
-        uint64_t k = (lo - cur.cost0 + tile_cost - 1) / tile_cost; // first tile starting at or after lo
-        while (true) {
-            if (k >= cur.n_tiles) {
-                ++it;
-                if (it >= n_items) break;
-                cur = items[it];
-                tile_cost = static_cast<uint64_t>(cur.g1 - cur.g0) + kTileFixedCost;
-                k = 0;
-            }
-            if (cur.cost0 + k * tile_cost >= hi) break;
-
-            // ---- one tile: 2048 candidates of bucket cur.bucket, tile k -----------------------
-            const uint32_t tile = tile_first[cur.bucket] + static_cast<uint32_t>(k);
-            const uint4 *__restrict__ src =
-                reinterpret_cast<const uint4 *>(scan_stream + static_cast<uint64_t>(tile) * kTileCands);
-            uint32_t c[kRegs];
-#pragma unroll
-            for (int q = 0; q < kRegs / 4; ++q) {
-                const uint4 t4 = src[q * 256 + threadIdx.x];
-                c[4 * q + 0] = t4.x; c[4 * q + 1] = t4.y; c[4 * q + 2] = t4.z; c[4 * q + 3] = t4.w;
-            }
-            // Full groups of 8 guides: guide words arrive by one wide scalar load, the next group is
-            // requested before the current one is compared.  The (< 8) guides of the last group
-            // take the guarded loop below.
-            const uint32_t g_full = cur.g0 + ((cur.g1 - cur.g0) & ~(kGuideGroup - 1u));
-            uint32_t g = cur.g0;
-            if (g < g_full) {
-                GuideGroup gg = *reinterpret_cast<const GuideGroup *>(gword_stream + g);
-                for (; g < g_full; g += kGuideGroup) {
-                    const uint32_t g_next = (g + kGuideGroup < cur.g1) ? g + kGuideGroup : g;
-                    const GuideGroup gn = *reinterpret_cast<const GuideGroup *>(gword_stream + g_next);
-                    uint32_t pending = 0; // bit u: some lane of this wave is within max_dist of guide g+u
-#pragma unroll
-                    for (uint32_t u = 0; u < kGuideGroup; ++u) {
-                        const uint32_t gw = gg.w[u];
-                        uint32_t best = 64;
-#pragma unroll
-                        for (int r = 0; r < kRegs; ++r) {
-                            const uint32_t y = c[r] ^ gw;
-                            uint32_t o;
-                            if (SDWA) o = fold_halves(y);
-                            else o = (y | (y >> 16)) & 0xFFFFu;
-                            const uint32_t d = __builtin_popcount(o);
-                            best = d < best ? d : best;
-                        }
-                        if (__ballot(best <= thr) != 0ull) pending |= 1u << u;
-                    }
-                    while (pending) {
-                        const uint32_t u = static_cast<uint32_t>(__builtin_ctz(pending));
-                        pending &= pending - 1u;
-                        record_hits(v, ws, guides, c, g + u, cur.bucket, static_cast<uint32_t>(k), max_dist);
-                    }
-                    gg = gn;
-                }
-            }
-            if (g < cur.g1) {
-                const GuideGroup gg = *reinterpret_cast<const GuideGroup *>(gword_stream + g);
-                uint32_t pending = 0;
-#pragma unroll
-                for (uint32_t u = 0; u < kGuideGroup - 1u; ++u) {
-                    if (g + u < cur.g1) {
-                        const uint32_t gw = gg.w[u];
-                        uint32_t best = 64;
-#pragma unroll
-                        for (int r = 0; r < kRegs; ++r) {
-                            const uint32_t y = c[r] ^ gw;
-                            uint32_t o;
-                            if (SDWA) o = fold_halves(y);
-                            else o = (y | (y >> 16)) & 0xFFFFu;
-                            const uint32_t d = __builtin_popcount(o);
-                            best = d < best ? d : best;
-                        }
-                        if (__ballot(best <= thr) != 0ull) pending |= 1u << u;
-                    }
-                }
-                while (pending) {
-                    const uint32_t u = static_cast<uint32_t>(__builtin_ctz(pending));
-                    pending &= pending - 1u;
-                    record_hits(v, ws, guides, c, g + u, cur.bucket, static_cast<uint32_t>(k), max_dist);
-                }
-            }
-            ++tiles_done;
-            ++k;
-        }
-    }
-    if (threadIdx.x == 0 && tiles_done)
-        atomicAdd(reinterpret_cast<unsigned long long *>(&ws.counters->tiles), static_cast<unsigned long long>(tiles_done));
-}
-
-static int g_scan_variant = -1; // -1: read ISSL_SCAN_VARIANT once
-
 void launch_scan(const ImageView &v, const Workspace &ws, const uint64_t *d_guides, uint32_t n, int max_dist,
-                 void *stream)
+                 void *stream_)
 {
     (void)n;
-    if (g_scan_variant < 0) {
-        const char *e = getenv("ISSL_SCAN_VARIANT");
-        g_scan_variant = (e && e[0] == '0') ? 0 : 1;
-    }
-    const uint32_t grid = 256u * 8u;    // 256 CUs x 8 resident workgroups of 256 threads
-    const uint32_t n_ranges = grid * 4u; // static round-robin over equal-cost ranges
-    if (g_scan_variant == 1)
-        hipLaunchKernelGGL(k_scan<true>, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), v.scan,
-                           v.tile_first, ws.items, ws.plan, ws.gword, v, ws, d_guides, max_dist, n_ranges);
+    (void)d_guides;
+    if (max_dist < 0) return; // isslScoreOfftargets.cpp:382: no distance satisfies 0 <= dist <= maxDist
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    // ISSL_SCAN_VARIANT=0 selects the build of the kernel without the sub-dword (SDWA) fold: A/B aid.
+    const char *variant_env = getenv("ISSL_SCAN_VARIANT");
+    const int variant = (variant_env && variant_env[0] == '0') ? 0 : 1;
+    const uint32_t grid = kScanGridBlocks; // 256 CUs x 8 workgroups of 4 independent waves
+    const uint32_t max_chunks = static_cast<uint32_t>(ws.cap_chunks);
+    if (variant == 1)
+        hipLaunchKernelGGL(k_scan<true>, dim3(grid), dim3(256), 0, stream, v.scan, v.tile_first, ws.items, ws.plan,
+                           ws.gword, ws.raw, max_chunks, ws.counters, max_dist);
     else
-        hipLaunchKernelGGL(k_scan<false>, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), v.scan,
-                           v.tile_first, ws.items, ws.plan, ws.gword, v, ws, d_guides, max_dist, n_ranges);
+        hipLaunchKernelGGL(k_scan<false>, dim3(grid), dim3(256), 0, stream, v.scan, v.tile_first, ws.items, ws.plan,
+                           ws.gword, ws.raw, max_chunks, ws.counters, max_dist);
+}
+
+void launch_verify(const ImageView &v, const Workspace &ws, const uint64_t *d_guides, int max_dist, void *stream)
+{
+    if (max_dist < 0) return;
+    hipLaunchKernelGGL(k_verify, dim3(4096), dim3(kChunkRecs), 0, static_cast<hipStream_t>(stream), v, ws, d_guides,
+                       max_dist);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -17,6 +17,18 @@ def pytest_configure(config):
 
 
 @pytest.fixture(scope="session", autouse=True)
+def _torch_first():
+    """On a GPU box let torch create its HIP context BEFORE libissl_hip.so makes its first HIP call: both share
+    one runtime (crackling_amd/_lib.py), and torch's lazy CUDA init was seen to hang when it ran after a long
+    series of direct HIP calls in the same process.  bench.py follows the same order."""
+    import torch
+    if torch.cuda.is_available():
+        torch.cuda.init()
+        torch.zeros(1, device="cuda:0")
+        torch.cuda.synchronize()
+
+
+@pytest.fixture(scope="session", autouse=True)
 def _built():
     """Product library + oracle (checker) must exist; build them if the tree is fresh."""
     if not (ROOT / "crackling_amd" / "libissl_hip.so").exists() or not (ROOT / "bin" / "isslScoreOfftargets").exists():

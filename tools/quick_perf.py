@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Ad-hoc timing of the scoring pipeline on synthetic data (development aid, not the bench)."""
+import argparse, sys, time, pathlib
+import numpy as np
+ROOT = pathlib.Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
+import crackling_amd as ca
+from synth import random_sites, random_guides
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--sites", type=int, default=5_000_000)
+ap.add_argument("--guides", type=int, default=10_000)
+ap.add_argument("--reps", type=int, default=5)
+ap.add_argument("--thr", type=float, default=0.0)
+ap.add_argument("--variants", default="1")
+ap.add_argument("--write-issl", default=None)
+ap.add_argument("--write-guides", default=None)
+a = ap.parse_args()
+t = time.time(); sigs, occ = random_sites(a.sites, seed=1); guides = random_guides(sigs, a.guides, seed=2)
+print(f"synth {time.time()-t:.1f}s  distinct={len(sigs)}", flush=True)
+t = time.time(); ix = ca.IsslIndex.build_from_sites(sigs, occ); print(f"build {time.time()-t:.1f}s", flush=True)
+if a.write_issl:
+    t = time.time(); ix.write(a.write_issl); print(f"write issl {time.time()-t:.1f}s", flush=True)
+if a.write_guides:
+    open(a.write_guides, "w").write("".join(s + "\n" for s in ca.decode_guides(guides)))
+t = time.time(); ix.upload(0); print(f"upload {time.time()-t:.1f}s  image={ix.device_bytes()/1e9:.2f} GB", flush=True)
+import os
+for variant in a.variants.split(","):
+  os.environ["ISSL_SCAN_VARIANT"] = variant
+  print(f"-- scan variant {variant}", flush=True)
+  for r in range(a.reps):
+    t = time.time(); mit, cfd = ix.score(guides, 4, a.thr, "and"); dt = time.time() - t
+    st = ix.stats()
+    algo = 8.0 * st["candidates"]
+    print(f"rep{r}: wall {dt*1e3:.2f} ms | bin {st['ms_bin']:.3f} scan {st['ms_scan']:.3f} group {st['ms_group']:.3f} "
+          f"replay {st['ms_replay']:.3f} ms | cand {st['candidates']:.3e} hits {st['hits']} tiles {st['scan_tiles']} | "
+          f"scan: {st['candidates']/st['ms_scan']/1e9:.2f} Tcmp/s, algorithmic {algo/st['ms_scan']/1e9:.1f} TB/s | "
+          f"{a.guides/st['ms_total']*1e3:.0f} guides/s (kernels)", flush=True)
