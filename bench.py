@@ -231,7 +231,7 @@ def main():
                         "the kernel streams each bucket tile once for all guides of the bucket (4 B/candidate), so "
                         "achieved can exceed the HBM peak: then the scan is VALU-bound, see DESIGN.md",
             },
-            "kernel_ms": {"bin": st["ms_bin"], "scan": scan_avg_ms, "group": st["ms_group"], "replay": st["ms_replay"],
+            "kernel_ms": {"bin": st["ms_bin"], "scan": scan_avg_ms, "verify": st["ms_verify"], "group": st["ms_group"], "replay": st["ms_replay"],
                           "pipeline": float(np.mean(total_ms))},
             "hits_per_step": st["hits"],
             "setup_s": timings,

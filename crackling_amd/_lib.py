@@ -54,8 +54,8 @@ class Hit(C.Structure):
 class Stats(C.Structure):
     _fields_ = [
         ("n_guides", C.c_uint64), ("candidates", C.c_uint64), ("hits", C.c_uint64), ("scan_tiles", C.c_uint64),
-        ("ms_bin", C.c_double), ("ms_scan", C.c_double), ("ms_group", C.c_double), ("ms_replay", C.c_double),
-        ("ms_total", C.c_double), ("scan_launches", C.c_uint64),
+        ("ms_bin", C.c_double), ("ms_scan", C.c_double), ("ms_verify", C.c_double), ("ms_group", C.c_double),
+        ("ms_replay", C.c_double), ("ms_total", C.c_double), ("scan_launches", C.c_uint64), ("raw_records", C.c_uint64),
     ]
 
 

@@ -79,7 +79,7 @@ struct issl_index {
     ImageHeader hdr{};
     ImageView view{};
     Workspace ws;
-    hipEvent_t ev[5] = {};
+    hipEvent_t ev[6] = {};
     bool have_events = false;
     issl_stats stats{};
 };
@@ -318,6 +318,7 @@ static int score_core(issl_index *ix, const uint64_t *d_guides, size_t n, int ma
         launch_scan(ix->view, ix->ws, d_guides, n32, max_dist, stream);
         HIP_TRY(hipEventRecord(ix->ev[2], stream));
         launch_verify(ix->view, ix->ws, d_guides, max_dist, stream);
+        HIP_TRY(hipEventRecord(ix->ev[3], stream));
         HIP_TRY(hipMemcpyAsync(&c, ix->ws.counters, sizeof c, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipMemcpyAsync(&pl, ix->ws.plan, sizeof pl, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
@@ -347,19 +348,21 @@ static int score_core(issl_index *ix, const uint64_t *d_guides, size_t n, int ma
         ix->ws.cap_hitrec = ix->ws.cap_hits;
     }
     launch_group_hits(ix->ws, n32, stream);
-    HIP_TRY(hipEventRecord(ix->ev[3], stream));
+    HIP_TRY(hipEventRecord(ix->ev[4], stream));
     launch_replay(ix->view, ix->ws, d_guides, n32, p, d_mit, d_cfd, dump ? ix->ws.d_kept : nullptr,
                   dump ? ix->ws.d_hitrec : nullptr, stream);
-    HIP_TRY(hipEventRecord(ix->ev[4], stream));
+    HIP_TRY(hipEventRecord(ix->ev[5], stream));
     HIP_TRY(hipStreamSynchronize(stream));
     HIP_TRY(hipGetLastError());
-    float ms[4] = {0, 0, 0, 0};
-    for (int i = 0; i < 4; ++i) (void)hipEventElapsedTime(&ms[i], ix->ev[i], ix->ev[i + 1]);
+    float ms[5] = {0, 0, 0, 0, 0};
+    for (int i = 0; i < 5; ++i) (void)hipEventElapsedTime(&ms[i], ix->ev[i], ix->ev[i + 1]);
     ix->stats.ms_bin = ms[0];
     ix->stats.ms_scan = ms[1];
-    ix->stats.ms_group = ms[2];
-    ix->stats.ms_replay = ms[3];
-    ix->stats.ms_total = ms[0] + ms[1] + ms[2] + ms[3];
+    ix->stats.ms_verify = ms[2];
+    ix->stats.ms_group = ms[3];
+    ix->stats.ms_replay = ms[4];
+    ix->stats.ms_total = ms[0] + ms[1] + ms[2] + ms[3] + ms[4];
+    ix->stats.raw_records = static_cast<uint64_t>(c.raw_chunks) * (kChunkRecs - 1);
     ix->stats.candidates = pl.candidates;
     ix->stats.hits = c.n_hits;
     ix->stats.scan_tiles = c.tiles;

@@ -76,10 +76,12 @@ typedef struct {
     uint64_t scan_tiles;    /* candidate tiles x guide groups processed by the scan kernel */
     double ms_bin;          /* guide binning kernels */
     double ms_scan;         /* XOR/popcount scan kernel (the roofline kernel) */
+    double ms_verify;       /* exact re-test of the candidates the scan noted, first-matching-slice rule */
     double ms_group;        /* hit grouping (count/scan/scatter) */
     double ms_replay;       /* ordered MIT/CFD accumulation */
     double ms_total;        /* first kernel to last kernel */
-    uint64_t scan_launches; /* >1 when the hit buffer had to grow and the scan was repeated */
+    uint64_t scan_launches; /* >1 when a hit buffer had to grow and the scan was repeated */
+    uint64_t raw_records;   /* upper bound of candidates noted by the scan (chunks handed out x chunk size) */
 } issl_stats;
 
 const char *issl_last_error(void);

@@ -32,7 +32,7 @@ for variant in a.variants.split(","):
     t = time.time(); mit, cfd = ix.score(guides, 4, a.thr, "and"); dt = time.time() - t
     st = ix.stats()
     algo = 8.0 * st["candidates"]
-    print(f"rep{r}: wall {dt*1e3:.2f} ms | bin {st['ms_bin']:.3f} scan {st['ms_scan']:.3f} group {st['ms_group']:.3f} "
+    print(f"rep{r}: wall {dt*1e3:.2f} ms | bin {st['ms_bin']:.3f} scan {st['ms_scan']:.3f} verify {st['ms_verify']:.3f} group {st['ms_group']:.3f} "
           f"replay {st['ms_replay']:.3f} ms | cand {st['candidates']:.3e} hits {st['hits']} tiles {st['scan_tiles']} | "
           f"scan: {st['candidates']/st['ms_scan']/1e9:.2f} Tcmp/s, algorithmic {algo/st['ms_scan']/1e9:.1f} TB/s | "
           f"{a.guides/st['ms_total']*1e3:.0f} guides/s (kernels)", flush=True)
