@@ -10,9 +10,9 @@
 //              accumulate MIT / CFD sequentially with the reference's early exit            (A8-A11)
 //
 // The scan is the bandwidth/ALU-critical kernel.  It streams 4 B per candidate (the signature
-// with the bucket's own slice removed) and keeps a tile of 2048 candidates in registers while the
-// guide words of the bucket arrive through scalar loads, so one HBM read of a bucket tile serves
-// every guide of the batch that falls into this bucket.
+// with the bucket's own slice removed, stored bit-sliced: 32 candidates per 32-bit plane) and keeps
+// a tile of 2048 candidates in registers while the guide words of the bucket arrive through scalar
+// loads, so one HBM read of a bucket tile serves every guide of the batch that falls into this bucket.
 #include <hip/hip_runtime.h>
 
 #include "issl_device.hpp"
@@ -58,14 +58,14 @@ __host__ __device__ inline uint64_t mismatch_mask(uint64_t a, uint64_t b)
     return ((x & 0xAAAAAAAAAAAAAAAAull) >> 1) | (x & 0x5555555555555555ull);
 }
 
-// (x.hi16 | x.lo16), zero-extended: one VALU op with sub-dword operand selects.
-__device__ __forceinline__ uint32_t fold_halves(uint32_t x)
+// Bit-sliced tile layout.  A tile holds 2048 candidates = 64 groups of 32.  Group G is owned by lane G of
+// the scanning wave and consists of 32 PLANES: plane r < 16 holds, for its 32 candidates (bit j =
+// candidate at tile offset 32 G + j), the low bit of the 2-bit code at position r of the scan word;
+// plane 16 + r the high bit.  The word of (plane r, group G) sits at index ((r / 4) * 64 + G) * 4 + r % 4,
+// so the scanning wave fetches its 32 planes with 8 coalesced 16-byte loads per lane.
+__host__ __device__ inline uint32_t plane_word(uint32_t r, uint32_t group)
 {
-    uint32_t o;
-    asm("v_or_b32_sdwa %0, %1, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_0"
-        : "=v"(o)
-        : "v"(x));
-    return o;
+    return ((r >> 2) * 64u + group) * 4u + (r & 3u);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -87,8 +87,14 @@ __global__ __launch_bounds__(256) void k_pack_scan_stream(ImageView v, uint32_t 
         const uint64_t start = v.bucket_start[b];
         const uint64_t len = v.bucket_start[b + 1] - start;
         const uint64_t tile_pos = static_cast<uint64_t>(t - v.tile_first[b]) * kTileCands;
-        for (uint32_t k = threadIdx.x; k < kTileCands; k += 256) {
-            const uint64_t pos = tile_pos + k;
+        // 64 consecutive candidates per wave and step: lane j computes the scan word of candidate j, then the
+        // wave transposes the 64 x 32 bit matrix with ballots: plane r of the two 32-candidate groups is
+        // the low / high half of ballot(bit r).  Lane r (< 32) keeps plane r and stores it.
+        const uint32_t lane = threadIdx.x & 63u;
+        const uint32_t wave = threadIdx.x >> 6;
+        uint32_t *tile_out = scan_out + static_cast<uint64_t>(t) * kTileCands;
+        for (uint32_t k0 = wave * 64u; k0 < kTileCands; k0 += 256u) {
+            const uint64_t pos = tile_pos + k0 + lane;
             uint32_t w = 0;
             if (pos < len) {
                 const uint64_t e = v.entries[start + pos];
@@ -96,7 +102,16 @@ __global__ __launch_bounds__(256) void k_pack_scan_stream(ImageView v, uint32_t 
                 if (id < v.n_sites) w = scan_word(v.sites[id], slice);
                 else atomicOr(error_flag, 1u);
             }
-            scan_out[static_cast<uint64_t>(t) * kTileCands + k] = w;
+            uint32_t mine_lo = 0, mine_hi = 0;
+            for (uint32_t r = 0; r < 32; ++r) {
+                const uint64_t m = __ballot((w >> r) & 1u);
+                if (lane == r) { mine_lo = static_cast<uint32_t>(m); mine_hi = static_cast<uint32_t>(m >> 32); }
+            }
+            if (lane < 32) {
+                const uint32_t group = k0 >> 5; // lane index (in the scan kernel) that owns candidates k0..k0+31
+                tile_out[plane_word(lane, group)] = mine_lo;
+                tile_out[plane_word(lane, group + 1u)] = mine_hi;
+            }
         }
     }
 }
@@ -293,40 +308,7 @@ struct alignas(4 * kGuideGroup) GuideGroup {
     uint32_t w[kGuideGroup];
 };
 
-constexpr int kRegs = kTileCands / 64; // candidates per lane: one wave owns a whole tile
-
-// Position inside the tile of register r of lane `lane` (tiles are read as 16-byte vectors, lane-major).
-__device__ __forceinline__ uint32_t tile_offset(int r, uint32_t lane)
-{
-    return (static_cast<uint32_t>(r >> 2) * 64u + lane) * 4u + static_cast<uint32_t>(r & 3);
-}
-
-// min over the lane's candidates of the mismatches against guide word gw, folded into `best`.
-// Written in blocks of 8 candidates, stage by stage, so that no instruction consumes the result of
-// the one right before it (the sub-dword OR needs a wait state before its result is read).
-template <bool SDWA>
-__device__ __forceinline__ uint32_t closest(const uint32_t (&c)[kRegs], uint32_t gw, uint32_t best)
-{
-#pragma unroll
-    for (int r0 = 0; r0 < kRegs; r0 += 8) {
-        uint32_t y[8], o[8], d[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) y[i] = c[r0 + i] ^ gw;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            if (SDWA) o[i] = fold_halves(y[i]);
-            else o[i] = (y[i] | (y[i] >> 16)) & 0xFFFFu;
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) d[i] = __builtin_popcount(o[i]);
-#pragma unroll
-        for (int i = 0; i < 8; i += 2) {
-            const uint32_t m = d[i] < d[i + 1] ? d[i] : d[i + 1];
-            best = m < best ? m : best;
-        }
-    }
-    return best;
-}
+constexpr int kPlanes = 32; // planes per lane = VGPRs holding the lane's 32 candidates
 
 // ---- raw records ------------------------------------------------------------------------------
 // A candidate that the scan finds within max_dist of a guide is only NOTED by the scan kernel, as an
@@ -364,55 +346,119 @@ __device__ __forceinline__ void raw_acquire(RawWriter &w, uint64_t *raw, uint32_
     w.fill = 1;
 }
 
-// Cold block of the scan: the wave knows that SOME lane has a candidate within thr of guide word gw.
-// Find them and note them.  Register r of lane l sits at tile offset tile_offset(r, l).
-template <bool SDWA>
-__device__ __forceinline__ void note_candidates(const uint32_t (&c)[kRegs], uint32_t gw, uint32_t thr, uint32_t gslot,
-                                                uint32_t tile, uint32_t lane, RawWriter &w, uint64_t *raw,
-                                                uint32_t max_chunks, Counters *counters)
+// ---- bit-sliced distance test -------------------------------------------------------------------
+// 3:2 and 2:2 counters on bit planes; v_bitop3_b32 evaluates any 3-input boolean function in one op.
+__device__ __forceinline__ void full_add(uint32_t a, uint32_t b, uint32_t c, uint32_t &sum, uint32_t &carry)
 {
+    sum = __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);   // a ^ b ^ c
+    carry = __builtin_amdgcn_bitop3_b32(a, b, c, 0xE8); // majority(a, b, c)
+}
+__device__ __forceinline__ void half_add(uint32_t a, uint32_t b, uint32_t &sum, uint32_t &carry)
+{
+    sum = a ^ b;
+    carry = a & b;
+}
+
+// For the lane's 32 candidates (planes c[]) and one guide scan word gw: the plane of candidates whose
+// mismatch count over the 16 positions is <= THR (THR = 0..4 compiled in; THR < 0: runtime `thr`, any value).
+// Position p mismatches iff low or high bit differs: (c[p] ^ G0p) | (c[16+p] ^ G1p) with the guide's bits
+// broadcast to all-zero / all-one scalars (isslScoreOfftargets.cpp:376-380 in transposed form); the 16 mismatch
+// planes are then counted with a carry-save adder tree.
+template <int THR>
+__device__ __forceinline__ uint32_t near_plane(const uint32_t (&c)[kPlanes], uint32_t gw, uint32_t thr)
+{
+    uint32_t m[16];
 #pragma unroll
-    for (int r = 0; r < kRegs; ++r) {
-        const uint32_t y = c[r] ^ gw;
-        const uint32_t d = __builtin_popcount((y | (y >> 16)) & 0xFFFFu);
-        const bool near = d <= thr;
-        const uint64_t who = __ballot(near);
-        if (who != 0ull) {
-            const uint32_t n = static_cast<uint32_t>(__builtin_popcountll(who));
-            if (w.fill + n > kChunkRecs) {
-                raw_retire(w, lane);
-                raw_acquire(w, raw, max_chunks, counters, lane);
-            }
-            if (near) {
-                const uint32_t rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(who >> 32),
-                                                                __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(who), 0u));
-                w.chunk[w.fill + rank] = raw_record(gslot, tile, tile_offset(r, lane));
-            }
-            w.fill += n;
+    for (int p = 0; p < 16; ++p) {
+        const uint32_t g0 = 0u - ((gw >> p) & 1u);
+        const uint32_t g1 = 0u - ((gw >> (16 + p)) & 1u);
+        m[p] = (c[p] ^ g0) | (c[16 + p] ^ g1);
+    }
+    uint32_t s0, s1, s2, s3, s4, t, u, n0, n1, n2;
+    uint32_t k2[8], k4[4], k8a, k8b;
+    // weight 1: 16 planes
+    full_add(m[0], m[1], m[2], s0, k2[0]);
+    full_add(m[3], m[4], m[5], s1, k2[1]);
+    full_add(m[6], m[7], m[8], s2, k2[2]);
+    full_add(m[9], m[10], m[11], s3, k2[3]);
+    full_add(m[12], m[13], m[14], s4, k2[4]);
+    full_add(s0, s1, s2, t, k2[5]);
+    full_add(s3, s4, m[15], u, k2[6]);
+    half_add(t, u, n0, k2[7]);
+    // weight 2: 8 planes
+    uint32_t a2, b2, c2;
+    full_add(k2[0], k2[1], k2[2], a2, k4[0]);
+    full_add(k2[3], k2[4], k2[5], b2, k4[1]);
+    full_add(k2[6], k2[7], a2, c2, k4[2]);
+    half_add(b2, c2, n1, k4[3]);
+    // weight 4: 4 planes
+    uint32_t a4;
+    full_add(k4[0], k4[1], k4[2], a4, k8a);
+    half_add(a4, k4[3], n2, k8b);
+    if (THR == 0) return ~(k8a | k8b | n2 | n1 | n0);
+    if (THR == 1) return ~(k8a | k8b | n2 | n1);
+    if (THR == 2) return ~(k8a | k8b | n2 | (n1 & n0));
+    if (THR == 3) return ~(k8a | k8b | n2);
+    if (THR == 4) return ~(k8a | k8b | (n2 & (n1 | n0)));
+    // generic threshold: count = n0 + 2 n1 + 4 n2 + 8 n3 + 16 n4, compared MSB first with the uniform thr
+    const uint32_t n[5] = {n0, n1, n2, k8a ^ k8b, k8a & k8b};
+    uint32_t gt = 0u, eq = ~0u;
+#pragma unroll
+    for (int b = 4; b >= 0; --b) {
+        if ((thr >> b) & 1u) {
+            eq &= n[b];
+        } else {
+            gt |= eq & n[b];
+            eq &= ~n[b];
         }
+    }
+    return ~gt;
+}
+
+// Cold block of the scan: the wave knows that SOME lane has a candidate within thr of the guide in slot
+// gslot.  `ok` = this lane's plane of such candidates; candidate bit j of lane l sits at tile offset 32 l + j.
+__device__ __forceinline__ void note_candidates(uint32_t ok, uint32_t gslot, uint32_t tile, uint32_t lane,
+                                                RawWriter &w, uint64_t *raw, uint32_t max_chunks, Counters *counters)
+{
+    while (true) {
+        const bool has = ok != 0u;
+        const uint64_t who = __ballot(has);
+        if (who == 0ull) break;
+        const uint32_t n = static_cast<uint32_t>(__builtin_popcountll(who));
+        if (w.fill + n > kChunkRecs) {
+            raw_retire(w, lane);
+            raw_acquire(w, raw, max_chunks, counters, lane);
+        }
+        if (has) {
+            const uint32_t j = static_cast<uint32_t>(__builtin_ctz(ok));
+            ok &= ok - 1u;
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(who >> 32),
+                                                            __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(who), 0u));
+            w.chunk[w.fill + rank] = raw_record(gslot, tile, lane * 32u + j);
+        }
+        w.fill += n;
     }
 }
 
 // Scan kernel.  Every WAVE is an independent worker: it takes ranges of the cost axis (the first one
 // by its global wave number, further ones from an atomic ticket), and for every tile of the range
-// keeps the tile's 2048 scan words in registers (32 per lane) while the guide words of the item
-// stream through scalar registers, 8 per scalar load.
-// The streams the hot loop reads (scan words, tile table, items, guide words, plan) are separate
+// keeps the tile's 2048 candidates in registers (32 bit planes per lane) while the guide words of the
+// item stream through scalar registers, 8 per scalar load.
+// The streams the hot loop reads (scan planes, tile table, items, guide words, plan) are separate
 // `const __restrict__` kernel arguments: they are never written by this kernel, which lets the
 // compiler fetch the wave-uniform ones through the scalar cache.
-template <bool SDWA>
-__global__ __launch_bounds__(256, 8) void k_scan(const uint32_t *__restrict__ scan_stream,
+template <int THR>
+__global__ __launch_bounds__(256, 6) void k_scan(const uint32_t *__restrict__ scan_stream,
                                                  const uint32_t *__restrict__ tile_first,
                                                  const ScanItem *__restrict__ items,
                                                  const PlanInfo *__restrict__ plan,
                                                  const uint32_t *__restrict__ gword_stream, uint64_t *raw,
-                                                 uint32_t max_chunks, Counters *counters, int max_dist)
+                                                 uint32_t max_chunks, Counters *counters, uint32_t thr)
 {
     const uint32_t n_items = plan->n_items;
     const uint64_t total = plan->total_cost;
     const uint32_t n_ranges = plan->n_ranges;
     if (n_items == 0 || total == 0 || n_ranges == 0) return;
-    const uint32_t thr = static_cast<uint32_t>(max_dist);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
     uint32_t range = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
@@ -454,9 +500,9 @@ __global__ __launch_bounds__(256, 8) void k_scan(const uint32_t *__restrict__ sc
                 const uint32_t tile = tile_first[cur.bucket] + static_cast<uint32_t>(k);
                 const uint4 *__restrict__ src =
                     reinterpret_cast<const uint4 *>(scan_stream + static_cast<uint64_t>(tile) * kTileCands);
-                uint32_t c[kRegs];
+                uint32_t c[kPlanes];
 #pragma unroll
-                for (int q = 0; q < kRegs / 4; ++q) {
+                for (int q = 0; q < kPlanes / 4; ++q) {
                     const uint4 t4 = src[q * 64 + lane];
                     c[4 * q + 0] = t4.x; c[4 * q + 1] = t4.y; c[4 * q + 2] = t4.z; c[4 * q + 3] = t4.w;
                 }
@@ -467,30 +513,21 @@ __global__ __launch_bounds__(256, 8) void k_scan(const uint32_t *__restrict__ sc
                     uint32_t flagged = 0; // bit u: a lane has a candidate within thr of guide g+u
 #pragma unroll
                     for (uint32_t u = 0; u < kGuideGroup; ++u) {
-                        const uint32_t best = closest<SDWA>(c, gg.w[u], 64u);
-                        if (__ballot(best <= thr) != 0ull) flagged |= 1u << u;
+                        const uint32_t ok = near_plane<THR>(c, gg.w[u], thr);
+                        if (__ballot(ok != 0u) != 0ull) flagged |= 1u << u;
                     }
-                    while (flagged) { // ~4 % of the guide-tile pairs on random data
+                    while (flagged) { // ~4 % of the (guide, tile) pairs on random data
                         const uint32_t u = static_cast<uint32_t>(__builtin_ctz(flagged));
                         flagged &= flagged - 1u;
-                        note_candidates<SDWA>(c, gword_stream[g + u], thr, g + u, tile, lane, w, raw, max_chunks, counters);
+                        const uint32_t ok = near_plane<THR>(c, gword_stream[g + u], thr);
+                        note_candidates(ok, g + u, tile, lane, w, raw, max_chunks, counters);
                         own_chunk = true;
                     }
                 }
-                if (g < cur.g1) { // last, partial group: padding words are not compared
-                    const GuideGroup gg = *reinterpret_cast<const GuideGroup *>(gword_stream + g);
-                    uint32_t flagged = 0;
-#pragma unroll
-                    for (uint32_t u = 0; u < kGuideGroup - 1u; ++u) {
-                        if (g + u < cur.g1) {
-                            const uint32_t best = closest<SDWA>(c, gg.w[u], 64u);
-                            if (__ballot(best <= thr) != 0ull) flagged |= 1u << u;
-                        }
-                    }
-                    while (flagged) {
-                        const uint32_t u = static_cast<uint32_t>(__builtin_ctz(flagged));
-                        flagged &= flagged - 1u;
-                        note_candidates<SDWA>(c, gword_stream[g + u], thr, g + u, tile, lane, w, raw, max_chunks, counters);
+                for (; g < cur.g1; ++g) { // the (< 8) guides of the last, partial group
+                    const uint32_t ok = near_plane<THR>(c, gword_stream[g], thr);
+                    if (__ballot(ok != 0u) != 0ull) {
+                        note_candidates(ok, g, tile, lane, w, raw, max_chunks, counters);
                         own_chunk = true;
                     }
                 }
@@ -556,6 +593,13 @@ __global__ __launch_bounds__(kChunkRecs) void k_verify(ImageView v, Workspace ws
     }
 }
 
+template <int THR>
+static void launch_scan_thr(const ImageView &v, const Workspace &ws, uint32_t thr, hipStream_t stream)
+{
+    hipLaunchKernelGGL(k_scan<THR>, dim3(kScanGridBlocks), dim3(256), 0, stream, v.scan, v.tile_first, ws.items, ws.plan,
+                       ws.gword, ws.raw, static_cast<uint32_t>(ws.cap_chunks), ws.counters, thr);
+}
+
 void launch_scan(const ImageView &v, const Workspace &ws, const uint64_t *d_guides, uint32_t n, int max_dist,
                  void *stream_)
 {
@@ -563,17 +607,16 @@ void launch_scan(const ImageView &v, const Workspace &ws, const uint64_t *d_guid
     (void)d_guides;
     if (max_dist < 0) return; // isslScoreOfftargets.cpp:382: no distance satisfies 0 <= dist <= maxDist
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    // ISSL_SCAN_VARIANT=0 selects the build of the kernel without the sub-dword (SDWA) fold: A/B aid.
-    const char *variant_env = getenv("ISSL_SCAN_VARIANT");
-    const int variant = (variant_env && variant_env[0] == '0') ? 0 : 1;
-    const uint32_t grid = kScanGridBlocks; // 256 CUs x 8 workgroups of 4 independent waves
-    const uint32_t max_chunks = static_cast<uint32_t>(ws.cap_chunks);
-    if (variant == 1)
-        hipLaunchKernelGGL(k_scan<true>, dim3(grid), dim3(256), 0, stream, v.scan, v.tile_first, ws.items, ws.plan,
-                           ws.gword, ws.raw, max_chunks, ws.counters, max_dist);
-    else
-        hipLaunchKernelGGL(k_scan<false>, dim3(grid), dim3(256), 0, stream, v.scan, v.tile_first, ws.items, ws.plan,
-                           ws.gword, ws.raw, max_chunks, ws.counters, max_dist);
+    const uint32_t thr = max_dist > 31 ? 31u : static_cast<uint32_t>(max_dist);
+    // ISSL_SCAN_GENERIC=1 forces the runtime-threshold build of the kernel (A/B and test aid).
+    const char *generic_env = getenv("ISSL_SCAN_GENERIC");
+    const bool generic = generic_env && generic_env[0] == '1';
+    if (generic || thr > 4) launch_scan_thr<-1>(v, ws, thr, stream);
+    else if (thr == 0) launch_scan_thr<0>(v, ws, thr, stream);
+    else if (thr == 1) launch_scan_thr<1>(v, ws, thr, stream);
+    else if (thr == 2) launch_scan_thr<2>(v, ws, thr, stream);
+    else if (thr == 3) launch_scan_thr<3>(v, ws, thr, stream);
+    else launch_scan_thr<4>(v, ws, thr, stream);
 }
 
 void launch_verify(const ImageView &v, const Workspace &ws, const uint64_t *d_guides, int max_dist, void *stream)

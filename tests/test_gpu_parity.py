@@ -150,6 +150,24 @@ def test_large_max_dist_and_single_guide(config0):
     assert mit[0] == omit[0] and cfd[0] == ocfd[0]
 
 
+def test_runtime_threshold_build_of_the_scan_kernel(config0, monkeypatch):
+    """The scan kernel is compiled with max_dist 0..4 as constants and once with a runtime threshold (used for
+    max_dist > 4).  Force the runtime-threshold build for small distances too and compare."""
+    ix, oracle, sigs, guides = config0
+    monkeypatch.setenv("ISSL_SCAN_GENERIC", "1")
+    for dist in (0, 1, 2, 3, 4, 5, 16):
+        mit, cfd = ix.score(guides[:256], dist, 0.0, "and")
+        omit, ocfd = oracle.score(guides[:256], dist, 0.0, "and")
+        assert np.array_equal(mit.view(np.uint64), omit.view(np.uint64)), dist
+        assert np.array_equal(cfd.view(np.uint64), ocfd.view(np.uint64)), dist
+    monkeypatch.delenv("ISSL_SCAN_GENERIC")
+    for dist in (1, 2, 3):
+        mit, cfd = ix.score(guides[:256], dist, 0.0, "and")
+        omit, ocfd = oracle.score(guides[:256], dist, 0.0, "and")
+        assert np.array_equal(mit.view(np.uint64), omit.view(np.uint64)), dist
+        assert np.array_equal(cfd.view(np.uint64), ocfd.view(np.uint64)), dist
+
+
 def test_skewed_batch_and_poly_a(config0):
     """Ragged work: many guides in one bucket, homopolymers, guide words equal to the zero padding."""
     ix, oracle, sigs, guides = config0

@@ -5,6 +5,52 @@
 #include <cstdio>
 #include <cstdint>
 
+// ---- bit-sliced variant: a lane holds 32 candidates as 32 bit planes (16 positions x {low,high} bit) ----
+__device__ __forceinline__ void fa(uint32_t a, uint32_t b, uint32_t c, uint32_t &sum, uint32_t &carry)
+{
+    sum = __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);   // a ^ b ^ c
+    carry = __builtin_amdgcn_bitop3_b32(a, b, c, 0xE8); // majority
+}
+__device__ __forceinline__ void ha(uint32_t a, uint32_t b, uint32_t &sum, uint32_t &carry)
+{
+    sum = a ^ b;
+    carry = a & b;
+}
+// planes c[0..15] = low bits, c[16..31] = high bits; g = guide scan word; returns plane of candidates with <= 4 mismatches
+__device__ __forceinline__ uint32_t sliced_le4(const uint32_t (&c)[32], uint32_t g)
+{
+    uint32_t m[16];
+#pragma unroll
+    for (int p = 0; p < 16; ++p) {
+        const uint32_t s0 = 0u - ((g >> p) & 1u);
+        const uint32_t s1 = 0u - ((g >> (16 + p)) & 1u);
+        m[p] = (c[p] ^ s0) | (c[16 + p] ^ s1);
+    }
+    // weight-1 column: 16 inputs
+    uint32_t s[6], k2[8], n0, n1, n2, k4[4], k8[2], t, u;
+    fa(m[0], m[1], m[2], s[0], k2[0]);
+    fa(m[3], m[4], m[5], s[1], k2[1]);
+    fa(m[6], m[7], m[8], s[2], k2[2]);
+    fa(m[9], m[10], m[11], s[3], k2[3]);
+    fa(m[12], m[13], m[14], s[4], k2[4]);
+    fa(s[0], s[1], s[2], t, k2[5]);
+    fa(s[3], s[4], m[15], u, k2[6]);
+    ha(t, u, n0, k2[7]);
+    // weight-2 column: 8 inputs
+    uint32_t a2, b2, c2;
+    fa(k2[0], k2[1], k2[2], a2, k4[0]);
+    fa(k2[3], k2[4], k2[5], b2, k4[1]);
+    fa(k2[6], k2[7], a2, c2, k4[2]);
+    ha(b2, c2, n1, k4[3]);
+    // weight-4 column: 4 inputs
+    uint32_t a4;
+    fa(k4[0], k4[1], k4[2], a4, k8[0]);
+    ha(a4, k4[3], n2, k8[1]);
+    // count <= 4  <=>  no weight-8/16 bit and (n2 == 0 or n1 == n0 == 0)
+    const uint32_t big = k8[0] | k8[1];
+    return ~(big | (n2 & (n1 | n0)));
+}
+
 template <int MODE>
 __global__ __launch_bounds__(256) void k(uint32_t *out, uint32_t seed, int iters)
 {
@@ -38,6 +84,22 @@ __global__ __launch_bounds__(256) void k(uint32_t *out, uint32_t seed, int iters
                 acc = d < acc ? d : acc;
             } else if (MODE == 5) { // plain add chain-free: v_add_u32 x1 per candidate
                 acc += c[r] ^ g;
+            } else if (MODE == 7) { // bitop3 rate
+                acc = __builtin_amdgcn_bitop3_b32(acc, c[r], g, 0x96);
+            } else if (MODE == 8) { // bfi rate
+                asm volatile("v_bfi_b32 %0, %1, %2, %0" : "+v"(acc) : "v"(c[r]), "s"(g));
+            }
+        }
+    }
+    if (MODE == 6) { // bit-sliced: 32 planes, 4 guides per iteration
+        uint32_t pl[32];
+        for (int i = 0; i < 32; ++i) pl[i] = seed * (threadIdx.x + 3) + i * 0x85EBCA6Bu + blockIdx.x;
+        uint32_t gg = seed;
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                gg = gg * 1664525u + 1013904223u;
+                acc |= sliced_le4(pl, gg);
             }
         }
     }
@@ -73,5 +135,19 @@ int main()
     run<2>("v_or_sdwa + xor-acc (2 ops)", 2, d_out);
     run<3>("scan mix sdwa (3.5 ops)", 4, d_out);
     run<4>("scan mix no-sdwa (4.5 ops)", 5, d_out);
+    run<7>("v_bitop3 chain (1 op)", 1, d_out);
+    run<8>("v_bfi chain (1 op)", 1, d_out);
+    {   // bit-sliced: each iteration = 4 guides x 32 candidates per lane = 128 comparisons per lane
+        const int iters = 4000, blocks = 256 * 8;
+        hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+        hipLaunchKernelGGL(k<6>, dim3(blocks), dim3(256), 0, 0, d_out, 12345u, 10);
+        hipDeviceSynchronize();
+        hipEventRecord(a);
+        hipLaunchKernelGGL(k<6>, dim3(blocks), dim3(256), 0, 0, d_out, 12345u, iters);
+        hipEventRecord(b); hipEventSynchronize(b);
+        float ms = 0; hipEventElapsedTime(&ms, a, b);
+        const double cmps = double(iters) * 128 * 256 * blocks;
+        printf("%-34s %8.3f ms  %7.2f Tcand/s\n", "bit-sliced le4 (32 cand/lane-op)", ms, cmps / ms / 1e9);
+    }
     return 0;
 }
