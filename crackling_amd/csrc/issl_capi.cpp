@@ -19,7 +19,7 @@ namespace issl {
 
 static uint64_t align256(uint64_t x) { return (x + 255ull) & ~255ull; }
 
-void layout_image(ImageHeader &h, const Geometry &g, uint64_t n_scores_unique, uint64_t n_tiles)
+void layout_image(ImageHeader &h, const Geometry &g, uint64_t n_scores_unique, uint64_t n_tiles, bool dense_mit)
 {
     std::memset(&h, 0, sizeof h);
     h.magic = kImageMagic;
@@ -40,6 +40,7 @@ void layout_image(ImageHeader &h, const Geometry &g, uint64_t n_scores_unique, u
     h.off_tile_first = off;   off = align256(off + 4 * (h.n_buckets + 1));
     h.off_score_mask = off;   off = align256(off + 8 * n_scores_unique);
     h.off_score_val = off;    off = align256(off + 8 * n_scores_unique);
+    if (dense_mit) { h.off_mit_dense = off; off = align256(off + 8ull * (1u << 20)); }
     h.off_sites = off;        off = align256(off + 8 * g.n_sites);
     h.off_entries = off;      off = align256(off + 8 * g.n_sites * g.n_slices);
     h.off_scan = off;         off = align256(off + 4ull * kTileCands * n_tiles);
@@ -54,6 +55,7 @@ ImageView make_view(const ImageHeader &h, void *base)
     v.tile_first = reinterpret_cast<const uint32_t *>(p + h.off_tile_first);
     v.score_mask = reinterpret_cast<const uint64_t *>(p + h.off_score_mask);
     v.score_val = reinterpret_cast<const double *>(p + h.off_score_val);
+    v.mit_dense = h.off_mit_dense ? reinterpret_cast<const double *>(p + h.off_mit_dense) : nullptr;
     v.sites = reinterpret_cast<const uint64_t *>(p + h.off_sites);
     v.entries = reinterpret_cast<const uint64_t *>(p + h.off_entries);
     v.scan = reinterpret_cast<const uint32_t *>(p + h.off_scan);
@@ -120,7 +122,7 @@ static int select_device(int device)
 
 static void free_workspace(Workspace &w)
 {
-    void *ptrs[] = {w.ng, w.gfill, w.gstart, w.gword, w.gidx, w.items, w.plan, w.counters, w.hits, w.sorted, w.gcount,
+    void *ptrs[] = {w.ng, w.gfill, w.gstart, w.gword, w.gidx, w.items, w.plan, w.range_start, w.counters, w.sorted, w.gcount,
                     w.goff, w.gcur, w.blocksum, w.d_guides, w.d_mit, w.d_cfd, w.d_kept, w.d_hitrec};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -143,7 +145,6 @@ static int ensure_hit_capacity(issl_index *ix, size_t want)
     Workspace &w = ix->ws;
     if (want <= w.cap_hits) return ISSL_OK;
     int rc;
-    if ((rc = dev_alloc(w.hits, want))) return rc;
     if ((rc = dev_alloc(w.sorted, want))) return rc;
     w.cap_hits = want;
     return ISSL_OK;
@@ -170,13 +171,14 @@ static int ensure_workspace(issl_index *ix, size_t n)
         if ((rc = dev_alloc(w.gstart, nb + 1))) return rc;
         if ((rc = dev_alloc(w.counters, 1))) return rc;
         if ((rc = dev_alloc(w.plan, 1))) return rc;
+        if ((rc = dev_alloc(w.range_start, kMaxRanges + 2))) return rc;
 
         w.n_buckets = static_cast<uint32_t>(nb);
     }
     if (n > w.cap_guides) {
         const size_t cap = std::max<size_t>(n, 1024);
         const size_t slots = cap * ix->hdr.n_slices + kGuideGroup * nb;
-        const size_t items = nb + cap * ix->hdr.n_slices / kItemGuides + 2;
+        const size_t items = nb + cap * ix->hdr.n_slices / 8 + 2; // item sizes down to 8 guides (ISSL_SCHED)
         if ((rc = dev_alloc(w.gword, slots))) return rc;
         if ((rc = dev_alloc(w.gidx, slots))) return rc;
         if ((rc = dev_alloc(w.items, items + 1))) return rc;
@@ -192,10 +194,6 @@ static int ensure_workspace(issl_index *ix, size_t n)
         w.cap_gslots = slots;
         w.cap_items = items;
     }
-    if (w.cap_hits == 0) {
-        const size_t want = std::max<size_t>(size_t(1) << 20, 64 * n);
-        if ((rc = ensure_hit_capacity(ix, want))) return rc;
-    }
     if (w.cap_chunks == 0) {
         // every scan wave may hold one partly filled chunk; beyond that ~1 record per 50k comparisons
         const size_t want = std::max<size_t>(size_t(kScanGridBlocks) * 4 * 4, n);
@@ -206,6 +204,22 @@ static int ensure_workspace(issl_index *ix, size_t n)
         ix->have_events = true;
     }
     return ISSL_OK;
+}
+
+// The local MIT table can be indexed directly by the 20 mismatch flags when every mask keeps to the even bits
+// below bit 40 (always true for tables written by isslCreateIndex.cpp:239-252).
+static bool masks_are_dense(const std::vector<uint64_t> &masks)
+{
+    for (uint64_t m : masks)
+        if (m & ~0x5555555555ull) return false;
+    return true;
+}
+
+static uint32_t dense_index(uint64_t mask)
+{
+    uint32_t idx = 0;
+    for (uint32_t p = 0; p < 20; ++p) idx |= static_cast<uint32_t>((mask >> (2 * p)) & 1ull) << p;
+    return idx;
 }
 
 static int finish_upload(issl_index *ix)
@@ -232,6 +246,11 @@ static int finish_upload(issl_index *ix)
     if (!masks.empty()) {
         HIP_TRY(hipMemcpy(base + ix->hdr.off_score_mask, masks.data(), 8 * masks.size(), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(base + ix->hdr.off_score_val, vals.data(), 8 * vals.size(), hipMemcpyHostToDevice));
+    }
+    if (ix->hdr.off_mit_dense) {
+        std::vector<double> dense(size_t(1) << 20, 0.0);
+        for (size_t i = 0; i < masks.size(); ++i) dense[dense_index(masks[i])] = vals[i];
+        HIP_TRY(hipMemcpy(base + ix->hdr.off_mit_dense, dense.data(), 8 * dense.size(), hipMemcpyHostToDevice));
     }
     HIP_TRY(hipMemcpy(base + ix->hdr.off_sites, h.sites, 8 * g.n_sites, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(base + ix->hdr.off_entries, h.entries, 8 * g.n_sites * g.n_slices, hipMemcpyHostToDevice));
@@ -311,7 +330,17 @@ static int score_core(issl_index *ix, const uint64_t *d_guides, size_t n, int ma
     const uint32_t n32 = static_cast<uint32_t>(n);
     Counters c{};
     PlanInfo pl{};
+    uint32_t total_hits = 0;
     for (int attempt = 0;; ++attempt) {
+        // `sorted` always has room for every raw slot, so the whole pipeline runs without a host round trip;
+        // an exhausted raw buffer is detected at the end and the batch is re-run with a larger one.
+        rc = ensure_hit_capacity(ix, ix->ws.cap_chunks * (kChunkRecs - 1));
+        if (rc) return rc;
+        if (dump && ix->ws.cap_hitrec < ix->ws.cap_hits) {
+            rc = dev_alloc(ix->ws.d_hitrec, ix->ws.cap_hits);
+            if (rc) return rc;
+            ix->ws.cap_hitrec = ix->ws.cap_hits;
+        }
         HIP_TRY(hipEventRecord(ix->ev[0], stream));
         launch_bin_guides(ix->view, ix->ws, d_guides, n32, stream);
         HIP_TRY(hipEventRecord(ix->ev[1], stream));
@@ -319,8 +348,14 @@ static int score_core(issl_index *ix, const uint64_t *d_guides, size_t n, int ma
         HIP_TRY(hipEventRecord(ix->ev[2], stream));
         launch_verify(ix->view, ix->ws, d_guides, max_dist, stream);
         HIP_TRY(hipEventRecord(ix->ev[3], stream));
+        launch_group_hits(ix->ws, n32, stream);
+        HIP_TRY(hipEventRecord(ix->ev[4], stream));
+        launch_replay(ix->view, ix->ws, d_guides, n32, p, d_mit, d_cfd, dump ? ix->ws.d_kept : nullptr,
+                      dump ? ix->ws.d_hitrec : nullptr, stream);
+        HIP_TRY(hipEventRecord(ix->ev[5], stream));
         HIP_TRY(hipMemcpyAsync(&c, ix->ws.counters, sizeof c, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipMemcpyAsync(&pl, ix->ws.plan, sizeof pl, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(&total_hits, ix->ws.goff + n32, sizeof total_hits, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         HIP_TRY(hipGetLastError());
         ix->stats.scan_launches = attempt + 1;
@@ -328,32 +363,15 @@ static int score_core(issl_index *ix, const uint64_t *d_guides, size_t n, int ma
             set_error("internal error: scan item list overflow");
             return ISSL_E_DEVICE;
         }
-        if (c.n_hits <= ix->ws.cap_hits && !c.raw_overflow) break;
+        if (!c.raw_overflow) break;
         if (attempt >= 6) {
-            set_error("internal error: hit buffers kept overflowing");
+            set_error("internal error: raw record buffer kept overflowing");
             return ISSL_E_DEVICE;
         }
-        if (c.raw_overflow) { // raw_chunks counts every request, so it is the exact need of this batch
-            rc = ensure_raw_capacity(ix, static_cast<size_t>(c.raw_chunks) + c.raw_chunks / 8 + 1024);
-            if (rc) return rc;
-        }
-        if (c.n_hits > ix->ws.cap_hits) {
-            rc = ensure_hit_capacity(ix, static_cast<size_t>(c.n_hits) + c.n_hits / 8 + 1024);
-            if (rc) return rc;
-        }
-    }
-    if (dump && ix->ws.cap_hitrec < ix->ws.cap_hits) {
-        rc = dev_alloc(ix->ws.d_hitrec, ix->ws.cap_hits);
+        // raw_chunks counts every request, so it is the exact need of this batch
+        rc = ensure_raw_capacity(ix, static_cast<size_t>(c.raw_chunks) + c.raw_chunks / 8 + 1024);
         if (rc) return rc;
-        ix->ws.cap_hitrec = ix->ws.cap_hits;
     }
-    launch_group_hits(ix->ws, n32, stream);
-    HIP_TRY(hipEventRecord(ix->ev[4], stream));
-    launch_replay(ix->view, ix->ws, d_guides, n32, p, d_mit, d_cfd, dump ? ix->ws.d_kept : nullptr,
-                  dump ? ix->ws.d_hitrec : nullptr, stream);
-    HIP_TRY(hipEventRecord(ix->ev[5], stream));
-    HIP_TRY(hipStreamSynchronize(stream));
-    HIP_TRY(hipGetLastError());
     float ms[5] = {0, 0, 0, 0, 0};
     for (int i = 0; i < 5; ++i) (void)hipEventElapsedTime(&ms[i], ix->ev[i], ix->ev[i + 1]);
     ix->stats.ms_bin = ms[0];
@@ -364,8 +382,8 @@ static int score_core(issl_index *ix, const uint64_t *d_guides, size_t n, int ma
     ix->stats.ms_total = ms[0] + ms[1] + ms[2] + ms[3] + ms[4];
     ix->stats.raw_records = static_cast<uint64_t>(c.raw_chunks) * (kChunkRecs - 1);
     ix->stats.candidates = pl.candidates;
-    ix->stats.hits = c.n_hits;
-    ix->stats.scan_tiles = c.tiles;
+    ix->stats.hits = total_hits;
+    ix->stats.scan_tiles = pl.tiles;
     return ISSL_OK;
 }
 
@@ -462,7 +480,7 @@ int issl_index_device_bytes(const issl_index *idx, size_t *out)
     std::vector<double> v;
     idx->host->unique_scores(m, v);
     ImageHeader h;
-    layout_image(h, idx->geo, m.size(), count_tiles(*idx->host));
+    layout_image(h, idx->geo, m.size(), count_tiles(*idx->host), masks_are_dense(m));
     *out = h.total_bytes;
     return ISSL_OK;
 }
@@ -479,7 +497,7 @@ static int upload_common(issl_index *idx, int device, void *buf, size_t bytes)
     std::vector<uint64_t> m;
     std::vector<double> v;
     idx->host->unique_scores(m, v);
-    layout_image(idx->hdr, idx->geo, m.size(), count_tiles(*idx->host));
+    layout_image(idx->hdr, idx->geo, m.size(), count_tiles(*idx->host), masks_are_dense(m));
     idx->device = device;
     if (buf) {
         if (bytes < idx->hdr.total_bytes || (reinterpret_cast<uintptr_t>(buf) & 255u)) {

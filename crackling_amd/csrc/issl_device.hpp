@@ -21,12 +21,13 @@ namespace issl {
 //   score_val      f64[ns]     their local MIT scores
 //   sites          u64[N]      packed signatures                (:200-204)
 //   entries        u64[N*S]    bucket contents occ<<32|id       (:235-240)
+//   mit_dense      f64[2^20]   local MIT scores indexed by the 20 mismatch flags (when the table allows it)
 //   scan           u32[tiles*kTileCands]  the scan stream: for every bucket, in bucket order, the
 //                              candidate signature with its own slice removed, 16 positions, even
 //                              bits in the low half-word and odd bits in the high half-word;
 //                              each bucket zero-padded to a whole number of tiles.
 constexpr uint64_t kImageMagic = 0x314C535349444D41ull; // "AMDISSL1"
-constexpr uint32_t kImageVersion = 1;
+constexpr uint32_t kImageVersion = 2;
 constexpr uint32_t kTileCands = 2048; // candidates per scan tile: one wave, 64 lanes x 32 registers
 constexpr uint32_t kHeaderBytes = 4096;
 
@@ -42,6 +43,7 @@ struct ImageHeader {
     uint64_t total_bytes;
     uint64_t off_bucket_start, off_tile_first, off_score_mask, off_score_val, off_sites, off_entries,
         off_scan;
+    uint64_t off_mit_dense; // 0: absent (table holds masks outside the 20 even bits)
 };
 static_assert(sizeof(ImageHeader) <= kHeaderBytes, "header must fit its block");
 
@@ -51,6 +53,7 @@ struct ImageView {
     const uint32_t *tile_first;
     const uint64_t *score_mask;
     const double *score_val;
+    const double *mit_dense; // 2^20 doubles indexed by the 20 mismatch flags, or null
     const uint64_t *sites;
     const uint64_t *entries;
     const uint32_t *scan;
@@ -64,7 +67,7 @@ struct ImageView {
 
 // Layout computation shared by upload and attach.  Fills every field of `h` from the geometry,
 // the number of unique scores and the bucket sizes (sizes may be null when n_tiles is given).
-void layout_image(ImageHeader &h, const Geometry &g, uint64_t n_scores_unique, uint64_t n_tiles);
+void layout_image(ImageHeader &h, const Geometry &g, uint64_t n_scores_unique, uint64_t n_tiles, bool dense_mit);
 ImageView make_view(const ImageHeader &h, void *base);
 
 // ---- scoring workspace -------------------------------------------------------------------------
@@ -72,9 +75,14 @@ constexpr uint32_t kGuideGroup = 8;    // guide words fetched per scalar load
 constexpr uint32_t kItemGuides = 512;  // guides per scan item (bounds one tile's work)
 constexpr uint32_t kTileFixedCost = 4; // cost of fetching a tile, in guide-comparisons of that tile
 constexpr uint32_t kNoGuide = 0xFFFFFFFFu;
+constexpr uint32_t kPadGuideWord = 0xFFFFFFFFu; // scan word of padding guide slots: 16 x T, distance 16 from tile padding
 constexpr uint32_t kScanGridBlocks = 256u * 8u; // scan launch: 256 CUs x 8 workgroups of 4 independent waves
-constexpr uint32_t kScanRangesPerWave = 4;      // upper bound of cost ranges = waves x this
+constexpr uint32_t kScanWaves = kScanGridBlocks * 4u;
+constexpr uint32_t kStaticRounds = 3;           // equal-cost ranges per wave dealt out statically
+constexpr uint32_t kDynamicRanges = 8192;       // at most this many small ranges in the ticketed tail
+constexpr uint32_t kMaxRanges = kScanWaves * kStaticRounds + kDynamicRanges;
 constexpr uint32_t kChunkRecs = 128;            // raw-record chunk: 1 KiB, slot 0 is the fill count
+constexpr uint64_t kDeadKey = ~0ull;            // raw slot that did not survive the exact check
 
 // One unit of scan work: all tiles of one bucket against one group of guides of that bucket.
 struct ScanItem {
@@ -84,23 +92,31 @@ struct ScanItem {
     uint64_t cost0;  // sum of costs of all earlier items; tile cost = (g1-g0)+kTileFixedCost
 };
 
+// First tile of a cost range of the scan: (item, tile inside the item); item == n_items marks the end.
+struct RangeStart {
+    uint32_t item;
+    uint32_t tile;
+};
+
 // Written by the planning kernel, read-only for the scan.
 struct PlanInfo {
     uint32_t n_items;
     uint32_t error;       // bit 1: item list overflow
-    uint32_t n_ranges;    // equal-cost ranges the scan's waves work through
-    uint32_t pad;
+    uint32_t n_ranges;    // ranges the scan's waves work through: n_static equal-cost ones + the ticketed tail
+    uint32_t n_static;
+    uint64_t static_cost; // cost covered by the static ranges
     uint64_t total_cost;
     uint64_t candidates;  // sum over guides of their bucket lengths
+    uint64_t tiles;       // (tile, item) pairs the scan works through
 };
 
 // Updated by the scan with atomics.
 struct Counters {
-    uint32_t n_hits;      // hits the scan wanted to record (may exceed capacity)
-    uint32_t next_range;  // ticket counter of the scan's dynamic range assignment
+    uint32_t next_range;  // ticket counter of the scan's dynamic tail
+    uint32_t pad0;
     uint32_t raw_chunks;  // chunks of the raw record buffer handed out
     uint32_t raw_overflow; // set when the raw buffer was too small
-    uint64_t tiles;       // (tile, item) pairs processed
+    uint64_t reserved2;
 };
 
 struct Workspace {
@@ -111,11 +127,11 @@ struct Workspace {
     uint32_t *gidx = nullptr;    // guide index, kNoGuide in padding
     ScanItem *items = nullptr;   // [max_items+1]
     PlanInfo *plan = nullptr;
+    RangeStart *range_start = nullptr; // [kMaxRanges + 1]
     uint64_t *raw = nullptr;     // [(cap_chunks+1) * kChunkRecs] raw records of the scan, chunked
     size_t cap_chunks = 0;
     Counters *counters = nullptr;
-    uint64_t *hits = nullptr;    // [hit_cap] keys guide<<35 | slice<<32 | pos
-    uint64_t *sorted = nullptr;  // [hit_cap] grouped by guide
+    uint64_t *sorted = nullptr;  // [hit_cap] keys guide<<35 | slice<<32 | pos, grouped by guide
     uint32_t *gcount = nullptr;  // [G+1] hits per guide
     uint32_t *goff = nullptr;    // [G+1] exclusive prefix
     uint32_t *gcur = nullptr;    // [G]

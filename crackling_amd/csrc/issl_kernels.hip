@@ -15,6 +15,9 @@
 // loads, so one HBM read of a bucket tile serves every guide of the batch that falls into this bucket.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cstdio>
+
 #include "issl_device.hpp"
 
 namespace issl {
@@ -172,7 +175,8 @@ __device__ inline uint64_t block_exclusive_scan(uint64_t v, uint64_t *lds /*[256
 // One block: lay out the bucket-sorted guide arrays and the list of scan items.
 __global__ __launch_bounds__(256) void k_plan(ImageView v, const uint32_t *__restrict__ ng,
                                               uint32_t *__restrict__ gstart, ScanItem *__restrict__ items,
-                                              uint32_t cap_items, PlanInfo *__restrict__ plan)
+                                              uint32_t cap_items, PlanInfo *__restrict__ plan, uint32_t static_rounds,
+                                              uint32_t dyn_shift, uint32_t item_guides)
 {
     __shared__ uint64_t lds[256];
     const uint32_t nb = v.n_buckets;
@@ -186,7 +190,7 @@ __global__ __launch_bounds__(256) void k_plan(ImageView v, const uint32_t *__res
         const uint32_t nt = v.tile_first[b + 1] - v.tile_first[b];
         slots += (g + kGuideGroup - 1u) / kGuideGroup * kGuideGroup;
         if (g && nt) {
-            const uint32_t k = (g + kItemGuides - 1u) / kItemGuides;
+            const uint32_t k = (g + item_guides - 1u) / item_guides;
             n_it += k;
             cost += static_cast<uint64_t>(nt) * (static_cast<uint64_t>(g) + static_cast<uint64_t>(k) * kTileFixedCost);
             cand += (v.bucket_start[b + 1] - v.bucket_start[b]) * g;
@@ -206,8 +210,8 @@ __global__ __launch_bounds__(256) void k_plan(ImageView v, const uint32_t *__res
         const uint32_t nt = v.tile_first[b + 1] - v.tile_first[b];
         gstart[b] = static_cast<uint32_t>(slot_at);
         if (g && nt && !overflow) {
-            for (uint32_t done = 0; done < g; done += kItemGuides) {
-                const uint32_t len = (g - done < kItemGuides) ? g - done : kItemGuides;
+            for (uint32_t done = 0; done < g; done += item_guides) {
+                const uint32_t len = (g - done < item_guides) ? g - done : item_guides;
                 ScanItem it;
                 it.bucket = b;
                 it.g0 = static_cast<uint32_t>(slot_at) + done;
@@ -230,11 +234,63 @@ __global__ __launch_bounds__(256) void k_plan(ImageView v, const uint32_t *__res
         plan->n_items = overflow ? 0u : static_cast<uint32_t>(tot_items);
         plan->total_cost = overflow ? 0ull : tot_cost;
         plan->candidates = tot_cand;
-        // one range per tile while that keeps the ticket traffic low, else cost-balanced ranges
-        const uint64_t max_ranges = static_cast<uint64_t>(kScanGridBlocks) * 4u * kScanRangesPerWave;
-        plan->n_ranges = overflow ? 0u : static_cast<uint32_t>(tot_tiles < max_ranges ? tot_tiles : max_ranges);
+        plan->tiles = tot_tiles;
+        // Static part: kStaticRounds equal-cost ranges per scan wave, dealt out by wave number.  Dynamic part:
+        // the last ~1/8 of the cost in kDynamicRanges small ranges handed out by a ticket counter, to even out
+        // what the cost model cannot see (cold blocks, memory).  Tickets are device-wide atomics (~12 ns each,
+        // serialised), so their number is bounded by the work: about one per 2^22 comparisons.
+        uint32_t n_static = kScanWaves * static_rounds, n_dynamic = 0;
+        if (tot_tiles < n_static) {
+            n_static = static_cast<uint32_t>(tot_tiles);
+        } else if (dyn_shift < 64) {
+            const uint64_t by_work = tot_cand >> dyn_shift;
+            n_dynamic = static_cast<uint32_t>(by_work < kDynamicRanges ? by_work : kDynamicRanges);
+            if (n_dynamic < 64) n_dynamic = 0;
+        }
+        plan->n_static = overflow ? 0u : n_static;
+        plan->n_ranges = overflow ? 0u : n_static + n_dynamic;
+        plan->static_cost = n_dynamic ? tot_cost - tot_cost / 8 : tot_cost;
         plan->error = overflow ? 2u : 0u;
     }
+}
+
+// First tile of every cost range: range r owns the tiles whose start cost lies in [lo(r), lo(r+1)).
+// Done once here so that the scan waves neither divide nor search.
+__global__ __launch_bounds__(256) void k_ranges(const PlanInfo *__restrict__ plan, const ScanItem *__restrict__ items,
+                                                RangeStart *__restrict__ starts)
+{
+    const uint32_t n_ranges = plan->n_ranges;
+    const uint32_t n_items = plan->n_items;
+    const uint64_t total = plan->total_cost;
+    const uint32_t r = blockIdx.x * 256 + threadIdx.x;
+    if (r > n_ranges || n_ranges == 0) return;
+    RangeStart out;
+    out.item = n_items;
+    out.tile = 0;
+    if (r < n_ranges) {
+        // no 128-bit intermediate: costs < 2^50 and range counts <= 2^15
+        const uint32_t n_static = plan->n_static;
+        const uint64_t s_cost = plan->static_cost;
+        uint64_t lo;
+        if (r < n_static) {
+            lo = s_cost / n_static * r + (s_cost % n_static) * r / n_static;
+        } else {
+            const uint64_t d_cost = total - s_cost;
+            const uint32_t nd = n_ranges - n_static, rd = r - n_static;
+            lo = s_cost + d_cost / nd * rd + (d_cost % nd) * rd / nd;
+        }
+        uint32_t a = 0, z = n_items; // last item with cost0 <= lo
+        while (z - a > 1) {
+            const uint32_t mid = (a + z) >> 1;
+            if (items[mid].cost0 <= lo) a = mid; else z = mid;
+        }
+        const ScanItem it = items[a];
+        const uint64_t tile_cost = static_cast<uint64_t>(it.g1 - it.g0) + kTileFixedCost;
+        const uint64_t k = (lo - it.cost0 + tile_cost - 1) / tile_cost; // first tile starting at or after lo
+        if (k >= it.n_tiles) { out.item = a + 1; out.tile = 0; }
+        else { out.item = a; out.tile = static_cast<uint32_t>(k); }
+    }
+    starts[r] = out;
 }
 
 // Scatter every guide into its bucket's range of (gword, gidx), once per slice.
@@ -280,24 +336,56 @@ __global__ __launch_bounds__(256) void k_guide_scatter(const uint64_t *__restric
     }
 }
 
+// Reset of everything a scoring call accumulates into (one launch instead of seven memsets).
+__global__ __launch_bounds__(256) void k_reset(Workspace ws, uint32_t nb, uint32_t n, uint32_t n_slots,
+                                               uint32_t n_scan_waves)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t stride = gridDim.x * 256;
+    for (uint32_t k = i; k < nb; k += stride) { ws.ng[k] = 0; ws.gfill[k] = 0; }
+    for (uint32_t k = i; k < n_slots; k += stride) { ws.gidx[k] = kNoGuide; ws.gword[k] = kPadGuideWord; }
+    for (uint32_t k = i; k <= n; k += stride) ws.gcount[k] = 0;
+    for (uint32_t k = i; k < n; k += stride) ws.gcur[k] = 0;
+    // chunk headers: a chunk nobody writes must read as empty; chunks [0, n_scan_waves) belong to the scan waves
+    for (uint32_t k = i; k < ws.cap_chunks; k += stride) ws.raw[static_cast<uint64_t>(k) * kChunkRecs] = 0;
+    if (i == 0) {
+        *ws.plan = PlanInfo{};
+        Counters c{};
+        c.raw_chunks = n_scan_waves;
+        *ws.counters = c;
+    }
+}
+
 void launch_bin_guides(const ImageView &v, const Workspace &ws, const uint64_t *d_guides, uint32_t n, void *stream_)
 {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const uint32_t nb = v.n_buckets;
-    (void)hipMemsetAsync(ws.ng, 0, sizeof(uint32_t) * nb, stream);
-    (void)hipMemsetAsync(ws.gfill, 0, sizeof(uint32_t) * nb, stream);
-    (void)hipMemsetAsync(ws.plan, 0, sizeof(PlanInfo), stream);
-    (void)hipMemsetAsync(ws.counters, 0, sizeof(Counters), stream);
-    (void)hipMemsetAsync(ws.gidx, 0xFF, sizeof(uint32_t) * ws.cap_gslots, stream);
-    (void)hipMemsetAsync(ws.gword, 0, sizeof(uint32_t) * ws.cap_gslots, stream);
-    (void)hipMemsetAsync(ws.gcount, 0, sizeof(uint32_t) * (static_cast<size_t>(n) + 1), stream);
+    // slots in use: 8-padded guides per bucket, at most n * slices + 8 * buckets
+    const uint32_t n_slots = static_cast<uint32_t>(
+        std::min<size_t>(ws.cap_gslots, static_cast<size_t>(n) * v.n_slices + static_cast<size_t>(kGuideGroup) * nb));
+    const uint32_t reset_blocks = std::min<uint32_t>(1024u, (std::max(n_slots, nb) + 255u) / 256u);
+    hipLaunchKernelGGL(k_reset, dim3(reset_blocks), dim3(256), 0, stream, ws, nb, n, n_slots, kScanGridBlocks * 4u);
     const uint32_t blocks = (n + 255u) / 256u;
     hipLaunchKernelGGL(k_guide_hist, dim3(blocks), dim3(256), 0, stream, d_guides, n, v.slice_width, v.n_slices, nb,
                        ws.ng);
+    // ISSL_SCHED="<static rounds>,<shift>,<guides per item>": scheduling knobs.  Default: three static rounds
+    // of equal-cost ranges and no ticketed tail (shift >= 64).  With shift s the last 1/8 of the cost is cut
+    // into (comparisons >> s) small ranges handed out by tickets; measured on MI355X the tickets cost more than
+    // they balance unless a batch has >~1e11 comparisons (each ticket is a serialised ~12 ns device atomic).
+    uint32_t rounds = kStaticRounds, shift = 99, item_guides = kItemGuides;
+    if (const char *e = getenv("ISSL_SCHED")) {
+        unsigned a = rounds, b = shift, c = item_guides;
+        if (sscanf(e, "%u,%u,%u", &a, &b, &c) >= 1) {
+            rounds = a ? a : 1; shift = b; item_guides = (c >= 8 && c <= kItemGuides) ? (c & ~7u) : kItemGuides;
+            if (rounds > kStaticRounds) rounds = kStaticRounds;
+        }
+    }
     hipLaunchKernelGGL(k_plan, dim3(1), dim3(256), 0, stream, v, ws.ng, ws.gstart, ws.items,
-                       static_cast<uint32_t>(ws.cap_items), ws.plan);
+                       static_cast<uint32_t>(ws.cap_items), ws.plan, rounds, shift, item_guides);
     hipLaunchKernelGGL(k_guide_scatter, dim3(blocks), dim3(256), 0, stream, d_guides, n, v.slice_width, v.n_slices,
                        nb, ws.gstart, ws.gfill, ws.gword, ws.gidx);
+    hipLaunchKernelGGL(k_ranges, dim3((kMaxRanges + 1 + 255) / 256), dim3(256), 0, stream, ws.plan, ws.items,
+                       ws.range_start);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -440,6 +528,18 @@ __device__ __forceinline__ void note_candidates(uint32_t ok, uint32_t gslot, uin
     }
 }
 
+// Next range of the ticketed tail, or n_ranges when there is none left.  The counter is read with a plain load
+// first: an exhausted counter costs the late waves no atomic (device-wide atomics serialise at ~12 ns each).
+__device__ __forceinline__ uint32_t take_ticket(Counters *counters, uint32_t n_static, uint32_t n_ranges, uint32_t lane)
+{
+    if (n_static + __hip_atomic_load(&counters->next_range, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= n_ranges)
+        return n_ranges;
+    uint32_t ticket = 0;
+    if (lane == 0) ticket = atomicAdd(&counters->next_range, 1u);
+    const uint32_t r = n_static + __builtin_amdgcn_readfirstlane(ticket);
+    return r < n_ranges ? r : n_ranges;
+}
+
 // Scan kernel.  Every WAVE is an independent worker: it takes ranges of the cost axis (the first one
 // by its global wave number, further ones from an atomic ticket), and for every tile of the range
 // keeps the tile's 2048 candidates in registers (32 bit planes per lane) while the guide words of the
@@ -447,68 +547,75 @@ __device__ __forceinline__ void note_candidates(uint32_t ok, uint32_t gslot, uin
 // The streams the hot loop reads (scan planes, tile table, items, guide words, plan) are separate
 // `const __restrict__` kernel arguments: they are never written by this kernel, which lets the
 // compiler fetch the wave-uniform ones through the scalar cache.
-template <int THR>
+// ABL (timing experiments only, results are wrong when non-zero): bit 0 = load the tile planes once per range
+// instead of per tile, bit 1 = never note candidates, bit 2 = no comparison work (loads only).
+template <int THR, bool STAGGER, int ABL = 0>
 __global__ __launch_bounds__(256, 6) void k_scan(const uint32_t *__restrict__ scan_stream,
                                                  const uint32_t *__restrict__ tile_first,
                                                  const ScanItem *__restrict__ items,
                                                  const PlanInfo *__restrict__ plan,
+                                                 const RangeStart *__restrict__ range_start,
                                                  const uint32_t *__restrict__ gword_stream, uint64_t *raw,
                                                  uint32_t max_chunks, Counters *counters, uint32_t thr)
 {
-    const uint32_t n_items = plan->n_items;
-    const uint64_t total = plan->total_cost;
     const uint32_t n_ranges = plan->n_ranges;
-    if (n_items == 0 || total == 0 || n_ranges == 0) return;
+    const uint32_t n_static = plan->n_static;
+    if (n_ranges == 0) return;
+    // The waves of a SIMD run the same program on tiles of equal cost: left alone they advance in lockstep,
+    // reach their tile loads together and leave the SIMD idle for a memory round trip per tile.  Distinct
+    // issue priorities per wave slot make them finish their tiles at different times.
+    if (STAGGER) {
+        const uint32_t slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4); // HW_ID.wave_id
+        if ((slot & 3u) == 1u) __builtin_amdgcn_s_setprio(1);
+        else if ((slot & 3u) == 2u) __builtin_amdgcn_s_setprio(2);
+        else if ((slot & 3u) == 3u) __builtin_amdgcn_s_setprio(3);
+    }
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
     uint32_t range = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
-    uint32_t tiles_done = 0;
+    // Raw records: the wave's first chunk is the one with its own number (no atomic); k_reset cleared its header.
     RawWriter w;
-    w.chunk = raw + static_cast<uint64_t>(max_chunks) * kChunkRecs; // spare chunk until the first real one
-    w.fill = kChunkRecs;                                             // "full": first note acquires a chunk
+    w.chunk = raw + static_cast<uint64_t>(range < max_chunks ? range : max_chunks) * kChunkRecs;
+    w.fill = 1;
     bool own_chunk = false;
 
+    if (range >= n_static) range = take_ticket(counters, n_static, n_ranges, lane);
     while (range < n_ranges) {
-        // Ranges cut the cost axis into equal parts; a tile belongs to the range that holds its
-        // start cost.  No 128-bit intermediate: total < 2^50 and n_ranges <= 2^15.
-        const uint64_t lo = total / n_ranges * range + (total % n_ranges) * range / n_ranges;
-        const uint64_t hi = (range + 1 == n_ranges)
-                                ? total
-                                : total / n_ranges * (range + 1) + (total % n_ranges) * (range + 1) / n_ranges;
-        if (hi > lo) {
-            // item holding `lo`: last i with items[i].cost0 <= lo
-            uint32_t a = 0, z = n_items;
-            while (z - a > 1) {
-                const uint32_t mid = (a + z) >> 1;
-                if (items[mid].cost0 <= lo) a = mid; else z = mid;
-            }
-            uint32_t it = a;
+        // tiles of this range: from range_start[range] up to (not including) range_start[range + 1]
+        const RangeStart first = range_start[range];
+        const RangeStart last = range_start[range + 1];
+        uint32_t it = first.item;
+        uint32_t k = first.tile;
+        if (it < last.item || (it == last.item && k < last.tile)) {
             ScanItem cur = items[it];
-            uint64_t tile_cost = static_cast<uint64_t>(cur.g1 - cur.g0) + kTileFixedCost;
-            uint64_t k = (lo - cur.cost0 + tile_cost - 1) / tile_cost; // first tile starting at or after lo
+            uint32_t c[kPlanes];
+            bool loaded = false;
             while (true) {
-                if (k >= cur.n_tiles) {
-                    ++it;
-                    if (it >= n_items) break;
-                    cur = items[it];
-                    tile_cost = static_cast<uint64_t>(cur.g1 - cur.g0) + kTileFixedCost;
-                    k = 0;
-                }
-                if (cur.cost0 + k * tile_cost >= hi) break;
-
                 // ---- one tile: 2048 candidates of bucket cur.bucket, tile k ---------------------
                 const uint32_t tile = tile_first[cur.bucket] + static_cast<uint32_t>(k);
                 const uint4 *__restrict__ src =
                     reinterpret_cast<const uint4 *>(scan_stream + static_cast<uint64_t>(tile) * kTileCands);
-                uint32_t c[kPlanes];
+                if (!(ABL & 1) || !loaded) {
 #pragma unroll
-                for (int q = 0; q < kPlanes / 4; ++q) {
-                    const uint4 t4 = src[q * 64 + lane];
-                    c[4 * q + 0] = t4.x; c[4 * q + 1] = t4.y; c[4 * q + 2] = t4.z; c[4 * q + 3] = t4.w;
+                    for (int q = 0; q < kPlanes / 4; ++q) {
+                        const uint4 t4 = src[q * 64 + lane];
+                        c[4 * q + 0] = t4.x; c[4 * q + 1] = t4.y; c[4 * q + 2] = t4.z; c[4 * q + 3] = t4.w;
+                    }
+                    loaded = true;
                 }
-                const uint32_t g_full = cur.g0 + ((cur.g1 - cur.g0) & ~(kGuideGroup - 1u));
-                uint32_t g = cur.g0;
-                for (; g < g_full; g += kGuideGroup) {
+                if (ABL & 4) {
+                    uint32_t acc = 0;
+#pragma unroll
+                    for (int r = 0; r < kPlanes; ++r) acc |= c[r];
+                    if (acc == 0x12345678u) own_chunk = true;
+                    ++k;
+                    if (k >= cur.n_tiles) { ++it; k = 0; if (it >= last.item && last.tile == 0) break; cur = items[it]; }
+                    if (it == last.item && k >= last.tile) break;
+                    continue;
+                }
+                // Guide slots are padded to groups of 8 with a word (all T) that is far from the zero padding
+                // of the tiles; a padding slot that does come near a real candidate is dropped by k_verify.
+                for (uint32_t g = cur.g0; g < cur.g1; g += kGuideGroup) {
                     const GuideGroup gg = *reinterpret_cast<const GuideGroup *>(gword_stream + g);
                     uint32_t flagged = 0; // bit u: a lane has a candidate within thr of guide g+u
 #pragma unroll
@@ -516,6 +623,7 @@ __global__ __launch_bounds__(256, 6) void k_scan(const uint32_t *__restrict__ sc
                         const uint32_t ok = near_plane<THR>(c, gg.w[u], thr);
                         if (__ballot(ok != 0u) != 0ull) flagged |= 1u << u;
                     }
+                    if (ABL & 2) { asm volatile("" ::"s"(flagged)); flagged = 0; }
                     while (flagged) { // ~4 % of the (guide, tile) pairs on random data
                         const uint32_t u = static_cast<uint32_t>(__builtin_ctz(flagged));
                         flagged &= flagged - 1u;
@@ -524,28 +632,30 @@ __global__ __launch_bounds__(256, 6) void k_scan(const uint32_t *__restrict__ sc
                         own_chunk = true;
                     }
                 }
-                for (; g < cur.g1; ++g) { // the (< 8) guides of the last, partial group
-                    const uint32_t ok = near_plane<THR>(c, gword_stream[g], thr);
-                    if (__ballot(ok != 0u) != 0ull) {
-                        note_candidates(ok, g, tile, lane, w, raw, max_chunks, counters);
-                        own_chunk = true;
-                    }
-                }
-                ++tiles_done;
                 ++k;
+                if (k >= cur.n_tiles) {
+                    ++it;
+                    k = 0;
+                    if (it >= last.item && last.tile == 0) break;
+                    cur = items[it];
+                }
+                if (it == last.item && k >= last.tile) break;
             }
         }
-        // next range: the ticket counter continues after the statically assigned first round
-        uint32_t ticket = 0;
-        if (lane == 0) ticket = atomicAdd(&counters->next_range, 1u);
-        range = n_waves + __builtin_amdgcn_readfirstlane(ticket);
+        // Static rounds by wave number, then the small ranges of the dynamic tail by ticket.
+        if (range < n_static) {
+            range += n_waves;
+            if (range >= n_static) range = take_ticket(counters, n_static, n_ranges, lane);
+        } else {
+            range = take_ticket(counters, n_static, n_ranges, lane);
+        }
     }
     if (own_chunk) raw_retire(w, lane);
-    if (lane == 0 && tiles_done)
-        atomicAdd(reinterpret_cast<unsigned long long *>(&counters->tiles), static_cast<unsigned long long>(tiles_done));
 }
 
-// Exact check of the raw records: one thread per record, one chunk per 128-thread workgroup.
+// Exact check of the raw records, IN PLACE: one thread per record, one chunk per 128-thread workgroup.
+// A record that survives is overwritten by its final key guide<<35 | slice<<32 | position-in-bucket,
+// every other slot by kDeadKey; the per-guide hit counts are accumulated for the grouping pass.
 __global__ __launch_bounds__(kChunkRecs) void k_verify(ImageView v, Workspace ws, const uint64_t *__restrict__ guides,
                                                        int max_dist)
 {
@@ -553,51 +663,77 @@ __global__ __launch_bounds__(kChunkRecs) void k_verify(ImageView v, Workspace ws
     if (n_chunks > ws.cap_chunks) n_chunks = static_cast<uint32_t>(ws.cap_chunks);
     const uint64_t low = (1ull << v.slice_width) - 1ull;
     for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
-        const uint64_t *recs = ws.raw + static_cast<uint64_t>(chunk) * kChunkRecs;
+        uint64_t *recs = ws.raw + static_cast<uint64_t>(chunk) * kChunkRecs;
         const uint32_t used = static_cast<uint32_t>(recs[0]);
         const uint32_t t = threadIdx.x + 1u;
         if (t >= used || t >= kChunkRecs) continue;
         const uint64_t rec = recs[t];
+        uint64_t key = kDeadKey;
         const uint32_t offset = static_cast<uint32_t>(rec) & (kTileCands - 1u);
         const uint32_t tile = static_cast<uint32_t>(rec >> 11) & 0x3FFFFFFu;
         const uint32_t gslot = static_cast<uint32_t>(rec >> 37);
         const uint32_t guide = ws.gidx[gslot];
-        if (guide == kNoGuide) continue;
-        // bucket of the tile: last b with tile_first[b] <= tile
-        uint32_t lo = 0, hi = v.n_buckets;
-        while (hi - lo > 1) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (v.tile_first[mid] <= tile) lo = mid; else hi = mid;
+        if (guide != kNoGuide) {
+            // bucket of the tile: last b with tile_first[b] <= tile
+            uint32_t lo = 0, hi = v.n_buckets;
+            while (hi - lo > 1) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (v.tile_first[mid] <= tile) lo = mid; else hi = mid;
+            }
+            const uint32_t bucket = lo;
+            const uint32_t slice = bucket >> v.slice_width;
+            const uint64_t start = v.bucket_start[bucket];
+            const uint64_t len = v.bucket_start[bucket + 1] - start;
+            const uint64_t pos = static_cast<uint64_t>(tile - v.tile_first[bucket]) * kTileCands + offset;
+            if (pos < len) { // else: zero padding of the bucket's last tile
+                const uint64_t gsig = guides[guide];
+                const uint64_t entry = v.entries[start + pos];
+                const uint64_t ot = v.sites[entry & 0xFFFFFFFFull];
+                if (__builtin_popcountll(mismatch_mask(gsig, ot)) <= max_dist) { // exact, full signatures (:376-382)
+                    // First-matching-slice rule (equivalent of the seen bitmap, isslScoreOfftargets.cpp:385-390,463):
+                    // the site was already met iff an earlier slice of the XOR is all zero.
+                    const uint64_t x = gsig ^ ot;
+                    bool earlier = false;
+                    for (uint32_t j = 0; j < slice; ++j)
+                        if (((x >> (v.slice_width * j)) & low) == 0) earlier = true;
+                    if (!earlier) {
+                        key = (static_cast<uint64_t>(guide) << 35) | (static_cast<uint64_t>(slice) << 32) | pos;
+                        atomicAdd(&ws.gcount[guide], 1u);
+                    }
+                }
+            }
         }
-        const uint32_t bucket = lo;
-        const uint32_t slice = bucket >> v.slice_width;
-        const uint64_t start = v.bucket_start[bucket];
-        const uint64_t len = v.bucket_start[bucket + 1] - start;
-        const uint64_t pos = static_cast<uint64_t>(tile - v.tile_first[bucket]) * kTileCands + offset;
-        if (pos >= len) continue; // zero padding of the bucket's last tile
-        const uint64_t gsig = guides[guide];
-        const uint64_t entry = v.entries[start + pos];
-        const uint64_t ot = v.sites[entry & 0xFFFFFFFFull];
-        if (__builtin_popcountll(mismatch_mask(gsig, ot)) > max_dist) continue; // exact, full signatures (:376-382)
-        // First-matching-slice rule (equivalent of the seen bitmap, isslScoreOfftargets.cpp:385-390,463):
-        // the site was already met iff an earlier slice of the XOR is all zero.
-        const uint64_t x = gsig ^ ot;
-        bool earlier = false;
-        for (uint32_t j = 0; j < slice; ++j)
-            if (((x >> (v.slice_width * j)) & low) == 0) earlier = true;
-        if (earlier) continue;
-        const uint32_t slot = atomicAdd(&ws.counters->n_hits, 1u);
-        atomicAdd(&ws.gcount[guide], 1u);
-        if (slot < ws.cap_hits)
-            ws.hits[slot] = (static_cast<uint64_t>(guide) << 35) | (static_cast<uint64_t>(slice) << 32) | pos;
+        recs[t] = key;
     }
 }
 
 template <int THR>
 static void launch_scan_thr(const ImageView &v, const Workspace &ws, uint32_t thr, hipStream_t stream)
 {
-    hipLaunchKernelGGL(k_scan<THR>, dim3(kScanGridBlocks), dim3(256), 0, stream, v.scan, v.tile_first, ws.items, ws.plan,
-                       ws.gword, ws.raw, static_cast<uint32_t>(ws.cap_chunks), ws.counters, thr);
+    // ISSL_SCAN_ABLATE=<bits>: timing experiments (wrong results), only for the default threshold build.
+    const char *abl_env = getenv("ISSL_SCAN_ABLATE");
+    const int abl = abl_env ? atoi(abl_env) : 0;
+    if (THR == 4 && abl) {
+#define ISSL_ABL_CASE(A)                                                                                        \
+    if (abl == A) {                                                                                                 \
+        hipLaunchKernelGGL((k_scan<4, false, A>), dim3(kScanGridBlocks), dim3(256), 0, stream, v.scan, v.tile_first, \
+                           ws.items, ws.plan, ws.range_start, ws.gword, ws.raw,                                     \
+                           static_cast<uint32_t>(ws.cap_chunks), ws.counters, thr);                                 \
+        return;                                                                                                     \
+    }
+        ISSL_ABL_CASE(1) ISSL_ABL_CASE(2) ISSL_ABL_CASE(4) ISSL_ABL_CASE(5)
+#undef ISSL_ABL_CASE
+    }
+    // ISSL_SCAN_STAGGER=0 disables the per-slot issue priorities (A/B aid).
+    const char *stagger_env = getenv("ISSL_SCAN_STAGGER");
+    if (stagger_env && stagger_env[0] == '0')
+        hipLaunchKernelGGL((k_scan<THR, false>), dim3(kScanGridBlocks), dim3(256), 0, stream, v.scan, v.tile_first,
+                           ws.items, ws.plan, ws.range_start, ws.gword, ws.raw, static_cast<uint32_t>(ws.cap_chunks),
+                           ws.counters, thr);
+    else
+        hipLaunchKernelGGL((k_scan<THR, true>), dim3(kScanGridBlocks), dim3(256), 0, stream, v.scan, v.tile_first,
+                           ws.items, ws.plan, ws.range_start, ws.gword, ws.raw, static_cast<uint32_t>(ws.cap_chunks),
+                           ws.counters, thr);
 }
 
 void launch_scan(const ImageView &v, const Workspace &ws, const uint64_t *d_guides, uint32_t n, int max_dist,
@@ -677,15 +813,58 @@ __global__ __launch_bounds__(256) void k_prefix_apply(const uint32_t *__restrict
     }
 }
 
-__global__ __launch_bounds__(256) void k_group_scatter(const uint64_t *__restrict__ hits,
-                                                       const Counters *__restrict__ counters, uint32_t cap,
-                                                       const uint32_t *__restrict__ goff, uint32_t *__restrict__ gcur,
-                                                       uint64_t *__restrict__ sorted)
+// Whole prefix sum in one workgroup (used while n is moderate; saves two launches).
+__global__ __launch_bounds__(1024) void k_prefix_single(const uint32_t *__restrict__ in, uint32_t n,
+                                                        uint32_t *__restrict__ out)
 {
-    uint32_t n = counters->n_hits;
-    if (n > cap) n = cap;
-    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-        const uint64_t key = hits[i];
+    __shared__ uint32_t wave_sum[16];
+    __shared__ uint32_t carry_s;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < n; base += 4096) {
+        const uint32_t i0 = base + threadIdx.x * 4u;
+        uint32_t val[4];
+        uint32_t s = 0;
+        for (uint32_t i = 0; i < 4; ++i) {
+            val[i] = (i0 + i < n) ? in[i0 + i] : 0u;
+            s += val[i];
+        }
+        // inclusive scan of s inside the wave
+        uint32_t x = s;
+        for (uint32_t d = 1; d < 64; d <<= 1) {
+            const uint32_t y = __shfl_up(x, d, 64);
+            if (lane >= d) x += y;
+        }
+        if (lane == 63) wave_sum[wave] = x;
+        __syncthreads();
+        uint32_t before = carry_s;
+        for (uint32_t wv = 0; wv < wave; ++wv) before += wave_sum[wv];
+        uint32_t run = before + x - s;
+        for (uint32_t i = 0; i < 4; ++i) {
+            if (i0 + i < n) out[i0 + i] = run;
+            run += val[i];
+        }
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = run;
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(kChunkRecs) void k_group_scatter(const uint64_t *__restrict__ raw,
+                                                              const Counters *__restrict__ counters, uint32_t cap_chunks,
+                                                              const uint32_t *__restrict__ goff, uint32_t *__restrict__ gcur,
+                                                              uint64_t *__restrict__ sorted)
+{
+    uint32_t n_chunks = counters->raw_chunks;
+    if (n_chunks > cap_chunks) n_chunks = cap_chunks;
+    for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+        const uint64_t *recs = raw + static_cast<uint64_t>(chunk) * kChunkRecs;
+        const uint32_t used = static_cast<uint32_t>(recs[0]);
+        const uint32_t t = threadIdx.x + 1u;
+        if (t >= used || t >= kChunkRecs) continue;
+        const uint64_t key = recs[t];
+        if (key == kDeadKey) continue;
         const uint32_t guide = static_cast<uint32_t>(key >> 35);
         const uint32_t slot = goff[guide] + atomicAdd(&gcur[guide], 1u);
         sorted[slot] = key;
@@ -696,13 +875,16 @@ void launch_group_hits(const Workspace &ws, uint32_t n, void *stream_)
 {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const uint32_t m = n + 1; // gcount[n] = 0 so that goff[n] = total
-    const uint32_t blocks = (m + kScanChunk - 1) / kScanChunk;
-    (void)hipMemsetAsync(ws.gcur, 0, sizeof(uint32_t) * n, stream);
-    hipLaunchKernelGGL(k_prefix_block_sums, dim3(blocks), dim3(256), 0, stream, ws.gcount, m, ws.blocksum);
-    hipLaunchKernelGGL(k_prefix_of_sums, dim3(1), dim3(256), 0, stream, ws.blocksum, blocks);
-    hipLaunchKernelGGL(k_prefix_apply, dim3(blocks), dim3(256), 0, stream, ws.gcount, m, ws.blocksum, ws.goff);
-    hipLaunchKernelGGL(k_group_scatter, dim3(1024), dim3(256), 0, stream, ws.hits, ws.counters,
-                       static_cast<uint32_t>(ws.cap_hits), ws.goff, ws.gcur, ws.sorted);
+    if (m <= (1u << 18)) {
+        hipLaunchKernelGGL(k_prefix_single, dim3(1), dim3(1024), 0, stream, ws.gcount, m, ws.goff);
+    } else {
+        const uint32_t blocks = (m + kScanChunk - 1) / kScanChunk;
+        hipLaunchKernelGGL(k_prefix_block_sums, dim3(blocks), dim3(256), 0, stream, ws.gcount, m, ws.blocksum);
+        hipLaunchKernelGGL(k_prefix_of_sums, dim3(1), dim3(256), 0, stream, ws.blocksum, blocks);
+        hipLaunchKernelGGL(k_prefix_apply, dim3(blocks), dim3(256), 0, stream, ws.gcount, m, ws.blocksum, ws.goff);
+    }
+    hipLaunchKernelGGL(k_group_scatter, dim3(4096), dim3(kChunkRecs), 0, stream, ws.raw, ws.counters,
+                       static_cast<uint32_t>(ws.cap_chunks), ws.goff, ws.gcur, ws.sorted);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -742,8 +924,16 @@ __device__ inline double bcast_f64(double x, int lane)
 }
 
 // precalculatedScores[mask] with operator[] semantics: a missing mask contributes 0.0 (:394).
+// Reference-built tables hold masks with flags on even bits below bit 40 only; for those the image carries a
+// dense 2^20-entry table indexed by the 20 flags (one load instead of a 13-step search).
 __device__ inline double mit_lookup(const ImageView &v, uint64_t mask)
 {
+    if (v.mit_dense) {
+        if (mask >> 40) return 0.0;
+        const uint32_t idx = gather_even16(static_cast<uint32_t>(mask)) |
+                             (gather_even16(static_cast<uint32_t>(mask >> 32)) << 16);
+        return v.mit_dense[idx];
+    }
     uint32_t lo = 0, hi = v.n_scores;
     while (lo < hi) {
         const uint32_t mid = (lo + hi) >> 1;
@@ -754,87 +944,131 @@ __device__ inline double mit_lookup(const ImageView &v, uint64_t mask)
     return 0.0;
 }
 
+// MIT and CFD terms of one scored off-target (isslScoreOfftargets.cpp:392-460) and its record.
+struct HitTerms {
+    double mit, cfd;
+    issl_hit rec;
+};
+
+__device__ inline HitTerms hit_terms(const ImageView &v, uint64_t gsig, uint32_t g, uint64_t key, bool calc_mit,
+                                     bool calc_cfd)
+{
+    HitTerms t;
+    t.mit = 0.0;
+    t.cfd = 0.0;
+    const uint64_t low = (1ull << v.slice_width) - 1ull;
+    const uint32_t slice = static_cast<uint32_t>(key >> 32) & 7u;
+    const uint32_t pos = static_cast<uint32_t>(key);
+    const uint32_t bucket = (slice << v.slice_width) + static_cast<uint32_t>((gsig >> (v.slice_width * slice)) & low);
+    const uint64_t e = v.entries[v.bucket_start[bucket] + pos];
+    const uint32_t id = static_cast<uint32_t>(e);
+    const uint32_t occ = static_cast<uint32_t>(e >> 32);
+    const uint64_t ot = v.sites[id];
+    const uint64_t mm = mismatch_mask(gsig, ot);
+    const int dist = __builtin_popcountll(mm);
+    if (calc_mit && dist > 0) t.mit = mit_lookup(v, mm) * static_cast<double>(occ); // :394
+    if (calc_cfd) {                                                                // :399-460
+        double cfd;
+        if (dist == 0) {
+            cfd = 1.0;
+        } else {
+            cfd = issl_cfd_pam[10];
+            for (uint32_t q = 0; q < 20; ++q) {
+                const uint32_t gb = static_cast<uint32_t>(gsig >> (2 * q)) & 3u;
+                const uint32_t ob = static_cast<uint32_t>(ot >> (2 * q)) & 3u;
+                if (gb != ob) cfd *= issl_cfd_pos[(q << 4) | (gb << 2) | (ob ^ 3u)];
+            }
+        }
+        t.cfd = cfd * static_cast<double>(occ);
+    }
+    t.rec.guide = g; t.rec.slice = slice; t.rec.pos = pos; t.rec.id = id;
+    t.rec.dist = static_cast<uint32_t>(dist); t.rec.occ = occ;
+    return t;
+}
+
 __global__ __launch_bounds__(64) void k_replay(ImageView v, Workspace ws, const uint64_t *__restrict__ guides,
                                                uint32_t n, ScoreParams p, double *__restrict__ out_mit,
                                                double *__restrict__ out_cfd, uint32_t *__restrict__ out_kept,
                                                issl_hit *__restrict__ out_hits)
 {
     __shared__ uint64_t keys[kReplayLds];
+    __shared__ double ord_mit[64], ord_cfd[64];
     const bool calc_mit = p.method == ISSL_METHOD_MIT || p.method == ISSL_METHOD_AND || p.method == ISSL_METHOD_OR ||
                           p.method == ISSL_METHOD_AVG;
     const bool calc_cfd = p.method == ISSL_METHOD_CFD || p.method == ISSL_METHOD_AND || p.method == ISSL_METHOD_OR ||
                           p.method == ISSL_METHOD_AVG;
     const uint32_t lane = threadIdx.x;
-    const uint64_t low = (1ull << v.slice_width) - 1ull;
 
     for (uint32_t g = blockIdx.x; g < n; g += gridDim.x) {
         const uint32_t h0 = ws.goff[g];
         const uint32_t h = ws.goff[g + 1] - h0;
-        uint64_t *data;
-        if (h <= kReplayLds) {
-            for (uint32_t i = lane; i < h; i += 64) keys[i] = ws.sorted[h0 + i];
-            data = keys;
-        } else {
-            data = ws.sorted + h0;
-        }
-        __syncthreads();
-        wave_sort(data, h);
-        __syncthreads();
-
         const uint64_t gsig = guides[g];
         double tot_mit = 0.0, tot_cfd = 0.0;
         uint32_t kept = 0;
         bool stop = false;
-        for (uint32_t base = 0; base < h && !stop; base += 64) {
-            const uint32_t idx = base + lane;
-            double mit_term = 0.0, cfd_term = 0.0;
-            if (idx < h) {
-                const uint64_t key = data[idx];
-                const uint32_t slice = static_cast<uint32_t>(key >> 32) & 7u;
-                const uint32_t pos = static_cast<uint32_t>(key);
-                const uint32_t bucket =
-                    (slice << v.slice_width) + static_cast<uint32_t>((gsig >> (v.slice_width * slice)) & low);
-                const uint64_t e = v.entries[v.bucket_start[bucket] + pos];
-                const uint32_t id = static_cast<uint32_t>(e);
-                const uint32_t occ = static_cast<uint32_t>(e >> 32);
-                const uint64_t ot = v.sites[id];
-                const uint64_t mm = mismatch_mask(gsig, ot);
-                const int dist = __builtin_popcountll(mm);
-                if (calc_mit && dist > 0) mit_term = mit_lookup(v, mm) * static_cast<double>(occ); // :394
-                if (calc_cfd) {                                                                   // :399-460
-                    double cfd;
-                    if (dist == 0) {
-                        cfd = 1.0;
-                    } else {
-                        cfd = issl_cfd_pam[10];
-                        for (uint32_t q = 0; q < 20; ++q) {
-                            const uint32_t gb = static_cast<uint32_t>(gsig >> (2 * q)) & 3u;
-                            const uint32_t ob = static_cast<uint32_t>(ot >> (2 * q)) & 3u;
-                            if (gb != ob) cfd *= issl_cfd_pos[(q << 4) | (gb << 2) | (ob ^ 3u)];
-                        }
-                    }
-                    cfd_term = cfd * static_cast<double>(occ);
-                }
-                if (out_hits) {
-                    issl_hit rec;
-                    rec.guide = g; rec.slice = slice; rec.pos = pos; rec.id = id;
-                    rec.dist = static_cast<uint32_t>(dist); rec.occ = occ;
-                    out_hits[h0 + idx] = rec;
-                }
-            }
-            const uint32_t cnt = (h - base < 64u) ? h - base : 64u;
+
+        // Running totals in key order, same operations as the reference's (:394,:460), early exit of :467-496.
+        auto accumulate = [&](double mit_term, double cfd_term, uint32_t cnt) {
             for (uint32_t l = 0; l < cnt; ++l) {
-                // same order and same operations as the reference's running totals (:394,:460)
                 tot_mit += bcast_f64(mit_term, static_cast<int>(l));
                 tot_cfd += bcast_f64(cfd_term, static_cast<int>(l));
                 ++kept;
-                bool exit_now = false;                                            // :467-496
+                bool exit_now = false;
                 if (p.method == ISSL_METHOD_AND) exit_now = tot_mit > p.maximum_sum && tot_cfd > p.maximum_sum;
                 else if (p.method == ISSL_METHOD_OR) exit_now = tot_mit > p.maximum_sum || tot_cfd > p.maximum_sum;
                 else if (p.method == ISSL_METHOD_AVG) exit_now = ((tot_mit + tot_cfd) / 2.0) > p.maximum_sum;
                 else if (p.method == ISSL_METHOD_MIT) exit_now = tot_mit > p.maximum_sum;
                 else if (p.method == ISSL_METHOD_CFD) exit_now = tot_cfd > p.maximum_sum;
                 if (exit_now) { stop = true; break; }
+            }
+        };
+
+        if (h <= 64) {
+            // Common case: no sort.  Lane l takes key l, computes its terms, finds the rank of its key among the
+            // h keys by counting, and drops the terms at that rank; lane r then owns the r-th hit in key order.
+            uint64_t key = ~0ull;
+            HitTerms t;
+            t.mit = 0.0; t.cfd = 0.0;
+            if (lane < h) {
+                key = ws.sorted[h0 + lane];
+                t = hit_terms(v, gsig, g, key, calc_mit, calc_cfd);
+            }
+            uint32_t rank = 0;
+            for (uint32_t j = 0; j < h; ++j) {
+                const uint32_t klo = __builtin_amdgcn_readlane(static_cast<uint32_t>(key), static_cast<int>(j));
+                const uint32_t khi = __builtin_amdgcn_readlane(static_cast<uint32_t>(key >> 32), static_cast<int>(j));
+                const uint64_t other = (static_cast<uint64_t>(khi) << 32) | klo;
+                rank += (other < key) ? 1u : 0u;
+            }
+            if (lane < h) {
+                ord_mit[rank] = t.mit;
+                ord_cfd[rank] = t.cfd;
+                if (out_hits) out_hits[h0 + rank] = t.rec;
+            }
+            __syncthreads();
+            const double mit_term = lane < h ? ord_mit[lane] : 0.0;
+            const double cfd_term = lane < h ? ord_cfd[lane] : 0.0;
+            accumulate(mit_term, cfd_term, h);
+        } else {
+            uint64_t *data;
+            if (h <= kReplayLds) {
+                for (uint32_t i = lane; i < h; i += 64) keys[i] = ws.sorted[h0 + i];
+                data = keys;
+            } else {
+                data = ws.sorted + h0;
+            }
+            __syncthreads();
+            wave_sort(data, h);
+            __syncthreads();
+            for (uint32_t base = 0; base < h && !stop; base += 64) {
+                const uint32_t idx = base + lane;
+                HitTerms t;
+                t.mit = 0.0; t.cfd = 0.0;
+                if (idx < h) {
+                    t = hit_terms(v, gsig, g, data[idx], calc_mit, calc_cfd);
+                    if (out_hits) out_hits[h0 + idx] = t.rec;
+                }
+                accumulate(t.mit, t.cfd, (h - base < 64u) ? h - base : 64u);
             }
         }
         if (lane == 0) {
