@@ -196,7 +196,9 @@ static int ensure_workspace(issl_index *ix, size_t n)
     }
     if (w.cap_chunks == 0) {
         // every scan wave may hold one partly filled chunk; beyond that ~1 record per 50k comparisons
-        const size_t want = std::max<size_t>(size_t(kScanGridBlocks) * 4 * 4, n);
+        size_t want = std::max<size_t>(size_t(kScanGridBlocks) * 4 * 4, n);
+        // ISSL_RAW_CHUNKS=<n>: start with a small raw buffer (tests of the grow-and-rerun path)
+        if (const char *e = std::getenv("ISSL_RAW_CHUNKS")) want = std::max<size_t>(1, std::strtoull(e, nullptr, 10));
         if ((rc = ensure_raw_capacity(ix, want))) return rc;
     }
     if (!ix->have_events) {

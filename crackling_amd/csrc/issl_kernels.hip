@@ -575,7 +575,8 @@ __global__ __launch_bounds__(256, 6) void k_scan(const uint32_t *__restrict__ sc
     uint32_t range = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
     // Raw records: the wave's first chunk is the one with its own number (no atomic); k_reset cleared its header.
     RawWriter w;
-    w.chunk = raw + static_cast<uint64_t>(range < max_chunks ? range : max_chunks) * kChunkRecs;
+    const bool no_own_chunk = range >= max_chunks; // buffer smaller than the wave count: spare chunk + overflow flag
+    w.chunk = raw + static_cast<uint64_t>(no_own_chunk ? max_chunks : range) * kChunkRecs;
     w.fill = 1;
     bool own_chunk = false;
 
@@ -650,7 +651,10 @@ __global__ __launch_bounds__(256, 6) void k_scan(const uint32_t *__restrict__ sc
             range = take_ticket(counters, n_static, n_ranges, lane);
         }
     }
-    if (own_chunk) raw_retire(w, lane);
+    if (own_chunk) {
+        raw_retire(w, lane);
+        if (no_own_chunk && lane == 0) counters->raw_overflow = 1u;
+    }
 }
 
 // Exact check of the raw records, IN PLACE: one thread per record, one chunk per 128-thread workgroup.

@@ -225,9 +225,23 @@ def test_image_attach_and_caller_owned_memory(golden_uniform):
     att.close(); src.close()
 
 
-def test_hit_buffer_growth(golden):
-    """Force the overflow path: tiny first buffer cannot be requested through the ABI, so score a batch whose hits
-    exceed the initial 2^20 capacity only if the fixture is dense enough; otherwise check the counter."""
+def test_raw_buffer_growth_reruns_the_batch(golden_uniform, monkeypatch):
+    """Start with a raw-record buffer far too small for the batch (fewer chunks than scan waves): the library must
+    notice, grow it and re-run, with the golden results."""
+    monkeypatch.setenv("ISSL_RAW_CHUNKS", "7")
+    ix = ca.IsslIndex.open(golden_uniform.issl).upload(0)
+    sigs = ca.encode_guides([g.encode() for g in golden_uniform.guides])
+    mit, cfd = ix.score(sigs, 4, 75.0, "and")
+    st = ix.stats()
+    assert st["scan_launches"] >= 2, st
+    assert ca.format_scores(sigs, mit, cfd, "and") == golden_uniform.expected["and|75|4"]
+    hits = ix.dump_hits(sigs, 4, 0.0, "and")
+    assert np.array_equal(hits, golden_uniform.hits(0))
+    assert ix.stats()["scan_launches"] == 1  # capacity is kept
+    ix.close()
+
+
+def test_hit_counter(golden):
     ix = ca.IsslIndex.open(golden.issl).upload(0)
     sigs = ca.encode_guides([g.encode() for g in golden.guides])
     ix.score(sigs, 4, 0.0, "and")
