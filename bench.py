@@ -70,6 +70,8 @@ def main():
     ap.add_argument("--threshold", type=float, default=75.0)
     ap.add_argument("--max-dist", type=int, default=4)
     ap.add_argument("--method", default="and")
+    ap.add_argument("--dist", choices=["uniform", "markov"], default="uniform",
+                    help="site distribution: iid uniform bases (BASELINE configs) or an AT-rich order-3 Markov chain")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 
@@ -84,7 +86,7 @@ def main():
     import crackling_amd as ca  # loads libissl_hip.so (fails loudly if missing)
     import torch
     import torch.distributed as dist
-    from synth import random_sites, random_guides
+    from synth import random_sites, random_guides, markov_sites
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU path to time)")
@@ -104,7 +106,7 @@ def main():
     sigs = None
     timings = {}
     if rank == 0:
-        sigs, occ = random_sites(a.sites, seed=20261003)
+        sigs, occ = (markov_sites if a.dist == "markov" else random_sites)(a.sites, seed=20261003)
         timings["synth_s"] = time.perf_counter() - t0
         t1 = time.perf_counter()
         host = ca.IsslIndex.build_from_sites(sigs, occ)
@@ -221,9 +223,9 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"{a.guides} guides per GPU per step vs {a.sites}-line ({hdr['n_sites']} distinct sites) "
-                            f"uniform synthetic ISSL index, 20 bp, slice width 8, <= {a.max_dist} mismatches, "
+                            f"{'uniform' if a.dist == 'uniform' else 'AT-rich order-3 Markov'} synthetic ISSL index, 20 bp, slice width 8, <= {a.max_dist} mismatches, "
                             f"MIT+CFD ('{a.method}', threshold {a.threshold:g}); index and guides resident in HBM",
-                "guides_per_gpu": a.guides, "sites": a.sites, "distinct_sites": hdr["n_sites"],
+                "guides_per_gpu": a.guides, "sites": a.sites, "distribution": a.dist, "distinct_sites": hdr["n_sites"],
                 "max_dist": a.max_dist, "threshold": a.threshold, "method": a.method,
                 "parallelism": f"guide shards x{world}, replicated index" if world > 1 else "single GPU",
             },

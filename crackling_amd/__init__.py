@@ -10,6 +10,7 @@ library raises immediately -- there is no CPU fallback.
 from ._lib import lib, IsslError, LIB_PATH  # noqa: F401
 from .scorer import (  # noqa: F401
     IsslIndex,
+    IsslNode,
     METHODS,
     encode_guides,
     decode_guides,
@@ -19,6 +20,6 @@ from .scorer import (  # noqa: F401
 )
 
 __all__ = [
-    "IsslIndex", "IsslError", "METHODS", "encode_guides", "decode_guides", "format_scores",
+    "IsslIndex", "IsslNode", "IsslError", "METHODS", "encode_guides", "decode_guides", "format_scores",
     "run_scorer_binary", "parse_scorer_output", "lib", "LIB_PATH",
 ]

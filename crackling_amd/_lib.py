@@ -59,6 +59,11 @@ class Stats(C.Structure):
     ]
 
 
+class NodeInfo(C.Structure):
+    _fields_ = [("n_devices", C.c_int), ("used_rccl", C.c_int), ("ms_upload", C.c_double),
+                ("ms_broadcast", C.c_double), ("ms_last_score", C.c_double)]
+
+
 _P = C.c_void_p
 _u64p = C.POINTER(C.c_uint64)
 _f64p = C.POINTER(C.c_double)
@@ -89,6 +94,10 @@ _protos = {
     "issl_dump_hits": (C.c_int, [_P, _P, C.c_size_t, C.c_int, C.c_double, C.c_int, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     "issl_last_stats": (C.c_int, [_P, C.POINTER(Stats)]),
     "issl_count_candidates": (C.c_int, [_P, _P, C.c_size_t, C.POINTER(C.c_uint64)]),
+    "issl_node_create": (C.c_int, [_P, C.POINTER(C.c_int), C.c_int, C.POINTER(_P)]),
+    "issl_node_score": (C.c_int, [_P, _P, C.c_size_t, C.c_int, C.c_double, C.c_int, _P, _P]),
+    "issl_node_get_info": (C.c_int, [_P, C.POINTER(NodeInfo)]),
+    "issl_node_close": (C.c_int, [_P]),
 }
 for _name, (_res, _args) in _protos.items():
     _fn = getattr(lib, _name)  # AttributeError here = library/header mismatch: fail loudly

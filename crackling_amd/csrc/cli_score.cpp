@@ -7,6 +7,8 @@
 // that was not requested); diagnostics go to stderr; exit status 1 on any error.
 // Optional environment (the five positionals stay untouched so that Crackling needs no change):
 //   ISSL_DEVICE=<n>   HIP device to use (default 0)
+//   ISSL_DEVICES=all | <a,b,...>   several GPUs of the node: index image broadcast over RCCL/xGMI, guides sharded
+//                     (default: one device; all visible devices when the query file holds >= 2^20 guides)
 //   ISSL_TIMING=1     one JSON line with load/upload/score timings on stderr
 #include <chrono>
 #include <cstdio>
@@ -55,10 +57,39 @@ int main(int argc, char **argv)
     size_t n = 0;
     if (issl_read_query_file(argv[2], hdr.seq_len, &guides, &n)) return fail("cannot read query file");
     const double t1 = now_ms();
-    if (issl_index_upload(idx, device)) return fail("cannot upload index");
-    const double t2 = now_ms();
+    // device selection
+    std::vector<int> devices;
+    bool all_devices = false;
+    if (const char *list = std::getenv("ISSL_DEVICES")) {
+        if (!std::strcmp(list, "all")) {
+            all_devices = true;
+        } else {
+            for (const char *p = list; *p;) {
+                char *end = nullptr;
+                const long d = std::strtol(p, &end, 10);
+                if (end == p) break;
+                devices.push_back(static_cast<int>(d));
+                p = (*end == ',') ? end + 1 : end;
+            }
+        }
+    } else if (!dev_env && n >= (size_t(1) << 20)) {
+        all_devices = true;
+    }
     std::vector<double> mit(n), cfd(n);
-    if (issl_score(idx, guides, n, max_dist, threshold, method, mit.data(), cfd.data())) return fail("scoring failed");
+    issl_node *node = nullptr;
+    double t2;
+    if (all_devices || devices.size() > 1) {
+        if (issl_node_create(idx, all_devices ? nullptr : devices.data(), static_cast<int>(devices.size()), &node))
+            return fail("cannot set up the devices");
+        t2 = now_ms();
+        if (issl_node_score(node, guides, n, max_dist, threshold, method, mit.data(), cfd.data()))
+            return fail("scoring failed");
+    } else {
+        const int dev = devices.size() == 1 ? devices[0] : device;
+        if (issl_index_upload(idx, dev)) return fail("cannot upload index");
+        t2 = now_ms();
+        if (issl_score(idx, guides, n, max_dist, threshold, method, mit.data(), cfd.data())) return fail("scoring failed");
+    }
     const double t3 = now_ms();
 
     // :514-527
@@ -79,7 +110,14 @@ int main(int argc, char **argv)
         return 1;
     }
     std::fflush(stdout);
-    if (timing) {
+    if (timing && node) {
+        issl_node_info inf;
+        issl_node_get_info(node, &inf);
+        std::fprintf(stderr,
+                     "{\"guides\": %zu, \"devices\": %d, \"rccl\": %d, \"load_ms\": %.3f, \"upload_ms\": %.3f, "
+                     "\"broadcast_ms\": %.3f, \"score_ms\": %.3f}\n",
+                     n, inf.n_devices, inf.used_rccl, t1 - t0, inf.ms_upload, inf.ms_broadcast, inf.ms_last_score);
+    } else if (timing) {
         issl_stats st;
         issl_last_stats(idx, &st);
         std::fprintf(stderr,
@@ -89,6 +127,7 @@ int main(int argc, char **argv)
                      (unsigned long long)st.hits);
     }
     issl_free(guides);
+    if (node) issl_node_close(node);
     issl_index_close(idx);
     return 0;
 }

@@ -210,6 +210,45 @@ class IsslIndex:
             pass
 
 
+class IsslNode:
+    """Several GPUs of this node in one process: the index image is uploaded on devices[0], broadcast (RCCL over
+    xGMI, peer copies as fallback) and every batch is cut into contiguous shards, one host thread per device."""
+
+    def __init__(self, index, devices=None):
+        self._index = index  # keep the host arrays / root image alive
+        h = C.c_void_p()
+        if devices is None:
+            check(lib.issl_node_create(index._h, None, 0, C.byref(h)))
+        else:
+            arr = (C.c_int * len(devices))(*devices)
+            check(lib.issl_node_create(index._h, arr, len(devices), C.byref(h)))
+        self._h = h
+
+    def score(self, guides, max_dist=4, threshold=75.0, method="and"):
+        sigs = self._index._sigs(guides)
+        mit = np.empty(len(sigs), dtype=np.float64)
+        cfd = np.empty(len(sigs), dtype=np.float64)
+        check(lib.issl_node_score(self._h, sigs.ctypes.data, len(sigs), int(max_dist), float(threshold),
+                                  _method_code(method), mit.ctypes.data, cfd.ctypes.data))
+        return mit, cfd
+
+    def info(self):
+        inf = _lib.NodeInfo()
+        check(lib.issl_node_get_info(self._h, C.byref(inf)))
+        return {n: getattr(inf, n) for n, _ in inf._fields_}
+
+    def close(self):
+        if self._h:
+            lib.issl_node_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def run_scorer_binary(binary, issl_path, guides23, max_dist, threshold, method, workdir=None, env=None):
     """What Crackling.py:747-778 does for one page of guides: returns the scorer's stdout text.
 

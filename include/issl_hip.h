@@ -173,6 +173,30 @@ int issl_last_stats(const issl_index *idx, issl_stats *out);
 /* Sum over guides of the five bucket lengths (SURVEY 8d cross-check), host arithmetic only. */
 int issl_count_candidates(const issl_index *idx, const uint64_t *guides, size_t n, uint64_t *out);
 
+/* ---- one process, several GPUs of the node ------------------------------------------------ */
+/* The reference's outer loop is data-parallel over guides (isslScoreOfftargets.cpp:316-509 reads only the
+ * index): a node replicates the HBM image on every listed device -- uploaded once on devices[0], then broadcast
+ * with RCCL (ncclBroadcast over xGMI; peer copies when RCCL cannot be used, e.g. a device listed twice) -- and
+ * cuts every batch into contiguous shards, one host thread per device.  bin/isslScoreOfftargets uses it when
+ * ISSL_DEVICES names more than one device (or for very large query files). */
+typedef struct issl_node issl_node;
+
+typedef struct {
+    int n_devices;
+    int used_rccl;         /* 1: image moved by ncclBroadcast, 0: hipMemcpyPeer */
+    double ms_upload;      /* host -> devices[0] including the scan-stream transform */
+    double ms_broadcast;   /* devices[0] -> all others */
+    double ms_last_score;  /* wall time of the last issl_node_score call */
+} issl_node_info;
+
+/* idx must have host arrays (opened from a file or built); it stays owned by the caller and must outlive the
+ * node.  devices may be NULL: then all visible devices are used. */
+int issl_node_create(issl_index *idx, const int *devices, int n_devices, issl_node **out);
+int issl_node_score(issl_node *node, const uint64_t *guides, size_t n, int max_dist, double threshold,
+                    int method, double *mit, double *cfd);
+int issl_node_get_info(const issl_node *node, issl_node_info *out);
+int issl_node_close(issl_node *node);
+
 #ifdef __cplusplus
 }
 #endif

@@ -61,3 +61,35 @@ def sigs_to_text(sigs, occ=None, seq_len=20):
         arr[:, j] = letters[((sigs >> np.uint64(2 * j)) & np.uint64(3)).astype(np.int64)]
     arr[:, seq_len] = ord("\n")
     return arr.tobytes()
+
+
+def markov_sites(n_lines, seed, seq_len=20, at_bias=0.62, order=3):
+    """Skewed site list: order-3 Markov chain with an AT-rich stationary bias and context-dependent
+    transition rows drawn once from a Dirichlet.  Buckets of AT-rich slices come out several times larger than
+    GC-rich ones and near-duplicate neighbourhoods are frequent.  Returns (sigs, occ) like random_sites()."""
+    rng = np.random.default_rng(seed)
+    base_p = np.array([at_bias / 2, (1 - at_bias) / 2, (1 - at_bias) / 2, at_bias / 2])  # A C G T
+    n_ctx = 4 ** order
+    rows = rng.dirichlet(base_p * 6.0, size=n_ctx)          # one transition row per context
+    cum = np.cumsum(rows, axis=1)
+    cum[:, -1] = 1.0
+    codes = np.empty((seq_len, n_lines), dtype=np.uint8)
+    ctx = np.zeros(n_lines, dtype=np.int64)
+    for p in range(seq_len):
+        u = rng.random(n_lines)
+        c = cum[ctx] if p >= order else np.broadcast_to(np.cumsum(base_p), (n_lines, 4))
+        b = (u[:, None] > c[:, :3]).sum(axis=1).astype(np.uint8)
+        codes[p] = b
+        ctx = ((ctx * 4) + b) % n_ctx
+    sig = np.zeros(n_lines, dtype=np.uint64)
+    for p in range(seq_len):
+        sig |= codes[p].astype(np.uint64) << np.uint64(2 * p)
+    key = text_order_key(sig, seq_len)
+    order_ix = np.argsort(key, kind="stable")
+    sig = sig[order_ix]
+    key = key[order_ix]
+    first = np.ones(len(key), dtype=bool)
+    first[1:] = key[1:] != key[:-1]
+    idx = np.flatnonzero(first)
+    occ = np.diff(np.append(idx, len(key))).astype(np.uint32)
+    return sig[idx], occ

@@ -225,6 +225,42 @@ def test_image_attach_and_caller_owned_memory(golden_uniform):
     att.close(); src.close()
 
 
+def test_node_sharding_and_rccl_broadcast(golden_uniform, monkeypatch):
+    """In-process multi-GPU orchestration on the one GPU of the test box: (a) two replicas on device 0 (peer-copy
+    path: RCCL refuses a device listed twice) exercise sharding, host threads and the gather into the caller's
+    arrays; (b) a one-device node with ISSL_FORCE_RCCL=1 runs ncclCommInitAll + ncclBroadcast for real."""
+    sigs = ca.encode_guides([g.encode() for g in golden_uniform.guides])
+    want = golden_uniform.expected["and|75|4"]
+    ix = ca.IsslIndex.open(golden_uniform.issl)
+    node = ca.IsslNode(ix, devices=[0, 0, 0])
+    inf = node.info()
+    assert inf["n_devices"] == 3 and inf["used_rccl"] == 0
+    mit, cfd = node.score(sigs[:101], 4, 75.0, "and")  # ragged shards 34/34/33
+    assert ca.format_scores(sigs[:101], mit, cfd, "and") == "".join(want.splitlines(True)[:101])
+    mit, cfd = node.score(sigs, 4, 75.0, "and")
+    assert ca.format_scores(sigs, mit, cfd, "and") == want
+    mit, cfd = node.score(sigs[:2], 4, 75.0, "and")    # fewer guides than devices
+    assert ca.format_scores(sigs[:2], mit, cfd, "and") == "".join(want.splitlines(True)[:2])
+    node.close(); ix.close()
+    monkeypatch.setenv("ISSL_FORCE_RCCL", "1")
+    ix = ca.IsslIndex.open(golden_uniform.issl)
+    node = ca.IsslNode(ix, devices=[0])
+    assert node.info()["used_rccl"] == 1, "RCCL could not be loaded or the broadcast failed"
+    mit, cfd = node.score(sigs, 4, 75.0, "and")
+    assert ca.format_scores(sigs, mit, cfd, "and") == want
+    node.close(); ix.close()
+
+
+def test_cli_multi_device_env(golden_uniform):
+    exe = ROOT / "bin" / "isslScoreOfftargets"
+    env = dict(os.environ, ISSL_DEVICES="0,0", ISSL_TIMING="1")
+    r = subprocess.run([str(exe), str(golden_uniform.issl), str(golden_uniform.guides_txt), "4", "75", "and"],
+                       capture_output=True, env=env)
+    assert r.returncode == 0, r.stderr.decode()
+    assert r.stdout.decode() == golden_uniform.expected["and|75|4"]
+    assert b'"devices": 2' in r.stderr
+
+
 def test_raw_buffer_growth_reruns_the_batch(golden_uniform, monkeypatch):
     """Start with a raw-record buffer far too small for the batch (fewer chunks than scan waves): the library must
     notice, grow it and re-run, with the golden results."""
