@@ -225,6 +225,47 @@ def test_image_attach_and_caller_owned_memory(golden_uniform):
     att.close(); src.close()
 
 
+def test_guides_with_thousands_of_hits(tmp_path):
+    """Dense neighbourhoods: one guide with ~6000 scored off-targets (replay sorts in HBM, beyond the 2048-key LDS
+    buffer), one with ~1500 (LDS sort) and one with a few dozen (rank path), each with and without early exit."""
+    rng = np.random.default_rng(77)
+    centres = rng.integers(0, 1 << 40, size=3, dtype=np.uint64)
+
+    def neighbours(c, count, max_sub):
+        out = set()
+        while len(out) < count:
+            s = int(c)
+            for p in rng.choice(20, size=int(rng.integers(0, max_sub + 1)), replace=False):
+                s ^= int(rng.integers(1, 4)) << (2 * int(p))
+            out.add(s)
+        return out
+
+    sites = neighbours(centres[0], 6000, 4) | neighbours(centres[1], 1500, 3) | neighbours(centres[2], 40, 2)
+    sites |= set(int(x) for x in rng.integers(0, 1 << 40, size=20000, dtype=np.uint64))
+    sig = np.array(sorted(sites), dtype=np.uint64)
+    from synth import text_order_key
+    sig = sig[np.argsort(text_order_key(sig), kind="stable")]
+    occ = rng.integers(1, 4, size=len(sig)).astype(np.uint32)
+    ix = ca.IsslIndex.build_from_sites(sig, occ)
+    p = tmp_path / "dense.issl"
+    ix.write(p)
+    ix.upload(0)
+    oracle = ou.OracleIndex(p)
+    guides = np.concatenate([centres, centres ^ np.uint64(3)])
+    for thr in (0.0, 75.0, 99.0):
+        for method in ("and", "or", "mit", "cfd"):
+            mit, cfd = ix.score(guides, 4, thr, method)
+            omit, ocfd = oracle.score(guides, 4, thr, method)
+            assert np.array_equal(mit.view(np.uint64), omit.view(np.uint64)), (thr, method)
+            assert np.array_equal(cfd.view(np.uint64), ocfd.view(np.uint64)), (thr, method)
+    hits = ix.dump_hits(guides, 4, 0.0, "and")
+    _, _, ohits = oracle.score(guides, 4, 0.0, "and", want_hits=True)
+    assert np.array_equal(hits, ohits)
+    per_guide = np.bincount(hits[:, 0], minlength=len(guides))
+    assert per_guide.max() > 2048 and 64 < per_guide[1] <= 2048
+    ix.close()
+
+
 def test_node_sharding_and_rccl_broadcast(golden_uniform, monkeypatch):
     """In-process multi-GPU orchestration on the one GPU of the test box: (a) two replicas on device 0 (peer-copy
     path: RCCL refuses a device listed twice) exercise sharding, host threads and the gather into the caller's
