@@ -55,7 +55,7 @@ class Stats(C.Structure):
     _fields_ = [
         ("n_guides", C.c_uint64), ("candidates", C.c_uint64), ("hits", C.c_uint64), ("scan_tiles", C.c_uint64),
         ("ms_bin", C.c_double), ("ms_scan", C.c_double), ("ms_verify", C.c_double), ("ms_group", C.c_double),
-        ("ms_replay", C.c_double), ("ms_total", C.c_double), ("scan_launches", C.c_uint64), ("raw_records", C.c_uint64),
+        ("ms_replay", C.c_double), ("ms_total", C.c_double), ("scan_launches", C.c_uint64), ("raw_records", C.c_uint64), ("n_batches", C.c_uint64),
     ]
 
 
@@ -91,6 +91,8 @@ _protos = {
     "issl_method_from_string": (C.c_int, [C.c_char_p]),
     "issl_score": (C.c_int, [_P, _P, C.c_size_t, C.c_int, C.c_double, C.c_int, _P, _P]),
     "issl_score_device": (C.c_int, [_P, _P, C.c_size_t, C.c_int, C.c_double, C.c_int, _P, _P, _P]),
+    "issl_score_device_async": (C.c_int, [_P, _P, C.c_size_t, C.c_int, C.c_double, C.c_int, _P, _P, _P]),
+    "issl_score_finish": (C.c_int, [_P, _P]),
     "issl_dump_hits": (C.c_int, [_P, _P, C.c_size_t, C.c_int, C.c_double, C.c_int, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     "issl_last_stats": (C.c_int, [_P, C.POINTER(Stats)]),
     "issl_count_candidates": (C.c_int, [_P, _P, C.c_size_t, C.POINTER(C.c_uint64)]),

@@ -70,6 +70,8 @@ ImageView make_view(const ImageHeader &h, void *base)
 
 } // namespace issl
 
+constexpr uint32_t kRing = 64;
+
 struct issl_index {
     std::unique_ptr<HostIndex> host; // absent for attached images
     Geometry geo;
@@ -82,8 +84,13 @@ struct issl_index {
     ImageView view{};
     Workspace ws;
     hipEvent_t ev[6] = {};
+    hipEvent_t ring[2 * kRing] = {}; // scan begin/end of the batches enqueued since the last finish
     bool have_events = false;
     issl_stats stats{};
+    // batches enqueued and not yet finished
+    uint32_t n_pending = 0;
+    uint32_t last_n = 0;
+    bool last_dump = false;
 };
 
 #define HIP_TRY(expr)                                                                              \
@@ -122,7 +129,7 @@ static int select_device(int device)
 
 static void free_workspace(Workspace &w)
 {
-    void *ptrs[] = {w.ng, w.gfill, w.gstart, w.gword, w.gidx, w.items, w.plan, w.range_start, w.counters, w.sorted, w.gcount,
+    void *ptrs[] = {w.ng, w.gfill, w.gstart, w.gword, w.gidx, w.items, w.plan, w.range_start, w.counters, w.sticky, w.sorted, w.gcount,
                     w.goff, w.gcur, w.blocksum, w.d_guides, w.d_mit, w.d_cfd, w.d_kept, w.d_hitrec};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -203,7 +210,12 @@ static int ensure_workspace(issl_index *ix, size_t n)
     }
     if (!ix->have_events) {
         for (auto &e : ix->ev) HIP_TRY(hipEventCreate(&e));
+        for (auto &e : ix->ring) HIP_TRY(hipEventCreate(&e));
         ix->have_events = true;
+    }
+    if (!w.sticky) {
+        if ((rc = dev_alloc(w.sticky, 4))) return rc;
+        HIP_TRY(hipMemset(w.sticky, 0, 16));
     }
     return ISSL_OK;
 }
@@ -286,6 +298,7 @@ static void release_device(issl_index *ix)
     free_workspace(ix->ws);
     if (ix->have_events) {
         for (auto &e : ix->ev) (void)hipEventDestroy(e);
+        for (auto &e : ix->ring) (void)hipEventDestroy(e);
         ix->have_events = false;
     }
     if (ix->d_image && ix->owns_image) (void)hipFree(ix->d_image);
@@ -308,8 +321,10 @@ static int new_index_from_host(std::unique_ptr<HostIndex> h, issl_index **out)
 }
 
 // The scoring pipeline.  Guides and outputs are device pointers on ix->device.
-static int score_core(issl_index *ix, const uint64_t *d_guides, size_t n, int max_dist, double threshold, int method,
-                      double *d_mit, double *d_cfd, hipStream_t stream, bool dump)
+// enqueue_batch() only launches (no host round trip); finish_batches() synchronises, checks the sticky overflow
+// word the pipeline leaves behind, and fills the statistics.
+static int enqueue_batch(issl_index *ix, const uint64_t *d_guides, size_t n, int max_dist, double threshold,
+                         int method, double *d_mit, double *d_cfd, hipStream_t stream, bool dump)
 {
     if (!ix->d_image) {
         set_error("index has no device image: call issl_index_upload first");
@@ -320,73 +335,120 @@ static int score_core(issl_index *ix, const uint64_t *d_guides, size_t n, int ma
         return ISSL_E_ARG;
     }
     HIP_TRY(hipSetDevice(ix->device));
-    ix->stats = issl_stats{};
-    ix->stats.n_guides = n;
     if (n == 0) return ISSL_OK;
     int rc = ensure_workspace(ix, n);
     if (rc) return rc;
+    // `sorted` always has room for every raw slot, so the whole pipeline runs without a host round trip;
+    // an exhausted raw buffer is detected in finish_batches() and the batch is re-run with a larger one.
+    rc = ensure_hit_capacity(ix, ix->ws.cap_chunks * (kChunkRecs - 1));
+    if (rc) return rc;
+    if (dump && ix->ws.cap_hitrec < ix->ws.cap_hits) {
+        rc = dev_alloc(ix->ws.d_hitrec, ix->ws.cap_hits);
+        if (rc) return rc;
+        ix->ws.cap_hitrec = ix->ws.cap_hits;
+    }
     ScoreParams p;
     p.max_dist = max_dist;
     p.method = method;
     p.maximum_sum = (10000.0 - threshold * 100) / threshold; // isslScoreOfftargets.cpp:326
     const uint32_t n32 = static_cast<uint32_t>(n);
-    Counters c{};
+    const uint32_t slot = ix->n_pending % kRing;
+    HIP_TRY(hipEventRecord(ix->ev[0], stream));
+    launch_bin_guides(ix->view, ix->ws, d_guides, n32, stream);
+    HIP_TRY(hipEventRecord(ix->ev[1], stream));
+    HIP_TRY(hipEventRecord(ix->ring[2 * slot], stream));
+    launch_scan(ix->view, ix->ws, d_guides, n32, max_dist, stream);
+    HIP_TRY(hipEventRecord(ix->ring[2 * slot + 1], stream));
+    HIP_TRY(hipEventRecord(ix->ev[2], stream));
+    launch_verify(ix->view, ix->ws, d_guides, max_dist, stream);
+    HIP_TRY(hipEventRecord(ix->ev[3], stream));
+    launch_group_hits(ix->ws, n32, stream);
+    HIP_TRY(hipEventRecord(ix->ev[4], stream));
+    launch_replay(ix->view, ix->ws, d_guides, n32, p, d_mit, d_cfd, dump ? ix->ws.d_kept : nullptr,
+                  dump ? ix->ws.d_hitrec : nullptr, stream);
+    HIP_TRY(hipEventRecord(ix->ev[5], stream));
+    ix->n_pending += 1;
+    ix->last_n = n32;
+    ix->last_dump = dump;
+    return ISSL_OK;
+}
+
+// Returns ISSL_OK, or ISSL_E_RETRY when a batch since the last finish ran out of raw-record space (the buffers
+// have been enlarged; the caller enqueues those batches again).
+static int finish_batches(issl_index *ix, hipStream_t stream)
+{
+    if (!ix->d_image || ix->n_pending == 0) return ISSL_OK;
+    HIP_TRY(hipSetDevice(ix->device));
+    uint32_t sticky[4] = {0, 0, 0, 0};
     PlanInfo pl{};
     uint32_t total_hits = 0;
-    for (int attempt = 0;; ++attempt) {
-        // `sorted` always has room for every raw slot, so the whole pipeline runs without a host round trip;
-        // an exhausted raw buffer is detected at the end and the batch is re-run with a larger one.
-        rc = ensure_hit_capacity(ix, ix->ws.cap_chunks * (kChunkRecs - 1));
+    HIP_TRY(hipMemcpyAsync(sticky, ix->ws.sticky, sizeof sticky, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(&pl, ix->ws.plan, sizeof pl, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(&total_hits, ix->ws.goff + ix->last_n, sizeof total_hits, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    HIP_TRY(hipGetLastError());
+    const uint32_t batches = ix->n_pending;
+    ix->n_pending = 0;
+    if (sticky[2] & 2u) {
+        HIP_TRY(hipMemset(ix->ws.sticky, 0, 16));
+        set_error("internal error: scan item list overflow");
+        return ISSL_E_DEVICE;
+    }
+    if (sticky[0]) {
+        HIP_TRY(hipMemset(ix->ws.sticky, 0, 16));
+        // sticky[1] = largest number of chunks any batch asked for
+        int rc = ensure_raw_capacity(ix, static_cast<size_t>(sticky[1]) + sticky[1] / 8 + 1024);
         if (rc) return rc;
-        if (dump && ix->ws.cap_hitrec < ix->ws.cap_hits) {
-            rc = dev_alloc(ix->ws.d_hitrec, ix->ws.cap_hits);
-            if (rc) return rc;
-            ix->ws.cap_hitrec = ix->ws.cap_hits;
-        }
-        HIP_TRY(hipEventRecord(ix->ev[0], stream));
-        launch_bin_guides(ix->view, ix->ws, d_guides, n32, stream);
-        HIP_TRY(hipEventRecord(ix->ev[1], stream));
-        launch_scan(ix->view, ix->ws, d_guides, n32, max_dist, stream);
-        HIP_TRY(hipEventRecord(ix->ev[2], stream));
-        launch_verify(ix->view, ix->ws, d_guides, max_dist, stream);
-        HIP_TRY(hipEventRecord(ix->ev[3], stream));
-        launch_group_hits(ix->ws, n32, stream);
-        HIP_TRY(hipEventRecord(ix->ev[4], stream));
-        launch_replay(ix->view, ix->ws, d_guides, n32, p, d_mit, d_cfd, dump ? ix->ws.d_kept : nullptr,
-                      dump ? ix->ws.d_hitrec : nullptr, stream);
-        HIP_TRY(hipEventRecord(ix->ev[5], stream));
-        HIP_TRY(hipMemcpyAsync(&c, ix->ws.counters, sizeof c, hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipMemcpyAsync(&pl, ix->ws.plan, sizeof pl, hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipMemcpyAsync(&total_hits, ix->ws.goff + n32, sizeof total_hits, hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipStreamSynchronize(stream));
-        HIP_TRY(hipGetLastError());
-        ix->stats.scan_launches = attempt + 1;
-        if (pl.error & 2u) {
-            set_error("internal error: scan item list overflow");
-            return ISSL_E_DEVICE;
-        }
-        if (!c.raw_overflow) break;
-        if (attempt >= 6) {
-            set_error("internal error: raw record buffer kept overflowing");
-            return ISSL_E_DEVICE;
-        }
-        // raw_chunks counts every request, so it is the exact need of this batch
-        rc = ensure_raw_capacity(ix, static_cast<size_t>(c.raw_chunks) + c.raw_chunks / 8 + 1024);
-        if (rc) return rc;
+        set_error("raw record buffer was too small for a batch; it has been enlarged, score the batch again");
+        return ISSL_E_RETRY;
     }
     float ms[5] = {0, 0, 0, 0, 0};
     for (int i = 0; i < 5; ++i) (void)hipEventElapsedTime(&ms[i], ix->ev[i], ix->ev[i + 1]);
+    double scan_sum = 0.0;
+    const uint32_t have = batches < kRing ? batches : kRing;
+    for (uint32_t i = 0; i < have; ++i) {
+        float t = 0;
+        (void)hipEventElapsedTime(&t, ix->ring[2 * i], ix->ring[2 * i + 1]);
+        scan_sum += t;
+    }
+    ix->stats = issl_stats{};
+    ix->stats.n_guides = ix->last_n;
     ix->stats.ms_bin = ms[0];
-    ix->stats.ms_scan = ms[1];
+    ix->stats.ms_scan = have ? scan_sum / have : ms[1]; // mean over the batches since the last finish
     ix->stats.ms_verify = ms[2];
     ix->stats.ms_group = ms[3];
     ix->stats.ms_replay = ms[4];
     ix->stats.ms_total = ms[0] + ms[1] + ms[2] + ms[3] + ms[4];
-    ix->stats.raw_records = static_cast<uint64_t>(c.raw_chunks) * (kChunkRecs - 1);
+    ix->stats.raw_records = static_cast<uint64_t>(sticky[1]) * (kChunkRecs - 1);
     ix->stats.candidates = pl.candidates;
     ix->stats.hits = total_hits;
     ix->stats.scan_tiles = pl.tiles;
+    ix->stats.n_batches = batches;
     return ISSL_OK;
+}
+
+static int score_core(issl_index *ix, const uint64_t *d_guides, size_t n, int max_dist, double threshold, int method,
+                      double *d_mit, double *d_cfd, hipStream_t stream, bool dump)
+{
+    int rc = finish_batches(ix, stream); // anything enqueued asynchronously before
+    if (rc) return rc;
+    ix->stats = issl_stats{};
+    ix->stats.n_guides = n;
+    if (n == 0) return ISSL_OK;
+    for (int attempt = 0;; ++attempt) {
+        rc = enqueue_batch(ix, d_guides, n, max_dist, threshold, method, d_mit, d_cfd, stream, dump);
+        if (rc) return rc;
+        rc = finish_batches(ix, stream);
+        if (rc == ISSL_OK) {
+            ix->stats.scan_launches = attempt + 1;
+            return ISSL_OK;
+        }
+        if (rc != ISSL_E_RETRY) return rc;
+        if (attempt >= 6) {
+            set_error("internal error: raw record buffer kept overflowing");
+            return ISSL_E_DEVICE;
+        }
+    }
 }
 
 extern "C" {
@@ -639,6 +701,20 @@ int issl_score_device(issl_index *idx, const uint64_t *d_guides, size_t n, int m
     if (!idx || (n && (!d_guides || !d_mit || !d_cfd))) { set_error("null argument"); return ISSL_E_ARG; }
     return score_core(idx, d_guides, n, max_dist, threshold, method, d_mit, d_cfd, static_cast<hipStream_t>(stream),
                       false);
+}
+
+int issl_score_device_async(issl_index *idx, const uint64_t *d_guides, size_t n, int max_dist, double threshold,
+                            int method, double *d_mit, double *d_cfd, void *stream)
+{
+    if (!idx || (n && (!d_guides || !d_mit || !d_cfd))) { set_error("null argument"); return ISSL_E_ARG; }
+    return enqueue_batch(idx, d_guides, n, max_dist, threshold, method, d_mit, d_cfd, static_cast<hipStream_t>(stream),
+                         false);
+}
+
+int issl_score_finish(issl_index *idx, void *stream)
+{
+    if (!idx) { set_error("null argument"); return ISSL_E_ARG; }
+    return finish_batches(idx, static_cast<hipStream_t>(stream));
 }
 
 int issl_score(issl_index *idx, const uint64_t *guides, size_t n, int max_dist, double threshold, int method,

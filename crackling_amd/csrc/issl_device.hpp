@@ -131,6 +131,7 @@ struct Workspace {
     uint64_t *raw = nullptr;     // [(cap_chunks+1) * kChunkRecs] raw records of the scan, chunked
     size_t cap_chunks = 0;
     Counters *counters = nullptr;
+    uint32_t *sticky = nullptr;  // [4] survives k_reset: [0] raw overflow seen, [1] max chunks asked, [2] plan errors
     uint64_t *sorted = nullptr;  // [hit_cap] keys guide<<35 | slice<<32 | pos, grouped by guide
     uint32_t *gcount = nullptr;  // [G+1] hits per guide
     uint32_t *goff = nullptr;    // [G+1] exclusive prefix

@@ -664,6 +664,11 @@ __global__ __launch_bounds__(kChunkRecs) void k_verify(ImageView v, Workspace ws
                                                        int max_dist)
 {
     uint32_t n_chunks = ws.counters->raw_chunks;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { // what the host needs to know after any number of batches
+        if (ws.counters->raw_overflow) atomicOr(&ws.sticky[0], 1u);
+        atomicMax(&ws.sticky[1], n_chunks);
+        if (ws.plan->error) atomicOr(&ws.sticky[2], ws.plan->error);
+    }
     if (n_chunks > ws.cap_chunks) n_chunks = static_cast<uint32_t>(ws.cap_chunks);
     const uint64_t low = (1ull << v.slice_width) - 1ull;
     for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {

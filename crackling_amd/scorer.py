@@ -168,6 +168,20 @@ class IsslIndex:
                                     _method_code(method), d_mit.data_ptr(), d_cfd.data_ptr(),
                                     C.c_void_p(stream) if stream else None))
 
+    def score_device_async(self, d_guides, d_mit, d_cfd, max_dist=4, threshold=75.0, method="and", stream=None):
+        """Enqueue only; call finish() before trusting the outputs."""
+        check(lib.issl_score_device_async(self._h, d_guides.data_ptr(), d_guides.numel(), int(max_dist),
+                                          float(threshold), _method_code(method), d_mit.data_ptr(), d_cfd.data_ptr(),
+                                          C.c_void_p(stream) if stream else None))
+
+    def finish(self, stream=None):
+        """Synchronise the enqueued batches.  Returns False when they must be enqueued again (scratch space grew)."""
+        rc = lib.issl_score_finish(self._h, C.c_void_p(stream) if stream else None)
+        if rc == -8:
+            return False
+        check(rc)
+        return True
+
     def dump_hits(self, guides, max_dist=4, threshold=0.0, method="and"):
         """Scored off-targets in the reference's scoring order: array of (guide, slice, pos, id, dist, occ)."""
         sigs = self._sigs(guides)

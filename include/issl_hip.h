@@ -33,7 +33,8 @@ enum {
     ISSL_E_UNSUPPORTED = -4, /* geometry the kernels do not implement */
     ISSL_E_DEVICE = -5,   /* HIP error or no device */
     ISSL_E_NOMEM = -6,
-    ISSL_E_STATE = -7     /* call order (e.g. score before upload) */
+    ISSL_E_STATE = -7,    /* call order (e.g. score before upload) */
+    ISSL_E_RETRY = -8     /* issl_score_finish: a batch ran out of scratch space; buffers grown, enqueue it again */
 };
 
 /* Score methods, isslScoreOfftargets.cpp:44,121-143. */
@@ -82,6 +83,7 @@ typedef struct {
     double ms_total;        /* first kernel to last kernel */
     uint64_t scan_launches; /* >1 when a hit buffer had to grow and the scan was repeated */
     uint64_t raw_records;   /* upper bound of candidates noted by the scan (chunks handed out x chunk size) */
+    uint64_t n_batches;     /* batches covered by these statistics (ms_scan is their mean) */
 } issl_stats;
 
 const char *issl_last_error(void);
@@ -161,6 +163,15 @@ int issl_score(issl_index *idx, const uint64_t *guides, size_t n, int max_dist, 
  * on `stream` (a hipStream_t, may be NULL) except when the hit buffer must grow. */
 int issl_score_device(issl_index *idx, const uint64_t *d_guides, size_t n, int max_dist,
                       double threshold, int method, double *d_mit, double *d_cfd, void *stream);
+
+/* Enqueue one batch on `stream` and return at once; any number of batches may be enqueued before
+ * issl_score_finish() synchronises the stream and checks them.  ISSL_E_RETRY from finish means that a batch needed
+ * more scratch space than was allocated (first large batch on an index): the buffers have been enlarged and the
+ * batches since the previous finish must be enqueued again.  issl_last_stats() then describes the last batch,
+ * with ms_scan averaged over all of them. */
+int issl_score_device_async(issl_index *idx, const uint64_t *d_guides, size_t n, int max_dist,
+                            double threshold, int method, double *d_mit, double *d_cfd, void *stream);
+int issl_score_finish(issl_index *idx, void *stream);
 
 /* Parity helper: the scored off-targets of every guide in the reference's scoring order
  * (slice, then position in bucket), truncated by early exit exactly as :467-496.

@@ -225,6 +225,25 @@ def test_image_attach_and_caller_owned_memory(golden_uniform):
     att.close(); src.close()
 
 
+def test_async_batches(config0):
+    """issl_score_device_async / issl_score_finish: several batches in flight on one stream."""
+    import torch
+    ix, oracle, sigs, guides = config0
+    stream = torch.cuda.current_stream().cuda_stream
+    parts = [guides[:300], guides[300:301], guides[301:]]
+    outs = []
+    for g in parts:
+        d_g = torch.from_numpy(g.view(np.int64)).cuda()
+        d_m = torch.empty(len(g), dtype=torch.float64, device="cuda:0"); d_c = torch.empty_like(d_m)
+        ix.score_device_async(d_g, d_m, d_c, 4, 75.0, "and", stream=stream)
+        outs.append((d_g, d_m, d_c))
+    assert ix.finish(stream)
+    assert ix.stats()["n_batches"] == 3
+    mit = np.concatenate([o[1].cpu().numpy() for o in outs]); cfd = np.concatenate([o[2].cpu().numpy() for o in outs])
+    omit, ocfd = oracle.score(guides, 4, 75.0, "and")
+    assert np.array_equal(mit.view(np.uint64), omit.view(np.uint64)) and np.array_equal(cfd.view(np.uint64), ocfd.view(np.uint64))
+
+
 def test_guides_with_thousands_of_hits(tmp_path):
     """Dense neighbourhoods: one guide with ~6000 scored off-targets (replay sorts in HBM, beyond the 2048-key LDS
     buffer), one with ~1500 (LDS sort) and one with a few dozen (rank path), each with and without early exit."""
