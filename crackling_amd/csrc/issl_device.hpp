@@ -92,10 +92,12 @@ struct ScanItem {
     uint64_t cost0;  // sum of costs of all earlier items; tile cost = (g1-g0)+kTileFixedCost
 };
 
-// First tile of a cost range of the scan: (item, tile inside the item); item == n_items marks the end.
+// Start of a cost range of the scan: (item, tile inside the item, guide offset); item == n_items marks the end.
 struct RangeStart {
     uint32_t item;
     uint32_t tile;
+    uint32_t goff; // guide offset inside the item (multiple of 8): a tile may be shared by two ranges
+    uint32_t pad;
 };
 
 // Written by the planning kernel, read-only for the scan.

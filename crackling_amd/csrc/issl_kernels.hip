@@ -267,6 +267,8 @@ __global__ __launch_bounds__(256) void k_ranges(const PlanInfo *__restrict__ pla
     RangeStart out;
     out.item = n_items;
     out.tile = 0;
+    out.goff = 0;
+    out.pad = 0;
     if (r < n_ranges) {
         // no 128-bit intermediate: costs < 2^50 and range counts <= 2^15
         const uint32_t n_static = plan->n_static;
@@ -284,11 +286,24 @@ __global__ __launch_bounds__(256) void k_ranges(const PlanInfo *__restrict__ pla
             const uint32_t mid = (a + z) >> 1;
             if (items[mid].cost0 <= lo) a = mid; else z = mid;
         }
+        // A tile of an item costs kTileFixedCost (fetching it) + one unit per guide.  A boundary may fall between two
+        // groups of 8 guides INSIDE a tile: then two waves share that tile (both fetch it), which makes the ranges
+        // equal to within 8 guides instead of within one tile.
         const ScanItem it = items[a];
-        const uint64_t tile_cost = static_cast<uint64_t>(it.g1 - it.g0) + kTileFixedCost;
-        const uint64_t k = (lo - it.cost0 + tile_cost - 1) / tile_cost; // first tile starting at or after lo
-        if (k >= it.n_tiles) { out.item = a + 1; out.tile = 0; }
-        else { out.item = a; out.tile = static_cast<uint32_t>(k); }
+        const uint32_t len = it.g1 - it.g0;
+        const uint64_t tile_cost = static_cast<uint64_t>(len) + kTileFixedCost;
+        const uint64_t rel = lo - it.cost0;
+        uint64_t k = rel / tile_cost;
+        const uint64_t rem = rel % tile_cost;
+        uint32_t goff = 0;
+        if (rem > kTileFixedCost) {
+            goff = (static_cast<uint32_t>(rem - kTileFixedCost) + kGuideGroup - 1u) & ~(kGuideGroup - 1u);
+            if (goff >= len) { goff = 0; ++k; }
+        } else if (rem > 0) {
+            // inside the fetch part: the tile starts the range (positions stay monotone in r)
+        }
+        if (k >= it.n_tiles) { out.item = a + 1; out.tile = 0; out.goff = 0; }
+        else { out.item = a; out.tile = static_cast<uint32_t>(k); out.goff = goff; }
     }
     starts[r] = out;
 }
@@ -547,8 +562,7 @@ __device__ __forceinline__ uint32_t take_ticket(Counters *counters, uint32_t n_s
 // The streams the hot loop reads (scan planes, tile table, items, guide words, plan) are separate
 // `const __restrict__` kernel arguments: they are never written by this kernel, which lets the
 // compiler fetch the wave-uniform ones through the scalar cache.
-// ABL (timing experiments only, results are wrong when non-zero): bit 0 = load the tile planes once per range
-// instead of per tile, bit 1 = never note candidates, bit 2 = no comparison work (loads only).
+// ABL (timing experiments only, results are wrong when non-zero): bit 1 = never note candidates.
 template <int THR, bool STAGGER, int ABL = 0>
 __global__ __launch_bounds__(256, 6) void k_scan(const uint32_t *__restrict__ scan_stream,
                                                  const uint32_t *__restrict__ tile_first,
@@ -582,66 +596,49 @@ __global__ __launch_bounds__(256, 6) void k_scan(const uint32_t *__restrict__ sc
 
     if (range >= n_static) range = take_ticket(counters, n_static, n_ranges, lane);
     while (range < n_ranges) {
-        // tiles of this range: from range_start[range] up to (not including) range_start[range + 1]
+        // work of this range: from range_start[range] up to (not including) range_start[range + 1]; a position is
+        // (item, tile of the item, guide offset inside the item in multiples of 8)
         const RangeStart first = range_start[range];
         const RangeStart last = range_start[range + 1];
         uint32_t it = first.item;
         uint32_t k = first.tile;
-        if (it < last.item || (it == last.item && k < last.tile)) {
-            ScanItem cur = items[it];
+        uint32_t gs = first.goff;
+        uint32_t cur_it = 0xFFFFFFFFu;
+        ScanItem cur{};
+        while (it < last.item || (it == last.item && (k < last.tile || (k == last.tile && gs < last.goff)))) {
+            if (it != cur_it) { cur = items[it]; cur_it = it; }
+            const bool end_tile = it == last.item && k == last.tile;
+            const uint32_t g_begin = cur.g0 + gs;
+            const uint32_t g_end = end_tile ? cur.g0 + last.goff : cur.g1;
+
+            // ---- one tile: 2048 candidates of bucket cur.bucket, tile k, guide slots [g_begin, g_end) -------
+            const uint32_t tile = tile_first[cur.bucket] + k;
+            const uint4 *__restrict__ src =
+                reinterpret_cast<const uint4 *>(scan_stream + static_cast<uint64_t>(tile) * kTileCands);
             uint32_t c[kPlanes];
-            bool loaded = false;
-            while (true) {
-                // ---- one tile: 2048 candidates of bucket cur.bucket, tile k ---------------------
-                const uint32_t tile = tile_first[cur.bucket] + static_cast<uint32_t>(k);
-                const uint4 *__restrict__ src =
-                    reinterpret_cast<const uint4 *>(scan_stream + static_cast<uint64_t>(tile) * kTileCands);
-                if (!(ABL & 1) || !loaded) {
 #pragma unroll
-                    for (int q = 0; q < kPlanes / 4; ++q) {
-                        const uint4 t4 = src[q * 64 + lane];
-                        c[4 * q + 0] = t4.x; c[4 * q + 1] = t4.y; c[4 * q + 2] = t4.z; c[4 * q + 3] = t4.w;
-                    }
-                    loaded = true;
-                }
-                if (ABL & 4) {
-                    uint32_t acc = 0;
+            for (int q = 0; q < kPlanes / 4; ++q) {
+                const uint4 t4 = src[q * 64 + lane];
+                c[4 * q + 0] = t4.x; c[4 * q + 1] = t4.y; c[4 * q + 2] = t4.z; c[4 * q + 3] = t4.w;
+            }
+            // Guide slots are padded to groups of 8 with a word (all T) that is far from the zero padding of the
+            // tiles; a padding slot that does come near a real candidate is dropped by k_verify.
+            for (uint32_t g = g_begin; g < g_end; g += kGuideGroup) {
+                const GuideGroup gg = *reinterpret_cast<const GuideGroup *>(gword_stream + g);
 #pragma unroll
-                    for (int r = 0; r < kPlanes; ++r) acc |= c[r];
-                    if (acc == 0x12345678u) own_chunk = true;
-                    ++k;
-                    if (k >= cur.n_tiles) { ++it; k = 0; if (it >= last.item && last.tile == 0) break; cur = items[it]; }
-                    if (it == last.item && k >= last.tile) break;
-                    continue;
-                }
-                // Guide slots are padded to groups of 8 with a word (all T) that is far from the zero padding
-                // of the tiles; a padding slot that does come near a real candidate is dropped by k_verify.
-                for (uint32_t g = cur.g0; g < cur.g1; g += kGuideGroup) {
-                    const GuideGroup gg = *reinterpret_cast<const GuideGroup *>(gword_stream + g);
-                    uint32_t flagged = 0; // bit u: a lane has a candidate within thr of guide g+u
-#pragma unroll
-                    for (uint32_t u = 0; u < kGuideGroup; ++u) {
-                        const uint32_t ok = near_plane<THR>(c, gg.w[u], thr);
-                        if (__ballot(ok != 0u) != 0ull) flagged |= 1u << u;
-                    }
-                    if (ABL & 2) { asm volatile("" ::"s"(flagged)); flagged = 0; }
-                    while (flagged) { // ~4 % of the (guide, tile) pairs on random data
-                        const uint32_t u = static_cast<uint32_t>(__builtin_ctz(flagged));
-                        flagged &= flagged - 1u;
-                        const uint32_t ok = near_plane<THR>(c, gword_stream[g + u], thr);
+                for (uint32_t u = 0; u < kGuideGroup; ++u) {
+                    const uint32_t ok = near_plane<THR>(c, gg.w[u], thr);
+                    if (ABL & 2) { asm volatile("" ::"v"(ok)); continue; }
+                    if (__ballot(ok != 0u) != 0ull) { // ~4 % of the (guide, tile) pairs on random data
                         note_candidates(ok, g + u, tile, lane, w, raw, max_chunks, counters);
                         own_chunk = true;
                     }
                 }
-                ++k;
-                if (k >= cur.n_tiles) {
-                    ++it;
-                    k = 0;
-                    if (it >= last.item && last.tile == 0) break;
-                    cur = items[it];
-                }
-                if (it == last.item && k >= last.tile) break;
             }
+            if (end_tile) break;
+            gs = 0;
+            ++k;
+            if (k >= cur.n_tiles) { ++it; k = 0; }
         }
         // Static rounds by wave number, then the small ranges of the dynamic tail by ticket.
         if (range < n_static) {
@@ -730,7 +727,7 @@ static void launch_scan_thr(const ImageView &v, const Workspace &ws, uint32_t th
                            static_cast<uint32_t>(ws.cap_chunks), ws.counters, thr);                                 \
         return;                                                                                                     \
     }
-        ISSL_ABL_CASE(1) ISSL_ABL_CASE(2) ISSL_ABL_CASE(4) ISSL_ABL_CASE(5)
+        ISSL_ABL_CASE(2)
 #undef ISSL_ABL_CASE
     }
     // ISSL_SCAN_STAGGER=0 disables the per-slot issue priorities (A/B aid).
@@ -900,7 +897,7 @@ void launch_group_hits(const Workspace &ws, uint32_t n, void *stream_)
 // replay: ordered MIT/CFD accumulation, one wave per guide
 // ------------------------------------------------------------------------------------------------
 
-constexpr uint32_t kReplayLds = 2048; // keys sorted in LDS; longer lists are sorted in place in HBM
+constexpr uint32_t kReplayLds = 512; // keys sorted in LDS (4 KiB keeps 32 one-wave workgroups per CU); longer lists are sorted in place in HBM
 
 // Ascending sort of data[0..n) by one wave (block = 64 threads).  Bitonic network with every
 // comparator ascending; comparators that touch an index >= n are no-ops (virtual +inf padding).

@@ -245,8 +245,8 @@ def test_async_batches(config0):
 
 
 def test_guides_with_thousands_of_hits(tmp_path):
-    """Dense neighbourhoods: one guide with ~6000 scored off-targets (replay sorts in HBM, beyond the 2048-key LDS
-    buffer), one with ~1500 (LDS sort) and one with a few dozen (rank path), each with and without early exit."""
+    """Dense neighbourhoods: guides with ~6000 and ~1500 scored off-targets (replay sorts in HBM, beyond the 512-key
+    LDS buffer), one with ~300 (LDS sort) and one with a few dozen (rank path), each with and without early exit."""
     rng = np.random.default_rng(77)
     centres = rng.integers(0, 1 << 40, size=3, dtype=np.uint64)
 
@@ -260,6 +260,8 @@ def test_guides_with_thousands_of_hits(tmp_path):
         return out
 
     sites = neighbours(centres[0], 6000, 4) | neighbours(centres[1], 1500, 3) | neighbours(centres[2], 40, 2)
+    centres = np.append(centres, rng.integers(0, 1 << 40, dtype=np.uint64))
+    sites |= neighbours(centres[3], 300, 3)  # 64 < hits <= 512: the LDS sort
     sites |= set(int(x) for x in rng.integers(0, 1 << 40, size=20000, dtype=np.uint64))
     sig = np.array(sorted(sites), dtype=np.uint64)
     from synth import text_order_key
@@ -281,7 +283,7 @@ def test_guides_with_thousands_of_hits(tmp_path):
     _, _, ohits = oracle.score(guides, 4, 0.0, "and", want_hits=True)
     assert np.array_equal(hits, ohits)
     per_guide = np.bincount(hits[:, 0], minlength=len(guides))
-    assert per_guide.max() > 2048 and 64 < per_guide[1] <= 2048
+    assert per_guide.max() > 2048 and per_guide[1] > 512 and 64 < per_guide[3] <= 512 and per_guide[2] <= 64
     ix.close()
 
 
