@@ -129,7 +129,7 @@ static int select_device(int device)
 
 static void free_workspace(Workspace &w)
 {
-    void *ptrs[] = {w.ng, w.gfill, w.gstart, w.gword, w.gidx, w.items, w.plan, w.range_start, w.counters, w.sticky, w.sorted, w.gcount,
+    void *ptrs[] = {w.ng, w.gfill, w.gstart, w.gword, w.gidx, w.items, w.plan, w.range_start, w.counters, w.sticky, w.gcur_big, w.terms, w.sorted, w.gcount,
                     w.goff, w.gcur, w.blocksum, w.d_guides, w.d_mit, w.d_cfd, w.d_kept, w.d_hitrec};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -153,6 +153,7 @@ static int ensure_hit_capacity(issl_index *ix, size_t want)
     if (want <= w.cap_hits) return ISSL_OK;
     int rc;
     if ((rc = dev_alloc(w.sorted, want))) return rc;
+    if ((rc = dev_alloc(w.terms, 2 * want))) return rc;
     w.cap_hits = want;
     return ISSL_OK;
 }
@@ -192,6 +193,7 @@ static int ensure_workspace(issl_index *ix, size_t n)
         if ((rc = dev_alloc(w.gcount, cap + 1))) return rc;
         if ((rc = dev_alloc(w.goff, cap + 1))) return rc;
         if ((rc = dev_alloc(w.gcur, cap))) return rc;
+        if ((rc = dev_alloc(w.gcur_big, cap + 1))) return rc;
         if ((rc = dev_alloc(w.blocksum, (cap + 1) / 2048 + 2))) return rc;
         if ((rc = dev_alloc(w.d_guides, cap))) return rc;
         if ((rc = dev_alloc(w.d_mit, cap))) return rc;

@@ -115,7 +115,7 @@ struct PlanInfo {
 // Updated by the scan with atomics.
 struct Counters {
     uint32_t next_range;  // ticket counter of the scan's dynamic tail
-    uint32_t pad0;
+    uint32_t n_big;       // guides with more than kReplayLds hits (k_replay_big's list)
     uint32_t raw_chunks;  // chunks of the raw record buffer handed out
     uint32_t raw_overflow; // set when the raw buffer was too small
     uint64_t reserved2;
@@ -138,6 +138,8 @@ struct Workspace {
     uint32_t *gcount = nullptr;  // [G+1] hits per guide
     uint32_t *goff = nullptr;    // [G+1] exclusive prefix
     uint32_t *gcur = nullptr;    // [G]
+    uint32_t *gcur_big = nullptr; // [G] guides handed to k_replay_big
+    double *terms = nullptr;     // [2 * hit_cap] MIT/CFD terms of the hits of those guides
     uint32_t *blocksum = nullptr;
     uint64_t *d_guides = nullptr; // staging for the host API
     double *d_mit = nullptr, *d_cfd = nullptr;

@@ -773,6 +773,8 @@ void launch_verify(const ImageView &v, const Workspace &ws, const uint64_t *d_gu
 // ------------------------------------------------------------------------------------------------
 
 constexpr uint32_t kScanChunk = 2048; // elements per block in the device-wide prefix sum
+constexpr uint32_t kReplayLds = 512;  // guides with more hits than this go to k_replay_big (a whole workgroup each)
+constexpr uint32_t kBigLds = 8192;    // keys k_replay_big sorts in LDS (64 KiB); longer lists are sorted in HBM
 
 __global__ __launch_bounds__(256) void k_prefix_block_sums(const uint32_t *__restrict__ in, uint32_t n,
                                                            uint32_t *__restrict__ sums)
@@ -802,7 +804,8 @@ __global__ __launch_bounds__(256) void k_prefix_of_sums(uint32_t *__restrict__ s
 }
 
 __global__ __launch_bounds__(256) void k_prefix_apply(const uint32_t *__restrict__ in, uint32_t n,
-                                                      const uint32_t *__restrict__ sums, uint32_t *__restrict__ out)
+                                                      const uint32_t *__restrict__ sums, uint32_t *__restrict__ out,
+                                                      uint32_t *__restrict__ big, Counters *__restrict__ counters)
 {
     __shared__ uint64_t lds[256];
     const uint32_t base = blockIdx.x * kScanChunk + threadIdx.x * 8u;
@@ -811,6 +814,7 @@ __global__ __launch_bounds__(256) void k_prefix_apply(const uint32_t *__restrict
     for (uint32_t i = 0; i < 8; ++i) {
         val[i] = (base + i < n) ? in[base + i] : 0u;
         s += val[i];
+        if (val[i] > kReplayLds) big[atomicAdd(&counters->n_big, 1u)] = base + i; // guides for k_replay_big
     }
     uint64_t run = block_exclusive_scan(s, lds, nullptr) + sums[blockIdx.x];
     for (uint32_t i = 0; i < 8; ++i) {
@@ -821,7 +825,8 @@ __global__ __launch_bounds__(256) void k_prefix_apply(const uint32_t *__restrict
 
 // Whole prefix sum in one workgroup (used while n is moderate; saves two launches).
 __global__ __launch_bounds__(1024) void k_prefix_single(const uint32_t *__restrict__ in, uint32_t n,
-                                                        uint32_t *__restrict__ out)
+                                                        uint32_t *__restrict__ out, uint32_t *__restrict__ big,
+                                                        Counters *__restrict__ counters)
 {
     __shared__ uint32_t wave_sum[16];
     __shared__ uint32_t carry_s;
@@ -835,6 +840,7 @@ __global__ __launch_bounds__(1024) void k_prefix_single(const uint32_t *__restri
         for (uint32_t i = 0; i < 4; ++i) {
             val[i] = (i0 + i < n) ? in[i0 + i] : 0u;
             s += val[i];
+            if (val[i] > kReplayLds) big[atomicAdd(&counters->n_big, 1u)] = i0 + i; // guides for k_replay_big
         }
         // inclusive scan of s inside the wave
         uint32_t x = s;
@@ -882,12 +888,14 @@ void launch_group_hits(const Workspace &ws, uint32_t n, void *stream_)
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const uint32_t m = n + 1; // gcount[n] = 0 so that goff[n] = total
     if (m <= (1u << 18)) {
-        hipLaunchKernelGGL(k_prefix_single, dim3(1), dim3(1024), 0, stream, ws.gcount, m, ws.goff);
+        hipLaunchKernelGGL(k_prefix_single, dim3(1), dim3(1024), 0, stream, ws.gcount, m, ws.goff, ws.gcur_big,
+                           ws.counters);
     } else {
         const uint32_t blocks = (m + kScanChunk - 1) / kScanChunk;
         hipLaunchKernelGGL(k_prefix_block_sums, dim3(blocks), dim3(256), 0, stream, ws.gcount, m, ws.blocksum);
         hipLaunchKernelGGL(k_prefix_of_sums, dim3(1), dim3(256), 0, stream, ws.blocksum, blocks);
-        hipLaunchKernelGGL(k_prefix_apply, dim3(blocks), dim3(256), 0, stream, ws.gcount, m, ws.blocksum, ws.goff);
+        hipLaunchKernelGGL(k_prefix_apply, dim3(blocks), dim3(256), 0, stream, ws.gcount, m, ws.blocksum, ws.goff,
+                           ws.gcur_big, ws.counters);
     }
     hipLaunchKernelGGL(k_group_scatter, dim3(4096), dim3(kChunkRecs), 0, stream, ws.raw, ws.counters,
                        static_cast<uint32_t>(ws.cap_chunks), ws.goff, ws.gcur, ws.sorted);
@@ -897,10 +905,9 @@ void launch_group_hits(const Workspace &ws, uint32_t n, void *stream_)
 // replay: ordered MIT/CFD accumulation, one wave per guide
 // ------------------------------------------------------------------------------------------------
 
-constexpr uint32_t kReplayLds = 512; // keys sorted in LDS (4 KiB keeps 32 one-wave workgroups per CU); longer lists are sorted in place in HBM
 
-// Ascending sort of data[0..n) by one wave (block = 64 threads).  Bitonic network with every
-// comparator ascending; comparators that touch an index >= n are no-ops (virtual +inf padding).
+// Ascending sort of data[0..n) by the whole workgroup.  Bitonic network with every comparator
+// ascending; comparators that touch an index >= n are no-ops (virtual +inf padding).
 __device__ inline void wave_sort(uint64_t *data, uint32_t n)
 {
     if (n < 2) return;
@@ -908,7 +915,7 @@ __device__ inline void wave_sort(uint64_t *data, uint32_t n)
     while (np < n) np <<= 1;
     for (uint32_t k = 2; k <= np; k <<= 1) {
         for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-            for (uint32_t t = threadIdx.x; t < (np >> 1); t += 64) {
+            for (uint32_t t = threadIdx.x; t < (np >> 1); t += blockDim.x) {
                 const uint32_t i = ((t & ~(j - 1u)) << 1) | (t & (j - 1u)); // bit log2(j) of i is 0
                 const uint32_t l = (j == (k >> 1)) ? (i ^ (k - 1u)) : (i | j);
                 if (l < n) {
@@ -1008,6 +1015,7 @@ __global__ __launch_bounds__(64) void k_replay(ImageView v, Workspace ws, const 
     for (uint32_t g = blockIdx.x; g < n; g += gridDim.x) {
         const uint32_t h0 = ws.goff[g];
         const uint32_t h = ws.goff[g + 1] - h0;
+        if (h > kReplayLds) continue; // k_replay_big's
         const uint64_t gsig = guides[g];
         double tot_mit = 0.0, tot_cfd = 0.0;
         uint32_t kept = 0;
@@ -1056,13 +1064,8 @@ __global__ __launch_bounds__(64) void k_replay(ImageView v, Workspace ws, const 
             const double cfd_term = lane < h ? ord_cfd[lane] : 0.0;
             accumulate(mit_term, cfd_term, h);
         } else {
-            uint64_t *data;
-            if (h <= kReplayLds) {
-                for (uint32_t i = lane; i < h; i += 64) keys[i] = ws.sorted[h0 + i];
-                data = keys;
-            } else {
-                data = ws.sorted + h0;
-            }
+            uint64_t *data = keys;
+            for (uint32_t i = lane; i < h; i += 64) keys[i] = ws.sorted[h0 + i];
             __syncthreads();
             wave_sort(data, h);
             __syncthreads();
@@ -1086,6 +1089,77 @@ __global__ __launch_bounds__(64) void k_replay(ImageView v, Workspace ws, const 
     }
 }
 
+// Guides with many hits (dense neighbourhoods, repeats): one 1024-thread workgroup each.  Sort the keys (LDS up to
+// 8192, else in place in HBM), compute every hit's MIT/CFD terms in parallel, then wave 0 walks the terms in key
+// order with the reference's running totals and early exit.
+__global__ __launch_bounds__(1024) void k_replay_big(ImageView v, Workspace ws, const uint64_t *__restrict__ guides,
+                                                     ScoreParams p, double *__restrict__ out_mit,
+                                                     double *__restrict__ out_cfd, uint32_t *__restrict__ out_kept,
+                                                     issl_hit *__restrict__ out_hits)
+{
+    __shared__ uint64_t keys[kBigLds];
+    const bool calc_mit = p.method == ISSL_METHOD_MIT || p.method == ISSL_METHOD_AND || p.method == ISSL_METHOD_OR ||
+                          p.method == ISSL_METHOD_AVG;
+    const bool calc_cfd = p.method == ISSL_METHOD_CFD || p.method == ISSL_METHOD_AND || p.method == ISSL_METHOD_OR ||
+                          p.method == ISSL_METHOD_AVG;
+    const uint32_t n_big = ws.counters->n_big;
+    for (uint32_t b = blockIdx.x; b < n_big; b += gridDim.x) {
+        const uint32_t g = ws.gcur_big[b];
+        const uint32_t h0 = ws.goff[g];
+        const uint32_t h = ws.goff[g + 1] - h0;
+        const uint64_t gsig = guides[g];
+        uint64_t *seg = ws.sorted + h0;
+        if (h <= kBigLds) {
+            for (uint32_t i = threadIdx.x; i < h; i += blockDim.x) keys[i] = seg[i];
+            __syncthreads();
+            wave_sort(keys, h);
+            __syncthreads();
+            for (uint32_t i = threadIdx.x; i < h; i += blockDim.x) seg[i] = keys[i];
+        } else {
+            __syncthreads();
+            wave_sort(seg, h);
+        }
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < h; i += blockDim.x) {
+            const HitTerms t = hit_terms(v, gsig, g, seg[i], calc_mit, calc_cfd);
+            ws.terms[2ull * (h0 + i)] = t.mit;
+            ws.terms[2ull * (h0 + i) + 1] = t.cfd;
+            if (out_hits) out_hits[h0 + i] = t.rec;
+        }
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            const uint32_t lane = threadIdx.x;
+            double tot_mit = 0.0, tot_cfd = 0.0;
+            uint32_t kept = 0;
+            bool stop = false;
+            for (uint32_t base = 0; base < h && !stop; base += 64) {
+                const uint32_t idx = base + lane;
+                const double mit_term = idx < h ? ws.terms[2ull * (h0 + idx)] : 0.0;
+                const double cfd_term = idx < h ? ws.terms[2ull * (h0 + idx) + 1] : 0.0;
+                const uint32_t cnt = (h - base < 64u) ? h - base : 64u;
+                for (uint32_t l = 0; l < cnt; ++l) { // :394, :460, :467-496
+                    tot_mit += bcast_f64(mit_term, static_cast<int>(l));
+                    tot_cfd += bcast_f64(cfd_term, static_cast<int>(l));
+                    ++kept;
+                    bool exit_now = false;
+                    if (p.method == ISSL_METHOD_AND) exit_now = tot_mit > p.maximum_sum && tot_cfd > p.maximum_sum;
+                    else if (p.method == ISSL_METHOD_OR) exit_now = tot_mit > p.maximum_sum || tot_cfd > p.maximum_sum;
+                    else if (p.method == ISSL_METHOD_AVG) exit_now = ((tot_mit + tot_cfd) / 2.0) > p.maximum_sum;
+                    else if (p.method == ISSL_METHOD_MIT) exit_now = tot_mit > p.maximum_sum;
+                    else if (p.method == ISSL_METHOD_CFD) exit_now = tot_cfd > p.maximum_sum;
+                    if (exit_now) { stop = true; break; }
+                }
+            }
+            if (lane == 0) {
+                out_mit[g] = 10000.0 / (100.0 + tot_mit); // :505
+                out_cfd[g] = 10000.0 / (100.0 + tot_cfd); // :506
+                if (out_kept) out_kept[g] = kept;
+            }
+        }
+        __syncthreads();
+    }
+}
+
 void launch_replay(const ImageView &v, const Workspace &ws, const uint64_t *d_guides, uint32_t n,
                    const ScoreParams &p, double *d_mit, double *d_cfd, uint32_t *d_kept, issl_hit *d_hitrec,
                    void *stream)
@@ -1093,6 +1167,8 @@ void launch_replay(const ImageView &v, const Workspace &ws, const uint64_t *d_gu
     if (n == 0) return;
     const uint32_t grid = n < 65536u ? n : 65536u;
     hipLaunchKernelGGL(k_replay, dim3(grid), dim3(64), 0, static_cast<hipStream_t>(stream), v, ws, d_guides, n, p,
+                       d_mit, d_cfd, d_kept, d_hitrec);
+    hipLaunchKernelGGL(k_replay_big, dim3(256), dim3(1024), 0, static_cast<hipStream_t>(stream), v, ws, d_guides, p,
                        d_mit, d_cfd, d_kept, d_hitrec);
 }
 
