@@ -10,124 +10,433 @@
 //   ISSL_DEVICES=all | <a,b,...>   several GPUs of the node: index image broadcast over RCCL/xGMI, guides sharded
 //                     (default: one device; all visible devices when the query file holds >= 2^20 guides)
 //   ISSL_TIMING=1     one JSON line with load/upload/score timings on stderr
+//   ISSL_SERVER=<unix socket path>   resident mode, see below
+//
+// Resident mode.  Crackling starts one scorer process per page of guides (config.ini:106-112) and the reference
+// reloads the whole index every time.  `isslScoreOfftargets --serve <socket>` keeps every index it has been asked
+// for uploaded in HBM; a normal invocation with ISSL_SERVER=<socket> set hands its five arguments to that server
+// and copies the answer to stdout (same bytes, same exit status).  If the server cannot be reached the process
+// scores by itself, so the variable is always safe to set.  `isslScoreOfftargets --stop <socket>` ends the server.
+#include <cerrno>
 #include <chrono>
+#include <climits>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <string>
+#include <sys/socket.h>
+#include <sys/stat.h>
+#include <sys/un.h>
+#include <unistd.h>
 #include <vector>
 
 #include "../../include/issl_hip.h"
 
-static double now_ms()
+namespace {
+
+double now_ms()
 {
     using namespace std::chrono;
     return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
 }
 
-static int fail(const char *what)
+std::string last_error(const char *fallback)
 {
-    std::fprintf(stderr, "%s\n", issl_last_error()[0] ? issl_last_error() : what);
-    return 1;
+    const char *e = issl_last_error();
+    return (e && e[0]) ? e : fallback;
 }
 
-int main(int argc, char **argv)
-{
-    if (argc < 6) { // the reference checks argc < 4 and then reads argv[4], argv[5] regardless (:93,112,121)
-        std::fprintf(stderr, "Usage: %s [issltable] [query file] [max distance] [score-threshold] [score-method]\n",
-                     argv[0]);
-        return 1;
-    }
-    const int max_dist = std::atoi(argv[3]);      // :109
-    const double threshold = std::atof(argv[4]);  // :112
-    const int method = issl_method_from_string(argv[5]);
-    const bool want_mit = method == ISSL_METHOD_MIT || method == ISSL_METHOD_AND || method == ISSL_METHOD_OR ||
-                          method == ISSL_METHOD_AVG;
-    const bool want_cfd = method == ISSL_METHOD_CFD || method == ISSL_METHOD_AND || method == ISSL_METHOD_OR ||
-                          method == ISSL_METHOD_AVG;
-    const char *dev_env = std::getenv("ISSL_DEVICE");
-    const int device = dev_env ? std::atoi(dev_env) : 0;
-    const bool timing = std::getenv("ISSL_TIMING") != nullptr;
+struct DeviceChoice {
+    bool all = false;
+    std::vector<int> list;
+    int single = 0;
+    bool single_given = false;
+};
 
-    const double t0 = now_ms();
-    issl_index *idx = nullptr;
-    if (issl_index_open(argv[1], &idx)) return fail("cannot open index");
-    issl_header hdr;
-    issl_index_header(idx, &hdr);
-    uint64_t *guides = nullptr;
-    size_t n = 0;
-    if (issl_read_query_file(argv[2], hdr.seq_len, &guides, &n)) return fail("cannot read query file");
-    const double t1 = now_ms();
-    // device selection
-    std::vector<int> devices;
-    bool all_devices = false;
+DeviceChoice device_choice_from_env()
+{
+    DeviceChoice c;
+    if (const char *d = std::getenv("ISSL_DEVICE")) {
+        c.single = std::atoi(d);
+        c.single_given = true;
+    }
     if (const char *list = std::getenv("ISSL_DEVICES")) {
         if (!std::strcmp(list, "all")) {
-            all_devices = true;
+            c.all = true;
         } else {
             for (const char *p = list; *p;) {
                 char *end = nullptr;
                 const long d = std::strtol(p, &end, 10);
                 if (end == p) break;
-                devices.push_back(static_cast<int>(d));
+                c.list.push_back(static_cast<int>(d));
                 p = (*end == ',') ? end + 1 : end;
             }
         }
-    } else if (!dev_env && n >= (size_t(1) << 20)) {
-        all_devices = true;
+    }
+    return c;
+}
+
+// An index kept ready for scoring: host view + HBM image(s).
+struct Resident {
+    issl_index *idx = nullptr;
+    issl_node *node = nullptr; // when several devices are used
+    issl_header hdr{};
+    double load_ms = 0, upload_ms = 0, broadcast_ms = 0;
+    int n_devices = 1, used_rccl = 0;
+    // identity of the file it was loaded from
+    off_t size = 0;
+    time_t mtime = 0;
+};
+
+void release(Resident &r)
+{
+    if (r.node) issl_node_close(r.node);
+    if (r.idx) issl_index_close(r.idx);
+    r = Resident{};
+}
+
+// Open + upload.  n_guides_hint decides whether all devices are worth setting up when nothing was asked for.
+bool make_resident(const char *issl_path, const DeviceChoice &dc, size_t n_guides_hint, Resident &r, std::string &err)
+{
+    const double t0 = now_ms();
+    if (issl_index_open(issl_path, &r.idx)) { err = last_error("cannot open index"); return false; }
+    issl_index_header(r.idx, &r.hdr);
+    r.load_ms = now_ms() - t0;
+    const bool all = dc.all || (!dc.single_given && dc.list.empty() && n_guides_hint >= (size_t(1) << 20));
+    const double t1 = now_ms();
+    if (all || dc.list.size() > 1) {
+        if (issl_node_create(r.idx, all ? nullptr : dc.list.data(), static_cast<int>(dc.list.size()), &r.node)) {
+            err = last_error("cannot set up the devices");
+            release(r);
+            return false;
+        }
+        issl_node_info inf;
+        issl_node_get_info(r.node, &inf);
+        r.upload_ms = inf.ms_upload;
+        r.broadcast_ms = inf.ms_broadcast;
+        r.n_devices = inf.n_devices;
+        r.used_rccl = inf.used_rccl;
+    } else {
+        const int dev = dc.list.size() == 1 ? dc.list[0] : dc.single;
+        if (issl_index_upload(r.idx, dev)) {
+            err = last_error("cannot upload index");
+            release(r);
+            return false;
+        }
+        r.upload_ms = now_ms() - t1;
+    }
+    return true;
+}
+
+struct Request {
+    std::string issl, query, method_arg;
+    int max_dist = 4;
+    double threshold = 75.0;
+};
+
+// Score one request against a resident index: the TSV text of isslScoreOfftargets.cpp:514-527 in `out`.
+bool score_request(Resident &r, const Request &q, std::string &out, std::string &err, std::string &timing_json,
+                   bool resident_hit)
+{
+    const int method = issl_method_from_string(q.method_arg.c_str()); // :121-143
+    const bool want_mit = method == ISSL_METHOD_MIT || method == ISSL_METHOD_AND || method == ISSL_METHOD_OR ||
+                          method == ISSL_METHOD_AVG;
+    const bool want_cfd = method == ISSL_METHOD_CFD || method == ISSL_METHOD_AND || method == ISSL_METHOD_OR ||
+                          method == ISSL_METHOD_AVG;
+    uint64_t *guides = nullptr;
+    size_t n = 0;
+    if (issl_read_query_file(q.query.c_str(), r.hdr.seq_len, &guides, &n)) { // :275-305
+        err = last_error("cannot read query file");
+        return false;
     }
     std::vector<double> mit(n), cfd(n);
-    issl_node *node = nullptr;
-    double t2;
-    if (all_devices || devices.size() > 1) {
-        if (issl_node_create(idx, all_devices ? nullptr : devices.data(), static_cast<int>(devices.size()), &node))
-            return fail("cannot set up the devices");
-        t2 = now_ms();
-        if (issl_node_score(node, guides, n, max_dist, threshold, method, mit.data(), cfd.data()))
-            return fail("scoring failed");
-    } else {
-        const int dev = devices.size() == 1 ? devices[0] : device;
-        if (issl_index_upload(idx, dev)) return fail("cannot upload index");
-        t2 = now_ms();
-        if (issl_score(idx, guides, n, max_dist, threshold, method, mit.data(), cfd.data())) return fail("scoring failed");
+    const double t0 = now_ms();
+    const int rc = r.node ? issl_node_score(r.node, guides, n, q.max_dist, q.threshold, method, mit.data(), cfd.data())
+                          : issl_score(r.idx, guides, n, q.max_dist, q.threshold, method, mit.data(), cfd.data());
+    const double score_ms = now_ms() - t0;
+    if (rc) {
+        err = last_error("scoring failed");
+        issl_free(guides);
+        return false;
     }
-    const double t3 = now_ms();
-
-    // :514-527
-    std::vector<char> out;
+    out.clear();
     out.reserve(n * 48 + 16);
     char seq[40], line[128];
-    for (size_t i = 0; i < n; ++i) {
-        issl_decode_guide(guides[i], hdr.seq_len, seq);
+    for (size_t i = 0; i < n; ++i) { // :514-527
+        issl_decode_guide(guides[i], r.hdr.seq_len, seq);
         int k = std::snprintf(line, sizeof line, "%s\t", seq);
         if (want_mit) k += std::snprintf(line + k, sizeof line - k, "%f\t", mit[i]);
         else k += std::snprintf(line + k, sizeof line - k, "-1\t");
         if (want_cfd) k += std::snprintf(line + k, sizeof line - k, "%f\n", cfd[i]);
         else k += std::snprintf(line + k, sizeof line - k, "-1\n");
-        out.insert(out.end(), line, line + k);
+        out.append(line, static_cast<size_t>(k));
+    }
+    issl_free(guides);
+    char buf[512];
+    if (r.node) {
+        std::snprintf(buf, sizeof buf,
+                      "{\"guides\": %zu, \"devices\": %d, \"rccl\": %d, \"resident\": %s, \"load_ms\": %.3f, "
+                      "\"upload_ms\": %.3f, \"broadcast_ms\": %.3f, \"score_ms\": %.3f}",
+                      n, r.n_devices, r.used_rccl, resident_hit ? "true" : "false", r.load_ms, r.upload_ms,
+                      r.broadcast_ms, score_ms);
+    } else {
+        issl_stats st;
+        issl_last_stats(r.idx, &st);
+        std::snprintf(buf, sizeof buf,
+                      "{\"guides\": %zu, \"devices\": 1, \"resident\": %s, \"load_ms\": %.3f, \"upload_ms\": %.3f, "
+                      "\"score_ms\": %.3f, \"scan_ms\": %.3f, \"replay_ms\": %.3f, \"candidates\": %llu, \"hits\": %llu}",
+                      n, resident_hit ? "true" : "false", r.load_ms, r.upload_ms, score_ms, st.ms_scan, st.ms_replay,
+                      (unsigned long long)st.candidates, (unsigned long long)st.hits);
+    }
+    timing_json = buf;
+    return true;
+}
+
+// ---- resident mode: tiny line protocol over a unix stream socket ---------------------------------------------
+//   request : "SCORE\t<issl>\t<query>\t<maxDist>\t<threshold>\t<method>\n"   |  "QUIT\n"
+//   response: "OK <nbytes> <timing json>\n" + nbytes of TSV               |  "ERR <message>\n"
+
+bool write_all(int fd, const char *p, size_t n)
+{
+    while (n) {
+        const ssize_t k = ::write(fd, p, n);
+        if (k < 0) {
+            if (errno == EINTR) continue;
+            return false;
+        }
+        p += k;
+        n -= static_cast<size_t>(k);
+    }
+    return true;
+}
+
+bool read_line(int fd, std::string &line)
+{
+    line.clear();
+    char c;
+    while (true) {
+        const ssize_t k = ::read(fd, &c, 1);
+        if (k == 0) return !line.empty();
+        if (k < 0) {
+            if (errno == EINTR) continue;
+            return false;
+        }
+        if (c == '\n') return true;
+        line.push_back(c);
+        if (line.size() > 65536) return false;
+    }
+}
+
+int unix_socket(const char *path, sockaddr_un &addr)
+{
+    if (std::strlen(path) >= sizeof(addr.sun_path)) return -1;
+    const int fd = ::socket(AF_UNIX, SOCK_STREAM, 0);
+    if (fd < 0) return -1;
+    std::memset(&addr, 0, sizeof addr);
+    addr.sun_family = AF_UNIX;
+    std::strncpy(addr.sun_path, path, sizeof(addr.sun_path) - 1);
+    return fd;
+}
+
+int serve(const char *sock_path)
+{
+    sockaddr_un addr;
+    const int lfd = unix_socket(sock_path, addr);
+    if (lfd < 0) { std::fprintf(stderr, "cannot create socket %s\n", sock_path); return 1; }
+    ::unlink(sock_path);
+    if (::bind(lfd, reinterpret_cast<sockaddr *>(&addr), sizeof addr) != 0 || ::listen(lfd, 16) != 0) {
+        std::fprintf(stderr, "cannot listen on %s: %s\n", sock_path, std::strerror(errno));
+        return 1;
+    }
+    std::fprintf(stderr, "isslScoreOfftargets: serving on %s\n", sock_path);
+    const DeviceChoice dc = device_choice_from_env();
+    std::map<std::string, Resident> cache;
+    bool quit = false;
+    while (!quit) {
+        const int fd = ::accept(lfd, nullptr, nullptr);
+        if (fd < 0) {
+            if (errno == EINTR) continue;
+            break;
+        }
+        std::string line;
+        if (read_line(fd, line)) {
+            if (line == "QUIT") {
+                write_all(fd, "OK 0 {}\n", 8);
+                quit = true;
+            } else {
+                std::vector<std::string> f;
+                size_t a = 0;
+                while (true) {
+                    const size_t b = line.find('\t', a);
+                    f.push_back(line.substr(a, b == std::string::npos ? std::string::npos : b - a));
+                    if (b == std::string::npos) break;
+                    a = b + 1;
+                }
+                std::string err, out, tj;
+                bool ok = false;
+                if (f.size() == 6 && f[0] == "SCORE") {
+                    Request q;
+                    q.issl = f[1]; q.query = f[2]; q.max_dist = std::atoi(f[3].c_str());
+                    q.threshold = std::atof(f[4].c_str()); q.method_arg = f[5];
+                    struct stat st;
+                    if (::stat(q.issl.c_str(), &st) != 0) {
+                        err = "cannot open index file '" + q.issl + "': " + std::strerror(errno);
+                    } else {
+                        auto it = cache.find(q.issl);
+                        bool hit = it != cache.end() && it->second.size == st.st_size && it->second.mtime == st.st_mtime;
+                        if (it != cache.end() && !hit) { release(it->second); cache.erase(it); it = cache.end(); }
+                        if (it == cache.end()) {
+                            Resident r;
+                            if (make_resident(q.issl.c_str(), dc, 0, r, err)) {
+                                r.size = st.st_size;
+                                r.mtime = st.st_mtime;
+                                it = cache.emplace(q.issl, r).first;
+                            }
+                        }
+                        if (it != cache.end()) ok = score_request(it->second, q, out, err, tj, hit);
+                    }
+                } else {
+                    err = "malformed request";
+                }
+                if (ok) {
+                    const std::string head = "OK " + std::to_string(out.size()) + " " + tj + "\n";
+                    write_all(fd, head.data(), head.size()) && write_all(fd, out.data(), out.size());
+                } else {
+                    for (char &c : err) if (c == '\n') c = ' ';
+                    const std::string head = "ERR " + err + "\n";
+                    write_all(fd, head.data(), head.size());
+                }
+            }
+        }
+        ::close(fd);
+    }
+    for (auto &kv : cache) release(kv.second);
+    ::close(lfd);
+    ::unlink(sock_path);
+    return 0;
+}
+
+// Returns -1 when the server cannot be reached (caller scores locally), else the exit status.
+int try_server(const char *sock_path, char **argv, bool timing)
+{
+    sockaddr_un addr;
+    const int fd = unix_socket(sock_path, addr);
+    if (fd < 0) return -1;
+    if (::connect(fd, reinterpret_cast<sockaddr *>(&addr), sizeof addr) != 0) {
+        ::close(fd);
+        return -1;
+    }
+    char issl_abs[PATH_MAX], query_abs[PATH_MAX];
+    if (!::realpath(argv[1], issl_abs)) std::snprintf(issl_abs, sizeof issl_abs, "%s", argv[1]);
+    if (!::realpath(argv[2], query_abs)) std::snprintf(query_abs, sizeof query_abs, "%s", argv[2]);
+    const std::string req = std::string("SCORE\t") + issl_abs + "\t" + query_abs + "\t" + argv[3] + "\t" + argv[4] + "\t" +
+                            argv[5] + "\n";
+    std::string head;
+    if (!write_all(fd, req.data(), req.size()) || !read_line(fd, head)) {
+        ::close(fd);
+        return -1;
+    }
+    if (head.compare(0, 3, "OK ") != 0) {
+        std::fprintf(stderr, "%s\n", head.size() > 4 ? head.c_str() + 4 : "scoring failed");
+        ::close(fd);
+        return 1;
+    }
+    char *end = nullptr;
+    size_t left = std::strtoull(head.c_str() + 3, &end, 10);
+    if (timing && end && *end) std::fprintf(stderr, "%s\n", end + 1);
+    std::vector<char> buf(1 << 16);
+    while (left) {
+        const ssize_t k = ::read(fd, buf.data(), left < buf.size() ? left : buf.size());
+        if (k <= 0) {
+            if (k < 0 && errno == EINTR) continue;
+            std::fprintf(stderr, "resident scorer closed the connection early\n");
+            ::close(fd);
+            return 1;
+        }
+        if (std::fwrite(buf.data(), 1, static_cast<size_t>(k), stdout) != static_cast<size_t>(k)) {
+            std::fprintf(stderr, "short write on stdout\n");
+            ::close(fd);
+            return 1;
+        }
+        left -= static_cast<size_t>(k);
+    }
+    std::fflush(stdout);
+    ::close(fd);
+    return 0;
+}
+
+} // namespace
+
+int main(int argc, char **argv)
+{
+    if (argc == 3 && !std::strcmp(argv[1], "--serve")) return serve(argv[2]);
+    if (argc == 3 && !std::strcmp(argv[1], "--stop")) {
+        sockaddr_un addr;
+        const int fd = unix_socket(argv[2], addr);
+        if (fd < 0 || ::connect(fd, reinterpret_cast<sockaddr *>(&addr), sizeof addr) != 0) return 1;
+        std::string line;
+        const bool ok = write_all(fd, "QUIT\n", 5) && read_line(fd, line);
+        ::close(fd);
+        return ok ? 0 : 1;
+    }
+    if (argc < 6) { // the reference checks argc < 4 and then reads argv[4], argv[5] regardless (:93,112,121)
+        std::fprintf(stderr, "Usage: %s [issltable] [query file] [max distance] [score-threshold] [score-method]\n",
+                     argv[0]);
+        return 1;
+    }
+    const bool timing = std::getenv("ISSL_TIMING") != nullptr;
+    if (const char *sock = std::getenv("ISSL_SERVER")) {
+        const int rc = try_server(sock, argv, timing);
+        if (rc >= 0) return rc;
+    }
+    Request q;
+    q.issl = argv[1];
+    q.query = argv[2];
+    q.max_dist = std::atoi(argv[3]);     // :109
+    q.threshold = std::atof(argv[4]);    // :112
+    q.method_arg = argv[5];
+    // size of the query file decides whether a lone process spreads over all GPUs
+    size_t n_hint = 0;
+    struct stat st;
+    if (::stat(argv[2], &st) == 0) n_hint = static_cast<size_t>(st.st_size) / 21;
+    Resident r;
+    std::string err, out, tj;
+    {   // same order of checks as the reference: index file first, then the query file (:152-294), before any
+        // device work
+        issl_index *probe = nullptr;
+        if (issl_index_open(argv[1], &probe)) {
+            std::fprintf(stderr, "%s\n", last_error("cannot open index").c_str());
+            return 1;
+        }
+        issl_header h;
+        issl_index_header(probe, &h);
+        uint64_t *g = nullptr;
+        size_t n = 0;
+        const int rc = issl_read_query_file(argv[2], h.seq_len, &g, &n);
+        if (rc == 0) issl_free(g);
+        issl_index_close(probe);
+        if (rc) {
+            std::fprintf(stderr, "%s\n", last_error("cannot read query file").c_str());
+            return 1;
+        }
+    }
+    if (!make_resident(argv[1], device_choice_from_env(), n_hint, r, err)) {
+        std::fprintf(stderr, "%s\n", err.c_str());
+        return 1;
+    }
+    if (!score_request(r, q, out, err, tj, false)) {
+        std::fprintf(stderr, "%s\n", err.c_str());
+        release(r);
+        return 1;
     }
     if (!out.empty() && std::fwrite(out.data(), 1, out.size(), stdout) != out.size()) {
         std::fprintf(stderr, "short write on stdout\n");
+        release(r);
         return 1;
     }
     std::fflush(stdout);
-    if (timing && node) {
-        issl_node_info inf;
-        issl_node_get_info(node, &inf);
-        std::fprintf(stderr,
-                     "{\"guides\": %zu, \"devices\": %d, \"rccl\": %d, \"load_ms\": %.3f, \"upload_ms\": %.3f, "
-                     "\"broadcast_ms\": %.3f, \"score_ms\": %.3f}\n",
-                     n, inf.n_devices, inf.used_rccl, t1 - t0, inf.ms_upload, inf.ms_broadcast, inf.ms_last_score);
-    } else if (timing) {
-        issl_stats st;
-        issl_last_stats(idx, &st);
-        std::fprintf(stderr,
-                     "{\"guides\": %zu, \"load_ms\": %.3f, \"upload_ms\": %.3f, \"score_ms\": %.3f, \"scan_ms\": %.3f, "
-                     "\"replay_ms\": %.3f, \"candidates\": %llu, \"hits\": %llu}\n",
-                     n, t1 - t0, t2 - t1, t3 - t2, st.ms_scan, st.ms_replay, (unsigned long long)st.candidates,
-                     (unsigned long long)st.hits);
-    }
-    issl_free(guides);
-    if (node) issl_node_close(node);
-    issl_index_close(idx);
+    if (timing) std::fprintf(stderr, "%s\n", tj.c_str());
+    release(r);
     return 0;
 }

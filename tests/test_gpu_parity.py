@@ -323,6 +323,48 @@ def test_cli_multi_device_env(golden_uniform):
     assert b'"devices": 2' in r.stderr
 
 
+def test_resident_server_mode(golden, tmp_path):
+    """`isslScoreOfftargets --serve <socket>` keeps the index in HBM; invocations with ISSL_SERVER set get the same
+    bytes from it (second call: resident hit); an unreachable server falls back to in-process scoring."""
+    import time
+    exe = str(ROOT / "bin" / "isslScoreOfftargets")
+    sock = str(tmp_path / "issl.sock")
+    server = subprocess.Popen([exe, "--serve", sock], stderr=subprocess.PIPE)
+    try:
+        for _ in range(100):
+            if os.path.exists(sock):
+                break
+            time.sleep(0.05)
+        assert os.path.exists(sock)
+        env = dict(os.environ, ISSL_SERVER=sock, ISSL_TIMING="1")
+        keys = [k for k in ("and|75|4", "mit|0|4", "xyz|0|4") if k in golden.expected]
+        for i, key in enumerate(keys + keys[:1]):
+            method, thr, dist = key.split("|")
+            r = subprocess.run([exe, str(golden.issl), str(golden.guides_txt), dist, thr, method], capture_output=True,
+                               env=env, cwd=str(tmp_path))
+            assert r.returncode == 0, r.stderr.decode()
+            assert r.stdout.decode() == golden.expected[key], key
+            assert (b'"resident": true' in r.stderr) == (i > 0), r.stderr
+        # errors travel back with exit status 1 and nothing on stdout
+        r = subprocess.run([exe, str(tmp_path / "missing.issl"), str(golden.guides_txt), "4", "75", "and"],
+                           capture_output=True, env=env)
+        assert r.returncode == 1 and r.stdout == b"" and b"cannot open index" in r.stderr
+        bad = tmp_path / "bad.txt"; bad.write_text("ACGT\n")
+        r = subprocess.run([exe, str(golden.issl), str(bad), "4", "75", "and"], capture_output=True, env=env)
+        assert r.returncode == 1 and r.stdout == b"" and b"multiple of the expected line length" in r.stderr
+    finally:
+        subprocess.run([exe, "--stop", sock], capture_output=True)
+        try:
+            server.wait(timeout=20)
+        except subprocess.TimeoutExpired:
+            server.kill()
+    assert server.returncode == 0
+    # no server behind the socket path: the process scores by itself
+    env = dict(os.environ, ISSL_SERVER=str(tmp_path / "nobody.sock"))
+    r = subprocess.run([exe, str(golden.issl), str(golden.guides_txt), "4", "75", "and"], capture_output=True, env=env)
+    assert r.returncode == 0 and r.stdout.decode() == golden.expected["and|75|4"]
+
+
 def test_raw_buffer_growth_reruns_the_batch(golden_uniform, monkeypatch):
     """Start with a raw-record buffer far too small for the batch (fewer chunks than scan waves): the library must
     notice, grow it and re-run, with the golden results."""
