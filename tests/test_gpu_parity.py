@@ -388,3 +388,51 @@ def test_hit_counter(golden):
     st = ix.stats()
     assert st["scan_launches"] == 1 and st["hits"] == len(golden.hits(0))
     ix.close()
+
+
+@pytest.fixture(scope="module")
+def config1(tmp_path_factory):
+    """BASELINE.json configs[1] at full size: 10k guides vs a 50M-line synthetic index (48.8M distinct sites)."""
+    sigs, occ = random_sites(50_000_000, seed=20261003)
+    guides = random_guides(sigs, 10_000, seed=777)
+    ix = ca.IsslIndex.build_from_sites(sigs, occ)
+    ix.upload(0)
+    yield ix, sigs, occ, guides
+    ix.close()
+
+
+def test_config1_full_size_properties_and_oracle_sample(config1, tmp_path):
+    """Full-size run of the bench workload: size-independent properties on all 10k guides and bit-exact parity with
+    the CPU oracle on a sample (the oracle needs ~12 ms per guide and core at this index size)."""
+    ix, sigs, occ, guides = config1
+    mit, cfd = ix.score(guides, 4, 75.0, "and")
+    st = ix.stats()
+    assert st["candidates"] == ix.count_candidates(guides)              # every bucket of every guide was scanned
+    assert st["scan_launches"] == 1
+    assert np.all((mit > 0) & (mit <= 100) & (cfd > 0) & (cfd <= 100))
+    # permutation and split invariance
+    perm = np.random.default_rng(3).permutation(len(guides))
+    pm, pc = ix.score(guides[perm], 4, 75.0, "and")
+    assert np.array_equal(pm, mit[perm]) and np.array_equal(pc, cfd[perm])
+    a = ix.score(guides[:3333], 4, 75.0, "and"); b = ix.score(guides[3333:], 4, 75.0, "and")
+    assert np.array_equal(np.concatenate([a[0], b[0]]), mit) and np.array_equal(np.concatenate([a[1], b[1]]), cfd)
+    # a guide that IS a site: its exact match contributes occ to the CFD total and nothing to MIT (dist 0)
+    hits = ix.dump_hits(sigs[1000:1064], 0, 0.0, "and")
+    assert len(hits) == 64 and np.array_equal(hits[:, 3], np.arange(1000, 1064)) and np.all(hits[:, 4] == 0)
+    assert np.array_equal(hits[:, 5], occ[1000:1064])
+    # checksum of checksums: hits found with max_dist d are a subset of those with d+1, first-slice rule included
+    h3 = ix.dump_hits(guides[:500], 3, 0.0, "and"); h4 = ix.dump_hits(guides[:500], 4, 0.0, "and")
+    k3 = set(map(tuple, h3[:, [0, 3]])); k4 = set(map(tuple, h4[:, [0, 3]]))
+    assert k3 <= k4 and len(k4) > len(k3) and np.all(h3[:, 4] <= 3)
+    # oracle on a sample
+    p = tmp_path / "cfg1.issl"
+    ix.write(p)
+    oracle = ou.OracleIndex(p)
+    sample = np.concatenate([guides[:160], guides[-96:]])
+    gm = np.concatenate([mit[:160], mit[-96:]]); gc = np.concatenate([cfd[:160], cfd[-96:]])
+    omit, ocfd = oracle.score(sample, 4, 75.0, "and")
+    assert np.array_equal(gm.view(np.uint64), omit.view(np.uint64)) and np.array_equal(gc.view(np.uint64), ocfd.view(np.uint64))
+    _, _, ohits = oracle.score(sample[:64], 4, 0.0, "and", want_hits=True)
+    assert np.array_equal(ix.dump_hits(sample[:64], 4, 0.0, "and"), ohits)
+    oracle.close()
+    os.unlink(p)
