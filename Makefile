@@ -20,9 +20,10 @@ bin/isslScoreOfftargets: $(CSRC)/cli_score.cpp $(LIB)
 	@mkdir -p bin
 	$(HIPCC) $(CXXFLAGS) -o $@ $< -Lcrackling_amd -lissl_hip -Wl,-rpath,'$$ORIGIN/../crackling_amd'
 
-bin/isslCreateIndex: $(CSRC)/cli_create.cpp $(LIB)
+# host-only executable: no HIP runtime behind it (start-up of libamdhip64 alone costs ~1.5 s)
+bin/isslCreateIndex: $(CSRC)/cli_create.cpp $(CSRC)/issl_host.cpp $(CSRC)/issl_host.hpp
 	@mkdir -p bin
-	$(HIPCC) $(CXXFLAGS) -o $@ $< -Lcrackling_amd -lissl_hip -Wl,-rpath,'$$ORIGIN/../crackling_amd'
+	g++ $(CXXFLAGS) -o $@ $(CSRC)/cli_create.cpp $(CSRC)/issl_host.cpp -lpthread
 
 oracle:
 	$(MAKE) -C oracle all

@@ -9,7 +9,7 @@
 #include <cstdlib>
 #include <vector>
 
-#include "../../include/issl_hip.h"
+#include "issl_host.hpp"
 
 int main(int argc, char **argv)
 {
@@ -48,19 +48,13 @@ int main(int argc, char **argv)
     std::fclose(fp);
     const size_t n_lines = text.size() / line;
     std::fprintf(stderr, "Number of sequences: %zu\n", n_lines);
-    issl_index *idx = nullptr;
-    if (issl_index_build_from_text(text.data(), n_lines, seq_len, slice_width, &idx)) {
-        std::fprintf(stderr, "%s\n", issl_last_error());
+    // host-only code path: this executable does not touch the GPU and does not load the HIP runtime
+    issl::HostIndex idx;
+    if (idx.build_from_text(text.data(), n_lines, seq_len, slice_width) || idx.write_file(argv[4])) {
+        std::fprintf(stderr, "%s\n", issl::get_error());
         return 1;
     }
-    if (issl_index_write(idx, argv[4])) {
-        std::fprintf(stderr, "%s\n", issl_last_error());
-        return 1;
-    }
-    issl_header h;
-    issl_index_header(idx, &h);
-    std::printf("Done. %llu distinct sites, %llu slices of %llu bits.\n", (unsigned long long)h.n_sites,
-                (unsigned long long)h.n_slices, (unsigned long long)h.slice_width);
-    issl_index_close(idx);
+    std::printf("Done. %llu distinct sites, %llu slices of %llu bits.\n", (unsigned long long)idx.geo.n_sites,
+                (unsigned long long)idx.geo.n_slices, (unsigned long long)idx.geo.slice_width);
     return 0;
 }

@@ -118,7 +118,6 @@ struct Counters {
     uint32_t n_big;       // guides with more than kReplayLds hits (k_replay_big's list)
     uint32_t raw_chunks;  // chunks of the raw record buffer handed out
     uint32_t raw_overflow; // set when the raw buffer was too small
-    uint64_t reserved2;
 };
 
 struct Workspace {

@@ -197,20 +197,41 @@ int HostIndex::build_from_text(const char *text, size_t n_lines, size_t seq_len,
         return ISSL_E_ARG;
     }
     // Collapse runs of identical consecutive lines (the list is assumed sorted,
-    // isslCreateIndex.cpp:184-207).  The run never extends past the last line.
+    // isslCreateIndex.cpp:184-207; lines are compared as text, exactly like the reference's memcmp, so two lines
+    // that differ only in a non-ACGT byte stay two sites).  The run never extends past the last line.
     const size_t stride = seq_len + 1;
+    std::vector<uint64_t> line_sig(n_lines);
+    std::vector<uint8_t> starts_run(n_lines);
+    {
+        const size_t n_threads = std::max<size_t>(1, std::min<size_t>(std::thread::hardware_concurrency(), 16));
+        std::vector<std::thread> pool;
+        for (size_t t = 0; t < n_threads; ++t) {
+            pool.emplace_back([&, t]() {
+                const size_t lo = n_lines * t / n_threads, hi = n_lines * (t + 1) / n_threads;
+                for (size_t i = lo; i < hi; ++i) {
+                    const char *cur = text + i * stride;
+                    line_sig[i] = encode_guide(cur, seq_len);
+                    starts_run[i] = (i == 0) || std::memcmp(cur - stride, cur, seq_len) != 0;
+                }
+            });
+        }
+        for (auto &th : pool) th.join();
+    }
     std::vector<uint64_t> sigs;
     std::vector<uint32_t> occ;
     sigs.reserve(n_lines);
     occ.reserve(n_lines);
-    size_t i = 0;
-    while (i < n_lines) {
-        const char *cur = text + i * stride;
-        size_t run = 1;
-        while (i + run < n_lines && std::memcmp(cur, cur + run * stride, seq_len) == 0) ++run;
-        sigs.push_back(encode_guide(cur, seq_len));
-        occ.push_back(static_cast<uint32_t>(run));
-        i += run;
+    for (size_t i = 0; i < n_lines; ++i) {
+        if (starts_run[i]) {
+            sigs.push_back(line_sig[i]);
+            occ.push_back(1);
+        } else {
+            ++occ.back();
+        }
+    }
+    if (n_lines == 0) {
+        set_error("site list is empty");
+        return ISSL_E_ARG;
     }
     return build_from_sites(sigs.data(), occ.data(), sigs.size(), n_lines, seq_len, slice_width);
 }

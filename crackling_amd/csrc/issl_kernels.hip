@@ -562,8 +562,7 @@ __device__ __forceinline__ uint32_t take_ticket(Counters *counters, uint32_t n_s
 // The streams the hot loop reads (scan planes, tile table, items, guide words, plan) are separate
 // `const __restrict__` kernel arguments: they are never written by this kernel, which lets the
 // compiler fetch the wave-uniform ones through the scalar cache.
-// ABL (timing experiments only, results are wrong when non-zero): bit 1 = never note candidates.
-template <int THR, bool STAGGER, int ABL = 0>
+template <int THR>
 __global__ __launch_bounds__(256, 6) void k_scan(const uint32_t *__restrict__ scan_stream,
                                                  const uint32_t *__restrict__ tile_first,
                                                  const ScanItem *__restrict__ items,
@@ -575,15 +574,6 @@ __global__ __launch_bounds__(256, 6) void k_scan(const uint32_t *__restrict__ sc
     const uint32_t n_ranges = plan->n_ranges;
     const uint32_t n_static = plan->n_static;
     if (n_ranges == 0) return;
-    // The waves of a SIMD run the same program on tiles of equal cost: left alone they advance in lockstep,
-    // reach their tile loads together and leave the SIMD idle for a memory round trip per tile.  Distinct
-    // issue priorities per wave slot make them finish their tiles at different times.
-    if (STAGGER) {
-        const uint32_t slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4); // HW_ID.wave_id
-        if ((slot & 3u) == 1u) __builtin_amdgcn_s_setprio(1);
-        else if ((slot & 3u) == 2u) __builtin_amdgcn_s_setprio(2);
-        else if ((slot & 3u) == 3u) __builtin_amdgcn_s_setprio(3);
-    }
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
     uint32_t range = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
@@ -628,7 +618,6 @@ __global__ __launch_bounds__(256, 6) void k_scan(const uint32_t *__restrict__ sc
 #pragma unroll
                 for (uint32_t u = 0; u < kGuideGroup; ++u) {
                     const uint32_t ok = near_plane<THR>(c, gg.w[u], thr);
-                    if (ABL & 2) { asm volatile("" ::"v"(ok)); continue; }
                     if (__ballot(ok != 0u) != 0ull) { // ~4 % of the (guide, tile) pairs on random data
                         note_candidates(ok, g + u, tile, lane, w, raw, max_chunks, counters);
                         own_chunk = true;
@@ -716,30 +705,8 @@ __global__ __launch_bounds__(kChunkRecs) void k_verify(ImageView v, Workspace ws
 template <int THR>
 static void launch_scan_thr(const ImageView &v, const Workspace &ws, uint32_t thr, hipStream_t stream)
 {
-    // ISSL_SCAN_ABLATE=<bits>: timing experiments (wrong results), only for the default threshold build.
-    const char *abl_env = getenv("ISSL_SCAN_ABLATE");
-    const int abl = abl_env ? atoi(abl_env) : 0;
-    if (THR == 4 && abl) {
-#define ISSL_ABL_CASE(A)                                                                                        \
-    if (abl == A) {                                                                                                 \
-        hipLaunchKernelGGL((k_scan<4, false, A>), dim3(kScanGridBlocks), dim3(256), 0, stream, v.scan, v.tile_first, \
-                           ws.items, ws.plan, ws.range_start, ws.gword, ws.raw,                                     \
-                           static_cast<uint32_t>(ws.cap_chunks), ws.counters, thr);                                 \
-        return;                                                                                                     \
-    }
-        ISSL_ABL_CASE(2)
-#undef ISSL_ABL_CASE
-    }
-    // ISSL_SCAN_STAGGER=0 disables the per-slot issue priorities (A/B aid).
-    const char *stagger_env = getenv("ISSL_SCAN_STAGGER");
-    if (stagger_env && stagger_env[0] == '0')
-        hipLaunchKernelGGL((k_scan<THR, false>), dim3(kScanGridBlocks), dim3(256), 0, stream, v.scan, v.tile_first,
-                           ws.items, ws.plan, ws.range_start, ws.gword, ws.raw, static_cast<uint32_t>(ws.cap_chunks),
-                           ws.counters, thr);
-    else
-        hipLaunchKernelGGL((k_scan<THR, true>), dim3(kScanGridBlocks), dim3(256), 0, stream, v.scan, v.tile_first,
-                           ws.items, ws.plan, ws.range_start, ws.gword, ws.raw, static_cast<uint32_t>(ws.cap_chunks),
-                           ws.counters, thr);
+    hipLaunchKernelGGL(k_scan<THR>, dim3(kScanGridBlocks), dim3(256), 0, stream, v.scan, v.tile_first, ws.items, ws.plan,
+                       ws.range_start, ws.gword, ws.raw, static_cast<uint32_t>(ws.cap_chunks), ws.counters, thr);
 }
 
 void launch_scan(const ImageView &v, const Workspace &ws, const uint64_t *d_guides, uint32_t n, int max_dist,

@@ -12,7 +12,7 @@ ap.add_argument("--sites", type=int, default=5_000_000)
 ap.add_argument("--guides", type=int, default=10_000)
 ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--thr", type=float, default=0.0)
-ap.add_argument("--variants", default="3:99:512")
+ap.add_argument("--variants", default="3:99:512", help="ISSL_SCHED settings to compare, a:b:c separated by /")
 ap.add_argument("--write-issl", default=None)
 ap.add_argument("--write-guides", default=None)
 a = ap.parse_args()
