@@ -9,14 +9,18 @@ CXXFLAGS = -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-result
 HIPFLAGS = $(CXXFLAGS) --offload-arch=$(ARCH)
 LIB      = crackling_amd/libissl_hip.so
 
-all: $(LIB) bin/isslScoreOfftargets bin/isslCreateIndex
+all: $(LIB) bin/isslScoreOfftargets bin/isslCreateIndex bin/extractOfftargets
 
-$(LIB): $(CSRC)/issl_kernels.hip $(CSRC)/issl_capi.cpp $(CSRC)/issl_host.cpp $(CSRC)/issl_node.cpp \
-        $(CSRC)/issl_host.hpp $(CSRC)/issl_device.hpp $(CSRC)/cfd_tables.inc include/issl_hip.h
-	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/issl_kernels.hip $(CSRC)/issl_capi.cpp $(CSRC)/issl_host.cpp \
-	    $(CSRC)/issl_node.cpp -lpthread -ldl
+$(LIB): $(CSRC)/issl_kernels.hip $(CSRC)/issl_extract.hip $(CSRC)/issl_capi.cpp $(CSRC)/issl_host.cpp \
+        $(CSRC)/issl_node.cpp $(CSRC)/issl_host.hpp $(CSRC)/issl_device.hpp $(CSRC)/cfd_tables.inc include/issl_hip.h
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/issl_kernels.hip $(CSRC)/issl_extract.hip $(CSRC)/issl_capi.cpp \
+	    $(CSRC)/issl_host.cpp $(CSRC)/issl_node.cpp -lpthread -ldl
 
 bin/isslScoreOfftargets: $(CSRC)/cli_score.cpp $(LIB)
+	@mkdir -p bin
+	$(HIPCC) $(CXXFLAGS) -o $@ $< -Lcrackling_amd -lissl_hip -Wl,-rpath,'$$ORIGIN/../crackling_amd'
+
+bin/extractOfftargets: $(CSRC)/cli_extract.cpp $(LIB)
 	@mkdir -p bin
 	$(HIPCC) $(CXXFLAGS) -o $@ $< -Lcrackling_amd -lissl_hip -Wl,-rpath,'$$ORIGIN/../crackling_amd'
 

@@ -13,6 +13,7 @@ from .scorer import (  # noqa: F401
     IsslNode,
     METHODS,
     encode_guides,
+    extract_offtargets,
     decode_guides,
     format_scores,
     run_scorer_binary,
@@ -20,6 +21,6 @@ from .scorer import (  # noqa: F401
 )
 
 __all__ = [
-    "IsslIndex", "IsslNode", "IsslError", "METHODS", "encode_guides", "decode_guides", "format_scores",
+    "IsslIndex", "IsslNode", "IsslError", "METHODS", "encode_guides", "extract_offtargets", "decode_guides", "format_scores",
     "run_scorer_binary", "parse_scorer_output", "lib", "LIB_PATH",
 ]

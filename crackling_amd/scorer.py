@@ -263,6 +263,21 @@ class IsslNode:
             pass
 
 
+def extract_offtargets(fasta_blobs, device=0):
+    """Sorted site list (bytes, one 20-mer per line) of FASTA / multi-FASTA contents -- the GPU counterpart of
+    crackling/utils/extractOfftargets.py.  fasta_blobs: iterable of bytes."""
+    blobs = [b if isinstance(b, bytes) else b.encode() for b in fasta_blobs]
+    files = (C.c_char_p * len(blobs))(*blobs)
+    lens = (C.c_size_t * len(blobs))(*[len(b) for b in blobs])
+    out = C.c_void_p()
+    n = C.c_size_t()
+    sites = C.c_uint64()
+    check(lib.issl_extract_from_memory(files, lens, len(blobs), device, C.byref(out), C.byref(n), C.byref(sites)))
+    data = C.string_at(out, n.value) if n.value else b""
+    lib.issl_free(out)
+    return data
+
+
 def run_scorer_binary(binary, issl_path, guides23, max_dist, threshold, method, workdir=None, env=None):
     """What Crackling.py:747-778 does for one page of guides: returns the scorer's stdout text.
 

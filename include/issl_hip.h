@@ -208,6 +208,17 @@ int issl_node_score(issl_node *node, const uint64_t *guides, size_t n, int max_d
 int issl_node_get_info(const issl_node *node, issl_node_info *out);
 int issl_node_close(issl_node *node);
 
+/* ---- off-target site extraction (the step before the index builder) ------------------------------ */
+/* Counterpart of src/crackling/utils/extractOfftargets.py: every N20 site next to a PAM on either strand
+ * (patterns of :23-24, overlapping matches, first 20 characters of the match, reverse-complemented for the
+ * reverse pattern), sorted as text, duplicates kept, one per line.  Runs on `device`; no CPU fallback.
+ * files[i]/lens[i]: the bytes of FASTA / multi-FASTA files.  *out_text is malloc'd (issl_free). */
+int issl_extract_from_memory(const char *const *files, const size_t *lens, int n_files, int device,
+                             char **out_text, size_t *out_len, uint64_t *n_sites);
+/* Same from files on disk into `output_path` (what bin/extractOfftargets calls). */
+int issl_extract_offtargets(const char *const *inputs, int n_inputs, const char *output_path, int device,
+                            uint64_t *n_sites);
+
 #ifdef __cplusplus
 }
 #endif
