@@ -71,6 +71,7 @@ ImageView make_view(const ImageHeader &h, void *base)
 } // namespace issl
 
 constexpr uint32_t kRing = 64;
+constexpr size_t kMaxBatch = size_t(1) << 24; // guides per pipeline launch
 
 struct issl_index {
     std::unique_ptr<HostIndex> host; // absent for attached images
@@ -332,8 +333,8 @@ static int enqueue_batch(issl_index *ix, const uint64_t *d_guides, size_t n, int
         set_error("index has no device image: call issl_index_upload first");
         return ISSL_E_STATE;
     }
-    if (n >= (size_t(1) << 29)) {
-        set_error("at most 2^29-1 guides per call");
+    if (n > kMaxBatch) { // guide slots are 27-bit fields of the raw records: 5 slots per guide + padding
+        set_error("at most 2^24 guides per device batch (issl_score splits larger batches itself)");
         return ISSL_E_ARG;
     }
     HIP_TRY(hipSetDevice(ix->device));
@@ -726,14 +727,27 @@ int issl_score(issl_index *idx, const uint64_t *guides, size_t n, int max_dist, 
     if (!idx->d_image) { set_error("index has no device image: call issl_index_upload first"); return ISSL_E_STATE; }
     if (n == 0) return ISSL_OK;
     HIP_TRY(hipSetDevice(idx->device));
-    int rc = ensure_workspace(idx, n);
-    if (rc) return rc;
-    HIP_TRY(hipMemcpy(idx->ws.d_guides, guides, 8 * n, hipMemcpyHostToDevice));
-    rc = score_core(idx, idx->ws.d_guides, n, max_dist, threshold, method, idx->ws.d_mit, idx->ws.d_cfd, nullptr,
-                    false);
-    if (rc) return rc;
-    HIP_TRY(hipMemcpy(mit, idx->ws.d_mit, 8 * n, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(cfd, idx->ws.d_cfd, 8 * n, hipMemcpyDeviceToHost));
+    // Crackling hands over pages of up to 5 M guides (config.ini:112); larger batches go through in pieces.
+    const size_t piece = size_t(1) << 22;
+    issl_stats total{};
+    for (size_t at = 0; at < n; at += piece) {
+        const size_t cnt = std::min(piece, n - at);
+        int rc = ensure_workspace(idx, cnt);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpy(idx->ws.d_guides, guides + at, 8 * cnt, hipMemcpyHostToDevice));
+        rc = score_core(idx, idx->ws.d_guides, cnt, max_dist, threshold, method, idx->ws.d_mit, idx->ws.d_cfd, nullptr,
+                        false);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpy(mit + at, idx->ws.d_mit, 8 * cnt, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(cfd + at, idx->ws.d_cfd, 8 * cnt, hipMemcpyDeviceToHost));
+        const issl_stats &s = idx->stats;
+        total.n_guides += s.n_guides; total.candidates += s.candidates; total.hits += s.hits;
+        total.scan_tiles += s.scan_tiles; total.ms_bin += s.ms_bin; total.ms_scan += s.ms_scan;
+        total.ms_verify += s.ms_verify; total.ms_group += s.ms_group; total.ms_replay += s.ms_replay;
+        total.ms_total += s.ms_total; total.scan_launches += s.scan_launches;
+        total.raw_records = std::max(total.raw_records, s.raw_records); total.n_batches += s.n_batches;
+    }
+    idx->stats = total;
     return ISSL_OK;
 }
 
@@ -744,6 +758,7 @@ int issl_dump_hits(issl_index *idx, const uint64_t *guides, size_t n, int max_di
     if (!idx->d_image) { set_error("index has no device image: call issl_index_upload first"); return ISSL_E_STATE; }
     *n_hits = 0;
     if (n == 0) return ISSL_OK;
+    if (n > (size_t(1) << 22)) { set_error("issl_dump_hits takes at most 2^22 guides per call"); return ISSL_E_ARG; }
     HIP_TRY(hipSetDevice(idx->device));
     int rc = ensure_workspace(idx, n);
     if (rc) return rc;

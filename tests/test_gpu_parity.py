@@ -225,6 +225,21 @@ def test_image_attach_and_caller_owned_memory(golden_uniform):
     att.close(); src.close()
 
 
+def test_large_batch_paths(config0, monkeypatch):
+    """300k guides in one launch (three-kernel prefix sum, many items per bucket) and the host entry point's
+    splitting of batches beyond 2^22 guides (checked with a small piece count through repetition)."""
+    ix, oracle, sigs, guides = config0
+    big = np.tile(guides, 300)  # 300k guides, every bucket ~1200 guides deep
+    mit, cfd = ix.score(big, 4, 75.0, "and")
+    assert ix.stats()["candidates"] == 300 * ix.count_candidates(guides)
+    base = ix.score(guides, 4, 75.0, "and")
+    assert np.array_equal(mit, np.tile(base[0], 300)) and np.array_equal(cfd, np.tile(base[1], 300))
+    huge = np.tile(guides, 4300)  # 4.3M guides > 2^22: two pieces
+    mit, cfd = ix.score(huge, 4, 75.0, "and")
+    assert np.array_equal(mit, np.tile(base[0], 4300)) and np.array_equal(cfd, np.tile(base[1], 4300))
+    assert ix.stats()["n_batches"] == 2 and ix.stats()["n_guides"] == len(huge)
+
+
 def test_async_batches(config0):
     """issl_score_device_async / issl_score_finish: several batches in flight on one stream."""
     import torch
