@@ -60,6 +60,21 @@ def test_oracle_known_sites():
     assert oracle_extract([b">a\nTCGTACGTACGTACGTACGTAGG\n"]) == b""
 
 
+def test_extraction_without_device_fails_loudly(tmp_path):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import crackling_amd as ca
+    with pytest.raises(ca.IsslError) as e:
+        ca.extract_offtargets([(GOLD / "multi.fa").read_bytes()])
+    assert e.value.code == -5 and "no CPU fallback" in str(e.value)
+    r = subprocess.run([str(ROOT / "bin" / "extractOfftargets"), str(tmp_path / "o.txt"), str(GOLD / "multi.fa")],
+                       capture_output=True)
+    assert r.returncode == 1 and b"no HIP device" in r.stderr and not (tmp_path / "o.txt").exists()
+    r = subprocess.run([str(ROOT / "bin" / "extractOfftargets"), str(tmp_path / "o.txt")], capture_output=True)
+    assert r.returncode == 2 and b"usage" in r.stderr
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", SETS)
 def test_gpu_extraction_matches_reference_golden(name):

@@ -240,6 +240,22 @@ def test_large_batch_paths(config0, monkeypatch):
     assert ix.stats()["n_batches"] == 2 and ix.stats()["n_guides"] == len(huge)
 
 
+def test_one_site_index(tmp_path):
+    """Smallest possible index: one site, 1279 empty buckets."""
+    sig = np.array([0x123456789A], dtype=np.uint64)
+    ix = ca.IsslIndex.build_from_sites(sig, np.array([7], dtype=np.uint32))
+    p = tmp_path / "one.issl"; ix.write(p); ix.upload(0)
+    oracle = ou.OracleIndex(p)
+    guides = np.array([0x123456789A, 0x123456789B, 0x0, (1 << 40) - 1], dtype=np.uint64)
+    for thr in (0.0, 75.0):
+        mit, cfd = ix.score(guides, 4, thr, "and")
+        omit, ocfd = oracle.score(guides, 4, thr, "and")
+        assert np.array_equal(mit.view(np.uint64), omit.view(np.uint64)) and np.array_equal(cfd.view(np.uint64), ocfd.view(np.uint64))
+    hits = ix.dump_hits(guides, 4, 0.0, "and")
+    assert len(hits) == 2 and list(hits[0]) == [0, 0, 0, 0, 0, 7] and hits[1][4] == 1
+    ix.close()
+
+
 def test_async_batches(config0):
     """issl_score_device_async / issl_score_finish: several batches in flight on one stream."""
     import torch
