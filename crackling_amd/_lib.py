@@ -92,6 +92,7 @@ _protos = {
     "issl_score": (C.c_int, [_P, _P, C.c_size_t, C.c_int, C.c_double, C.c_int, _P, _P]),
     "issl_score_device": (C.c_int, [_P, _P, C.c_size_t, C.c_int, C.c_double, C.c_int, _P, _P, _P]),
     "issl_score_device_async": (C.c_int, [_P, _P, C.c_size_t, C.c_int, C.c_double, C.c_int, _P, _P, _P]),
+    "issl_score_wait": (C.c_int, [_P, _P]),
     "issl_score_finish": (C.c_int, [_P, _P]),
     "issl_dump_hits": (C.c_int, [_P, _P, C.c_size_t, C.c_int, C.c_double, C.c_int, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     "issl_last_stats": (C.c_int, [_P, C.POINTER(Stats)]),

@@ -73,6 +73,17 @@ ImageView make_view(const ImageHeader &h, void *base)
 constexpr uint32_t kRing = 64;
 constexpr size_t kMaxBatch = size_t(1) << 24; // guides per pipeline launch
 
+struct Lane {
+    Workspace ws;
+    hipEvent_t ev[6] = {};      // stage boundaries of the lane's last batch
+    hipEvent_t done = nullptr;  // end of the lane's last batch
+    hipEvent_t scan_done = nullptr; // end of the scan of the lane's last batch
+    hipStream_t stream = nullptr; // internal stream of asynchronous batches
+    bool ready = false;         // events and stream created
+    uint32_t last_n = 0;
+    uint32_t pending = 0;       // batches enqueued on this lane since the last finish
+};
+
 struct issl_index {
     std::unique_ptr<HostIndex> host; // absent for attached images
     Geometry geo;
@@ -83,15 +94,14 @@ struct issl_index {
     bool owns_image = false;
     ImageHeader hdr{};
     ImageView view{};
-    Workspace ws;
-    hipEvent_t ev[6] = {};
+    // A lane = one complete workspace + an internal stream.  Synchronous calls use lane 0 on the caller's stream;
+    // asynchronous batches run on lane 0's internal stream (and alternate with lane 1 only under ISSL_LANES=2).
+    Lane lanes[2];
     hipEvent_t ring[2 * kRing] = {}; // scan begin/end of the batches enqueued since the last finish
     bool have_events = false;
     issl_stats stats{};
-    // batches enqueued and not yet finished
-    uint32_t n_pending = 0;
-    uint32_t last_n = 0;
-    bool last_dump = false;
+    uint32_t n_pending = 0;  // batches enqueued and not yet finished
+    uint32_t last_lane = 0;
 };
 
 #define HIP_TRY(expr)                                                                              \
@@ -148,9 +158,8 @@ template <typename T> static int dev_alloc(T *&p, size_t count)
     return ISSL_OK;
 }
 
-static int ensure_hit_capacity(issl_index *ix, size_t want)
+static int ensure_hit_capacity(Workspace &w, size_t want)
 {
-    Workspace &w = ix->ws;
     if (want <= w.cap_hits) return ISSL_OK;
     int rc;
     if ((rc = dev_alloc(w.sorted, want))) return rc;
@@ -159,9 +168,8 @@ static int ensure_hit_capacity(issl_index *ix, size_t want)
     return ISSL_OK;
 }
 
-static int ensure_raw_capacity(issl_index *ix, size_t chunks)
+static int ensure_raw_capacity(Workspace &w, size_t chunks)
 {
-    Workspace &w = ix->ws;
     if (chunks <= w.cap_chunks) return ISSL_OK;
     int rc = dev_alloc(w.raw, (chunks + 1) * kChunkRecs); // +1: spare chunk that absorbs writes after exhaustion
     if (rc) return rc;
@@ -169,9 +177,9 @@ static int ensure_raw_capacity(issl_index *ix, size_t chunks)
     return ISSL_OK;
 }
 
-static int ensure_workspace(issl_index *ix, size_t n)
+static int ensure_workspace(issl_index *ix, Lane &lane, size_t n)
 {
-    Workspace &w = ix->ws;
+    Workspace &w = lane.ws;
     const size_t nb = ix->hdr.n_buckets;
     int rc;
     if (w.n_buckets != nb) {
@@ -209,12 +217,18 @@ static int ensure_workspace(issl_index *ix, size_t n)
         size_t want = std::max<size_t>(size_t(kScanGridBlocks) * 4 * 4, n);
         // ISSL_RAW_CHUNKS=<n>: start with a small raw buffer (tests of the grow-and-rerun path)
         if (const char *e = std::getenv("ISSL_RAW_CHUNKS")) want = std::max<size_t>(1, std::strtoull(e, nullptr, 10));
-        if ((rc = ensure_raw_capacity(ix, want))) return rc;
+        if ((rc = ensure_raw_capacity(w, want))) return rc;
     }
     if (!ix->have_events) {
-        for (auto &e : ix->ev) HIP_TRY(hipEventCreate(&e));
         for (auto &e : ix->ring) HIP_TRY(hipEventCreate(&e));
         ix->have_events = true;
+    }
+    if (!lane.ready) {
+        for (auto &e : lane.ev) HIP_TRY(hipEventCreate(&e));
+        HIP_TRY(hipEventCreate(&lane.done));
+        HIP_TRY(hipEventCreate(&lane.scan_done));
+        HIP_TRY(hipStreamCreateWithFlags(&lane.stream, hipStreamNonBlocking));
+        lane.ready = true;
     }
     if (!w.sticky) {
         if ((rc = dev_alloc(w.sticky, 4))) return rc;
@@ -298,12 +312,24 @@ static uint64_t count_tiles(const HostIndex &h)
 static void release_device(issl_index *ix)
 {
     if (ix->device >= 0) (void)hipSetDevice(ix->device);
-    free_workspace(ix->ws);
+    for (Lane &lane : ix->lanes) {
+        if (lane.ready) {
+            (void)hipStreamSynchronize(lane.stream);
+            for (auto &e : lane.ev) (void)hipEventDestroy(e);
+            (void)hipEventDestroy(lane.done);
+            (void)hipEventDestroy(lane.scan_done);
+            (void)hipStreamDestroy(lane.stream);
+            lane.ready = false;
+        }
+        free_workspace(lane.ws);
+        lane.last_n = 0;
+        lane.pending = 0;
+    }
     if (ix->have_events) {
-        for (auto &e : ix->ev) (void)hipEventDestroy(e);
         for (auto &e : ix->ring) (void)hipEventDestroy(e);
         ix->have_events = false;
     }
+    ix->n_pending = 0;
     if (ix->d_image && ix->owns_image) (void)hipFree(ix->d_image);
     ix->d_image = nullptr;
     ix->owns_image = false;
@@ -325,9 +351,9 @@ static int new_index_from_host(std::unique_ptr<HostIndex> h, issl_index **out)
 
 // The scoring pipeline.  Guides and outputs are device pointers on ix->device.
 // enqueue_batch() only launches (no host round trip); finish_batches() synchronises, checks the sticky overflow
-// word the pipeline leaves behind, and fills the statistics.
-static int enqueue_batch(issl_index *ix, const uint64_t *d_guides, size_t n, int max_dist, double threshold,
-                         int method, double *d_mit, double *d_cfd, hipStream_t stream, bool dump)
+// words the pipelines leave behind, and fills the statistics.
+static int enqueue_batch(issl_index *ix, Lane &lane, hipStream_t stream, const uint64_t *d_guides, size_t n,
+                         int max_dist, double threshold, int method, double *d_mit, double *d_cfd, bool dump)
 {
     if (!ix->d_image) {
         set_error("index has no device image: call issl_index_upload first");
@@ -339,16 +365,17 @@ static int enqueue_batch(issl_index *ix, const uint64_t *d_guides, size_t n, int
     }
     HIP_TRY(hipSetDevice(ix->device));
     if (n == 0) return ISSL_OK;
-    int rc = ensure_workspace(ix, n);
+    int rc = ensure_workspace(ix, lane, n);
     if (rc) return rc;
+    Workspace &ws = lane.ws;
     // `sorted` always has room for every raw slot, so the whole pipeline runs without a host round trip;
     // an exhausted raw buffer is detected in finish_batches() and the batch is re-run with a larger one.
-    rc = ensure_hit_capacity(ix, ix->ws.cap_chunks * (kChunkRecs - 1));
+    rc = ensure_hit_capacity(ws, ws.cap_chunks * (kChunkRecs - 1));
     if (rc) return rc;
-    if (dump && ix->ws.cap_hitrec < ix->ws.cap_hits) {
-        rc = dev_alloc(ix->ws.d_hitrec, ix->ws.cap_hits);
+    if (dump && ws.cap_hitrec < ws.cap_hits) {
+        rc = dev_alloc(ws.d_hitrec, ws.cap_hits);
         if (rc) return rc;
-        ix->ws.cap_hitrec = ix->ws.cap_hits;
+        ws.cap_hitrec = ws.cap_hits;
     }
     ScoreParams p;
     p.max_dist = max_dist;
@@ -356,57 +383,79 @@ static int enqueue_batch(issl_index *ix, const uint64_t *d_guides, size_t n, int
     p.maximum_sum = (10000.0 - threshold * 100) / threshold; // isslScoreOfftargets.cpp:326
     const uint32_t n32 = static_cast<uint32_t>(n);
     const uint32_t slot = ix->n_pending % kRing;
-    HIP_TRY(hipEventRecord(ix->ev[0], stream));
-    launch_bin_guides(ix->view, ix->ws, d_guides, n32, stream);
-    HIP_TRY(hipEventRecord(ix->ev[1], stream));
+    HIP_TRY(hipEventRecord(lane.ev[0], stream));
+    launch_bin_guides(ix->view, ws, d_guides, n32, stream);
+    HIP_TRY(hipEventRecord(lane.ev[1], stream));
+    // The scan assumes the whole GPU (its ranges are dealt out statically to co-resident waves): scans of different
+    // lanes never overlap each other, only the short kernels around them do.
+    Lane &other = ix->lanes[1 - (&lane - ix->lanes)];
+    if (other.ready && other.pending) HIP_TRY(hipStreamWaitEvent(stream, other.scan_done, 0));
     HIP_TRY(hipEventRecord(ix->ring[2 * slot], stream));
-    launch_scan(ix->view, ix->ws, d_guides, n32, max_dist, stream);
+    launch_scan(ix->view, ws, d_guides, n32, max_dist, stream);
     HIP_TRY(hipEventRecord(ix->ring[2 * slot + 1], stream));
-    HIP_TRY(hipEventRecord(ix->ev[2], stream));
-    launch_verify(ix->view, ix->ws, d_guides, max_dist, stream);
-    HIP_TRY(hipEventRecord(ix->ev[3], stream));
-    launch_group_hits(ix->ws, n32, stream);
-    HIP_TRY(hipEventRecord(ix->ev[4], stream));
-    launch_replay(ix->view, ix->ws, d_guides, n32, p, d_mit, d_cfd, dump ? ix->ws.d_kept : nullptr,
-                  dump ? ix->ws.d_hitrec : nullptr, stream);
-    HIP_TRY(hipEventRecord(ix->ev[5], stream));
+    HIP_TRY(hipEventRecord(lane.scan_done, stream));
+    HIP_TRY(hipEventRecord(lane.ev[2], stream));
+    launch_verify(ix->view, ws, d_guides, max_dist, stream);
+    HIP_TRY(hipEventRecord(lane.ev[3], stream));
+    launch_group_hits(ws, n32, stream);
+    HIP_TRY(hipEventRecord(lane.ev[4], stream));
+    launch_replay(ix->view, ws, d_guides, n32, p, d_mit, d_cfd, dump ? ws.d_kept : nullptr,
+                  dump ? ws.d_hitrec : nullptr, stream);
+    HIP_TRY(hipEventRecord(lane.ev[5], stream));
+    HIP_TRY(hipEventRecord(lane.done, stream));
     ix->n_pending += 1;
-    ix->last_n = n32;
-    ix->last_dump = dump;
+    lane.pending += 1;
+    lane.last_n = n32;
+    ix->last_lane = static_cast<uint32_t>(&lane - ix->lanes);
     return ISSL_OK;
 }
 
-// Returns ISSL_OK, or ISSL_E_RETRY when a batch since the last finish ran out of raw-record space (the buffers
-// have been enlarged; the caller enqueues those batches again).
+// Synchronises everything that was enqueued (lane streams and, for synchronous calls, `stream`).  Returns ISSL_OK,
+// or ISSL_E_RETRY when a batch since the last finish ran out of raw-record space (the buffers have been enlarged;
+// the caller enqueues those batches again).
 static int finish_batches(issl_index *ix, hipStream_t stream)
 {
     if (!ix->d_image || ix->n_pending == 0) return ISSL_OK;
     HIP_TRY(hipSetDevice(ix->device));
-    uint32_t sticky[4] = {0, 0, 0, 0};
-    PlanInfo pl{};
-    uint32_t total_hits = 0;
-    HIP_TRY(hipMemcpyAsync(sticky, ix->ws.sticky, sizeof sticky, hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipMemcpyAsync(&pl, ix->ws.plan, sizeof pl, hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipMemcpyAsync(&total_hits, ix->ws.goff + ix->last_n, sizeof total_hits, hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
+    for (Lane &lane : ix->lanes)
+        if (lane.ready && lane.pending) HIP_TRY(hipStreamSynchronize(lane.stream));
     HIP_TRY(hipGetLastError());
     const uint32_t batches = ix->n_pending;
     ix->n_pending = 0;
-    if (sticky[2] & 2u) {
-        HIP_TRY(hipMemset(ix->ws.sticky, 0, 16));
-        set_error("internal error: scan item list overflow");
-        return ISSL_E_DEVICE;
+    bool retry = false;
+    uint32_t max_chunks = 0;
+    for (Lane &lane : ix->lanes) {
+        if (!lane.pending) continue;
+        lane.pending = 0;
+        uint32_t sticky[4] = {0, 0, 0, 0};
+        HIP_TRY(hipMemcpy(sticky, lane.ws.sticky, sizeof sticky, hipMemcpyDeviceToHost));
+        max_chunks = std::max(max_chunks, sticky[1]);
+        if (sticky[2] & 2u) {
+            HIP_TRY(hipMemset(lane.ws.sticky, 0, 16));
+            set_error("internal error: scan item list overflow");
+            return ISSL_E_DEVICE;
+        }
+        if (sticky[0]) retry = true;
     }
-    if (sticky[0]) {
-        HIP_TRY(hipMemset(ix->ws.sticky, 0, 16));
-        // sticky[1] = largest number of chunks any batch asked for
-        int rc = ensure_raw_capacity(ix, static_cast<size_t>(sticky[1]) + sticky[1] / 8 + 1024);
-        if (rc) return rc;
+    if (retry) {
+        // max_chunks = largest number of chunks any batch asked for; both lanes get the room
+        for (Lane &lane : ix->lanes) {
+            if (!lane.ready) continue;
+            HIP_TRY(hipMemset(lane.ws.sticky, 0, 16));
+            int rc = ensure_raw_capacity(lane.ws, static_cast<size_t>(max_chunks) + max_chunks / 8 + 1024);
+            if (rc) return rc;
+        }
         set_error("raw record buffer was too small for a batch; it has been enlarged, score the batch again");
         return ISSL_E_RETRY;
     }
+    Lane &last = ix->lanes[ix->last_lane];
+    PlanInfo pl{};
+    uint32_t total_hits = 0;
+    HIP_TRY(hipMemcpy(&pl, last.ws.plan, sizeof pl, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&total_hits, last.ws.goff + last.last_n, sizeof total_hits, hipMemcpyDeviceToHost));
     float ms[5] = {0, 0, 0, 0, 0};
-    for (int i = 0; i < 5; ++i) (void)hipEventElapsedTime(&ms[i], ix->ev[i], ix->ev[i + 1]);
+    for (int i = 0; i < 5; ++i) (void)hipEventElapsedTime(&ms[i], last.ev[i], last.ev[i + 1]);
     double scan_sum = 0.0;
     const uint32_t have = batches < kRing ? batches : kRing;
     for (uint32_t i = 0; i < have; ++i) {
@@ -415,14 +464,14 @@ static int finish_batches(issl_index *ix, hipStream_t stream)
         scan_sum += t;
     }
     ix->stats = issl_stats{};
-    ix->stats.n_guides = ix->last_n;
+    ix->stats.n_guides = last.last_n;
     ix->stats.ms_bin = ms[0];
     ix->stats.ms_scan = have ? scan_sum / have : ms[1]; // mean over the batches since the last finish
     ix->stats.ms_verify = ms[2];
     ix->stats.ms_group = ms[3];
     ix->stats.ms_replay = ms[4];
     ix->stats.ms_total = ms[0] + ms[1] + ms[2] + ms[3] + ms[4];
-    ix->stats.raw_records = static_cast<uint64_t>(sticky[1]) * (kChunkRecs - 1);
+    ix->stats.raw_records = static_cast<uint64_t>(max_chunks) * (kChunkRecs - 1);
     ix->stats.candidates = pl.candidates;
     ix->stats.hits = total_hits;
     ix->stats.scan_tiles = pl.tiles;
@@ -430,6 +479,7 @@ static int finish_batches(issl_index *ix, hipStream_t stream)
     return ISSL_OK;
 }
 
+// Synchronous batch on lane 0 and the caller's stream.
 static int score_core(issl_index *ix, const uint64_t *d_guides, size_t n, int max_dist, double threshold, int method,
                       double *d_mit, double *d_cfd, hipStream_t stream, bool dump)
 {
@@ -439,7 +489,7 @@ static int score_core(issl_index *ix, const uint64_t *d_guides, size_t n, int ma
     ix->stats.n_guides = n;
     if (n == 0) return ISSL_OK;
     for (int attempt = 0;; ++attempt) {
-        rc = enqueue_batch(ix, d_guides, n, max_dist, threshold, method, d_mit, d_cfd, stream, dump);
+        rc = enqueue_batch(ix, ix->lanes[0], stream, d_guides, n, max_dist, threshold, method, d_mit, d_cfd, dump);
         if (rc) return rc;
         rc = finish_batches(ix, stream);
         if (rc == ISSL_OK) {
@@ -710,8 +760,32 @@ int issl_score_device_async(issl_index *idx, const uint64_t *d_guides, size_t n,
                             int method, double *d_mit, double *d_cfd, void *stream)
 {
     if (!idx || (n && (!d_guides || !d_mit || !d_cfd))) { set_error("null argument"); return ISSL_E_ARG; }
-    return enqueue_batch(idx, d_guides, n, max_dist, threshold, method, d_mit, d_cfd, static_cast<hipStream_t>(stream),
-                         false);
+    if (!idx->d_image) { set_error("index has no device image: call issl_index_upload first"); return ISSL_E_STATE; }
+    if (n == 0) return ISSL_OK;
+    HIP_TRY(hipSetDevice(idx->device));
+    // One lane by default: batches run back to back on one internal stream.  ISSL_LANES=2 alternates two lanes so
+    // that the tail of a batch overlaps the next scan -- measured SLOWER on MI355X (0.83 vs 0.64 ms per 10k-guide
+    // step): the scan deals its ranges out statically to waves it assumes co-resident, and the other lane's small
+    // kernels delay some of its workgroups.  Kept as an experiment switch.
+    const char *lanes_env = std::getenv("ISSL_LANES");
+    const bool one_lane = !(lanes_env && lanes_env[0] == '2');
+    Lane &lane = idx->lanes[one_lane ? 0u : (idx->n_pending & 1u)];
+    int rc = ensure_workspace(idx, lane, n); // creates the lane's stream on first use
+    if (rc) return rc;
+    if (stream) { // inputs are produced on the caller's stream: the batch starts after what is enqueued there now
+        HIP_TRY(hipEventRecord(lane.ev[0], static_cast<hipStream_t>(stream)));
+        HIP_TRY(hipStreamWaitEvent(lane.stream, lane.ev[0], 0));
+    }
+    return enqueue_batch(idx, lane, lane.stream, d_guides, n, max_dist, threshold, method, d_mit, d_cfd, false);
+}
+
+int issl_score_wait(issl_index *idx, void *stream)
+{
+    if (!idx) { set_error("null argument"); return ISSL_E_ARG; }
+    if (idx->device >= 0) HIP_TRY(hipSetDevice(idx->device));
+    for (Lane &lane : idx->lanes)
+        if (lane.ready && lane.pending) HIP_TRY(hipStreamWaitEvent(static_cast<hipStream_t>(stream), lane.done, 0));
+    return ISSL_OK;
 }
 
 int issl_score_finish(issl_index *idx, void *stream)
@@ -732,14 +806,16 @@ int issl_score(issl_index *idx, const uint64_t *guides, size_t n, int max_dist, 
     issl_stats total{};
     for (size_t at = 0; at < n; at += piece) {
         const size_t cnt = std::min(piece, n - at);
-        int rc = ensure_workspace(idx, cnt);
+        Workspace &ws = idx->lanes[0].ws;
+        int rc = finish_batches(idx, nullptr); // asynchronous batches may still use the staging buffers
         if (rc) return rc;
-        HIP_TRY(hipMemcpy(idx->ws.d_guides, guides + at, 8 * cnt, hipMemcpyHostToDevice));
-        rc = score_core(idx, idx->ws.d_guides, cnt, max_dist, threshold, method, idx->ws.d_mit, idx->ws.d_cfd, nullptr,
-                        false);
+        rc = ensure_workspace(idx, idx->lanes[0], cnt);
         if (rc) return rc;
-        HIP_TRY(hipMemcpy(mit + at, idx->ws.d_mit, 8 * cnt, hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(cfd + at, idx->ws.d_cfd, 8 * cnt, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(ws.d_guides, guides + at, 8 * cnt, hipMemcpyHostToDevice));
+        rc = score_core(idx, ws.d_guides, cnt, max_dist, threshold, method, ws.d_mit, ws.d_cfd, nullptr, false);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpy(mit + at, ws.d_mit, 8 * cnt, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(cfd + at, ws.d_cfd, 8 * cnt, hipMemcpyDeviceToHost));
         const issl_stats &s = idx->stats;
         total.n_guides += s.n_guides; total.candidates += s.candidates; total.hits += s.hits;
         total.scan_tiles += s.scan_tiles; total.ms_bin += s.ms_bin; total.ms_scan += s.ms_scan;
@@ -760,17 +836,19 @@ int issl_dump_hits(issl_index *idx, const uint64_t *guides, size_t n, int max_di
     if (n == 0) return ISSL_OK;
     if (n > (size_t(1) << 22)) { set_error("issl_dump_hits takes at most 2^22 guides per call"); return ISSL_E_ARG; }
     HIP_TRY(hipSetDevice(idx->device));
-    int rc = ensure_workspace(idx, n);
+    int rc = finish_batches(idx, nullptr);
     if (rc) return rc;
-    HIP_TRY(hipMemcpy(idx->ws.d_guides, guides, 8 * n, hipMemcpyHostToDevice));
-    rc = score_core(idx, idx->ws.d_guides, n, max_dist, threshold, method, idx->ws.d_mit, idx->ws.d_cfd, nullptr,
-                    true);
+    Workspace &ws = idx->lanes[0].ws;
+    rc = ensure_workspace(idx, idx->lanes[0], n);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(ws.d_guides, guides, 8 * n, hipMemcpyHostToDevice));
+    rc = score_core(idx, ws.d_guides, n, max_dist, threshold, method, ws.d_mit, ws.d_cfd, nullptr, true);
     if (rc) return rc;
     std::vector<uint32_t> goff(n + 1), kept(n);
-    HIP_TRY(hipMemcpy(goff.data(), idx->ws.goff, 4 * (n + 1), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(kept.data(), idx->ws.d_kept, 4 * n, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(goff.data(), ws.goff, 4 * (n + 1), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(kept.data(), ws.d_kept, 4 * n, hipMemcpyDeviceToHost));
     std::vector<issl_hit> all(goff[n]);
-    if (goff[n]) HIP_TRY(hipMemcpy(all.data(), idx->ws.d_hitrec, sizeof(issl_hit) * goff[n], hipMemcpyDeviceToHost));
+    if (goff[n]) HIP_TRY(hipMemcpy(all.data(), ws.d_hitrec, sizeof(issl_hit) * goff[n], hipMemcpyDeviceToHost));
     size_t total = 0;
     for (size_t g = 0; g < n; ++g) {
         for (uint32_t k = 0; k < kept[g]; ++k) {

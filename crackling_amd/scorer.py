@@ -174,6 +174,10 @@ class IsslIndex:
                                           float(threshold), _method_code(method), d_mit.data_ptr(), d_cfd.data_ptr(),
                                           C.c_void_p(stream) if stream else None))
 
+    def wait(self, stream):
+        """Make `stream` wait for every batch enqueued so far (no host synchronisation)."""
+        check(lib.issl_score_wait(self._h, C.c_void_p(stream) if stream else None))
+
     def finish(self, stream=None):
         """Synchronise the enqueued batches.  Returns False when they must be enqueued again (scratch space grew)."""
         rc = lib.issl_score_finish(self._h, C.c_void_p(stream) if stream else None)

@@ -164,13 +164,19 @@ int issl_score(issl_index *idx, const uint64_t *guides, size_t n, int max_dist, 
 int issl_score_device(issl_index *idx, const uint64_t *d_guides, size_t n, int max_dist,
                       double threshold, int method, double *d_mit, double *d_cfd, void *stream);
 
-/* Enqueue one batch on `stream` and return at once; any number of batches may be enqueued before
- * issl_score_finish() synchronises the stream and checks them.  ISSL_E_RETRY from finish means that a batch needed
- * more scratch space than was allocated (first large batch on an index): the buffers have been enlarged and the
- * batches since the previous finish must be enqueued again.  issl_last_stats() then describes the last batch,
- * with ms_scan averaged over all of them. */
+/* Enqueue one batch and return at once; any number of batches may be enqueued before issl_score_finish().
+ * Batches run back to back on an internal stream of the index, independent of the caller's streams; use different
+ * output buffers for batches whose results are consumed later.
+ * `stream`: if not NULL the batch starts after the work enqueued on that stream so far (the producer of d_guides);
+ * NULL means the inputs are ready now.  Results are valid after issl_score_finish(), or, on a stream, behind
+ * issl_score_wait(idx, stream), which makes that stream wait for every batch enqueued so far (no host sync).
+ * issl_score_finish() synchronises (internal streams and `stream`) and checks the batches: ISSL_E_RETRY means that a
+ * batch needed more scratch space than was allocated (first large batch on an index); the buffers have been enlarged
+ * and the batches since the previous finish must be enqueued again.  issl_last_stats() then describes the last
+ * batch, with ms_scan averaged over all of them. */
 int issl_score_device_async(issl_index *idx, const uint64_t *d_guides, size_t n, int max_dist,
                             double threshold, int method, double *d_mit, double *d_cfd, void *stream);
+int issl_score_wait(issl_index *idx, void *stream);
 int issl_score_finish(issl_index *idx, void *stream);
 
 /* Parity helper: the scored off-targets of every guide in the reference's scoring order

@@ -256,9 +256,12 @@ def test_one_site_index(tmp_path):
     ix.close()
 
 
-def test_async_batches(config0):
-    """issl_score_device_async / issl_score_finish: several batches in flight on one stream."""
+@pytest.mark.parametrize("lanes", ["1", "2"])
+def test_async_batches(config0, monkeypatch, lanes):
+    """issl_score_device_async / issl_score_wait / issl_score_finish: several batches in flight, on one internal
+    lane (default) and alternating between two (ISSL_LANES=2)."""
     import torch
+    monkeypatch.setenv("ISSL_LANES", lanes)
     ix, oracle, sigs, guides = config0
     stream = torch.cuda.current_stream().cuda_stream
     parts = [guides[:300], guides[300:301], guides[301:]]
@@ -270,6 +273,17 @@ def test_async_batches(config0):
         outs.append((d_g, d_m, d_c))
     assert ix.finish(stream)
     assert ix.stats()["n_batches"] == 3
+    # batches without an input dependency, consumer stream waits through issl_score_wait
+    outs2 = []
+    for g, (d_g, _, _) in zip(parts, outs):
+        d_m = torch.zeros(len(g), dtype=torch.float64, device="cuda:0"); d_c = torch.zeros_like(d_m)
+        ix.score_device_async(d_g, d_m, d_c, 4, 75.0, "and", stream=None)
+        outs2.append((d_m, d_c))
+    ix.wait(stream)
+    copies = [(m.clone(), c.clone()) for m, c in outs2]  # on the torch stream, behind the wait
+    assert ix.finish(stream)
+    for (m, c), (_, m0, c0) in zip(copies, outs):
+        assert torch.equal(m, m0) and torch.equal(c, c0)
     mit = np.concatenate([o[1].cpu().numpy() for o in outs]); cfd = np.concatenate([o[2].cpu().numpy() for o in outs])
     omit, ocfd = oracle.score(guides, 4, 75.0, "and")
     assert np.array_equal(mit.view(np.uint64), omit.view(np.uint64)) and np.array_equal(cfd.view(np.uint64), ocfd.view(np.uint64))
