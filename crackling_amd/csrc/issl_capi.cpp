@@ -140,7 +140,7 @@ static int select_device(int device)
 
 static void free_workspace(Workspace &w)
 {
-    void *ptrs[] = {w.ng, w.gfill, w.gstart, w.gword, w.gidx, w.items, w.plan, w.range_start, w.counters, w.sticky, w.gcur_big, w.terms, w.sorted, w.gcount,
+    void *ptrs[] = {w.ng, w.gfill, w.gstart, w.gword, w.gidx, w.items, w.plan, w.range_start, w.counters, w.sticky, w.stamps, w.gcur_big, w.terms, w.sorted, w.gcount,
                     w.goff, w.gcur, w.blocksum, w.d_guides, w.d_mit, w.d_cfd, w.d_kept, w.d_hitrec};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -195,7 +195,7 @@ static int ensure_workspace(issl_index *ix, Lane &lane, size_t n)
     if (n > w.cap_guides) {
         const size_t cap = std::max<size_t>(n, 1024);
         const size_t slots = cap * ix->hdr.n_slices + kGuideGroup * nb;
-        const size_t items = nb + cap * ix->hdr.n_slices / 8 + 2; // item sizes down to 8 guides (ISSL_SCHED)
+        const size_t items = nb + cap * ix->hdr.n_slices / 8 + 2; // item sizes down to 8 guides (ISSL_ITEM_GUIDES)
         if ((rc = dev_alloc(w.gword, slots))) return rc;
         if ((rc = dev_alloc(w.gidx, slots))) return rc;
         if ((rc = dev_alloc(w.items, items + 1))) return rc;
@@ -214,7 +214,7 @@ static int ensure_workspace(issl_index *ix, Lane &lane, size_t n)
     }
     if (w.cap_chunks == 0) {
         // every scan wave may hold one partly filled chunk; beyond that ~1 record per 50k comparisons
-        size_t want = std::max<size_t>(size_t(kScanGridBlocks) * 4 * 4, n);
+        size_t want = std::max<size_t>(size_t(kScanWaves) * 4, n);
         // ISSL_RAW_CHUNKS=<n>: start with a small raw buffer (tests of the grow-and-rerun path)
         if (const char *e = std::getenv("ISSL_RAW_CHUNKS")) want = std::max<size_t>(1, std::strtoull(e, nullptr, 10));
         if ((rc = ensure_raw_capacity(w, want))) return rc;
@@ -229,6 +229,10 @@ static int ensure_workspace(issl_index *ix, Lane &lane, size_t n)
         HIP_TRY(hipEventCreate(&lane.scan_done));
         HIP_TRY(hipStreamCreateWithFlags(&lane.stream, hipStreamNonBlocking));
         lane.ready = true;
+    }
+    if (!w.stamps && std::getenv("ISSL_SCAN_STAMPS")) { // diagnostics: per-wave start/end times of the scan
+        if ((rc = dev_alloc(w.stamps, 2 * kScanWaves))) return rc;
+        HIP_TRY(hipMemset(w.stamps, 0, 16 * kScanWaves));
     }
     if (!w.sticky) {
         if ((rc = dev_alloc(w.sticky, 4))) return rc;
@@ -476,6 +480,14 @@ static int finish_batches(issl_index *ix, hipStream_t stream)
     ix->stats.hits = total_hits;
     ix->stats.scan_tiles = pl.tiles;
     ix->stats.n_batches = batches;
+    if (last.ws.stamps) { // ISSL_SCAN_STAMPS=<file>: dump the wave stamps of the last scan (binary u64 pairs)
+        std::vector<unsigned long long> st(2 * kScanWaves);
+        HIP_TRY(hipMemcpy(st.data(), last.ws.stamps, 16 * kScanWaves, hipMemcpyDeviceToHost));
+        if (FILE *f = std::fopen(std::getenv("ISSL_SCAN_STAMPS"), "wb")) {
+            std::fwrite(st.data(), 8, st.size(), f);
+            std::fclose(f);
+        }
+    }
     return ISSL_OK;
 }
 

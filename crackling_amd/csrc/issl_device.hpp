@@ -76,11 +76,9 @@ constexpr uint32_t kItemGuides = 512;  // guides per scan item (bounds one tile'
 constexpr uint32_t kTileFixedCost = 4; // cost of fetching a tile, in guide-comparisons of that tile
 constexpr uint32_t kNoGuide = 0xFFFFFFFFu;
 constexpr uint32_t kPadGuideWord = 0xFFFFFFFFu; // scan word of padding guide slots: 16 x T, distance 16 from tile padding
-constexpr uint32_t kScanGridBlocks = 256u * 8u; // scan launch: 256 CUs x 8 workgroups of 4 independent waves
-constexpr uint32_t kScanWaves = kScanGridBlocks * 4u;
-constexpr uint32_t kStaticRounds = 3;           // equal-cost ranges per wave dealt out statically
-constexpr uint32_t kDynamicRanges = 8192;       // at most this many small ranges in the ticketed tail
-constexpr uint32_t kMaxRanges = kScanWaves * kStaticRounds + kDynamicRanges;
+constexpr uint32_t kScanGridBlocks = 256u * 2u; // scan launch: 256 CUs x 2 workgroups of 16 waves
+constexpr uint32_t kScanWaves = kScanGridBlocks * 16u;
+constexpr uint32_t kMaxRanges = kScanGridBlocks; // one equal-cost range per workgroup
 constexpr uint32_t kChunkRecs = 128;            // raw-record chunk: 1 KiB, slot 0 is the fill count
 constexpr uint64_t kDeadKey = ~0ull;            // raw slot that did not survive the exact check
 
@@ -90,6 +88,8 @@ struct ScanItem {
     uint32_t g0, g1; // range in the bucket-sorted guide arrays, g0 % kGuideGroup == 0
     uint32_t n_tiles;
     uint64_t cost0;  // sum of costs of all earlier items; tile cost = (g1-g0)+kTileFixedCost
+    uint32_t tile0;  // sum of n_tiles of all earlier items (tiles are numbered in item order)
+    uint32_t pad;
 };
 
 // Start of a cost range of the scan: (item, tile inside the item, guide offset); item == n_items marks the end.
@@ -104,9 +104,8 @@ struct RangeStart {
 struct PlanInfo {
     uint32_t n_items;
     uint32_t error;       // bit 1: item list overflow
-    uint32_t n_ranges;    // ranges the scan's waves work through: n_static equal-cost ones + the ticketed tail
-    uint32_t n_static;
-    uint64_t static_cost; // cost covered by the static ranges
+    uint32_t n_ranges;    // equal-cost ranges of the scan, one per workgroup
+    uint32_t pad;
     uint64_t total_cost;
     uint64_t candidates;  // sum over guides of their bucket lengths
     uint64_t tiles;       // (tile, item) pairs the scan works through
@@ -132,6 +131,7 @@ struct Workspace {
     uint64_t *raw = nullptr;     // [(cap_chunks+1) * kChunkRecs] raw records of the scan, chunked
     size_t cap_chunks = 0;
     Counters *counters = nullptr;
+    unsigned long long *stamps = nullptr; // [2 * kScanWaves] wave start/end ticks (ISSL_SCAN_STAMPS diagnostics)
     uint32_t *sticky = nullptr;  // [4] survives k_reset: [0] raw overflow seen, [1] max chunks asked, [2] plan errors
     uint64_t *sorted = nullptr;  // [hit_cap] keys guide<<35 | slice<<32 | pos, grouped by guide
     uint32_t *gcount = nullptr;  // [G+1] hits per guide

@@ -175,8 +175,8 @@ __device__ inline uint64_t block_exclusive_scan(uint64_t v, uint64_t *lds /*[256
 // One block: lay out the bucket-sorted guide arrays and the list of scan items.
 __global__ __launch_bounds__(256) void k_plan(ImageView v, const uint32_t *__restrict__ ng,
                                               uint32_t *__restrict__ gstart, ScanItem *__restrict__ items,
-                                              uint32_t cap_items, PlanInfo *__restrict__ plan, uint32_t static_rounds,
-                                              uint32_t dyn_shift, uint32_t item_guides)
+                                              uint32_t cap_items, PlanInfo *__restrict__ plan, uint32_t item_guides,
+                                              uint32_t scan_blocks)
 {
     __shared__ uint64_t lds[256];
     const uint32_t nb = v.n_buckets;
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256) void k_plan(ImageView v, const uint32_t *__res
     uint64_t item_at = block_exclusive_scan(n_it, lds, &tot_items);
     uint64_t cost_at = block_exclusive_scan(cost, lds, &tot_cost);
     (void)block_exclusive_scan(cand, lds, &tot_cand);
-    (void)block_exclusive_scan(wtiles, lds, &tot_tiles);
+    uint64_t tile_at = block_exclusive_scan(wtiles, lds, &tot_tiles);
 
     const bool overflow = tot_items > cap_items;
     for (uint32_t b = b0; b < b1; ++b) {
@@ -218,8 +218,11 @@ __global__ __launch_bounds__(256) void k_plan(ImageView v, const uint32_t *__res
                 it.g1 = it.g0 + len;
                 it.n_tiles = nt;
                 it.cost0 = cost_at;
+                it.tile0 = static_cast<uint32_t>(tile_at);
+                it.pad = 0;
                 items[item_at++] = it;
                 cost_at += static_cast<uint64_t>(nt) * (len + kTileFixedCost);
+                tile_at += nt;
             }
         }
         slot_at += (g + kGuideGroup - 1u) / kGuideGroup * kGuideGroup;
@@ -229,27 +232,15 @@ __global__ __launch_bounds__(256) void k_plan(ImageView v, const uint32_t *__res
         if (!overflow) {
             ScanItem end;
             end.bucket = 0; end.g0 = 0; end.g1 = 0; end.n_tiles = 0; end.cost0 = tot_cost;
+            end.tile0 = static_cast<uint32_t>(tot_tiles); end.pad = 0;
             items[tot_items] = end;
         }
         plan->n_items = overflow ? 0u : static_cast<uint32_t>(tot_items);
         plan->total_cost = overflow ? 0ull : tot_cost;
         plan->candidates = tot_cand;
         plan->tiles = tot_tiles;
-        // Static part: kStaticRounds equal-cost ranges per scan wave, dealt out by wave number.  Dynamic part:
-        // the last ~1/8 of the cost in kDynamicRanges small ranges handed out by a ticket counter, to even out
-        // what the cost model cannot see (cold blocks, memory).  Tickets are device-wide atomics (~12 ns each,
-        // serialised), so their number is bounded by the work: about one per 2^22 comparisons.
-        uint32_t n_static = kScanWaves * static_rounds, n_dynamic = 0;
-        if (tot_tiles < n_static) {
-            n_static = static_cast<uint32_t>(tot_tiles);
-        } else if (dyn_shift < 64) {
-            const uint64_t by_work = tot_cand >> dyn_shift;
-            n_dynamic = static_cast<uint32_t>(by_work < kDynamicRanges ? by_work : kDynamicRanges);
-            if (n_dynamic < 64) n_dynamic = 0;
-        }
-        plan->n_static = overflow ? 0u : n_static;
-        plan->n_ranges = overflow ? 0u : n_static + n_dynamic;
-        plan->static_cost = n_dynamic ? tot_cost - tot_cost / 8 : tot_cost;
+        // one equal-cost range per scan workgroup; inside a workgroup the waves share the tiles dynamically
+        plan->n_ranges = (overflow || tot_tiles == 0) ? 0u : scan_blocks;
         plan->error = overflow ? 2u : 0u;
     }
 }
@@ -271,16 +262,7 @@ __global__ __launch_bounds__(256) void k_ranges(const PlanInfo *__restrict__ pla
     out.pad = 0;
     if (r < n_ranges) {
         // no 128-bit intermediate: costs < 2^50 and range counts <= 2^15
-        const uint32_t n_static = plan->n_static;
-        const uint64_t s_cost = plan->static_cost;
-        uint64_t lo;
-        if (r < n_static) {
-            lo = s_cost / n_static * r + (s_cost % n_static) * r / n_static;
-        } else {
-            const uint64_t d_cost = total - s_cost;
-            const uint32_t nd = n_ranges - n_static, rd = r - n_static;
-            lo = s_cost + d_cost / nd * rd + (d_cost % nd) * rd / nd;
-        }
+        const uint64_t lo = total / n_ranges * r + (total % n_ranges) * r / n_ranges;
         uint32_t a = 0, z = n_items; // last item with cost0 <= lo
         while (z - a > 1) {
             const uint32_t mid = (a + z) >> 1;
@@ -351,6 +333,17 @@ __global__ __launch_bounds__(256) void k_guide_scatter(const uint64_t *__restric
     }
 }
 
+// Workgroups of the scan launch: two 16-wave workgroups per CU by default.  ISSL_SCAN_BLOCKS=<n> (<= kScanGridBlocks)
+// is a tuning knob.
+static uint32_t scan_blocks()
+{
+    if (const char *e = getenv("ISSL_SCAN_BLOCKS")) {
+        const int b = atoi(e);
+        if (b >= 1 && static_cast<uint32_t>(b) <= kScanGridBlocks) return static_cast<uint32_t>(b);
+    }
+    return kScanGridBlocks;
+}
+
 // Reset of everything a scoring call accumulates into (one launch instead of seven memsets).
 __global__ __launch_bounds__(256) void k_reset(Workspace ws, uint32_t nb, uint32_t n, uint32_t n_slots,
                                                uint32_t n_scan_waves)
@@ -379,24 +372,18 @@ void launch_bin_guides(const ImageView &v, const Workspace &ws, const uint64_t *
     const uint32_t n_slots = static_cast<uint32_t>(
         std::min<size_t>(ws.cap_gslots, static_cast<size_t>(n) * v.n_slices + static_cast<size_t>(kGuideGroup) * nb));
     const uint32_t reset_blocks = std::min<uint32_t>(1024u, (std::max(n_slots, nb) + 255u) / 256u);
-    hipLaunchKernelGGL(k_reset, dim3(reset_blocks), dim3(256), 0, stream, ws, nb, n, n_slots, kScanGridBlocks * 4u);
+    hipLaunchKernelGGL(k_reset, dim3(reset_blocks), dim3(256), 0, stream, ws, nb, n, n_slots, scan_blocks() * 16u);
     const uint32_t blocks = (n + 255u) / 256u;
     hipLaunchKernelGGL(k_guide_hist, dim3(blocks), dim3(256), 0, stream, d_guides, n, v.slice_width, v.n_slices, nb,
                        ws.ng);
-    // ISSL_SCHED="<static rounds>,<shift>,<guides per item>": scheduling knobs.  Default: three static rounds
-    // of equal-cost ranges and no ticketed tail (shift >= 64).  With shift s the last 1/8 of the cost is cut
-    // into (comparisons >> s) small ranges handed out by tickets; measured on MI355X the tickets cost more than
-    // they balance unless a batch has >~1e11 comparisons (each ticket is a serialised ~12 ns device atomic).
-    uint32_t rounds = kStaticRounds, shift = 99, item_guides = kItemGuides;
-    if (const char *e = getenv("ISSL_SCHED")) {
-        unsigned a = rounds, b = shift, c = item_guides;
-        if (sscanf(e, "%u,%u,%u", &a, &b, &c) >= 1) {
-            rounds = a ? a : 1; shift = b; item_guides = (c >= 8 && c <= kItemGuides) ? (c & ~7u) : kItemGuides;
-            if (rounds > kStaticRounds) rounds = kStaticRounds;
-        }
+    // ISSL_ITEM_GUIDES=<n>: guides per scan item (default 512; multiples of 8) -- test and tuning knob
+    uint32_t item_guides = kItemGuides;
+    if (const char *e = getenv("ISSL_ITEM_GUIDES")) {
+        const unsigned c = static_cast<unsigned>(atoi(e));
+        if (c >= 8 && c <= kItemGuides) item_guides = c & ~7u;
     }
     hipLaunchKernelGGL(k_plan, dim3(1), dim3(256), 0, stream, v, ws.ng, ws.gstart, ws.items,
-                       static_cast<uint32_t>(ws.cap_items), ws.plan, rounds, shift, item_guides);
+                       static_cast<uint32_t>(ws.cap_items), ws.plan, item_guides, scan_blocks());
     hipLaunchKernelGGL(k_guide_scatter, dim3(blocks), dim3(256), 0, stream, d_guides, n, v.slice_width, v.n_slices,
                        nb, ws.gstart, ws.gfill, ws.gword, ws.gidx);
     hipLaunchKernelGGL(k_ranges, dim3((kMaxRanges + 1 + 255) / 256), dim3(256), 0, stream, ws.plan, ws.items,
@@ -543,103 +530,96 @@ __device__ __forceinline__ void note_candidates(uint32_t ok, uint32_t gslot, uin
     }
 }
 
-// Next range of the ticketed tail, or n_ranges when there is none left.  The counter is read with a plain load
-// first: an exhausted counter costs the late waves no atomic (device-wide atomics serialise at ~12 ns each).
-__device__ __forceinline__ uint32_t take_ticket(Counters *counters, uint32_t n_static, uint32_t n_ranges, uint32_t lane)
-{
-    if (n_static + __hip_atomic_load(&counters->next_range, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= n_ranges)
-        return n_ranges;
-    uint32_t ticket = 0;
-    if (lane == 0) ticket = atomicAdd(&counters->next_range, 1u);
-    const uint32_t r = n_static + __builtin_amdgcn_readfirstlane(ticket);
-    return r < n_ranges ? r : n_ranges;
-}
-
-// Scan kernel.  Every WAVE is an independent worker: it takes ranges of the cost axis (the first one
-// by its global wave number, further ones from an atomic ticket), and for every tile of the range
-// keeps the tile's 2048 candidates in registers (32 bit planes per lane) while the guide words of the
+// Scan kernel.  A workgroup of 16 waves (two per CU = 8 waves per SIMD) owns one equal-cost range of the work
+// and its waves share the tiles of that range through a ticket counter in LDS: the hardware favours the older
+// waves of a SIMD, so waves with equal static shares finish anywhere between 30 % and 100 % of the kernel time
+// (measured with ISSL_SCAN_STAMPS) and the SIMDs run half empty for the second half; with the LDS tickets all waves
+// of a workgroup stop within one tile of each other.  (A device-wide ticket counter would serialise at ~12 ns
+// per ticket; an LDS atomic costs a few hundred cycles and no global traffic.)
+// Per tile a wave keeps the 2048 candidates in registers (32 bit planes per lane) while the guide words of the
 // item stream through scalar registers, 8 per scalar load.
 // The streams the hot loop reads (scan planes, tile table, items, guide words, plan) are separate
-// `const __restrict__` kernel arguments: they are never written by this kernel, which lets the
-// compiler fetch the wave-uniform ones through the scalar cache.
+// `const __restrict__` kernel arguments: they are never written by this kernel, which lets the compiler fetch the
+// wave-uniform ones through the scalar cache.
 template <int THR>
-__global__ __launch_bounds__(256, 6) void k_scan(const uint32_t *__restrict__ scan_stream,
-                                                 const uint32_t *__restrict__ tile_first,
-                                                 const ScanItem *__restrict__ items,
-                                                 const PlanInfo *__restrict__ plan,
-                                                 const RangeStart *__restrict__ range_start,
-                                                 const uint32_t *__restrict__ gword_stream, uint64_t *raw,
-                                                 uint32_t max_chunks, Counters *counters, uint32_t thr)
+__global__ __launch_bounds__(1024, 8) void k_scan(const uint32_t *__restrict__ scan_stream,
+                                                  const uint32_t *__restrict__ tile_first,
+                                                  const ScanItem *__restrict__ items,
+                                                  const PlanInfo *__restrict__ plan,
+                                                  const RangeStart *__restrict__ range_start,
+                                                  const uint32_t *__restrict__ gword_stream, uint64_t *raw,
+                                                  uint32_t max_chunks, Counters *counters, uint32_t thr,
+                                                  unsigned long long *stamps)
 {
+    __shared__ uint32_t next_unit;
+    // stamps (diagnostics, normally null): start and end of every wave in 100 MHz ticks, nothing else reads them
+    const unsigned long long t_start = stamps ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    if (threadIdx.x == 0) next_unit = 0;
+    __syncthreads();
     const uint32_t n_ranges = plan->n_ranges;
-    const uint32_t n_static = plan->n_static;
-    if (n_ranges == 0) return;
+    if (blockIdx.x >= n_ranges) return;
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
-    uint32_t range = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    const uint32_t wave_id = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
     // Raw records: the wave's first chunk is the one with its own number (no atomic); k_reset cleared its header.
     RawWriter w;
-    const bool no_own_chunk = range >= max_chunks; // buffer smaller than the wave count: spare chunk + overflow flag
-    w.chunk = raw + static_cast<uint64_t>(no_own_chunk ? max_chunks : range) * kChunkRecs;
+    const bool no_own_chunk = wave_id >= max_chunks; // buffer smaller than the wave count: spare chunk + overflow flag
+    w.chunk = raw + static_cast<uint64_t>(no_own_chunk ? max_chunks : wave_id) * kChunkRecs;
     w.fill = 1;
     bool own_chunk = false;
 
-    if (range >= n_static) range = take_ticket(counters, n_static, n_ranges, lane);
-    while (range < n_ranges) {
-        // work of this range: from range_start[range] up to (not including) range_start[range + 1]; a position is
-        // (item, tile of the item, guide offset inside the item in multiples of 8)
-        const RangeStart first = range_start[range];
-        const RangeStart last = range_start[range + 1];
-        uint32_t it = first.item;
-        uint32_t k = first.tile;
-        uint32_t gs = first.goff;
-        uint32_t cur_it = 0xFFFFFFFFu;
-        ScanItem cur{};
-        while (it < last.item || (it == last.item && (k < last.tile || (k == last.tile && gs < last.goff)))) {
-            if (it != cur_it) { cur = items[it]; cur_it = it; }
-            const bool end_tile = it == last.item && k == last.tile;
-            const uint32_t g_begin = cur.g0 + gs;
-            const uint32_t g_end = end_tile ? cur.g0 + last.goff : cur.g1;
+    // Work of this workgroup: from `first` up to (not including) `last`; a position is (item, tile of the item,
+    // guide offset inside the item in multiples of 8).  Units = tiles, numbered from the first one; the first and
+    // the last tile may be shared with the neighbouring workgroups (guide offsets).
+    const RangeStart first = range_start[blockIdx.x];
+    const RangeStart last = range_start[blockIdx.x + 1];
+    const uint32_t tile_begin = items[first.item].tile0 + first.tile;
+    const uint32_t tile_last = items[last.item].tile0 + last.tile; // partly ours when last.goff > 0
+    const uint32_t n_units = tile_last - tile_begin + (last.goff ? 1u : 0u);
+    uint32_t it = first.item;
+    ScanItem cur = items[it];
 
-            // ---- one tile: 2048 candidates of bucket cur.bucket, tile k, guide slots [g_begin, g_end) -------
-            const uint32_t tile = tile_first[cur.bucket] + k;
-            const uint4 *__restrict__ src =
-                reinterpret_cast<const uint4 *>(scan_stream + static_cast<uint64_t>(tile) * kTileCands);
-            uint32_t c[kPlanes];
+    while (true) {
+        uint32_t u = 0;
+        if (lane == 0) u = atomicAdd(&next_unit, 1u);
+        u = __builtin_amdgcn_readfirstlane(u);
+        if (u >= n_units) break;
+        const uint32_t gt = tile_begin + u;            // tile number in item order
+        while (gt >= cur.tile0 + cur.n_tiles) cur = items[++it]; // tickets only grow: the cursor moves forward
+        const uint32_t k = gt - cur.tile0;
+        const uint32_t g_begin = cur.g0 + (u == 0 ? first.goff : 0u);
+        const uint32_t g_end = (gt == tile_last) ? cur.g0 + last.goff : cur.g1;
+
+        // ---- one tile: 2048 candidates of bucket cur.bucket, tile k, guide slots [g_begin, g_end) -----------
+        const uint32_t tile = tile_first[cur.bucket] + k;
+        const uint4 *__restrict__ src =
+            reinterpret_cast<const uint4 *>(scan_stream + static_cast<uint64_t>(tile) * kTileCands);
+        uint32_t c[kPlanes];
 #pragma unroll
-            for (int q = 0; q < kPlanes / 4; ++q) {
-                const uint4 t4 = src[q * 64 + lane];
-                c[4 * q + 0] = t4.x; c[4 * q + 1] = t4.y; c[4 * q + 2] = t4.z; c[4 * q + 3] = t4.w;
-            }
-            // Guide slots are padded to groups of 8 with a word (all T) that is far from the zero padding of the
-            // tiles; a padding slot that does come near a real candidate is dropped by k_verify.
-            for (uint32_t g = g_begin; g < g_end; g += kGuideGroup) {
-                const GuideGroup gg = *reinterpret_cast<const GuideGroup *>(gword_stream + g);
+        for (int q = 0; q < kPlanes / 4; ++q) {
+            const uint4 t4 = src[q * 64 + lane];
+            c[4 * q + 0] = t4.x; c[4 * q + 1] = t4.y; c[4 * q + 2] = t4.z; c[4 * q + 3] = t4.w;
+        }
+        // Guide slots are padded to groups of 8 with a word (all T) that is far from the zero padding of the tiles;
+        // a padding slot that does come near a real candidate is dropped by k_verify.
+        for (uint32_t g = g_begin; g < g_end; g += kGuideGroup) {
+            const GuideGroup gg = *reinterpret_cast<const GuideGroup *>(gword_stream + g);
 #pragma unroll
-                for (uint32_t u = 0; u < kGuideGroup; ++u) {
-                    const uint32_t ok = near_plane<THR>(c, gg.w[u], thr);
-                    if (__ballot(ok != 0u) != 0ull) { // ~4 % of the (guide, tile) pairs on random data
-                        note_candidates(ok, g + u, tile, lane, w, raw, max_chunks, counters);
-                        own_chunk = true;
-                    }
+            for (uint32_t uu = 0; uu < kGuideGroup; ++uu) {
+                const uint32_t ok = near_plane<THR>(c, gg.w[uu], thr);
+                if (__ballot(ok != 0u) != 0ull) { // ~4 % of the (guide, tile) pairs on random data
+                    note_candidates(ok, g + uu, tile, lane, w, raw, max_chunks, counters);
+                    own_chunk = true;
                 }
             }
-            if (end_tile) break;
-            gs = 0;
-            ++k;
-            if (k >= cur.n_tiles) { ++it; k = 0; }
-        }
-        // Static rounds by wave number, then the small ranges of the dynamic tail by ticket.
-        if (range < n_static) {
-            range += n_waves;
-            if (range >= n_static) range = take_ticket(counters, n_static, n_ranges, lane);
-        } else {
-            range = take_ticket(counters, n_static, n_ranges, lane);
         }
     }
     if (own_chunk) {
         raw_retire(w, lane);
         if (no_own_chunk && lane == 0) counters->raw_overflow = 1u;
+    }
+    if (stamps && lane == 0) {
+        stamps[2 * wave_id] = t_start;
+        stamps[2 * wave_id + 1] = __builtin_amdgcn_s_memrealtime();
     }
 }
 
@@ -705,8 +685,8 @@ __global__ __launch_bounds__(kChunkRecs) void k_verify(ImageView v, Workspace ws
 template <int THR>
 static void launch_scan_thr(const ImageView &v, const Workspace &ws, uint32_t thr, hipStream_t stream)
 {
-    hipLaunchKernelGGL(k_scan<THR>, dim3(kScanGridBlocks), dim3(256), 0, stream, v.scan, v.tile_first, ws.items, ws.plan,
-                       ws.range_start, ws.gword, ws.raw, static_cast<uint32_t>(ws.cap_chunks), ws.counters, thr);
+    hipLaunchKernelGGL(k_scan<THR>, dim3(scan_blocks()), dim3(1024), 0, stream, v.scan, v.tile_first, ws.items, ws.plan,
+                       ws.range_start, ws.gword, ws.raw, static_cast<uint32_t>(ws.cap_chunks), ws.counters, thr, ws.stamps);
 }
 
 void launch_scan(const ImageView &v, const Workspace &ws, const uint64_t *d_guides, uint32_t n, int max_dist,

@@ -169,19 +169,19 @@ def test_runtime_threshold_build_of_the_scan_kernel(config0, monkeypatch):
 
 
 def test_scheduling_knobs_do_not_change_results(config0, monkeypatch):
-    """Ticketed tail, one static round, 64-guide items: same hit lists and scores as the default schedule."""
+    """Smaller scan items (more, finer work units; tiles re-read per item): same hit lists and scores."""
     ix, oracle, sigs, guides = config0
     rng = np.random.default_rng(5)
     batch = np.concatenate([guides, guides[:1].repeat(700) ^ (rng.integers(0, 1 << 14, size=700, dtype=np.uint64) << np.uint64(20))])
     want = ix.dump_hits(batch, 4, 0.0, "and")
     wm, wc = ix.score(batch, 4, 75.0, "and")
-    for sched in ("1,10,64", "2,12,512", "3,99,8"):
-        monkeypatch.setenv("ISSL_SCHED", sched)
+    for sched in ("64", "8", "200"):
+        monkeypatch.setenv("ISSL_ITEM_GUIDES", sched)
         got = ix.dump_hits(batch, 4, 0.0, "and")
         assert np.array_equal(got, want), sched
         gm, gc = ix.score(batch, 4, 75.0, "and")
         assert np.array_equal(gm, wm) and np.array_equal(gc, wc), sched
-    monkeypatch.delenv("ISSL_SCHED")
+    monkeypatch.delenv("ISSL_ITEM_GUIDES")
     _, _, ohits = oracle.score(batch, 4, 0.0, "and", want_hits=True)
     assert np.array_equal(want, ohits)
 

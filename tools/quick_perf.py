@@ -12,7 +12,7 @@ ap.add_argument("--sites", type=int, default=5_000_000)
 ap.add_argument("--guides", type=int, default=10_000)
 ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--thr", type=float, default=0.0)
-ap.add_argument("--variants", default="3:99:512", help="ISSL_SCHED settings to compare, a:b:c separated by /")
+ap.add_argument("--variants", default="512", help="ISSL_SCAN_BLOCKS settings to compare, separated by /")
 ap.add_argument("--write-issl", default=None)
 ap.add_argument("--write-guides", default=None)
 a = ap.parse_args()
@@ -26,8 +26,8 @@ if a.write_guides:
 t = time.time(); ix.upload(0); print(f"upload {time.time()-t:.1f}s  image={ix.device_bytes()/1e9:.2f} GB", flush=True)
 import os
 for variant in a.variants.split("/"):
-  os.environ["ISSL_SCHED"] = variant.replace(":", ",")
-  print(f"-- sched {variant}", flush=True)
+  os.environ["ISSL_SCAN_BLOCKS"] = variant
+  print(f"-- scan blocks {variant}", flush=True)
   for r in range(a.reps):
     t = time.time(); mit, cfd = ix.score(guides, 4, a.thr, "and"); dt = time.time() - t
     st = ix.stats()
