@@ -13,18 +13,21 @@ ap.add_argument("--guides", type=int, default=10_000)
 ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--thr", type=float, default=0.0)
 ap.add_argument("--variants", default="512", help="ISSL_SCAN_BLOCKS settings to compare, separated by /")
+ap.add_argument("--json", default=None, help="write the best repetition (by scan time) of the last variant here")
 ap.add_argument("--write-issl", default=None)
 ap.add_argument("--write-guides", default=None)
 a = ap.parse_args()
 t = time.time(); sigs, occ = random_sites(a.sites, seed=1); guides = random_guides(sigs, a.guides, seed=2)
 print(f"synth {time.time()-t:.1f}s  distinct={len(sigs)}", flush=True)
-t = time.time(); ix = ca.IsslIndex.build_from_sites(sigs, occ); print(f"build {time.time()-t:.1f}s", flush=True)
+t = time.time(); ix = ca.IsslIndex.build_from_sites(sigs, occ); t_build = time.time() - t; print(f"build {t_build:.1f}s", flush=True)
 if a.write_issl:
     t = time.time(); ix.write(a.write_issl); print(f"write issl {time.time()-t:.1f}s", flush=True)
 if a.write_guides:
     open(a.write_guides, "w").write("".join(s + "\n" for s in ca.decode_guides(guides)))
-t = time.time(); ix.upload(0); print(f"upload {time.time()-t:.1f}s  image={ix.device_bytes()/1e9:.2f} GB", flush=True)
-import os
+t = time.time(); ix.upload(0); t_upload = time.time() - t
+print(f"upload {t_upload:.1f}s  image={ix.device_bytes()/1e9:.2f} GB", flush=True)
+import os, json
+best = None
 for variant in a.variants.split("/"):
   os.environ["ISSL_SCAN_BLOCKS"] = variant
   print(f"-- scan blocks {variant}", flush=True)
@@ -36,3 +39,13 @@ for variant in a.variants.split("/"):
           f"replay {st['ms_replay']:.3f} ms | cand {st['candidates']:.3e} hits {st['hits']} tiles {st['scan_tiles']} | "
           f"scan: {st['candidates']/st['ms_scan']/1e9:.2f} Tcmp/s, algorithmic {algo/st['ms_scan']/1e9:.1f} TB/s | "
           f"{a.guides/st['ms_total']*1e3:.0f} guides/s (kernels)", flush=True)
+    if r > 0 and (best is None or st["ms_scan"] < best["scan_ms"]):
+        best = {"what": f"tools/quick_perf.py --sites {a.sites} --guides {a.guides} --thr {a.thr} on one MI355X (best of {a.reps - 1} warm repetitions)",
+                "distinct_sites": int(len(sigs)), "image_GB": ix.device_bytes() / 1e9, "host_build_s": t_build, "upload_s": t_upload,
+                "wall_ms": dt * 1e3, "scan_ms": st["ms_scan"], "bin_ms": st["ms_bin"], "verify_ms": st["ms_verify"],
+                "group_ms": st["ms_group"], "replay_ms": st["ms_replay"], "pipeline_ms": st["ms_total"],
+                "comparisons": st["candidates"], "hits": st["hits"],
+                "scan_Tcmp_per_s": st["candidates"] / st["ms_scan"] / 1e9, "algorithmic_TBps": algo / st["ms_scan"] / 1e9,
+                "guides_per_s_kernels": a.guides / st["ms_total"] * 1e3}
+if a.json and best:
+    json.dump(best, open(a.json, "w"), indent=1)
