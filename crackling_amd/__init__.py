@@ -18,9 +18,10 @@ from .scorer import (  # noqa: F401
     format_scores,
     run_scorer_binary,
     parse_scorer_output,
+    verdicts,
 )
 
 __all__ = [
     "IsslIndex", "IsslNode", "IsslError", "METHODS", "encode_guides", "extract_offtargets", "decode_guides", "format_scores",
-    "run_scorer_binary", "parse_scorer_output", "lib", "LIB_PATH",
+    "run_scorer_binary", "parse_scorer_output", "verdicts", "lib", "LIB_PATH",
 ]

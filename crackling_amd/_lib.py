@@ -97,6 +97,7 @@ _protos = {
     "issl_dump_hits": (C.c_int, [_P, _P, C.c_size_t, C.c_int, C.c_double, C.c_int, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     "issl_last_stats": (C.c_int, [_P, C.POINTER(Stats)]),
     "issl_count_candidates": (C.c_int, [_P, _P, C.c_size_t, C.POINTER(C.c_uint64)]),
+    "issl_verdicts": (C.c_int, [_P, _P, C.c_size_t, C.c_double, C.c_char_p, _P]),
     "issl_extract_from_memory": (C.c_int, [C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_int, C.c_int,
                                            C.POINTER(_P), C.POINTER(C.c_size_t), C.POINTER(C.c_uint64)]),
     "issl_extract_offtargets": (C.c_int, [C.POINTER(C.c_char_p), C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_uint64)]),

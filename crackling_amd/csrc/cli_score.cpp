@@ -11,6 +11,8 @@
 //                     (default: one device; all visible devices when the query file holds >= 2^20 guides)
 //   ISSL_TIMING=1     one JSON line with load/upload/score timings on stderr
 //   ISSL_SERVER=<unix socket path>   resident mode, see below
+//   ISSL_VERDICTS=<file>   also write "<20-mer>\t<0|1>\n" per guide: the accept/reject decision Crackling derives
+//                     from stdout (Crackling.py:780-835), so that a caller can skip parsing the floats
 //
 // Resident mode.  Crackling starts one scorer process per page of guides (config.ini:106-112) and the reference
 // reloads the whole index every time.  `isslScoreOfftargets --serve <socket>` keeps every index it has been asked
@@ -130,7 +132,7 @@ bool make_resident(const char *issl_path, const DeviceChoice &dc, size_t n_guide
 }
 
 struct Request {
-    std::string issl, query, method_arg;
+    std::string issl, query, method_arg, verdict_path;
     int max_dist = 4;
     double threshold = 75.0;
 };
@@ -172,6 +174,28 @@ bool score_request(Resident &r, const Request &q, std::string &out, std::string 
         else k += std::snprintf(line + k, sizeof line - k, "-1\n");
         out.append(line, static_cast<size_t>(k));
     }
+    if (!q.verdict_path.empty()) { // Crackling.py:780-835, fused
+        std::vector<uint8_t> verdict(n);
+        std::string text;
+        text.reserve(n * 24);
+        if (issl_verdicts(mit.data(), cfd.data(), n, q.threshold, q.method_arg.c_str(), verdict.data())) {
+            err = last_error("thresholding failed");
+            issl_free(guides);
+            return false;
+        }
+        for (size_t i = 0; i < n; ++i) {
+            if (verdict[i] == ISSL_VERDICT_NONE) continue; // the caller leaves such guides untouched
+            issl_decode_guide(guides[i], r.hdr.seq_len, seq);
+            text.append(seq);
+            text.append(verdict[i] == ISSL_VERDICT_ACCEPTED ? "\t1\n" : "\t0\n");
+        }
+        FILE *vf = std::fopen(q.verdict_path.c_str(), "w");
+        if (!vf || std::fwrite(text.data(), 1, text.size(), vf) != text.size() || std::fclose(vf) != 0) {
+            err = "cannot write verdict file '" + q.verdict_path + "': " + std::strerror(errno);
+            issl_free(guides);
+            return false;
+        }
+    }
     issl_free(guides);
     char buf[512];
     if (r.node) {
@@ -194,7 +218,7 @@ bool score_request(Resident &r, const Request &q, std::string &out, std::string 
 }
 
 // ---- resident mode: tiny line protocol over a unix stream socket ---------------------------------------------
-//   request : "SCORE\t<issl>\t<query>\t<maxDist>\t<threshold>\t<method>\n"   |  "QUIT\n"
+//   request : "SCORE\t<issl>\t<query>\t<maxDist>\t<threshold>\t<method>[\t<verdict file>]\n"   |  "QUIT\n"
 //   response: "OK <nbytes> <timing json>\n" + nbytes of TSV               |  "ERR <message>\n"
 
 bool write_all(int fd, const char *p, size_t n)
@@ -275,8 +299,9 @@ int serve(const char *sock_path)
                 }
                 std::string err, out, tj;
                 bool ok = false;
-                if (f.size() == 6 && f[0] == "SCORE") {
+                if ((f.size() == 6 || f.size() == 7) && f[0] == "SCORE") {
                     Request q;
+                    if (f.size() == 7) q.verdict_path = f[6];
                     q.issl = f[1]; q.query = f[2]; q.max_dist = std::atoi(f[3].c_str());
                     q.threshold = std::atof(f[4].c_str()); q.method_arg = f[5];
                     struct stat st;
@@ -330,8 +355,15 @@ int try_server(const char *sock_path, char **argv, bool timing)
     char issl_abs[PATH_MAX], query_abs[PATH_MAX];
     if (!::realpath(argv[1], issl_abs)) std::snprintf(issl_abs, sizeof issl_abs, "%s", argv[1]);
     if (!::realpath(argv[2], query_abs)) std::snprintf(query_abs, sizeof query_abs, "%s", argv[2]);
-    const std::string req = std::string("SCORE\t") + issl_abs + "\t" + query_abs + "\t" + argv[3] + "\t" + argv[4] + "\t" +
-                            argv[5] + "\n";
+    std::string req = std::string("SCORE\t") + issl_abs + "\t" + query_abs + "\t" + argv[3] + "\t" + argv[4] + "\t" +
+                      argv[5];
+    if (const char *vp = std::getenv("ISSL_VERDICTS")) { // the server writes the file: make the path absolute
+        std::string abs = vp;
+        char cwd[PATH_MAX];
+        if (vp[0] != '/' && ::getcwd(cwd, sizeof cwd)) abs = std::string(cwd) + "/" + vp;
+        req += "\t" + abs;
+    }
+    req += "\n";
     std::string head;
     if (!write_all(fd, req.data(), req.size()) || !read_line(fd, head)) {
         ::close(fd);
@@ -396,6 +428,7 @@ int main(int argc, char **argv)
     q.max_dist = std::atoi(argv[3]);     // :109
     q.threshold = std::atof(argv[4]);    // :112
     q.method_arg = argv[5];
+    if (const char *vp = std::getenv("ISSL_VERDICTS")) q.verdict_path = vp;
     // size of the query file decides whether a lone process spreads over all GPUs
     size_t n_hint = 0;
     struct stat st;

@@ -3,6 +3,8 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <cctype>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -888,6 +890,46 @@ int issl_count_candidates(const issl_index *idx, const uint64_t *guides, size_t 
         for (uint64_t s = 0; s < idx->geo.n_slices; ++s)
             total += idx->bucket_sizes[s * per + ((guides[i] >> (idx->geo.slice_width * s)) & (per - 1))];
     *out = total;
+    return ISSL_OK;
+}
+
+// Crackling.py:780-835.  The caller compares float(<"%f" text>) with the threshold, so a score within 1e-6 of the
+// threshold is sent through the same text round trip; everything else compares the same way without it.
+int issl_verdicts(const double *mit, const double *cfd, size_t n, double threshold, const char *method,
+                  uint8_t *accepted)
+{
+    if (!method || (n && (!mit || !cfd || !accepted))) { set_error("null argument"); return ISSL_E_ARG; }
+    const int printed = method_from_string(method); // exact match, :121-143
+    const bool has_mit = printed == ISSL_METHOD_MIT || printed == ISSL_METHOD_AND || printed == ISSL_METHOD_OR ||
+                         printed == ISSL_METHOD_AVG;
+    const bool has_cfd = printed == ISSL_METHOD_CFD || printed == ISSL_METHOD_AND || printed == ISSL_METHOD_OR ||
+                         printed == ISSL_METHOD_AVG;
+    std::string m(method); // str(...).strip().lower()
+    const char *ws = " \t\n\r\f\v";
+    const size_t b = m.find_first_not_of(ws);
+    m = b == std::string::npos ? std::string() : m.substr(b, m.find_last_not_of(ws) - b + 1);
+    for (char &c : m) c = static_cast<char>(std::tolower(static_cast<unsigned char>(c)));
+    const int rule = method_from_string(m.c_str());
+    auto as_read = [&](double x, bool present) {
+        if (!present) return -1.0;
+        if (std::fabs(x - threshold) > 1e-5 && rule != ISSL_METHOD_AVG) return x; // text rounding cannot flip it
+        char buf[400];
+        std::snprintf(buf, sizeof buf, "%f", x);
+        return std::strtod(buf, nullptr);
+    };
+    for (size_t i = 0; i < n; ++i) {
+        const double a = as_read(mit[i], has_mit), c = as_read(cfd[i], has_cfd);
+        bool reject;
+        switch (rule) {
+        case ISSL_METHOD_MIT: reject = a < threshold; break;
+        case ISSL_METHOD_CFD: reject = c < threshold; break;
+        case ISSL_METHOD_AND: reject = a < threshold && c < threshold; break;
+        case ISSL_METHOD_OR: reject = a < threshold || c < threshold; break;
+        case ISSL_METHOD_AVG: reject = (a + c) / 2 < threshold; break;
+        default: accepted[i] = ISSL_VERDICT_NONE; continue;
+        }
+        accepted[i] = reject ? ISSL_VERDICT_REJECTED : ISSL_VERDICT_ACCEPTED;
+    }
     return ISSL_OK;
 }
 

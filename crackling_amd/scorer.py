@@ -306,3 +306,17 @@ def parse_scorer_output(text):
         if len(parts) == 3:
             out[parts[0]] = {"mit": float(parts[1]), "cfd": float(parts[2])}
     return out
+
+
+def verdicts(mit, cfd, threshold, method):
+    """Crackling.py:780-835 on arrays: 1 = accepted, 0 = rejected, 255 = no rule matches the method name.
+
+    `method` is the configured string (the scorer matches it exactly, the caller lower-cases it)."""
+    mit = np.ascontiguousarray(mit, dtype=np.float64)
+    cfd = np.ascontiguousarray(cfd, dtype=np.float64)
+    if mit.shape != cfd.shape or mit.ndim != 1:
+        raise ValueError("mit and cfd must be 1-D arrays of the same length")
+    out = np.empty(len(mit), dtype=np.uint8)
+    check(lib.issl_verdicts(mit.ctypes.data, cfd.ctypes.data, len(mit), float(threshold), str(method).encode(),
+                            out.ctypes.data))
+    return out

@@ -190,6 +190,19 @@ int issl_last_stats(const issl_index *idx, issl_stats *out);
 /* Sum over guides of the five bucket lengths (SURVEY 8d cross-check), host arithmetic only. */
 int issl_count_candidates(const issl_index *idx, const uint64_t *guides, size_t n, uint64_t *out);
 
+/* ---- caller-side thresholding (src/crackling/Crackling.py:780-835) ----------- */
+/* What Crackling does with the scorer's stdout: the scores are read back from the "%f" text (6 decimals; -1 for a
+ * score whose method was not requested, isslScoreOfftargets.cpp:517-525) and compared with the threshold under the
+ * lower-cased, stripped method name (`mit`: MIT < t rejects; `cfd`; `and`: both below; `or`: either; `avg`: mean).
+ * `method` is the string as configured: the scorer matches it exactly (:121-143) while the caller lower-cases it,
+ * so "AND" prints -1/-1 and then rejects -- reproduced here.  accepted[i] = ISSL_VERDICT_REJECTED (0, CODE_REJECTED),
+ * ISSL_VERDICT_ACCEPTED (1, CODE_ACCEPTED) or ISSL_VERDICT_NONE (the caller's if/elif chain matches no method and
+ * leaves the guide untouched).  Host arithmetic only.  bin/isslScoreOfftargets writes "<20-mer>\t<0|1>\n" lines to
+ * the file named by ISSL_VERDICTS when that variable is set (stdout is unchanged). */
+enum { ISSL_VERDICT_REJECTED = 0, ISSL_VERDICT_ACCEPTED = 1, ISSL_VERDICT_NONE = 255 };
+int issl_verdicts(const double *mit, const double *cfd, size_t n, double threshold, const char *method,
+                  uint8_t *accepted);
+
 /* ---- one process, several GPUs of the node ------------------------------------------------ */
 /* The reference's outer loop is data-parallel over guides (isslScoreOfftargets.cpp:316-509 reads only the
  * index): a node replicates the HBM image on every listed device -- uploaded once on devices[0], then broadcast
