@@ -30,6 +30,28 @@ def random_sites(n_lines, seed, dup_frac=0.025, seq_len=20):
     return allsig[idx], occ
 
 
+def random_sites_fast(n_lines, seed, threads=16, dup_frac=0.025):
+    """Multi-billion-site variant of random_sites (not the same stream): 20-mers drawn directly in text order as 256
+    independent chunks (one per leading four bases) on a thread pool; ~dup_frac of the sites occur twice."""
+    from concurrent.futures import ThreadPoolExecutor
+    per = int(n_lines / (1 + dup_frac)) // 256
+
+    def chunk(c):
+        rng = np.random.default_rng([seed, c])
+        low = rng.integers(0, 1 << 32, size=per, dtype=np.uint64)
+        low.sort()
+        keep = np.ones(per, dtype=bool)
+        keep[1:] = low[1:] != low[:-1]
+        low = low[keep]
+        occ = np.ones(len(low), dtype=np.uint32)
+        occ[rng.random(len(low)) < dup_frac] = 2
+        return text_order_key((np.uint64(c) << np.uint64(32)) | low), occ   # the key map is its own inverse
+
+    with ThreadPoolExecutor(max_workers=threads) as pool:
+        parts = list(pool.map(chunk, range(256)))
+    return np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts])
+
+
 def random_guides(sigs, n_guides, seed, seq_len=20):
     rng = np.random.default_rng(seed)
     g = np.empty(n_guides, dtype=np.uint64)

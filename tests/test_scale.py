@@ -1,0 +1,96 @@
+"""Scale point: one large index on one GPU, scores of a guide sample bit-identical to the oracle on the same index.
+
+Default size keeps the suite fast; the big points of profiles/ are the same test with
+ISSL_SCALE_SITES / ISSL_SCALE_GUIDES / ISSL_SCALE_JSON set (e.g. 3 000 000 000 sites = BASELINE configs[4]'s index,
+a 204 GB image, on ONE MI355X).  The .issl for the oracle goes to ISSL_SCALE_TMP (default: pytest's tmp dir; use
+/dev/shm for files larger than the disk)."""
+import json
+import os
+import pathlib
+import time
+
+import numpy as np
+import pytest
+
+import crackling_amd as ca
+import oracle_util as ou
+from synth import random_sites_fast, random_guides, text_order_key
+
+
+def test_fast_generator_is_sorted_and_distinct():
+    sigs, occ = random_sites_fast(300_000, seed=3, threads=4)
+    key = text_order_key(sigs)
+    assert (np.diff(key.astype(np.int64)) > 0).all() and set(np.unique(occ)) <= {1, 2}
+    assert abs(int(occ.sum()) - 300_000) < 3000 and 0.015 < (occ == 2).mean() < 0.035
+
+
+def _memory_limit_bytes():
+    """Smaller of the cgroup limit of this container and the machine's RAM (a pod that exceeds the former is killed)."""
+    limit = os.sysconf("SC_PAGE_SIZE") * os.sysconf("SC_PHYS_PAGES")
+    for f in ("/sys/fs/cgroup/memory.max", "/sys/fs/cgroup/memory/memory.limit_in_bytes"):
+        try:
+            limit = min(limit, int(open(f).read().strip()))
+        except (OSError, ValueError):
+            pass
+    return limit
+
+
+@pytest.mark.gpu
+def test_scale_point_matches_oracle_on_a_sample(tmp_path):
+    n_lines = int(os.environ.get("ISSL_SCALE_SITES", 20_000_000))
+    n_guides = int(os.environ.get("ISSL_SCALE_GUIDES", 20_000))
+    n_check = int(os.environ.get("ISSL_SCALE_CHECK", 48))
+    tmp = pathlib.Path(os.environ.get("ISSL_SCALE_TMP", tmp_path))
+    # host bytes per site: 12 generated (+12 while the chunks are concatenated), 48 host index, 48 for the oracle's
+    # own copy of the .issl, 48 more when the file itself lives in memory (/dev/shm)
+    need = n_lines * (72 + 48 + (48 if str(tmp).startswith("/dev/shm") else 0))
+    if need > 0.7 * _memory_limit_bytes():
+        pytest.skip(f"needs ~{need / 1e9:.0f} GB of host memory, limit is {_memory_limit_bytes() / 1e9:.0f} GB")
+    t = time.time(); sigs, occ = random_sites_fast(n_lines, seed=11, threads=min(32, os.cpu_count() or 8)); t_synth = time.time() - t
+    guides = random_guides(sigs, n_guides, seed=12)
+    print(f"synth {t_synth:.1f}s distinct={len(sigs)}", flush=True)
+    t = time.time(); ix = ca.IsslIndex.build_from_sites(sigs, occ); t_build = time.time() - t
+    print(f"build {t_build:.1f}s", flush=True)
+    del sigs, occ
+    t = time.time(); ix.upload(0); t_upload = time.time() - t
+    print(f"upload {t_upload:.1f}s image {ix.device_bytes() / 1e9:.1f} GB", flush=True)
+    best = None
+    for rep in range(4):
+        t = time.time(); mit, cfd = ix.score(guides, 4, 75.0, "and"); wall = time.time() - t
+        st = ix.stats()
+        print(f"rep{rep} wall {wall * 1e3:.1f} ms scan {st['ms_scan']:.2f} ms", flush=True)
+        if rep and (best is None or st["ms_scan"] < best[1]["ms_scan"]):
+            best = (wall, st)
+    wall, st = best
+    assert st["candidates"] == ix.count_candidates(guides)
+    hdr = ix.header
+    path = tmp / f"scale_{os.getpid()}.issl"
+    try:
+        t = time.time(); ix.write(path); t_write = time.time() - t
+        issl_gb = path.stat().st_size / 1e9
+        print(f"write {t_write:.1f}s ({issl_gb:.1f} GB)", flush=True)
+        t = time.time(); oracle = ou.OracleIndex(path); t_load = time.time() - t
+        print(f"oracle load {t_load:.1f}s", flush=True)
+        pick = np.linspace(0, n_guides - 1, n_check).astype(np.int64)
+        t = time.time(); omit, ocfd = oracle.score(guides[pick], 4, 75.0, "and", threads=min(n_check, os.cpu_count() or 8))
+        t_oracle = time.time() - t
+        oracle.close()
+    finally:
+        path.unlink(missing_ok=True)
+    assert np.array_equal(mit[pick].view(np.uint64), omit.view(np.uint64))
+    assert np.array_equal(cfd[pick].view(np.uint64), ocfd.view(np.uint64))
+    summary = {
+        "what": f"tests/test_scale.py: {n_guides} guides vs a {n_lines}-line synthetic index on one MI355X, 'and' thr 75 "
+                f"max_dist 4; {n_check} guides re-scored by the CPU oracle on the same .issl: bit-identical",
+        "distinct_sites": int(hdr["n_sites"]), "image_GB": ix.device_bytes() / 1e9, "issl_GB": issl_gb,
+        "synth_s": t_synth, "host_build_s": t_build, "upload_s": t_upload, "wall_ms": wall * 1e3,
+        "scan_ms": st["ms_scan"], "verify_ms": st["ms_verify"], "group_ms": st["ms_group"], "replay_ms": st["ms_replay"],
+        "pipeline_ms": st["ms_total"], "comparisons": st["candidates"], "hits": st["hits"],
+        "scan_Tcmp_per_s": st["candidates"] / st["ms_scan"] / 1e9, "algorithmic_TBps": 8.0 * st["candidates"] / st["ms_scan"] / 1e9,
+        "guides_per_s_kernels": n_guides / st["ms_total"] * 1e3,
+        "oracle_sample": {"guides": n_check, "seconds": t_oracle, "threads": min(n_check, os.cpu_count() or 8),
+                          "guides_per_s": n_check / t_oracle},
+    }
+    print(json.dumps(summary), flush=True)
+    if os.environ.get("ISSL_SCALE_JSON"):
+        json.dump(summary, open(os.environ["ISSL_SCALE_JSON"], "w"), indent=1)
