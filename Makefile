@@ -18,7 +18,7 @@ $(LIB): $(CSRC)/issl_kernels.hip $(CSRC)/issl_extract.hip $(CSRC)/issl_capi.cpp 
 
 bin/isslScoreOfftargets: $(CSRC)/cli_score.cpp $(LIB)
 	@mkdir -p bin
-	$(HIPCC) $(CXXFLAGS) -o $@ $< -Lcrackling_amd -lissl_hip -Wl,-rpath,'$$ORIGIN/../crackling_amd'
+	$(HIPCC) $(CXXFLAGS) -o $@ $< -Lcrackling_amd -lissl_hip -lpthread -Wl,-rpath,'$$ORIGIN/../crackling_amd'
 
 bin/extractOfftargets: $(CSRC)/cli_extract.cpp $(LIB)
 	@mkdir -p bin

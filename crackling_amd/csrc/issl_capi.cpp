@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <cctype>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -216,7 +217,7 @@ static int ensure_workspace(issl_index *ix, Lane &lane, size_t n)
     }
     if (w.cap_chunks == 0) {
         // every scan wave may hold one partly filled chunk; beyond that ~1 record per 50k comparisons
-        size_t want = std::max<size_t>(size_t(kScanWaves) * 4, n);
+        size_t want = std::max<size_t>(size_t(scan_blocks()) * 16 * 4, n);
         // ISSL_RAW_CHUNKS=<n>: start with a small raw buffer (tests of the grow-and-rerun path)
         if (const char *e = std::getenv("ISSL_RAW_CHUNKS")) want = std::max<size_t>(1, std::strtoull(e, nullptr, 10));
         if ((rc = ensure_raw_capacity(w, want))) return rc;
@@ -233,8 +234,8 @@ static int ensure_workspace(issl_index *ix, Lane &lane, size_t n)
         lane.ready = true;
     }
     if (!w.stamps && std::getenv("ISSL_SCAN_STAMPS")) { // diagnostics: per-wave start/end times of the scan
-        if ((rc = dev_alloc(w.stamps, 2 * kScanWaves))) return rc;
-        HIP_TRY(hipMemset(w.stamps, 0, 16 * kScanWaves));
+        if ((rc = dev_alloc(w.stamps, 4 * kScanWaves))) return rc;
+        HIP_TRY(hipMemset(w.stamps, 0, 32 * kScanWaves));
     }
     if (!w.sticky) {
         if ((rc = dev_alloc(w.sticky, 4))) return rc;
@@ -257,6 +258,18 @@ static uint32_t dense_index(uint64_t mask)
     uint32_t idx = 0;
     for (uint32_t p = 0; p < 20; ++p) idx |= static_cast<uint32_t>((mask >> (2 * p)) & 1ull) << p;
     return idx;
+}
+
+static double wall_ms()
+{
+    using namespace std::chrono;
+    return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+// ISSL_UPLOAD_TIMING=1: one diagnostic line per upload on stderr (where the time of an upload goes)
+static void upload_note(const char *what, double t0)
+{
+    if (std::getenv("ISSL_UPLOAD_TIMING")) std::fprintf(stderr, "[issl upload] %s %.1f ms\n", what, wall_ms() - t0);
 }
 
 static int finish_upload(issl_index *ix)
@@ -289,8 +302,15 @@ static int finish_upload(issl_index *ix)
         for (size_t i = 0; i < masks.size(); ++i) dense[dense_index(masks[i])] = vals[i];
         HIP_TRY(hipMemcpy(base + ix->hdr.off_mit_dense, dense.data(), 8 * dense.size(), hipMemcpyHostToDevice));
     }
+    double t0 = wall_ms();
+    // Plain copies from the (file-mapped) host arrays: measured 48 GB/s on a 14 GB index, where a 12-thread pipeline
+    // through pinned staging buffers reached 24 GB/s.
     HIP_TRY(hipMemcpy(base + ix->hdr.off_sites, h.sites, 8 * g.n_sites, hipMemcpyHostToDevice));
+    upload_note("sites", t0);
+    t0 = wall_ms();
     HIP_TRY(hipMemcpy(base + ix->hdr.off_entries, h.entries, 8 * g.n_sites * g.n_slices, hipMemcpyHostToDevice));
+    upload_note("entries", t0);
+    t0 = wall_ms();
     ix->view = make_view(ix->hdr, ix->d_image);
     // scan stream: built on the device from sites + entries
     uint32_t *flag = nullptr;
@@ -301,6 +321,7 @@ static int finish_upload(issl_index *ix)
     uint32_t err = 0;
     HIP_TRY(hipMemcpy(&err, flag, 4, hipMemcpyDeviceToHost));
     (void)hipFree(flag);
+    upload_note("scan stream", t0);
     if (err) {
         set_error("Error reading index: a slice entry refers to an off-target id beyond the site table");
         return ISSL_E_FORMAT;
@@ -482,9 +503,9 @@ static int finish_batches(issl_index *ix, hipStream_t stream)
     ix->stats.hits = total_hits;
     ix->stats.scan_tiles = pl.tiles;
     ix->stats.n_batches = batches;
-    if (last.ws.stamps) { // ISSL_SCAN_STAMPS=<file>: dump the wave stamps of the last scan (binary u64 pairs)
-        std::vector<unsigned long long> st(2 * kScanWaves);
-        HIP_TRY(hipMemcpy(st.data(), last.ws.stamps, 16 * kScanWaves, hipMemcpyDeviceToHost));
+    if (last.ws.stamps) { // ISSL_SCAN_STAMPS=<file>: dump the wave stamps of the last scan (4 u64 per wave)
+        std::vector<unsigned long long> st(4 * kScanWaves);
+        HIP_TRY(hipMemcpy(st.data(), last.ws.stamps, 32 * kScanWaves, hipMemcpyDeviceToHost));
         if (FILE *f = std::fopen(std::getenv("ISSL_SCAN_STAMPS"), "wb")) {
             std::fwrite(st.data(), 8, st.size(), f);
             std::fclose(f);
@@ -622,9 +643,13 @@ static int upload_common(issl_index *idx, int device, void *buf, size_t bytes)
     if (!idx->host) { set_error("index has no host arrays to upload"); return ISSL_E_STATE; }
     int rc = supported_geometry(idx->geo);
     if (rc) return rc;
+    double t0 = wall_ms();
     rc = select_device(device);
     if (rc) return rc;
     release_device(idx);
+    (void)hipFree(nullptr); // creates the context
+    upload_note("device runtime start", t0);
+    t0 = wall_ms();
     std::vector<uint64_t> m;
     std::vector<double> v;
     idx->host->unique_scores(m, v);
@@ -641,6 +666,7 @@ static int upload_common(issl_index *idx, int device, void *buf, size_t bytes)
         HIP_TRY(hipMalloc(&idx->d_image, idx->hdr.total_bytes));
         idx->owns_image = true;
     }
+    upload_note("layout + allocation", t0);
     rc = finish_upload(idx);
     if (rc) release_device(idx);
     return rc;
@@ -815,16 +841,42 @@ int issl_score(issl_index *idx, const uint64_t *guides, size_t n, int max_dist, 
     if (!idx->d_image) { set_error("index has no device image: call issl_index_upload first"); return ISSL_E_STATE; }
     if (n == 0) return ISSL_OK;
     HIP_TRY(hipSetDevice(idx->device));
-    // Crackling hands over pages of up to 5 M guides (config.ini:112); larger batches go through in pieces.
+    // Crackling hands over pages of up to 5 M guides (config.ini:112); larger batches go through in pieces of at most
+    // 2^22 guides.  The guides are in host memory here, so the comparison count is five table look-ups per guide
+    // away (SURVEY 8d cross-check).  Uniform data leaves one raw record per ~26 k comparisons (16 positions, <= 4
+    // mismatches); the record buffers (32 B per slot with the sorted keys and score terms) are sized for twice
+    // that up front, which saves the first large batch on an index its grow-and-rerun round, and a piece ends
+    // early when its estimate would not fit a quarter of the free HBM.  Denser data still grows the buffers.
     const size_t piece = size_t(1) << 22;
+    const bool presize = !std::getenv("ISSL_RAW_CHUNKS");
+    const double records_per_comparison = 8e-5;
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    const double budget_slots = std::max<double>(static_cast<double>(idx->lanes[0].ws.cap_chunks) * (kChunkRecs - 1),
+                                                 static_cast<double>(std::min<size_t>(free_b / 4, size_t(32) << 30)) / 32.0);
+    const uint64_t per = idx->geo.buckets_per_slice();
     issl_stats total{};
-    for (size_t at = 0; at < n; at += piece) {
-        const size_t cnt = std::min(piece, n - at);
+    for (size_t at = 0; at < n;) {
+        uint64_t cand = 0;
+        size_t cnt = 0;
+        while (at + cnt < n && cnt < piece) {
+            uint64_t c = 0;
+            for (uint64_t sl = 0; sl < idx->geo.n_slices; ++sl)
+                c += idx->bucket_sizes[sl * per + ((guides[at + cnt] >> (idx->geo.slice_width * sl)) & (per - 1))];
+            if (presize && cnt > 0 && static_cast<double>(cand + c) * records_per_comparison > budget_slots) break;
+            cand += c;
+            ++cnt;
+        }
         Workspace &ws = idx->lanes[0].ws;
         int rc = finish_batches(idx, nullptr); // asynchronous batches may still use the staging buffers
         if (rc) return rc;
         rc = ensure_workspace(idx, idx->lanes[0], cnt);
         if (rc) return rc;
+        if (presize) {
+            const double slots = std::min(static_cast<double>(cand) * records_per_comparison, budget_slots);
+            rc = ensure_raw_capacity(ws, static_cast<size_t>(slots / (kChunkRecs - 1)) + size_t(scan_blocks()) * 16 * 2);
+            if (rc) return rc;
+        }
         HIP_TRY(hipMemcpy(ws.d_guides, guides + at, 8 * cnt, hipMemcpyHostToDevice));
         rc = score_core(idx, ws.d_guides, cnt, max_dist, threshold, method, ws.d_mit, ws.d_cfd, nullptr, false);
         if (rc) return rc;
@@ -836,6 +888,7 @@ int issl_score(issl_index *idx, const uint64_t *guides, size_t n, int max_dist, 
         total.ms_verify += s.ms_verify; total.ms_group += s.ms_group; total.ms_replay += s.ms_replay;
         total.ms_total += s.ms_total; total.scan_launches += s.scan_launches;
         total.raw_records = std::max(total.raw_records, s.raw_records); total.n_batches += s.n_batches;
+        at += cnt;
     }
     idx->stats = total;
     return ISSL_OK;

@@ -77,8 +77,10 @@ constexpr uint32_t kTileFixedCost = 4; // cost of fetching a tile, in guide-comp
 constexpr uint32_t kNoGuide = 0xFFFFFFFFu;
 constexpr uint32_t kPadGuideWord = 0xFFFFFFFFu; // scan word of padding guide slots: 16 x T, distance 16 from tile padding
 constexpr uint32_t kScanGridBlocks = 256u * 2u; // scan launch: 256 CUs x 2 workgroups of 16 waves
-constexpr uint32_t kScanWaves = kScanGridBlocks * 16u;
-constexpr uint32_t kMaxRanges = kScanGridBlocks; // one equal-cost range per workgroup
+constexpr uint32_t kScanMaxBlocks = 8192u;       // upper bound of the ISSL_SCAN_BLOCKS knob
+constexpr uint32_t kScanWaves = kScanMaxBlocks * 16u;
+constexpr uint32_t kMaxRanges = kScanMaxBlocks;  // one equal-cost range per workgroup
+uint32_t scan_blocks();                          // workgroups of the scan launch (kScanGridBlocks unless ISSL_SCAN_BLOCKS)
 constexpr uint32_t kChunkRecs = 128;            // raw-record chunk: 1 KiB, slot 0 is the fill count
 constexpr uint64_t kDeadKey = ~0ull;            // raw slot that did not survive the exact check
 

@@ -333,13 +333,13 @@ __global__ __launch_bounds__(256) void k_guide_scatter(const uint64_t *__restric
     }
 }
 
-// Workgroups of the scan launch: two 16-wave workgroups per CU by default.  ISSL_SCAN_BLOCKS=<n> (<= kScanGridBlocks)
+// Workgroups of the scan launch: two 16-wave workgroups per CU by default.  ISSL_SCAN_BLOCKS=<n> (<= kScanMaxBlocks)
 // is a tuning knob.
-static uint32_t scan_blocks()
+uint32_t scan_blocks()
 {
     if (const char *e = getenv("ISSL_SCAN_BLOCKS")) {
         const int b = atoi(e);
-        if (b >= 1 && static_cast<uint32_t>(b) <= kScanGridBlocks) return static_cast<uint32_t>(b);
+        if (b >= 1 && static_cast<uint32_t>(b) <= kScanMaxBlocks) return static_cast<uint32_t>(b);
     }
     return kScanGridBlocks;
 }
@@ -552,8 +552,10 @@ __global__ __launch_bounds__(1024, 8) void k_scan(const uint32_t *__restrict__ s
                                                   unsigned long long *stamps)
 {
     __shared__ uint32_t next_unit;
-    // stamps (diagnostics, normally null): start and end of every wave in 100 MHz ticks, nothing else reads them
+    // stamps (diagnostics, normally null): per wave {start, end} in 100 MHz ticks, {XCC_ID, HW_ID} and the number of
+    // tiles it took; nothing else reads them
     const unsigned long long t_start = stamps ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    uint32_t units_done = 0;
     if (threadIdx.x == 0) next_unit = 0;
     __syncthreads();
     const uint32_t n_ranges = plan->n_ranges;
@@ -583,6 +585,7 @@ __global__ __launch_bounds__(1024, 8) void k_scan(const uint32_t *__restrict__ s
         if (lane == 0) u = atomicAdd(&next_unit, 1u);
         u = __builtin_amdgcn_readfirstlane(u);
         if (u >= n_units) break;
+        ++units_done;
         const uint32_t gt = tile_begin + u;            // tile number in item order
         while (gt >= cur.tile0 + cur.n_tiles) cur = items[++it]; // tickets only grow: the cursor moves forward
         const uint32_t k = gt - cur.tile0;
@@ -618,8 +621,11 @@ __global__ __launch_bounds__(1024, 8) void k_scan(const uint32_t *__restrict__ s
         if (no_own_chunk && lane == 0) counters->raw_overflow = 1u;
     }
     if (stamps && lane == 0) {
-        stamps[2 * wave_id] = t_start;
-        stamps[2 * wave_id + 1] = __builtin_amdgcn_s_memrealtime();
+        stamps[4 * wave_id] = t_start;
+        stamps[4 * wave_id + 1] = __builtin_amdgcn_s_memrealtime();
+        stamps[4 * wave_id + 2] = (static_cast<unsigned long long>(__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11))) << 32) |
+                                  __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); // XCC_ID, HW_ID
+        stamps[4 * wave_id + 3] = units_done;
     }
 }
 

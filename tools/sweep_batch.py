@@ -9,10 +9,10 @@ import json, subprocess, sys, pathlib
 ROOT = pathlib.Path(__file__).resolve().parent.parent
 out = sys.argv[1]
 big = "--big" in sys.argv
-res = {"what": "bench.py --guides G --steps 20 --no-cpu-baseline on one MI355X, 50M-line index (48.78M distinct sites); "
+res = {"what": "bench.py --guides G --steps 100 --no-cpu-baseline on one MI355X, 50M-line index (48.78M distinct sites); "
                "small G = HBM-bound regime (each bucket tile serves one guide), large G = VALU-bound", "by_guides": {}}
 for g in (64, 256, 1024, 4096, 10000):
-    p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--guides", str(g), "--steps", "20", "--no-cpu-baseline"],
+    p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--guides", str(g), "--steps", "100", "--no-cpu-baseline"],
                        stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True, text=True)
     d = json.loads(p.stdout.strip().splitlines()[-1])
     res["by_guides"][str(g)] = {"guides_per_s": d["value"], "ms_per_step": d["ms_per_step"], "scan_ms": d["kernel_ms"]["scan"],
