@@ -75,6 +75,15 @@ ImageView make_view(const ImageHeader &h, void *base)
 
 constexpr uint32_t kRing = 64;
 constexpr size_t kMaxBatch = size_t(1) << 24; // guides per pipeline launch
+constexpr uint32_t kMaxLanes = 3;
+
+// ISSL_LANES=<1..3>: workspaces/streams that consecutive asynchronous batches rotate through (default 1)
+static uint32_t lane_count()
+{
+    const char *e = std::getenv("ISSL_LANES");
+    if (e && e[0] >= '1' && e[0] <= '0' + static_cast<int>(kMaxLanes) && e[1] == 0) return static_cast<uint32_t>(e[0] - '0');
+    return 1;
+}
 
 struct Lane {
     Workspace ws;
@@ -98,8 +107,9 @@ struct issl_index {
     ImageHeader hdr{};
     ImageView view{};
     // A lane = one complete workspace + an internal stream.  Synchronous calls use lane 0 on the caller's stream;
-    // asynchronous batches run on lane 0's internal stream (and alternate with lane 1 only under ISSL_LANES=2).
-    Lane lanes[2];
+    // asynchronous batches run on lane 0's internal stream (and rotate through more lanes only under ISSL_LANES).
+    Lane lanes[kMaxLanes];
+    hipStream_t scan_stream = nullptr; // ISSL_LANES>1: high-priority stream that carries every scan
     hipEvent_t ring[2 * kRing] = {}; // scan begin/end of the batches enqueued since the last finish
     bool have_events = false;
     issl_stats stats{};
@@ -230,7 +240,16 @@ static int ensure_workspace(issl_index *ix, Lane &lane, size_t n)
         for (auto &e : lane.ev) HIP_TRY(hipEventCreate(&e));
         HIP_TRY(hipEventCreate(&lane.done));
         HIP_TRY(hipEventCreate(&lane.scan_done));
-        HIP_TRY(hipStreamCreateWithFlags(&lane.stream, hipStreamNonBlocking));
+        if (lane_count() > 1) {
+            // two lanes: the scans of both go to one high-priority stream, everything else to low-priority streams,
+            // so that the workgroups of a scan are placed before the small kernels of the other lane
+            int lo = 0, hi = 0;
+            HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi)); // lo = lowest priority (largest number)
+            HIP_TRY(hipStreamCreateWithPriority(&lane.stream, hipStreamNonBlocking, lo));
+            if (!ix->scan_stream) HIP_TRY(hipStreamCreateWithPriority(&ix->scan_stream, hipStreamNonBlocking, hi));
+        } else {
+            HIP_TRY(hipStreamCreateWithFlags(&lane.stream, hipStreamNonBlocking));
+        }
         lane.ready = true;
     }
     if (!w.stamps && std::getenv("ISSL_SCAN_STAMPS")) { // diagnostics: per-wave start/end times of the scan
@@ -352,6 +371,11 @@ static void release_device(issl_index *ix)
         lane.last_n = 0;
         lane.pending = 0;
     }
+    if (ix->scan_stream) {
+        (void)hipStreamSynchronize(ix->scan_stream);
+        (void)hipStreamDestroy(ix->scan_stream);
+        ix->scan_stream = nullptr;
+    }
     if (ix->have_events) {
         for (auto &e : ix->ring) (void)hipEventDestroy(e);
         ix->have_events = false;
@@ -413,14 +437,20 @@ static int enqueue_batch(issl_index *ix, Lane &lane, hipStream_t stream, const u
     HIP_TRY(hipEventRecord(lane.ev[0], stream));
     launch_bin_guides(ix->view, ws, d_guides, n32, stream);
     HIP_TRY(hipEventRecord(lane.ev[1], stream));
-    // The scan assumes the whole GPU (its ranges are dealt out statically to co-resident waves): scans of different
-    // lanes never overlap each other, only the short kernels around them do.
-    Lane &other = ix->lanes[1 - (&lane - ix->lanes)];
-    if (other.ready && other.pending) HIP_TRY(hipStreamWaitEvent(stream, other.scan_done, 0));
-    HIP_TRY(hipEventRecord(ix->ring[2 * slot], stream));
-    launch_scan(ix->view, ws, d_guides, n32, max_dist, stream);
-    HIP_TRY(hipEventRecord(ix->ring[2 * slot + 1], stream));
-    HIP_TRY(hipEventRecord(lane.scan_done, stream));
+    if (ix->scan_stream && stream == lane.stream) {
+        // scans of both lanes run one after the other on the high-priority stream
+        HIP_TRY(hipStreamWaitEvent(ix->scan_stream, lane.ev[1], 0));
+        HIP_TRY(hipEventRecord(ix->ring[2 * slot], ix->scan_stream));
+        launch_scan(ix->view, ws, d_guides, n32, max_dist, ix->scan_stream);
+        HIP_TRY(hipEventRecord(ix->ring[2 * slot + 1], ix->scan_stream));
+        HIP_TRY(hipEventRecord(lane.scan_done, ix->scan_stream));
+        HIP_TRY(hipStreamWaitEvent(stream, lane.scan_done, 0));
+    } else {
+        HIP_TRY(hipEventRecord(ix->ring[2 * slot], stream));
+        launch_scan(ix->view, ws, d_guides, n32, max_dist, stream);
+        HIP_TRY(hipEventRecord(ix->ring[2 * slot + 1], stream));
+        HIP_TRY(hipEventRecord(lane.scan_done, stream));
+    }
     HIP_TRY(hipEventRecord(lane.ev[2], stream));
     launch_verify(ix->view, ws, d_guides, max_dist, stream);
     HIP_TRY(hipEventRecord(lane.ev[3], stream));
@@ -803,13 +833,12 @@ int issl_score_device_async(issl_index *idx, const uint64_t *d_guides, size_t n,
     if (!idx->d_image) { set_error("index has no device image: call issl_index_upload first"); return ISSL_E_STATE; }
     if (n == 0) return ISSL_OK;
     HIP_TRY(hipSetDevice(idx->device));
-    // One lane by default: batches run back to back on one internal stream.  ISSL_LANES=2 alternates two lanes so
-    // that the tail of a batch overlaps the next scan -- measured SLOWER on MI355X (0.83 vs 0.64 ms per 10k-guide
-    // step): the scan deals its ranges out statically to waves it assumes co-resident, and the other lane's small
-    // kernels delay some of its workgroups.  Kept as an experiment switch.
-    const char *lanes_env = std::getenv("ISSL_LANES");
-    const bool one_lane = !(lanes_env && lanes_env[0] == '2');
-    Lane &lane = idx->lanes[one_lane ? 0u : (idx->n_pending & 1u)];
+    // One lane by default: batches run back to back on one internal stream.  ISSL_LANES=2|3 rotates through several
+    // lanes (workspace + low-priority stream each, every scan on one shared high-priority stream) so that the short
+    // kernels of a batch run in the shadow of the next scan.  Measured on MI355X at 10 k guides per batch: 0.52-0.55 ms
+    // per step against 0.55-0.56 with one lane -- the scan it shadows slows from 0.40 to 0.50 ms, which eats most of
+    // the hidden 0.15 ms -- so one lane stays the default and this an experiment switch.
+    Lane &lane = idx->lanes[idx->n_pending % lane_count()];
     int rc = ensure_workspace(idx, lane, n); // creates the lane's stream on first use
     if (rc) return rc;
     if (stream) { // inputs are produced on the caller's stream: the batch starts after what is enqueued there now

@@ -30,6 +30,10 @@ namespace issl {
 // bit helpers
 // ------------------------------------------------------------------------------------------------
 
+// The short kernels around the scan raise their wave priority: when they share the GPU with a scan (two lanes),
+// they are latency-bound and few, and should not queue behind the scan's older waves.
+__device__ __forceinline__ void short_kernel_priority() { __builtin_amdgcn_s_setprio(3); }
+
 // Even bits of a 32-bit word gathered into the low 16 bits.
 __host__ __device__ inline uint32_t gather_even16(uint32_t x)
 {
@@ -137,6 +141,7 @@ __global__ __launch_bounds__(256) void k_guide_hist(const uint64_t *__restrict__
                                                     uint32_t slice_width, uint32_t n_slices, uint32_t n_buckets,
                                                     uint32_t *__restrict__ ng)
 {
+    short_kernel_priority();
     __shared__ uint32_t hist[kMaxBuckets];
     for (uint32_t b = threadIdx.x; b < n_buckets; b += 256) hist[b] = 0;
     __syncthreads();
@@ -178,6 +183,7 @@ __global__ __launch_bounds__(256) void k_plan(ImageView v, const uint32_t *__res
                                               uint32_t cap_items, PlanInfo *__restrict__ plan, uint32_t item_guides,
                                               uint32_t scan_blocks)
 {
+    short_kernel_priority();
     __shared__ uint64_t lds[256];
     const uint32_t nb = v.n_buckets;
     const uint32_t per = (nb + 255u) / 256u;
@@ -250,6 +256,7 @@ __global__ __launch_bounds__(256) void k_plan(ImageView v, const uint32_t *__res
 __global__ __launch_bounds__(256) void k_ranges(const PlanInfo *__restrict__ plan, const ScanItem *__restrict__ items,
                                                 RangeStart *__restrict__ starts)
 {
+    short_kernel_priority();
     const uint32_t n_ranges = plan->n_ranges;
     const uint32_t n_items = plan->n_items;
     const uint64_t total = plan->total_cost;
@@ -297,6 +304,7 @@ __global__ __launch_bounds__(256) void k_guide_scatter(const uint64_t *__restric
                                                        uint32_t *__restrict__ gfill, uint32_t *__restrict__ gword,
                                                        uint32_t *__restrict__ gidx)
 {
+    short_kernel_priority();
     __shared__ uint32_t hist[kMaxBuckets];
     __shared__ uint32_t base[kMaxBuckets];
     for (uint32_t b = threadIdx.x; b < n_buckets; b += 256) hist[b] = 0;
@@ -348,6 +356,7 @@ uint32_t scan_blocks()
 __global__ __launch_bounds__(256) void k_reset(Workspace ws, uint32_t nb, uint32_t n, uint32_t n_slots,
                                                uint32_t n_scan_waves)
 {
+    short_kernel_priority();
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     const uint32_t stride = gridDim.x * 256;
     for (uint32_t k = i; k < nb; k += stride) { ws.ng[k] = 0; ws.gfill[k] = 0; }
@@ -635,6 +644,7 @@ __global__ __launch_bounds__(1024, 8) void k_scan(const uint32_t *__restrict__ s
 __global__ __launch_bounds__(kChunkRecs) void k_verify(ImageView v, Workspace ws, const uint64_t *__restrict__ guides,
                                                        int max_dist)
 {
+    short_kernel_priority();
     uint32_t n_chunks = ws.counters->raw_chunks;
     if (blockIdx.x == 0 && threadIdx.x == 0) { // what the host needs to know after any number of batches
         if (ws.counters->raw_overflow) atomicOr(&ws.sticky[0], 1u);
@@ -732,6 +742,7 @@ constexpr uint32_t kBigLds = 8192;    // keys k_replay_big sorts in LDS (64 KiB)
 __global__ __launch_bounds__(256) void k_prefix_block_sums(const uint32_t *__restrict__ in, uint32_t n,
                                                            uint32_t *__restrict__ sums)
 {
+    short_kernel_priority();
     __shared__ uint64_t lds[256];
     const uint32_t base = blockIdx.x * kScanChunk + threadIdx.x * 8u;
     uint64_t s = 0;
@@ -744,6 +755,7 @@ __global__ __launch_bounds__(256) void k_prefix_block_sums(const uint32_t *__res
 
 __global__ __launch_bounds__(256) void k_prefix_of_sums(uint32_t *__restrict__ sums, uint32_t n_blocks)
 {
+    short_kernel_priority();
     __shared__ uint64_t lds[256];
     uint64_t carry = 0;
     for (uint32_t base = 0; base < n_blocks; base += 256) {
@@ -760,6 +772,7 @@ __global__ __launch_bounds__(256) void k_prefix_apply(const uint32_t *__restrict
                                                       const uint32_t *__restrict__ sums, uint32_t *__restrict__ out,
                                                       uint32_t *__restrict__ big, Counters *__restrict__ counters)
 {
+    short_kernel_priority();
     __shared__ uint64_t lds[256];
     const uint32_t base = blockIdx.x * kScanChunk + threadIdx.x * 8u;
     uint32_t val[8];
@@ -781,6 +794,7 @@ __global__ __launch_bounds__(1024) void k_prefix_single(const uint32_t *__restri
                                                         uint32_t *__restrict__ out, uint32_t *__restrict__ big,
                                                         Counters *__restrict__ counters)
 {
+    short_kernel_priority();
     __shared__ uint32_t wave_sum[16];
     __shared__ uint32_t carry_s;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -821,6 +835,7 @@ __global__ __launch_bounds__(kChunkRecs) void k_group_scatter(const uint64_t *__
                                                               const uint32_t *__restrict__ goff, uint32_t *__restrict__ gcur,
                                                               uint64_t *__restrict__ sorted)
 {
+    short_kernel_priority();
     uint32_t n_chunks = counters->raw_chunks;
     if (n_chunks > cap_chunks) n_chunks = cap_chunks;
     for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
@@ -957,6 +972,7 @@ __global__ __launch_bounds__(64) void k_replay(ImageView v, Workspace ws, const 
                                                double *__restrict__ out_cfd, uint32_t *__restrict__ out_kept,
                                                issl_hit *__restrict__ out_hits)
 {
+    short_kernel_priority();
     __shared__ uint64_t keys[kReplayLds];
     __shared__ double ord_mit[64], ord_cfd[64];
     const bool calc_mit = p.method == ISSL_METHOD_MIT || p.method == ISSL_METHOD_AND || p.method == ISSL_METHOD_OR ||
@@ -1050,6 +1066,7 @@ __global__ __launch_bounds__(1024) void k_replay_big(ImageView v, Workspace ws, 
                                                      double *__restrict__ out_cfd, uint32_t *__restrict__ out_kept,
                                                      issl_hit *__restrict__ out_hits)
 {
+    short_kernel_priority();
     __shared__ uint64_t keys[kBigLds];
     const bool calc_mit = p.method == ISSL_METHOD_MIT || p.method == ISSL_METHOD_AND || p.method == ISSL_METHOD_OR ||
                           p.method == ISSL_METHOD_AVG;

@@ -256,10 +256,10 @@ def test_one_site_index(tmp_path):
     ix.close()
 
 
-@pytest.mark.parametrize("lanes", ["1", "2"])
+@pytest.mark.parametrize("lanes", ["1", "2", "3"])
 def test_async_batches(config0, monkeypatch, lanes):
     """issl_score_device_async / issl_score_wait / issl_score_finish: several batches in flight, on one internal
-    lane (default) and alternating between two (ISSL_LANES=2)."""
+    lane (default) and rotating through two or three (ISSL_LANES, scans on a shared high-priority stream)."""
     import torch
     monkeypatch.setenv("ISSL_LANES", lanes)
     ix, oracle, sigs, guides = config0

@@ -51,6 +51,46 @@ __device__ __forceinline__ uint32_t sliced_le4(const uint32_t (&c)[32], uint32_t
     return ~(big | (n2 & (n1 | n0)));
 }
 
+// same, with the guide's 32 broadcast masks read from memory (s_load) instead of 32 s_bfe per guide
+__device__ __forceinline__ uint32_t sliced_le4_masks(const uint32_t (&c)[32], const uint32_t *__restrict__ mk)
+{
+    uint32_t m[16];
+#pragma unroll
+    for (int p = 0; p < 16; ++p) m[p] = (c[p] ^ mk[p]) | (c[16 + p] ^ mk[16 + p]);
+    uint32_t s[6], k2[8], n0, n1, n2, k4[4], k8[2], t, u;
+    fa(m[0], m[1], m[2], s[0], k2[0]);
+    fa(m[3], m[4], m[5], s[1], k2[1]);
+    fa(m[6], m[7], m[8], s[2], k2[2]);
+    fa(m[9], m[10], m[11], s[3], k2[3]);
+    fa(m[12], m[13], m[14], s[4], k2[4]);
+    fa(s[0], s[1], s[2], t, k2[5]);
+    fa(s[3], s[4], m[15], u, k2[6]);
+    ha(t, u, n0, k2[7]);
+    uint32_t a2, b2, c2;
+    fa(k2[0], k2[1], k2[2], a2, k4[0]);
+    fa(k2[3], k2[4], k2[5], b2, k4[1]);
+    fa(k2[6], k2[7], a2, c2, k4[2]);
+    ha(b2, c2, n1, k4[3]);
+    uint32_t a4;
+    fa(k4[0], k4[1], k4[2], a4, k8[0]);
+    ha(a4, k4[3], n2, k8[1]);
+    const uint32_t big = k8[0] | k8[1];
+    return ~(big | (n2 & (n1 | n0)));
+}
+
+template <int WPB>
+__global__ __launch_bounds__(WPB * 64) void k_masks(uint32_t *out, const uint32_t *__restrict__ masks, uint32_t seed, int iters)
+{
+    uint32_t pl[32];
+    for (int i = 0; i < 32; ++i) pl[i] = seed * (threadIdx.x + 3) + i * 0x85EBCA6Bu + blockIdx.x;
+    uint32_t acc = 0;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc |= sliced_le4_masks(pl, masks + (((it * 4 + u) & 1023) * 32));
+    }
+    out[blockIdx.x * (WPB * 64) + threadIdx.x] = acc;
+}
+
 template <int MODE>
 __global__ __launch_bounds__(256) void k(uint32_t *out, uint32_t seed, int iters)
 {
@@ -148,6 +188,22 @@ int main()
         float ms = 0; hipEventElapsedTime(&ms, a, b);
         const double cmps = double(iters) * 128 * 256 * blocks;
         printf("%-34s %8.3f ms  %7.2f Tcand/s\n", "bit-sliced le4 (32 cand/lane-op)", ms, cmps / ms / 1e9);
+    }
+    {   // same with the masks read through the scalar cache
+        const int iters = 4000, blocks = 256 * 8;
+        uint32_t *d_masks; hipMalloc(&d_masks, 1024 * 32 * 4);
+        uint32_t *h = new uint32_t[1024 * 32];
+        for (int i = 0; i < 1024 * 32; ++i) h[i] = (i * 2654435761u >> 7) & 1u ? 0xFFFFFFFFu : 0u;
+        hipMemcpy(d_masks, h, 1024 * 32 * 4, hipMemcpyHostToDevice);
+        hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+        hipLaunchKernelGGL(k_masks<4>, dim3(blocks), dim3(256), 0, 0, d_out, d_masks, 12345u, 10);
+        hipDeviceSynchronize();
+        hipEventRecord(a);
+        hipLaunchKernelGGL(k_masks<4>, dim3(blocks), dim3(256), 0, 0, d_out, d_masks, 12345u, iters);
+        hipEventRecord(b); hipEventSynchronize(b);
+        float ms = 0; hipEventElapsedTime(&ms, a, b);
+        const double cmps = double(iters) * 128 * 256 * blocks;
+        printf("%-34s %8.3f ms  %7.2f Tcand/s\n", "bit-sliced le4, masks via s_load", ms, cmps / ms / 1e9);
     }
     return 0;
 }
