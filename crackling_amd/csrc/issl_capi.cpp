@@ -153,7 +153,7 @@ static int select_device(int device)
 
 static void free_workspace(Workspace &w)
 {
-    void *ptrs[] = {w.ng, w.gfill, w.gstart, w.gword, w.gidx, w.items, w.plan, w.range_start, w.counters, w.sticky, w.stamps, w.gcur_big, w.terms, w.sorted, w.gcount,
+    void *ptrs[] = {w.ng, w.gfill, w.gstart, w.gword, w.gidx, w.gbucket, w.items, w.plan, w.range_start, w.counters, w.sticky, w.stamps, w.gcur_big, w.terms, w.sorted, w.gcount,
                     w.goff, w.gcur, w.blocksum, w.d_guides, w.d_mit, w.d_cfd, w.d_kept, w.d_hitrec};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -198,6 +198,8 @@ static int ensure_workspace(issl_index *ix, Lane &lane, size_t n)
     if (w.n_buckets != nb) {
         if ((rc = dev_alloc(w.ng, nb))) return rc;
         if ((rc = dev_alloc(w.gfill, nb))) return rc;
+        HIP_TRY(hipMemset(w.ng, 0, 4 * nb)); // k_plan leaves both zeroed for the next batch
+        HIP_TRY(hipMemset(w.gfill, 0, 4 * nb));
         if ((rc = dev_alloc(w.gstart, nb + 1))) return rc;
         if ((rc = dev_alloc(w.counters, 1))) return rc;
         if ((rc = dev_alloc(w.plan, 1))) return rc;
@@ -211,6 +213,7 @@ static int ensure_workspace(issl_index *ix, Lane &lane, size_t n)
         const size_t items = nb + cap * ix->hdr.n_slices / 8 + 2; // item sizes down to 8 guides (ISSL_ITEM_GUIDES)
         if ((rc = dev_alloc(w.gword, slots))) return rc;
         if ((rc = dev_alloc(w.gidx, slots))) return rc;
+        if ((rc = dev_alloc(w.gbucket, slots))) return rc;
         if ((rc = dev_alloc(w.items, items + 1))) return rc;
         if ((rc = dev_alloc(w.gcount, cap + 1))) return rc;
         if ((rc = dev_alloc(w.goff, cap + 1))) return rc;

@@ -127,6 +127,7 @@ struct Workspace {
     uint32_t *gstart = nullptr;  // [nb+1] padded start of every bucket in gword/gidx
     uint32_t *gword = nullptr;   // scan word of the guide for that slice
     uint32_t *gidx = nullptr;    // guide index, kNoGuide in padding
+    uint32_t *gbucket = nullptr; // bucket of the slot (valid where gidx is a guide)
     ScanItem *items = nullptr;   // [max_items+1]
     PlanInfo *plan = nullptr;
     RangeStart *range_start = nullptr; // [kMaxRanges + 1]
@@ -134,7 +135,7 @@ struct Workspace {
     size_t cap_chunks = 0;
     Counters *counters = nullptr;
     unsigned long long *stamps = nullptr; // [2 * kScanWaves] wave start/end ticks (ISSL_SCAN_STAMPS diagnostics)
-    uint32_t *sticky = nullptr;  // [4] survives k_reset: [0] raw overflow seen, [1] max chunks asked, [2] plan errors
+    uint32_t *sticky = nullptr;  // [4] survives the per-batch resets: [0] raw overflow seen, [1] max chunks asked, [2] plan errors
     uint64_t *sorted = nullptr;  // [hit_cap] keys guide<<35 | slice<<32 | pos, grouped by guide
     uint32_t *gcount = nullptr;  // [G+1] hits per guide
     uint32_t *goff = nullptr;    // [G+1] exclusive prefix

@@ -137,9 +137,12 @@ void launch_pack_scan_stream(const ImageView &v, uint32_t *scan_out, uint32_t *e
 
 constexpr uint32_t kMaxBuckets = 2048;
 
-__global__ __launch_bounds__(256) void k_guide_hist(const uint64_t *__restrict__ guides, uint32_t n,
+// Histogram of the guides' slice keys, and -- in the same launch -- the reset of everything a scoring call
+// accumulates into (nothing here depends on it; the kernels that do come later on the stream).  ng and gfill are
+// not reset here: k_plan leaves them zeroed for the next batch.
+__global__ __launch_bounds__(256) void k_guide_hist(Workspace ws, const uint64_t *__restrict__ guides, uint32_t n,
                                                     uint32_t slice_width, uint32_t n_slices, uint32_t n_buckets,
-                                                    uint32_t *__restrict__ ng)
+                                                    uint32_t n_slots, uint32_t n_scan_waves)
 {
     short_kernel_priority();
     __shared__ uint32_t hist[kMaxBuckets];
@@ -154,9 +157,21 @@ __global__ __launch_bounds__(256) void k_guide_hist(const uint64_t *__restrict__
             atomicAdd(&hist[(s << slice_width) + key], 1u);
         }
     }
+    const uint32_t stride = gridDim.x * 256;
+    for (uint32_t k = g; k < n_slots; k += stride) { ws.gidx[k] = kNoGuide; ws.gword[k] = kPadGuideWord; }
+    for (uint32_t k = g; k <= n; k += stride) ws.gcount[k] = 0;
+    for (uint32_t k = g; k < n; k += stride) ws.gcur[k] = 0;
+    // chunk headers: a chunk nobody writes must read as empty; chunks [0, n_scan_waves) belong to the scan waves
+    for (uint32_t k = g; k < ws.cap_chunks; k += stride) ws.raw[static_cast<uint64_t>(k) * kChunkRecs] = 0;
+    if (g == 0) {
+        Counters c{};
+        c.raw_chunks = n_scan_waves;
+        *ws.counters = c;
+    }
     __syncthreads();
-    for (uint32_t b = threadIdx.x; b < n_buckets; b += 256)
-        if (hist[b]) atomicAdd(&ng[b], hist[b]);
+    if (blockIdx.x * 256 < n)
+        for (uint32_t b = threadIdx.x; b < n_buckets; b += 256)
+            if (hist[b]) atomicAdd(&ws.ng[b], hist[b]);
 }
 
 // Exclusive scan of one uint64 per thread over a 256-thread block.
@@ -177,8 +192,59 @@ __device__ inline uint64_t block_exclusive_scan(uint64_t v, uint64_t *lds /*[256
     return incl - v;
 }
 
+// Start of cost range r of n_ranges (r == n_ranges: the end marker).
+__device__ __forceinline__ RangeStart range_start_of(const ScanItem *__restrict__ items, uint32_t n_items, uint64_t total,
+                                                     uint32_t n_ranges, uint32_t r)
+{
+    RangeStart out;
+    out.item = n_items;
+    out.tile = 0;
+    out.goff = 0;
+    out.pad = 0;
+    if (r < n_ranges) {
+        // no 128-bit intermediate: costs < 2^50 and range counts <= 2^15
+        const uint64_t lo = total / n_ranges * r + (total % n_ranges) * r / n_ranges;
+        uint32_t a = 0, z = n_items; // last item with cost0 <= lo
+        while (z - a > 1) {
+            const uint32_t mid = (a + z) >> 1;
+            if (items[mid].cost0 <= lo) a = mid; else z = mid;
+        }
+        // A tile of an item costs kTileFixedCost (fetching it) + one unit per guide.  A boundary may fall between two
+        // groups of 8 guides INSIDE a tile: then two waves share that tile (both fetch it), which makes the ranges
+        // equal to within 8 guides instead of within one tile.
+        const ScanItem it = items[a];
+        const uint32_t len = it.g1 - it.g0;
+        const uint64_t tile_cost = static_cast<uint64_t>(len) + kTileFixedCost;
+        const uint64_t rel = lo - it.cost0;
+        uint64_t k = rel / tile_cost;
+        const uint64_t rem = rel % tile_cost;
+        uint32_t goff = 0;
+        if (rem > kTileFixedCost) {
+            goff = (static_cast<uint32_t>(rem - kTileFixedCost) + kGuideGroup - 1u) & ~(kGuideGroup - 1u);
+            if (goff >= len) { goff = 0; ++k; }
+        } else if (rem > 0) {
+            // inside the fetch part: the tile starts the range (positions stay monotone in r)
+        }
+        if (k >= it.n_tiles) { out.item = a + 1; out.tile = 0; out.goff = 0; }
+        else { out.item = a; out.tile = static_cast<uint32_t>(k); out.goff = goff; }
+    }
+    return out;
+}
+
+// First tile of every cost range: range r owns the tiles whose start cost lies in [lo(r), lo(r+1)).
+// Done once here so that the scan waves neither divide nor search.
+__global__ __launch_bounds__(256) void k_ranges(const PlanInfo *__restrict__ plan, const ScanItem *__restrict__ items,
+                                                RangeStart *__restrict__ starts)
+{
+    short_kernel_priority();
+    const uint32_t n_ranges = plan->n_ranges;
+    const uint32_t r = blockIdx.x * 256 + threadIdx.x;
+    if (r > n_ranges || n_ranges == 0) return;
+    starts[r] = range_start_of(items, plan->n_items, plan->total_cost, n_ranges, r);
+}
+
 // One block: lay out the bucket-sorted guide arrays and the list of scan items.
-__global__ __launch_bounds__(256) void k_plan(ImageView v, const uint32_t *__restrict__ ng,
+__global__ __launch_bounds__(256) void k_plan(ImageView v, uint32_t *__restrict__ ng, uint32_t *__restrict__ gfill,
                                               uint32_t *__restrict__ gstart, ScanItem *__restrict__ items,
                                               uint32_t cap_items, PlanInfo *__restrict__ plan, uint32_t item_guides,
                                               uint32_t scan_blocks)
@@ -232,6 +298,8 @@ __global__ __launch_bounds__(256) void k_plan(ImageView v, const uint32_t *__res
             }
         }
         slot_at += (g + kGuideGroup - 1u) / kGuideGroup * kGuideGroup;
+        ng[b] = 0;    // for the next batch's histogram
+        gfill[b] = 0; // for this batch's scatter
     }
     if (threadIdx.x == 255) {
         gstart[nb] = static_cast<uint32_t>(tot_slots);
@@ -251,58 +319,12 @@ __global__ __launch_bounds__(256) void k_plan(ImageView v, const uint32_t *__res
     }
 }
 
-// First tile of every cost range: range r owns the tiles whose start cost lies in [lo(r), lo(r+1)).
-// Done once here so that the scan waves neither divide nor search.
-__global__ __launch_bounds__(256) void k_ranges(const PlanInfo *__restrict__ plan, const ScanItem *__restrict__ items,
-                                                RangeStart *__restrict__ starts)
-{
-    short_kernel_priority();
-    const uint32_t n_ranges = plan->n_ranges;
-    const uint32_t n_items = plan->n_items;
-    const uint64_t total = plan->total_cost;
-    const uint32_t r = blockIdx.x * 256 + threadIdx.x;
-    if (r > n_ranges || n_ranges == 0) return;
-    RangeStart out;
-    out.item = n_items;
-    out.tile = 0;
-    out.goff = 0;
-    out.pad = 0;
-    if (r < n_ranges) {
-        // no 128-bit intermediate: costs < 2^50 and range counts <= 2^15
-        const uint64_t lo = total / n_ranges * r + (total % n_ranges) * r / n_ranges;
-        uint32_t a = 0, z = n_items; // last item with cost0 <= lo
-        while (z - a > 1) {
-            const uint32_t mid = (a + z) >> 1;
-            if (items[mid].cost0 <= lo) a = mid; else z = mid;
-        }
-        // A tile of an item costs kTileFixedCost (fetching it) + one unit per guide.  A boundary may fall between two
-        // groups of 8 guides INSIDE a tile: then two waves share that tile (both fetch it), which makes the ranges
-        // equal to within 8 guides instead of within one tile.
-        const ScanItem it = items[a];
-        const uint32_t len = it.g1 - it.g0;
-        const uint64_t tile_cost = static_cast<uint64_t>(len) + kTileFixedCost;
-        const uint64_t rel = lo - it.cost0;
-        uint64_t k = rel / tile_cost;
-        const uint64_t rem = rel % tile_cost;
-        uint32_t goff = 0;
-        if (rem > kTileFixedCost) {
-            goff = (static_cast<uint32_t>(rem - kTileFixedCost) + kGuideGroup - 1u) & ~(kGuideGroup - 1u);
-            if (goff >= len) { goff = 0; ++k; }
-        } else if (rem > 0) {
-            // inside the fetch part: the tile starts the range (positions stay monotone in r)
-        }
-        if (k >= it.n_tiles) { out.item = a + 1; out.tile = 0; out.goff = 0; }
-        else { out.item = a; out.tile = static_cast<uint32_t>(k); out.goff = goff; }
-    }
-    starts[r] = out;
-}
-
 // Scatter every guide into its bucket's range of (gword, gidx), once per slice.
 __global__ __launch_bounds__(256) void k_guide_scatter(const uint64_t *__restrict__ guides, uint32_t n,
                                                        uint32_t slice_width, uint32_t n_slices,
                                                        uint32_t n_buckets, const uint32_t *__restrict__ gstart,
                                                        uint32_t *__restrict__ gfill, uint32_t *__restrict__ gword,
-                                                       uint32_t *__restrict__ gidx)
+                                                       uint32_t *__restrict__ gidx, uint32_t *__restrict__ gbucket)
 {
     short_kernel_priority();
     __shared__ uint32_t hist[kMaxBuckets];
@@ -336,6 +358,7 @@ __global__ __launch_bounds__(256) void k_guide_scatter(const uint64_t *__restric
                 const uint32_t slot = gstart[b] + base[b] + rank[s];
                 gword[slot] = scan_word(sig, s);
                 gidx[slot] = g;
+                gbucket[slot] = b;
             }
         }
     }
@@ -352,27 +375,6 @@ uint32_t scan_blocks()
     return kScanGridBlocks;
 }
 
-// Reset of everything a scoring call accumulates into (one launch instead of seven memsets).
-__global__ __launch_bounds__(256) void k_reset(Workspace ws, uint32_t nb, uint32_t n, uint32_t n_slots,
-                                               uint32_t n_scan_waves)
-{
-    short_kernel_priority();
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    const uint32_t stride = gridDim.x * 256;
-    for (uint32_t k = i; k < nb; k += stride) { ws.ng[k] = 0; ws.gfill[k] = 0; }
-    for (uint32_t k = i; k < n_slots; k += stride) { ws.gidx[k] = kNoGuide; ws.gword[k] = kPadGuideWord; }
-    for (uint32_t k = i; k <= n; k += stride) ws.gcount[k] = 0;
-    for (uint32_t k = i; k < n; k += stride) ws.gcur[k] = 0;
-    // chunk headers: a chunk nobody writes must read as empty; chunks [0, n_scan_waves) belong to the scan waves
-    for (uint32_t k = i; k < ws.cap_chunks; k += stride) ws.raw[static_cast<uint64_t>(k) * kChunkRecs] = 0;
-    if (i == 0) {
-        *ws.plan = PlanInfo{};
-        Counters c{};
-        c.raw_chunks = n_scan_waves;
-        *ws.counters = c;
-    }
-}
-
 void launch_bin_guides(const ImageView &v, const Workspace &ws, const uint64_t *d_guides, uint32_t n, void *stream_)
 {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
@@ -380,22 +382,22 @@ void launch_bin_guides(const ImageView &v, const Workspace &ws, const uint64_t *
     // slots in use: 8-padded guides per bucket, at most n * slices + 8 * buckets
     const uint32_t n_slots = static_cast<uint32_t>(
         std::min<size_t>(ws.cap_gslots, static_cast<size_t>(n) * v.n_slices + static_cast<size_t>(kGuideGroup) * nb));
-    const uint32_t reset_blocks = std::min<uint32_t>(1024u, (std::max(n_slots, nb) + 255u) / 256u);
-    hipLaunchKernelGGL(k_reset, dim3(reset_blocks), dim3(256), 0, stream, ws, nb, n, n_slots, scan_blocks() * 16u);
+    // four launches: histogram (+ resets), plan, scatter, ranges
     const uint32_t blocks = (n + 255u) / 256u;
-    hipLaunchKernelGGL(k_guide_hist, dim3(blocks), dim3(256), 0, stream, d_guides, n, v.slice_width, v.n_slices, nb,
-                       ws.ng);
+    const uint32_t reset_blocks = std::min<uint32_t>(1024u, (std::max(n_slots, nb) + 255u) / 256u);
+    hipLaunchKernelGGL(k_guide_hist, dim3(std::max(blocks, reset_blocks)), dim3(256), 0, stream, ws, d_guides, n,
+                       v.slice_width, v.n_slices, nb, n_slots, scan_blocks() * 16u);
     // ISSL_ITEM_GUIDES=<n>: guides per scan item (default 512; multiples of 8) -- test and tuning knob
     uint32_t item_guides = kItemGuides;
     if (const char *e = getenv("ISSL_ITEM_GUIDES")) {
         const unsigned c = static_cast<unsigned>(atoi(e));
         if (c >= 8 && c <= kItemGuides) item_guides = c & ~7u;
     }
-    hipLaunchKernelGGL(k_plan, dim3(1), dim3(256), 0, stream, v, ws.ng, ws.gstart, ws.items,
+    hipLaunchKernelGGL(k_plan, dim3(1), dim3(256), 0, stream, v, ws.ng, ws.gfill, ws.gstart, ws.items,
                        static_cast<uint32_t>(ws.cap_items), ws.plan, item_guides, scan_blocks());
     hipLaunchKernelGGL(k_guide_scatter, dim3(blocks), dim3(256), 0, stream, d_guides, n, v.slice_width, v.n_slices,
-                       nb, ws.gstart, ws.gfill, ws.gword, ws.gidx);
-    hipLaunchKernelGGL(k_ranges, dim3((kMaxRanges + 1 + 255) / 256), dim3(256), 0, stream, ws.plan, ws.items,
+                       nb, ws.gstart, ws.gfill, ws.gword, ws.gidx, ws.gbucket);
+    hipLaunchKernelGGL(k_ranges, dim3((scan_blocks() + 1 + 255) / 256), dim3(256), 0, stream, ws.plan, ws.items,
                        ws.range_start);
 }
 
@@ -571,7 +573,7 @@ __global__ __launch_bounds__(1024, 8) void k_scan(const uint32_t *__restrict__ s
     if (blockIdx.x >= n_ranges) return;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave_id = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
-    // Raw records: the wave's first chunk is the one with its own number (no atomic); k_reset cleared its header.
+    // Raw records: the wave's first chunk is the one with its own number (no atomic); k_guide_hist cleared its header.
     RawWriter w;
     const bool no_own_chunk = wave_id >= max_chunks; // buffer smaller than the wave count: spare chunk + overflow flag
     w.chunk = raw + static_cast<uint64_t>(no_own_chunk ? max_chunks : wave_id) * kChunkRecs;
@@ -665,13 +667,7 @@ __global__ __launch_bounds__(kChunkRecs) void k_verify(ImageView v, Workspace ws
         const uint32_t gslot = static_cast<uint32_t>(rec >> 37);
         const uint32_t guide = ws.gidx[gslot];
         if (guide != kNoGuide) {
-            // bucket of the tile: last b with tile_first[b] <= tile
-            uint32_t lo = 0, hi = v.n_buckets;
-            while (hi - lo > 1) {
-                const uint32_t mid = (lo + hi) >> 1;
-                if (v.tile_first[mid] <= tile) lo = mid; else hi = mid;
-            }
-            const uint32_t bucket = lo;
+            const uint32_t bucket = ws.gbucket[gslot]; // the guide slot knows its bucket: no search for the tile's
             const uint32_t slice = bucket >> v.slice_width;
             const uint64_t start = v.bucket_start[bucket];
             const uint64_t len = v.bucket_start[bucket + 1] - start;
