@@ -11,9 +11,9 @@ LIB      = crackling_amd/libissl_hip.so
 
 all: $(LIB) bin/isslScoreOfftargets bin/isslCreateIndex bin/extractOfftargets
 
-$(LIB): $(CSRC)/issl_kernels.hip $(CSRC)/issl_extract.hip $(CSRC)/issl_capi.cpp $(CSRC)/issl_host.cpp \
-        $(CSRC)/issl_node.cpp $(CSRC)/issl_host.hpp $(CSRC)/issl_device.hpp $(CSRC)/cfd_tables.inc include/issl_hip.h
-	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/issl_kernels.hip $(CSRC)/issl_extract.hip $(CSRC)/issl_capi.cpp \
+$(LIB): $(CSRC)/issl_kernels.hip $(CSRC)/issl_extract.hip $(CSRC)/issl_build.hip $(CSRC)/issl_capi.cpp $(CSRC)/issl_host.cpp \
+        $(CSRC)/issl_node.cpp $(CSRC)/issl_host.hpp $(CSRC)/issl_device.hpp $(CSRC)/issl_radix.hpp $(CSRC)/cfd_tables.inc include/issl_hip.h
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/issl_kernels.hip $(CSRC)/issl_extract.hip $(CSRC)/issl_build.hip $(CSRC)/issl_capi.cpp \
 	    $(CSRC)/issl_host.cpp $(CSRC)/issl_node.cpp -lpthread -ldl
 
 bin/isslScoreOfftargets: $(CSRC)/cli_score.cpp $(LIB)

@@ -6,6 +6,7 @@
 #include <cctype>
 #include <chrono>
 #include <cmath>
+#include <cerrno>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -294,7 +295,13 @@ static void upload_note(const char *what, double t0)
     if (std::getenv("ISSL_UPLOAD_TIMING")) std::fprintf(stderr, "[issl upload] %s %.1f ms\n", what, wall_ms() - t0);
 }
 
-static int finish_upload(issl_index *ix)
+// Non-null when the slice lists are to be built on the device (the host index then has no arrays).
+struct DeviceBuildInput {
+    const uint64_t *sigs;
+    const uint32_t *occ;
+};
+
+static int finish_upload(issl_index *ix, const DeviceBuildInput *dbi = nullptr)
 {
     // sections that are plain copies
     const HostIndex &h = *ix->host;
@@ -327,11 +334,29 @@ static int finish_upload(issl_index *ix)
     double t0 = wall_ms();
     // Plain copies from the (file-mapped) host arrays: measured 48 GB/s on a 14 GB index, where a 12-thread pipeline
     // through pinned staging buffers reached 24 GB/s.
-    HIP_TRY(hipMemcpy(base + ix->hdr.off_sites, h.sites, 8 * g.n_sites, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(base + ix->hdr.off_sites, dbi ? dbi->sigs : h.sites, 8 * g.n_sites, hipMemcpyHostToDevice));
     upload_note("sites", t0);
     t0 = wall_ms();
-    HIP_TRY(hipMemcpy(base + ix->hdr.off_entries, h.entries, 8 * g.n_sites * g.n_slices, hipMemcpyHostToDevice));
-    upload_note("entries", t0);
+    if (dbi) { // isslCreateIndex.cpp:218-234 on the device
+        uint32_t *d_occ = nullptr;
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_occ), 4 * g.n_sites));
+        hipError_t ce = hipMemcpy(d_occ, dbi->occ, 4 * g.n_sites, hipMemcpyHostToDevice);
+        int brc = ISSL_OK;
+        if (ce != hipSuccess) {
+            set_error(std::string("HIP error: ") + hipGetErrorString(ce) + " (occurrence counts)");
+            brc = ISSL_E_DEVICE;
+        } else {
+            brc = launch_build_entries(reinterpret_cast<const uint64_t *>(base + ix->hdr.off_sites), d_occ, g.n_sites,
+                                       static_cast<uint32_t>(g.n_slices), static_cast<uint32_t>(g.slice_width),
+                                       reinterpret_cast<uint64_t *>(base + ix->hdr.off_entries));
+        }
+        (void)hipFree(d_occ);
+        if (brc) return brc;
+        upload_note("slice lists built on the device", t0);
+    } else {
+        HIP_TRY(hipMemcpy(base + ix->hdr.off_entries, h.entries, 8 * g.n_sites * g.n_slices, hipMemcpyHostToDevice));
+        upload_note("entries", t0);
+    }
     t0 = wall_ms();
     ix->view = make_view(ix->hdr, ix->d_image);
     // scan stream: built on the device from sites + entries
@@ -623,7 +648,35 @@ int issl_index_write(const issl_index *idx, const char *path)
 {
     if (!idx || !path) { set_error("null argument"); return ISSL_E_ARG; }
     if (!idx->host) { set_error("index was attached from a device image and has no host arrays"); return ISSL_E_STATE; }
-    return idx->host->write_file(path);
+    if (idx->host->has_arrays()) return idx->host->write_file(path);
+    // built on the device: header, score table and bucket sizes come from the host side, sites and slice lists are
+    // streamed out of the HBM image
+    if (!idx->d_image) { set_error("index has neither host arrays nor a device image"); return ISSL_E_STATE; }
+    HIP_TRY(hipSetDevice(idx->device));
+    FILE *fp = std::fopen(path, "wb");
+    if (!fp) {
+        set_error(std::string("cannot write index file '") + path + "': " + std::strerror(errno));
+        return ISSL_E_IO;
+    }
+    bool ok = idx->host->write_leading_sections(fp) == ISSL_OK;
+    const uint8_t *base = static_cast<const uint8_t *>(idx->d_image);
+    std::vector<uint8_t> stage(size_t(64) << 20);
+    auto stream_out = [&](uint64_t off, uint64_t bytes) {
+        for (uint64_t at = 0; ok && at < bytes; at += stage.size()) {
+            const size_t len = static_cast<size_t>(std::min<uint64_t>(stage.size(), bytes - at));
+            ok = hipMemcpy(stage.data(), base + off + at, len, hipMemcpyDeviceToHost) == hipSuccess &&
+                 std::fwrite(stage.data(), 1, len, fp) == len;
+        }
+    };
+    stream_out(idx->hdr.off_sites, 8 * idx->geo.n_sites);
+    ok = ok && std::fwrite(idx->host->sizes, 8, idx->geo.n_buckets(), fp) == idx->geo.n_buckets();
+    stream_out(idx->hdr.off_entries, 8 * idx->geo.n_sites * idx->geo.n_slices);
+    ok = (std::fclose(fp) == 0) && ok;
+    if (!ok) {
+        set_error(std::string("could not write '") + path + "' from the device image");
+        return ISSL_E_IO;
+    }
+    return ISSL_OK;
 }
 
 int issl_index_header(const issl_index *idx, issl_header *out)
@@ -670,10 +723,17 @@ int issl_index_device_bytes(const issl_index *idx, size_t *out)
     return ISSL_OK;
 }
 
-static int upload_common(issl_index *idx, int device, void *buf, size_t bytes)
+static int upload_common(issl_index *idx, int device, void *buf, size_t bytes, const DeviceBuildInput *dbi = nullptr)
 {
     if (!idx) { set_error("null argument"); return ISSL_E_ARG; }
     if (!idx->host) { set_error("index has no host arrays to upload"); return ISSL_E_STATE; }
+    if (!dbi && !idx->host->has_arrays()) {
+        // built on the device: its arrays exist only in that image
+        if (idx->d_image && idx->device == device && !buf) return ISSL_OK;
+        set_error("index was built on the device and has no host arrays: replicate its image with issl_index_image + "
+                  "issl_index_attach_image");
+        return ISSL_E_STATE;
+    }
     int rc = supported_geometry(idx->geo);
     if (rc) return rc;
     double t0 = wall_ms();
@@ -700,9 +760,30 @@ static int upload_common(issl_index *idx, int device, void *buf, size_t bytes)
         idx->owns_image = true;
     }
     upload_note("layout + allocation", t0);
-    rc = finish_upload(idx);
+    rc = finish_upload(idx, dbi);
     if (rc) release_device(idx);
     return rc;
+}
+
+int issl_index_build_on_device(const uint64_t *sigs, const uint32_t *occ, size_t n_sites, size_t n_lines,
+                               size_t seq_len, size_t slice_width, int device, issl_index **out)
+{
+    if (!sigs || !occ || !out) { set_error("null argument"); return ISSL_E_ARG; }
+    std::unique_ptr<HostIndex> h(new (std::nothrow) HostIndex());
+    if (!h) { set_error("out of memory"); return ISSL_E_NOMEM; }
+    int rc = h->init_without_arrays(sigs, n_sites, n_lines, seq_len, slice_width);
+    if (rc) return rc;
+    issl_index *ix = nullptr;
+    rc = new_index_from_host(std::move(h), &ix);
+    if (rc) return rc;
+    const DeviceBuildInput dbi{sigs, occ};
+    rc = upload_common(ix, device, nullptr, 0, &dbi);
+    if (rc) {
+        issl_index_close(ix);
+        return rc;
+    }
+    *out = ix;
+    return ISSL_OK;
 }
 
 int issl_index_upload(issl_index *idx, int device) { return upload_common(idx, device, nullptr, 0); }

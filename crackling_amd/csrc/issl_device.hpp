@@ -70,6 +70,11 @@ struct ImageView {
 void layout_image(ImageHeader &h, const Geometry &g, uint64_t n_scores_unique, uint64_t n_tiles, bool dense_mit);
 ImageView make_view(const ImageHeader &h, void *base);
 
+// Slice lists built on the device (issl_build.hip): d_entries[s * n_sites + k] for the n_slices slices, from the site
+// signatures and their occurrence counts, both already in device memory.  Synchronous.
+int launch_build_entries(const uint64_t *d_sites, const uint32_t *d_occ, uint64_t n_sites, uint32_t n_slices,
+                         uint32_t slice_width, uint64_t *d_entries);
+
 // ---- scoring workspace -------------------------------------------------------------------------
 constexpr uint32_t kGuideGroup = 8;    // guide words fetched per scalar load
 constexpr uint32_t kItemGuides = 512;  // guides per scan item (bounds one tile's work)

@@ -291,6 +291,49 @@ int HostIndex::build_from_sites(const uint64_t *sigs, const uint32_t *occ, size_
     return finish_build(slice_width);
 }
 
+int HostIndex::init_without_arrays(const uint64_t *sigs, size_t n_sites, size_t n_lines, size_t seq_len,
+                                   size_t slice_width)
+{
+    if (seq_len == 0 || seq_len > 32) {
+        set_error("sequence length must be 1..32");
+        return ISSL_E_ARG;
+    }
+    if (slice_width < 2 || slice_width > 8 || (seq_len * 2) / slice_width == 0) {
+        set_error("slice width must be 2..8 bits");
+        return ISSL_E_UNSUPPORTED;
+    }
+    if (n_sites == 0 || n_sites > 0xFFFFFFFFull) {
+        set_error("site count must be 1..2^32-1");
+        return ISSL_E_ARG;
+    }
+    geo.n_sites = n_sites;
+    geo.seq_len = seq_len;
+    geo.n_lines = n_lines;
+    geo.slice_width = slice_width;
+    geo.n_slices = (seq_len * 2) / slice_width;
+    const uint64_t per_slice = geo.buckets_per_slice();
+    const uint64_t nb = geo.n_buckets();
+    const unsigned n_threads = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    std::vector<std::vector<uint64_t>> part(n_threads, std::vector<uint64_t>(nb, 0));
+    auto count = [&](unsigned t) {
+        const size_t lo = n_sites * t / n_threads, hi = n_sites * (t + 1) / n_threads;
+        uint64_t *cnt = part[t].data();
+        for (size_t id = lo; id < hi; ++id)
+            for (uint64_t s = 0; s < geo.n_slices; ++s) ++cnt[s * per_slice + ((sigs[id] >> (slice_width * s)) & (per_slice - 1))];
+    };
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < n_threads; ++t) pool.emplace_back(count, t);
+    count(0);
+    for (auto &t : pool) t.join();
+    own_sizes_.assign(nb, 0);
+    for (const auto &p : part)
+        for (uint64_t b = 0; b < nb; ++b) own_sizes_[b] += p[b];
+    sizes = own_sizes_.data();
+    sites = nullptr;
+    entries = nullptr;
+    return finish_build(slice_width);
+}
+
 int HostIndex::finish_build(size_t slice_width)
 {
     // Local MIT scores for every placement of 1..maxDist mismatches on 20 positions, ascending
@@ -312,13 +355,8 @@ int HostIndex::finish_build(size_t slice_width)
     return ISSL_OK;
 }
 
-int HostIndex::write_file(const char *path) const
+int HostIndex::write_leading_sections(FILE *fp) const
 {
-    FILE *fp = std::fopen(path, "wb");
-    if (!fp) {
-        set_error(std::string("cannot write index file '") + path + "': " + std::strerror(errno));
-        return ISSL_E_IO;
-    }
     const uint64_t h[6] = {geo.n_sites, geo.seq_len, geo.n_lines, geo.slice_width, geo.n_slices, geo.n_scores};
     bool ok = std::fwrite(h, 8, 6, fp) == 6;
     std::vector<uint64_t> pairs(2 * geo.n_scores);
@@ -327,6 +365,17 @@ int HostIndex::write_file(const char *path) const
         std::memcpy(&pairs[2 * i + 1], &score_val[i], 8);
     }
     ok = ok && std::fwrite(pairs.data(), 8, pairs.size(), fp) == pairs.size();
+    return ok ? ISSL_OK : ISSL_E_IO;
+}
+
+int HostIndex::write_file(const char *path) const
+{
+    FILE *fp = std::fopen(path, "wb");
+    if (!fp) {
+        set_error(std::string("cannot write index file '") + path + "': " + std::strerror(errno));
+        return ISSL_E_IO;
+    }
+    bool ok = write_leading_sections(fp) == ISSL_OK;
     ok = ok && std::fwrite(sites, 8, geo.n_sites, fp) == geo.n_sites;
     ok = ok && std::fwrite(sizes, 8, geo.n_buckets(), fp) == geo.n_buckets();
     const uint64_t ne = geo.n_sites * geo.n_slices;

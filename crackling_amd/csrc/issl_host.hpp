@@ -3,6 +3,7 @@
 #pragma once
 #include <cstddef>
 #include <cstdint>
+#include <cstdio>
 #include <string>
 #include <vector>
 
@@ -44,6 +45,13 @@ class HostIndex {
     int build_from_sites(const uint64_t *sigs, const uint32_t *occ, size_t n_sites, size_t n_lines,
                          size_t seq_len, size_t slice_width);
     int write_file(const char *path) const;
+    // Geometry, MIT table and bucket sizes only (threaded histogram of the slice values); `sites` and `entries` stay
+    // null: the arrays of such an index exist only in the HBM image (issl_index_build_on_device).
+    int init_without_arrays(const uint64_t *sigs, size_t n_sites, size_t n_lines, size_t seq_len, size_t slice_width);
+    bool has_arrays() const { return sites != nullptr && entries != nullptr; }
+    // Header, score table (and, with `with_sites`, nothing more): the leading sections of write_file() for callers
+    // that stream the big arrays themselves.
+    int write_leading_sections(FILE *fp) const;
 
     // Sorted unique {mask, score} table, first occurrence wins (flat_hash_map::insert, :196).
     void unique_scores(std::vector<uint64_t> &masks, std::vector<double> &vals) const;

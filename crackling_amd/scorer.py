@@ -100,6 +100,18 @@ class IsslIndex:
         return cls(h)
 
     @classmethod
+    def build_on_device(cls, sigs, occ, device=0, n_lines=None, seq_len=20, slice_width=8):
+        """Like build_from_sites + upload, but the slice lists are built on the GPU (no 48 B/site host arrays)."""
+        sigs = np.ascontiguousarray(sigs, dtype=np.uint64)
+        occ = np.ascontiguousarray(occ, dtype=np.uint32)
+        if n_lines is None:
+            n_lines = int(occ.sum(dtype=np.uint64))
+        h = C.c_void_p()
+        check(lib.issl_index_build_on_device(sigs.ctypes.data, occ.ctypes.data, len(sigs), n_lines, seq_len,
+                                             slice_width, device, C.byref(h)))
+        return cls(h)
+
+    @classmethod
     def attach_tensor(cls, tensor):
         """Adopt an HBM image that arrived in a torch uint8 CUDA tensor (e.g. by RCCL broadcast)."""
         h = C.c_void_p()

@@ -110,6 +110,17 @@ int issl_index_build_from_sites(const uint64_t *sigs, const uint32_t *occ, size_
                                 size_t n_lines, size_t seq_len, size_t slice_width,
                                 issl_index **out);
 
+/* Same inputs, but the slice lists (isslCreateIndex.cpp:218-234) are built on `device`: the signatures are
+ * copied into the HBM image and one stable radix pass per slice writes the lists next to them.  The result is
+ * uploaded and ready to score; the host keeps only the geometry, the MIT table and the bucket sizes (12 B/site of
+ * input instead of 48 B/site of host arrays), so indexes up to the format's 2^32-1 sites fit a 288 GB GPU.
+ * issl_index_write() streams the arrays back out of the image (same bytes as the host builder);
+ * issl_index_upload() to another device is refused -- replicate with issl_index_image/attach_image.
+ * 20 bp / 8-bit slices only. */
+int issl_index_build_on_device(const uint64_t *sigs, const uint32_t *occ, size_t n_sites,
+                               size_t n_lines, size_t seq_len, size_t slice_width, int device,
+                               issl_index **out);
+
 /* Write the .issl bytes (isslCreateIndex.cpp:256-289). */
 int issl_index_write(const issl_index *idx, const char *path);
 

@@ -481,3 +481,44 @@ def test_config1_full_size_properties_and_oracle_sample(config1, tmp_path):
     assert np.array_equal(ix.dump_hits(sample[:64], 4, 0.0, "and"), ohits)
     oracle.close()
     os.unlink(p)
+
+
+def test_index_built_on_device_is_byte_identical(golden, tmp_path):
+    """issl_index_build_on_device: slice lists from one radix pass per slice on the GPU; written back out it is the
+    reference builder's file, and it scores like the host-built index."""
+    lines = golden.sites_txt.read_text().splitlines()
+    sigs_all = ca.encode_guides(lines)
+    # consecutive duplicates collapse (isslCreateIndex.cpp:189-193): the list is sorted
+    keep = np.ones(len(sigs_all), dtype=bool)
+    keep[1:] = sigs_all[1:] != sigs_all[:-1]
+    first = np.flatnonzero(keep)
+    sigs = sigs_all[first]
+    occ = np.diff(np.append(first, len(sigs_all))).astype(np.uint32)
+    ix = ca.IsslIndex.build_on_device(sigs, occ, device=0)
+    out = tmp_path / "dev.issl"
+    ix.write(out)
+    assert out.read_bytes() == golden.issl.read_bytes()
+    guides = ca.encode_guides(golden.guides)
+    mit, cfd = ix.score(guides, 4, 75.0, "and")
+    assert ca.format_scores(guides, mit, cfd, "and") == golden.expected["and|75|4"]
+    with pytest.raises(ca.IsslError, match="built on the device"):
+        ix.upload(1)   # its arrays exist only in the image on device 0
+    ix.upload(0)       # same device: nothing to do
+    ix.close()
+
+
+def test_device_builder_matches_host_builder_on_config0(config0, tmp_path):
+    """1 M sites (245 workgroups per radix pass): same .issl bytes as the host builder, same scores."""
+    ix, oracle, sigs, guides = config0
+    _, occ = random_sites(1_000_000, seed=2026)
+    dev = ca.IsslIndex.build_on_device(sigs, occ, device=0)
+    assert dev.device_bytes() == ix.device_bytes()
+    assert np.array_equal(dev.bucket_sizes(), ix.bucket_sizes())
+    a, b = tmp_path / "host.issl", tmp_path / "dev.issl"
+    ix.write(a)
+    dev.write(b)
+    assert a.read_bytes() == b.read_bytes()
+    mit, cfd = dev.score(guides, 4, 75.0, "and")
+    wm, wc = ix.score(guides, 4, 75.0, "and")
+    assert np.array_equal(mit, wm) and np.array_equal(cfd, wc)
+    dev.close()
