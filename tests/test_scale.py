@@ -94,3 +94,81 @@ def test_scale_point_matches_oracle_on_a_sample(tmp_path):
     print(json.dumps(summary), flush=True)
     if os.environ.get("ISSL_SCALE_JSON"):
         json.dump(summary, open(os.environ["ISSL_SCALE_JSON"], "w"), indent=1)
+
+
+def _neighbours(sigs, guide, max_dist, chunk=1 << 26):
+    """Indices of the sites within max_dist mismatches of guide: brute force over the whole table (numpy, chunked)."""
+    found = []
+    g = np.uint64(guide)
+    even = np.uint64(0x5555555555555555)
+    for lo in range(0, len(sigs), chunk):
+        x = sigs[lo:lo + chunk] ^ g
+        x |= x >> np.uint64(1)
+        x &= even
+        hit = np.flatnonzero(np.bitwise_count(x) <= max_dist)
+        if len(hit):
+            found.append(hit + lo)
+    return np.concatenate(found) if found else np.empty(0, dtype=np.int64)
+
+
+@pytest.mark.gpu
+def test_device_built_scale_point(tmp_path):
+    """Index built ON the GPU (issl_index_build_on_device: no 48 B/site host arrays), so the size is bounded by HBM.
+    Checker without the full .issl: for a sample of guides every site within 4 mismatches is found by brute force over
+    the site table; those sites (with their occurrences, in the same relative order) form a small index on which the
+    CPU oracle must give bit-identical scores -- sites farther away contribute nothing, and the scoring order
+    (slice, position in bucket) of the survivors is unchanged.  ISSL_SCALE_SITES=3000000000 is BASELINE configs[4]'s
+    index on ONE MI355X (204 GB image)."""
+    from concurrent.futures import ThreadPoolExecutor
+    n_lines = int(os.environ.get("ISSL_SCALE_SITES", 20_000_000))
+    n_guides = int(os.environ.get("ISSL_SCALE_GUIDES", 20_000))
+    n_check = int(os.environ.get("ISSL_SCALE_CHECK", 24))
+    threads = min(32, os.cpu_count() or 8)
+    need = n_lines * 40  # 12 B/site generated, twice while the chunks are concatenated, brute-force temporaries
+    if need > 0.7 * _memory_limit_bytes():
+        pytest.skip(f"needs ~{need / 1e9:.0f} GB of host memory, limit is {_memory_limit_bytes() / 1e9:.0f} GB")
+    t = time.time(); sigs, occ = random_sites_fast(n_lines, seed=11, threads=threads); t_synth = time.time() - t
+    guides = random_guides(sigs, n_guides, seed=12)
+    print(f"synth {t_synth:.1f}s distinct={len(sigs)}", flush=True)
+    t = time.time(); ix = ca.IsslIndex.build_on_device(sigs, occ, device=0); t_build = time.time() - t
+    print(f"built on the device in {t_build:.1f}s, image {ix.device_bytes() / 1e9:.1f} GB", flush=True)
+    best = None
+    for rep in range(4):
+        t = time.time(); mit, cfd = ix.score(guides, 4, 75.0, "and"); wall = time.time() - t
+        st = ix.stats()
+        print(f"rep{rep} wall {wall * 1e3:.1f} ms scan {st['ms_scan']:.2f} ms", flush=True)
+        if rep and (best is None or st["ms_scan"] < best[1]["ms_scan"]):
+            best = (wall, st)
+    wall, st = best
+    assert st["candidates"] == ix.count_candidates(guides)
+    pick = np.linspace(0, n_guides - 1, n_check).astype(np.int64)
+    t = time.time()
+    with ThreadPoolExecutor(max_workers=min(threads, 8)) as pool:
+        near = list(pool.map(lambda g: _neighbours(sigs, g, 4), guides[pick]))
+    t_brute = time.time() - t
+    print(f"brute force for {n_check} guides: {t_brute:.1f}s, {sum(len(x) for x in near)} sites within 4 mismatches", flush=True)
+    keep = np.unique(np.concatenate(near + [np.arange(0, len(sigs), max(1, len(sigs) // 5000))]))  # + some bystanders
+    mini = ca.IsslIndex.build_from_sites(sigs[keep], occ[keep])
+    path = tmp_path / "mini.issl"
+    mini.write(path)
+    oracle = ou.OracleIndex(path)
+    omit, ocfd = oracle.score(guides[pick], 4, 75.0, "and")
+    oracle.close()
+    assert np.array_equal(mit[pick].view(np.uint64), omit.view(np.uint64))
+    assert np.array_equal(cfd[pick].view(np.uint64), ocfd.view(np.uint64))
+    assert (omit < 100).any()  # the sample does meet off-targets
+    summary = {
+        "what": f"tests/test_scale.py::test_device_built_scale_point: {n_guides} guides vs a {n_lines}-line synthetic index "
+                f"built on one MI355X (issl_index_build_on_device), 'and' thr 75 max_dist 4; {n_check} guides checked "
+                f"bit-for-bit against the CPU oracle on the index of their brute-force neighbourhoods",
+        "distinct_sites": int(len(sigs)), "image_GB": ix.device_bytes() / 1e9, "synth_s": t_synth,
+        "device_build_s": t_build, "wall_ms": wall * 1e3, "scan_ms": st["ms_scan"], "verify_ms": st["ms_verify"],
+        "group_ms": st["ms_group"], "replay_ms": st["ms_replay"], "pipeline_ms": st["ms_total"],
+        "comparisons": st["candidates"], "hits": st["hits"], "scan_launches": st["scan_launches"],
+        "scan_Tcmp_per_s": st["candidates"] / st["ms_scan"] / 1e9,
+        "algorithmic_TBps": 8.0 * st["candidates"] / st["ms_scan"] / 1e9,
+        "guides_per_s_kernels": n_guides / st["ms_total"] * 1e3, "brute_force_check_s": t_brute,
+    }
+    print(json.dumps(summary), flush=True)
+    if os.environ.get("ISSL_SCALE_JSON"):
+        json.dump(summary, open(os.environ["ISSL_SCALE_JSON"], "w"), indent=1)
