@@ -13,7 +13,7 @@ import pytest
 
 import crackling_amd as ca
 import oracle_util as ou
-from synth import random_sites, random_guides, sigs_to_text
+from synth import random_sites, random_guides, sigs_to_text, text_order_key
 
 pytestmark = pytest.mark.gpu
 ROOT = pathlib.Path(__file__).resolve().parent.parent
@@ -522,3 +522,77 @@ def test_device_builder_matches_host_builder_on_config0(config0, tmp_path):
     wm, wc = ix.score(guides, 4, 75.0, "and")
     assert np.array_equal(mit, wm) and np.array_equal(cfd, wc)
     dev.close()
+
+
+@pytest.mark.parametrize("n_in_bucket", [1, 31, 32, 33, 2047, 2048, 2049, 4096, 4097])
+def test_bucket_lengths_around_group_and_tile_boundaries(tmp_path, n_in_bucket):
+    """Buckets whose length sits on the edges of the scan layout (32 candidates per lane, 2048 per tile): every site of
+    the index shares its first four bases, so slice 0 holds ONE bucket of exactly n sites (zero padding after it) and
+    the other slices are spread; hits at the first and the last position of the bucket."""
+    rng = np.random.default_rng(1000 + n_in_bucket)
+    low = np.uint64(0b10_01_11_00)                                   # positions 0..3 of every site
+    rest = np.unique(rng.integers(0, 1 << 32, size=n_in_bucket * 2, dtype=np.uint64))[:n_in_bucket]
+    assert len(rest) == n_in_bucket
+    sig = (rest << np.uint64(8)) | low
+    sig = sig[np.argsort(text_order_key(sig), kind="stable")]
+    occ = rng.integers(1, 5, size=len(sig)).astype(np.uint32)
+    ix = ca.IsslIndex.build_from_sites(sig, occ)
+    assert int(ix.bucket_sizes()[int(low)]) == n_in_bucket
+    p = tmp_path / "edge.issl"
+    ix.write(p)
+    ix.upload(0)
+    oracle = ou.OracleIndex(p)
+    # guides: the first and the last site of the bucket (in bucket order = id order), each also with substitutions
+    # outside and inside slice 0, plus guides made of padding-like words
+    picks = np.array([sig[0], sig[-1], sig[len(sig) // 2]], dtype=np.uint64)
+    guides = np.concatenate([picks, picks ^ np.uint64(1 << 20), picks ^ np.uint64((3 << 10) | (2 << 30)),
+                             picks ^ np.uint64(1), np.array([0, low, (1 << 40) - 1], dtype=np.uint64)])
+    for dist, thr in ((4, 0.0), (4, 75.0), (2, 0.0), (0, 0.0)):
+        hits = ix.dump_hits(guides, dist, thr, "and")
+        omit, ocfd, ohits = oracle.score(guides, dist, thr, "and", want_hits=True)
+        assert np.array_equal(hits, ohits), (dist, thr)
+        mit, cfd = ix.score(guides, dist, thr, "and")
+        assert np.array_equal(mit.view(np.uint64), omit.view(np.uint64)) and np.array_equal(cfd.view(np.uint64), ocfd.view(np.uint64))
+    assert len(ohits) >= 3
+    ix.close()
+
+
+def test_random_small_indexes_differential():
+    """Differential sweep: 12 random small indexes (clustered so that guides have neighbours at every distance), random
+    methods, thresholds and distances, hit lists and scores against the oracle."""
+    import tempfile
+    rng = np.random.default_rng(424242)
+    methods = ["and", "or", "avg", "mit", "cfd"]
+    with tempfile.TemporaryDirectory() as tmp:
+        for trial in range(12):
+            n_centres = int(rng.integers(1, 40))
+            centres = rng.integers(0, 1 << 40, size=n_centres, dtype=np.uint64)
+            sites = set(int(c) for c in centres)
+            for c in centres:
+                for _ in range(int(rng.integers(0, 60))):
+                    s = int(c)
+                    for pos in rng.choice(20, size=int(rng.integers(1, 6)), replace=False):
+                        s ^= int(rng.integers(1, 4)) << (2 * int(pos))
+                    sites.add(s)
+            sites |= set(int(x) for x in rng.integers(0, 1 << 40, size=int(rng.integers(0, 3000)), dtype=np.uint64))
+            sig = np.array(sorted(sites), dtype=np.uint64)
+            sig = sig[np.argsort(text_order_key(sig), kind="stable")]
+            occ = rng.integers(1, 7, size=len(sig)).astype(np.uint32)
+            ix = ca.IsslIndex.build_from_sites(sig, occ)
+            path = os.path.join(tmp, f"t{trial}.issl")
+            ix.write(path)
+            ix.upload(0)
+            oracle = ou.OracleIndex(path)
+            guides = np.concatenate([centres, centres ^ np.uint64(2 << 16), rng.integers(0, 1 << 40, size=5, dtype=np.uint64)])
+            for _ in range(4):
+                method = methods[int(rng.integers(0, 5))]
+                thr = float(rng.choice([0.0, 30.0, 75.0, 95.0, 100.0]))
+                dist = int(rng.integers(0, 5))
+                hits = ix.dump_hits(guides, dist, thr, method)
+                omit, ocfd, ohits = oracle.score(guides, dist, thr, method, want_hits=True)
+                assert np.array_equal(hits, ohits), (trial, method, thr, dist)
+                mit, cfd = ix.score(guides, dist, thr, method)
+                assert np.array_equal(mit.view(np.uint64), omit.view(np.uint64)), (trial, method, thr, dist)
+                assert np.array_equal(cfd.view(np.uint64), ocfd.view(np.uint64)), (trial, method, thr, dist)
+            oracle.close()
+            ix.close()
