@@ -155,7 +155,7 @@ static int select_device(int device)
 static void free_workspace(Workspace &w)
 {
     void *ptrs[] = {w.ng, w.gfill, w.gstart, w.gword, w.gidx, w.gbucket, w.items, w.plan, w.range_start, w.counters, w.sticky, w.stamps, w.gcur_big, w.terms, w.sorted, w.gcount,
-                    w.goff, w.gcur, w.blocksum, w.d_guides, w.d_mit, w.d_cfd, w.d_kept, w.d_hitrec};
+                    w.goff, w.blocksum, w.d_guides, w.d_mit, w.d_cfd, w.d_kept, w.d_hitrec};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (w.raw) (void)hipFree(w.raw);
@@ -218,7 +218,6 @@ static int ensure_workspace(issl_index *ix, Lane &lane, size_t n)
         if ((rc = dev_alloc(w.items, items + 1))) return rc;
         if ((rc = dev_alloc(w.gcount, cap + 1))) return rc;
         if ((rc = dev_alloc(w.goff, cap + 1))) return rc;
-        if ((rc = dev_alloc(w.gcur, cap))) return rc;
         if ((rc = dev_alloc(w.gcur_big, cap + 1))) return rc;
         if ((rc = dev_alloc(w.blocksum, (cap + 1) / 2048 + 2))) return rc;
         if ((rc = dev_alloc(w.d_guides, cap))) return rc;

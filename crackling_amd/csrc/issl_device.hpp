@@ -144,7 +144,6 @@ struct Workspace {
     uint64_t *sorted = nullptr;  // [hit_cap] keys guide<<35 | slice<<32 | pos, grouped by guide
     uint32_t *gcount = nullptr;  // [G+1] hits per guide
     uint32_t *goff = nullptr;    // [G+1] exclusive prefix
-    uint32_t *gcur = nullptr;    // [G]
     uint32_t *gcur_big = nullptr; // [G] guides handed to k_replay_big
     double *terms = nullptr;     // [2 * hit_cap] MIT/CFD terms of the hits of those guides
     uint32_t *blocksum = nullptr;

@@ -160,7 +160,6 @@ __global__ __launch_bounds__(256) void k_guide_hist(Workspace ws, const uint64_t
     const uint32_t stride = gridDim.x * 256;
     for (uint32_t k = g; k < n_slots; k += stride) { ws.gidx[k] = kNoGuide; ws.gword[k] = kPadGuideWord; }
     for (uint32_t k = g; k <= n; k += stride) ws.gcount[k] = 0;
-    for (uint32_t k = g; k < n; k += stride) ws.gcur[k] = 0;
     // chunk headers: a chunk nobody writes must read as empty; chunks [0, n_scan_waves) belong to the scan waves
     for (uint32_t k = g; k < ws.cap_chunks; k += stride) ws.raw[static_cast<uint64_t>(k) * kChunkRecs] = 0;
     if (g == 0) {
@@ -685,7 +684,10 @@ __global__ __launch_bounds__(kChunkRecs) void k_verify(ImageView v, Workspace ws
                         if (((x >> (v.slice_width * j)) & low) == 0) earlier = true;
                     if (!earlier) {
                         key = (static_cast<uint64_t>(guide) << 35) | (static_cast<uint64_t>(slice) << 32) | pos;
-                        atomicAdd(&ws.gcount[guide], 1u);
+                        // the count doubles as the hit's place in its guide's segment: the grouping pass scatters
+                        // without a second atomic (the ranks borrow the not-yet-used `terms` buffer)
+                        reinterpret_cast<uint32_t *>(ws.terms)[static_cast<uint64_t>(chunk) * kChunkRecs + t] =
+                            atomicAdd(&ws.gcount[guide], 1u);
                     }
                 }
             }
@@ -734,6 +736,7 @@ void launch_verify(const ImageView &v, const Workspace &ws, const uint64_t *d_gu
 constexpr uint32_t kScanChunk = 2048; // elements per block in the device-wide prefix sum
 constexpr uint32_t kReplayLds = 512;  // guides with more hits than this go to k_replay_big (a whole workgroup each)
 constexpr uint32_t kBigLds = 8192;    // keys k_replay_big sorts in LDS (64 KiB); longer lists are sorted in HBM
+constexpr uint32_t kLazyHits = 256;   // hits of a big guide that one wave walks before the workgroup computes the rest
 
 __global__ __launch_bounds__(256) void k_prefix_block_sums(const uint32_t *__restrict__ in, uint32_t n,
                                                            uint32_t *__restrict__ sums)
@@ -828,7 +831,8 @@ __global__ __launch_bounds__(1024) void k_prefix_single(const uint32_t *__restri
 
 __global__ __launch_bounds__(kChunkRecs) void k_group_scatter(const uint64_t *__restrict__ raw,
                                                               const Counters *__restrict__ counters, uint32_t cap_chunks,
-                                                              const uint32_t *__restrict__ goff, uint32_t *__restrict__ gcur,
+                                                              const uint32_t *__restrict__ goff,
+                                                              const uint32_t *__restrict__ rank,
                                                               uint64_t *__restrict__ sorted)
 {
     short_kernel_priority();
@@ -842,8 +846,7 @@ __global__ __launch_bounds__(kChunkRecs) void k_group_scatter(const uint64_t *__
         const uint64_t key = recs[t];
         if (key == kDeadKey) continue;
         const uint32_t guide = static_cast<uint32_t>(key >> 35);
-        const uint32_t slot = goff[guide] + atomicAdd(&gcur[guide], 1u);
-        sorted[slot] = key;
+        sorted[goff[guide] + rank[static_cast<uint64_t>(chunk) * kChunkRecs + t]] = key; // rank: k_verify's
     }
 }
 
@@ -862,7 +865,8 @@ void launch_group_hits(const Workspace &ws, uint32_t n, void *stream_)
                            ws.gcur_big, ws.counters);
     }
     hipLaunchKernelGGL(k_group_scatter, dim3(4096), dim3(kChunkRecs), 0, stream, ws.raw, ws.counters,
-                       static_cast<uint32_t>(ws.cap_chunks), ws.goff, ws.gcur, ws.sorted);
+                       static_cast<uint32_t>(ws.cap_chunks), ws.goff, reinterpret_cast<const uint32_t *>(ws.terms),
+                       ws.sorted);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1064,6 +1068,7 @@ __global__ __launch_bounds__(1024) void k_replay_big(ImageView v, Workspace ws, 
 {
     short_kernel_priority();
     __shared__ uint64_t keys[kBigLds];
+    __shared__ uint32_t walk_stopped;
     const bool calc_mit = p.method == ISSL_METHOD_MIT || p.method == ISSL_METHOD_AND || p.method == ISSL_METHOD_OR ||
                           p.method == ISSL_METHOD_AVG;
     const bool calc_cfd = p.method == ISSL_METHOD_CFD || p.method == ISSL_METHOD_AND || p.method == ISSL_METHOD_OR ||
@@ -1086,35 +1091,57 @@ __global__ __launch_bounds__(1024) void k_replay_big(ImageView v, Workspace ws, 
             wave_sort(seg, h);
         }
         __syncthreads();
-        for (uint32_t i = threadIdx.x; i < h; i += blockDim.x) {
-            const HitTerms t = hit_terms(v, gsig, g, seg[i], calc_mit, calc_cfd);
-            ws.terms[2ull * (h0 + i)] = t.mit;
-            ws.terms[2ull * (h0 + i) + 1] = t.cfd;
-            if (out_hits) out_hits[h0 + i] = t.rec;
+        // Terms of the hits in key order.  With a threshold the totals usually pass it within the first few dozen
+        // hits (:467-496), so wave 0 first walks kLazyHits of them on its own, 64 at a time (terms computed by its
+        // lanes, accumulated in order); only a guide that is still going afterwards has the terms of all its other
+        // hits computed by the whole workgroup.  The hit dump (parity tests) wants every record and takes the full
+        // path from the start.
+        const uint32_t lazy = out_hits ? 0u : (h < kLazyHits ? h : kLazyHits);
+        double tot_mit = 0.0, tot_cfd = 0.0;
+        uint32_t kept = 0;
+        bool stop = false;
+        const uint32_t lane = threadIdx.x & 63u;
+        auto accumulate = [&](double mit_term, double cfd_term, uint32_t cnt) { // :394, :460, :467-496
+            for (uint32_t l = 0; l < cnt; ++l) {
+                tot_mit += bcast_f64(mit_term, static_cast<int>(l));
+                tot_cfd += bcast_f64(cfd_term, static_cast<int>(l));
+                ++kept;
+                bool exit_now = false;
+                if (p.method == ISSL_METHOD_AND) exit_now = tot_mit > p.maximum_sum && tot_cfd > p.maximum_sum;
+                else if (p.method == ISSL_METHOD_OR) exit_now = tot_mit > p.maximum_sum || tot_cfd > p.maximum_sum;
+                else if (p.method == ISSL_METHOD_AVG) exit_now = ((tot_mit + tot_cfd) / 2.0) > p.maximum_sum;
+                else if (p.method == ISSL_METHOD_MIT) exit_now = tot_mit > p.maximum_sum;
+                else if (p.method == ISSL_METHOD_CFD) exit_now = tot_cfd > p.maximum_sum;
+                if (exit_now) { stop = true; break; }
+            }
+        };
+        if (threadIdx.x < 64) {
+            for (uint32_t base = 0; base < lazy && !stop; base += 64) {
+                const uint32_t idx = base + lane;
+                HitTerms t;
+                t.mit = 0.0; t.cfd = 0.0;
+                if (idx < lazy) t = hit_terms(v, gsig, g, seg[idx], calc_mit, calc_cfd);
+                accumulate(t.mit, t.cfd, (lazy - base < 64u) ? lazy - base : 64u);
+            }
+            if (lane == 0) walk_stopped = stop ? 1u : 0u;
+        }
+        __syncthreads();
+        const bool rest = walk_stopped == 0u && lazy < h; // uniform over the workgroup
+        if (rest) {
+            for (uint32_t i = lazy + threadIdx.x; i < h; i += blockDim.x) {
+                const HitTerms t = hit_terms(v, gsig, g, seg[i], calc_mit, calc_cfd);
+                ws.terms[2ull * (h0 + i)] = t.mit;
+                ws.terms[2ull * (h0 + i) + 1] = t.cfd;
+                if (out_hits) out_hits[h0 + i] = t.rec;
+            }
         }
         __syncthreads();
         if (threadIdx.x < 64) {
-            const uint32_t lane = threadIdx.x;
-            double tot_mit = 0.0, tot_cfd = 0.0;
-            uint32_t kept = 0;
-            bool stop = false;
-            for (uint32_t base = 0; base < h && !stop; base += 64) {
+            for (uint32_t base = lazy; rest && base < h && !stop; base += 64) {
                 const uint32_t idx = base + lane;
                 const double mit_term = idx < h ? ws.terms[2ull * (h0 + idx)] : 0.0;
                 const double cfd_term = idx < h ? ws.terms[2ull * (h0 + idx) + 1] : 0.0;
-                const uint32_t cnt = (h - base < 64u) ? h - base : 64u;
-                for (uint32_t l = 0; l < cnt; ++l) { // :394, :460, :467-496
-                    tot_mit += bcast_f64(mit_term, static_cast<int>(l));
-                    tot_cfd += bcast_f64(cfd_term, static_cast<int>(l));
-                    ++kept;
-                    bool exit_now = false;
-                    if (p.method == ISSL_METHOD_AND) exit_now = tot_mit > p.maximum_sum && tot_cfd > p.maximum_sum;
-                    else if (p.method == ISSL_METHOD_OR) exit_now = tot_mit > p.maximum_sum || tot_cfd > p.maximum_sum;
-                    else if (p.method == ISSL_METHOD_AVG) exit_now = ((tot_mit + tot_cfd) / 2.0) > p.maximum_sum;
-                    else if (p.method == ISSL_METHOD_MIT) exit_now = tot_mit > p.maximum_sum;
-                    else if (p.method == ISSL_METHOD_CFD) exit_now = tot_cfd > p.maximum_sum;
-                    if (exit_now) { stop = true; break; }
-                }
+                accumulate(mit_term, cfd_term, (h - base < 64u) ? h - base : 64u);
             }
             if (lane == 0) {
                 out_mit[g] = 10000.0 / (100.0 + tot_mit); // :505
@@ -1134,7 +1161,7 @@ void launch_replay(const ImageView &v, const Workspace &ws, const uint64_t *d_gu
     const uint32_t grid = n < 65536u ? n : 65536u;
     hipLaunchKernelGGL(k_replay, dim3(grid), dim3(64), 0, static_cast<hipStream_t>(stream), v, ws, d_guides, n, p,
                        d_mit, d_cfd, d_kept, d_hitrec);
-    hipLaunchKernelGGL(k_replay_big, dim3(256), dim3(1024), 0, static_cast<hipStream_t>(stream), v, ws, d_guides, p,
+    hipLaunchKernelGGL(k_replay_big, dim3(512), dim3(1024), 0, static_cast<hipStream_t>(stream), v, ws, d_guides, p,
                        d_mit, d_cfd, d_kept, d_hitrec);
 }
 
