@@ -735,8 +735,7 @@ void launch_verify(const ImageView &v, const Workspace &ws, const uint64_t *d_gu
 
 constexpr uint32_t kScanChunk = 2048; // elements per block in the device-wide prefix sum
 constexpr uint32_t kReplayLds = 512;  // guides with more hits than this go to k_replay_big (a whole workgroup each)
-constexpr uint32_t kBigLds = 8192;    // keys k_replay_big sorts in LDS (64 KiB); longer lists are sorted in HBM
-constexpr uint32_t kLazyHits = 256;   // hits of a big guide that one wave walks before the workgroup computes the rest
+constexpr uint32_t kBigLds = 7680;    // hits per slice k_replay_big sorts in LDS (2 x 30 KiB); longer slices are sorted in HBM
 
 __global__ __launch_bounds__(256) void k_prefix_block_sums(const uint32_t *__restrict__ in, uint32_t n,
                                                            uint32_t *__restrict__ sums)
@@ -904,6 +903,44 @@ __device__ inline double bcast_f64(double x, int lane)
     return __longlong_as_double((static_cast<uint64_t>(hi) << 32) | lo);
 }
 
+// Adds the terms held by lanes 0..cnt-1 (cnt <= 64; lanes beyond hold 0.0) to the running totals in lane order (:394,
+// :460) and applies the exit test of :467-496 after every hit.  The sums are a serial chain of f64 additions -- the
+// order is part of the result -- but the test is not: every lane keeps the totals as they stood after ITS hit, the
+// tests run side by side afterwards, and the first lane that passes decides where the walk stops.  (Testing inside
+// the chain costs a compare, a branch and their latencies per hit: ~200 cycles against ~50.)
+// Returns true when the walk stops; `kept` counts the hits that were scored, the totals are those at that point.
+__device__ __forceinline__ bool accumulate_chunk(double mit_term, double cfd_term, uint32_t cnt, const ScoreParams &p,
+                                                 uint32_t lane, double &tot_mit, double &tot_cfd, uint32_t &kept)
+{
+    double tm = tot_mit, tc = tot_cfd, mine_m = 0.0, mine_c = 0.0;
+    for (uint32_t l0 = 0; l0 < cnt; l0 += 8) {
+#pragma unroll
+        for (uint32_t l = 0; l < 8; ++l) { // x + 0.0 == x: the empty lanes of the last group change nothing
+            tm += bcast_f64(mit_term, static_cast<int>(l0 + l));
+            tc += bcast_f64(cfd_term, static_cast<int>(l0 + l));
+            if (lane == l0 + l) { mine_m = tm; mine_c = tc; }
+        }
+    }
+    bool exit_here = false;
+    if (p.method == ISSL_METHOD_AND) exit_here = mine_m > p.maximum_sum && mine_c > p.maximum_sum;
+    else if (p.method == ISSL_METHOD_OR) exit_here = mine_m > p.maximum_sum || mine_c > p.maximum_sum;
+    else if (p.method == ISSL_METHOD_AVG) exit_here = ((mine_m + mine_c) / 2.0) > p.maximum_sum;
+    else if (p.method == ISSL_METHOD_MIT) exit_here = mine_m > p.maximum_sum;
+    else if (p.method == ISSL_METHOD_CFD) exit_here = mine_c > p.maximum_sum;
+    const uint64_t exits = __ballot(exit_here && lane < cnt);
+    if (exits != 0ull) {
+        const int first = __builtin_ctzll(exits);
+        kept += static_cast<uint32_t>(first) + 1u;
+        tot_mit = bcast_f64(mine_m, first);
+        tot_cfd = bcast_f64(mine_c, first);
+        return true;
+    }
+    kept += cnt;
+    tot_mit = tm;
+    tot_cfd = tc;
+    return false;
+}
+
 // precalculatedScores[mask] with operator[] semantics: a missing mask contributes 0.0 (:394).
 // Reference-built tables hold masks with flags on even bits below bit 40 only; for those the image carries a
 // dense 2^20-entry table indexed by the 20 flags (one load instead of a 13-step search).
@@ -992,18 +1029,7 @@ __global__ __launch_bounds__(64) void k_replay(ImageView v, Workspace ws, const 
 
         // Running totals in key order, same operations as the reference's (:394,:460), early exit of :467-496.
         auto accumulate = [&](double mit_term, double cfd_term, uint32_t cnt) {
-            for (uint32_t l = 0; l < cnt; ++l) {
-                tot_mit += bcast_f64(mit_term, static_cast<int>(l));
-                tot_cfd += bcast_f64(cfd_term, static_cast<int>(l));
-                ++kept;
-                bool exit_now = false;
-                if (p.method == ISSL_METHOD_AND) exit_now = tot_mit > p.maximum_sum && tot_cfd > p.maximum_sum;
-                else if (p.method == ISSL_METHOD_OR) exit_now = tot_mit > p.maximum_sum || tot_cfd > p.maximum_sum;
-                else if (p.method == ISSL_METHOD_AVG) exit_now = ((tot_mit + tot_cfd) / 2.0) > p.maximum_sum;
-                else if (p.method == ISSL_METHOD_MIT) exit_now = tot_mit > p.maximum_sum;
-                else if (p.method == ISSL_METHOD_CFD) exit_now = tot_cfd > p.maximum_sum;
-                if (exit_now) { stop = true; break; }
-            }
+            stop = accumulate_chunk(mit_term, cfd_term, cnt, p, lane, tot_mit, tot_cfd, kept);
         };
 
         if (h <= 64) {
@@ -1058,21 +1084,104 @@ __global__ __launch_bounds__(64) void k_replay(ImageView v, Workspace ws, const 
     }
 }
 
-// Guides with many hits (dense neighbourhoods, repeats): one 1024-thread workgroup each.  Sort the keys (LDS up to
-// 8192, else in place in HBM), compute every hit's MIT/CFD terms in parallel, then wave 0 walks the terms in key
-// order with the reference's running totals and early exit.
-__global__ __launch_bounds__(1024) void k_replay_big(ImageView v, Workspace ws, const uint64_t *__restrict__ guides,
+// Sort by counting for the slices of a big guide: positions (low 32 key bits; guide and slice are common to the
+// slice) sit in LDS, every thread finds the rank of its K positions by comparing them with all `len` of them
+// (broadcast reads, no barrier inside) and writes the full keys to their final places.  A bitonic network over the same
+// keys costs ~80-90 workgroup barriers; positions are distinct, so the ranks are a permutation.
+template <uint32_t K>
+__device__ __forceinline__ void rank_sort_slice(const uint32_t *pos_lds, uint32_t len, uint64_t high_bits,
+                                                uint64_t *__restrict__ dst)
+{
+    uint32_t mine[K], rk[K];
+#pragma unroll
+    for (uint32_t k = 0; k < K; ++k) {
+        const uint32_t idx = threadIdx.x + k * 1024u;
+        mine[k] = idx < len ? pos_lds[idx] : 0xFFFFFFFFu;
+        rk[k] = 0;
+    }
+    // four positions per LDS read (the array is padded with 0xFFFFFFFF, which is below nothing), several reads in
+    // flight: the loop is bound by LDS latency otherwise
+    const uint4 *quads = reinterpret_cast<const uint4 *>(pos_lds);
+    const uint32_t n_quads = (len + 3u) >> 2;
+#pragma unroll 4
+    for (uint32_t j = 0; j < n_quads; ++j) {
+        const uint4 q = quads[j];
+#pragma unroll
+        for (uint32_t k = 0; k < K; ++k)
+            rk[k] += (q.x < mine[k] ? 1u : 0u) + (q.y < mine[k] ? 1u : 0u) + (q.z < mine[k] ? 1u : 0u) +
+                     (q.w < mine[k] ? 1u : 0u);
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < K; ++k)
+        if (threadIdx.x + k * 1024u < len) dst[rk[k]] = high_bits | mine[k];
+}
+
+// Longer slices: the same ranking, but only against the positions that share the top 8 bits (of the slice's largest
+// position): one counting pass groups the positions by those bits in `grouped`, then every position is ranked inside
+// its group -- len * len / 256 comparisons on evenly spread positions instead of len * len.
+__device__ __forceinline__ void rank_sort_slice_grouped(const uint32_t *pos_lds, uint32_t *grouped, uint32_t *group_at /*[257]*/,
+                                                        uint32_t *group_cur /*[256]*/, uint32_t *max_pos, uint32_t len,
+                                                        uint64_t high_bits, uint64_t *__restrict__ dst)
+{
+    if (threadIdx.x < 256) group_cur[threadIdx.x] = 0;
+    if (threadIdx.x == 0) *max_pos = 0;
+    __syncthreads();
+    uint32_t m = 0;
+    for (uint32_t i = threadIdx.x; i < len; i += blockDim.x) m = pos_lds[i] > m ? pos_lds[i] : m;
+    atomicMax(max_pos, m);
+    __syncthreads();
+    const uint32_t top = *max_pos;
+    const uint32_t shift = top < 256u ? 0u : 24u - static_cast<uint32_t>(__builtin_clz(top)); // group = pos >> shift < 256
+    for (uint32_t i = threadIdx.x; i < len; i += blockDim.x) atomicAdd(&group_cur[pos_lds[i] >> shift], 1u);
+    __syncthreads();
+    if (threadIdx.x < 64) { // exclusive scan of the 256 group sizes by one wave, 4 per lane
+        uint32_t v4[4], sum = 0;
+        for (uint32_t k = 0; k < 4; ++k) { v4[k] = group_cur[threadIdx.x * 4 + k]; sum += v4[k]; }
+        uint32_t x = sum;
+        for (uint32_t d = 1; d < 64; d <<= 1) {
+            const uint32_t y = __shfl_up(x, d, 64);
+            if (threadIdx.x >= d) x += y;
+        }
+        uint32_t run = x - sum;
+        for (uint32_t k = 0; k < 4; ++k) { group_at[threadIdx.x * 4 + k] = run; run += v4[k]; }
+        if (threadIdx.x == 63) group_at[256] = run;
+    }
+    __syncthreads();
+    if (threadIdx.x < 256) group_cur[threadIdx.x] = group_at[threadIdx.x];
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < len; i += blockDim.x) {
+        const uint32_t pos = pos_lds[i];
+        grouped[atomicAdd(&group_cur[pos >> shift], 1u)] = pos;
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < len; i += blockDim.x) {
+        const uint32_t pos = grouped[i];
+        const uint32_t g0 = group_at[pos >> shift], g1 = group_at[(pos >> shift) + 1u];
+        uint32_t rk = g0;
+        for (uint32_t j = g0; j < g1; ++j) rk += grouped[j] < pos ? 1u : 0u;
+        dst[rk] = high_bits | pos;
+    }
+}
+
+// Guides with many hits (dense neighbourhoods, repeats): one 1024-thread workgroup each, one slice at a time: sort
+// the slice's keys (by counting in LDS up to 8192 per slice, else a bitonic network in HBM), compute the terms of its
+// hits in parallel, let wave 0 add them up in key order with the reference's running totals and early exit.
+__global__ __launch_bounds__(1024, 8) void k_replay_big(ImageView v, Workspace ws, const uint64_t *__restrict__ guides,
                                                      ScoreParams p, double *__restrict__ out_mit,
                                                      double *__restrict__ out_cfd, uint32_t *__restrict__ out_kept,
-                                                     issl_hit *__restrict__ out_hits)
+                                                     issl_hit *__restrict__ out_hits, uint32_t dbg)
 {
     short_kernel_priority();
-    __shared__ uint64_t keys[kBigLds];
+    __shared__ __attribute__((aligned(16))) uint32_t pos_lds[kBigLds];
+    __shared__ uint32_t grouped[kBigLds];
+    __shared__ uint32_t group_at[257], group_cur[256], max_pos;
+    __shared__ uint32_t slice_cnt[8], slice_off[9], slice_cur[8];
     __shared__ uint32_t walk_stopped;
     const bool calc_mit = p.method == ISSL_METHOD_MIT || p.method == ISSL_METHOD_AND || p.method == ISSL_METHOD_OR ||
                           p.method == ISSL_METHOD_AVG;
     const bool calc_cfd = p.method == ISSL_METHOD_CFD || p.method == ISSL_METHOD_AND || p.method == ISSL_METHOD_OR ||
                           p.method == ISSL_METHOD_AVG;
+    const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n_big = ws.counters->n_big;
     for (uint32_t b = blockIdx.x; b < n_big; b += gridDim.x) {
         const uint32_t g = ws.gcur_big[b];
@@ -1080,74 +1189,104 @@ __global__ __launch_bounds__(1024) void k_replay_big(ImageView v, Workspace ws, 
         const uint32_t h = ws.goff[g + 1] - h0;
         const uint64_t gsig = guides[g];
         uint64_t *seg = ws.sorted + h0;
-        if (h <= kBigLds) {
-            for (uint32_t i = threadIdx.x; i < h; i += blockDim.x) keys[i] = seg[i];
-            __syncthreads();
-            wave_sort(keys, h);
-            __syncthreads();
-            for (uint32_t i = threadIdx.x; i < h; i += blockDim.x) seg[i] = keys[i];
-        } else {
-            __syncthreads();
-            wave_sort(seg, h);
+        uint64_t *tmp = ws.raw + h0; // the raw records are dead once they are grouped; the buffer holds >= all hits
+        unsigned long long *st = (ws.stamps && b < 4096u) ? ws.stamps + 65536u + 16u * b : nullptr;
+        if (st && threadIdx.x == 0) { st[0] = __builtin_amdgcn_s_memrealtime(); st[1] = h; st[15] = blockIdx.x; }
+
+        // The scoring order is (slice, position in bucket) and the walk usually ends inside the first slice (the
+        // totals pass the threshold, :467-496): split the keys by slice (bits 32..34) and sort and walk one slice at
+        // a time -- a fifth of the sorting work per step, in LDS up to 8192 hits PER SLICE, and none at all for the
+        // slices behind the exit.
+        if (threadIdx.x < 8) { slice_cnt[threadIdx.x] = 0; slice_cur[threadIdx.x] = 0; }
+        __syncthreads();
+        for (uint32_t base = 0; base < h; base += blockDim.x) {
+            const uint32_t i = base + threadIdx.x;
+            const uint32_t sl = i < h ? static_cast<uint32_t>(seg[i] >> 32) & 7u : 8u;
+            for (uint32_t s2 = 0; s2 < v.n_slices; ++s2) {
+                const uint64_t m = __ballot(sl == s2);
+                if (m != 0ull && lane == 0) atomicAdd(&slice_cnt[s2], static_cast<uint32_t>(__builtin_popcountll(m)));
+            }
         }
         __syncthreads();
-        // Terms of the hits in key order.  With a threshold the totals usually pass it within the first few dozen
-        // hits (:467-496), so wave 0 first walks kLazyHits of them on its own, 64 at a time (terms computed by its
-        // lanes, accumulated in order); only a guide that is still going afterwards has the terms of all its other
-        // hits computed by the whole workgroup.  The hit dump (parity tests) wants every record and takes the full
-        // path from the start.
-        const uint32_t lazy = out_hits ? 0u : (h < kLazyHits ? h : kLazyHits);
+        if (threadIdx.x == 0) {
+            uint32_t run = 0;
+            for (uint32_t s2 = 0; s2 < 8; ++s2) { slice_off[s2] = run; run += slice_cnt[s2]; }
+            slice_off[8] = run;
+        }
+        __syncthreads();
+        for (uint32_t base = 0; base < h; base += blockDim.x) {
+            const uint32_t i = base + threadIdx.x;
+            const uint64_t key = i < h ? seg[i] : 0ull;
+            const uint32_t sl = i < h ? static_cast<uint32_t>(key >> 32) & 7u : 8u;
+            for (uint32_t s2 = 0; s2 < v.n_slices; ++s2) {
+                const uint64_t m = __ballot(sl == s2);
+                if (m == 0ull) continue;
+                uint32_t at = 0;
+                if (lane == 0) at = atomicAdd(&slice_cur[s2], static_cast<uint32_t>(__builtin_popcountll(m)));
+                at = __builtin_amdgcn_readfirstlane(at);
+                if (sl == s2)
+                    tmp[slice_off[s2] + at + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32),
+                                                                        __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u))] = key;
+            }
+        }
+        __syncthreads();
+
+        if (st && threadIdx.x == 0) st[2] = __builtin_amdgcn_s_memrealtime();
         double tot_mit = 0.0, tot_cfd = 0.0;
         uint32_t kept = 0;
         bool stop = false;
-        const uint32_t lane = threadIdx.x & 63u;
-        auto accumulate = [&](double mit_term, double cfd_term, uint32_t cnt) { // :394, :460, :467-496
-            for (uint32_t l = 0; l < cnt; ++l) {
-                tot_mit += bcast_f64(mit_term, static_cast<int>(l));
-                tot_cfd += bcast_f64(cfd_term, static_cast<int>(l));
-                ++kept;
-                bool exit_now = false;
-                if (p.method == ISSL_METHOD_AND) exit_now = tot_mit > p.maximum_sum && tot_cfd > p.maximum_sum;
-                else if (p.method == ISSL_METHOD_OR) exit_now = tot_mit > p.maximum_sum || tot_cfd > p.maximum_sum;
-                else if (p.method == ISSL_METHOD_AVG) exit_now = ((tot_mit + tot_cfd) / 2.0) > p.maximum_sum;
-                else if (p.method == ISSL_METHOD_MIT) exit_now = tot_mit > p.maximum_sum;
-                else if (p.method == ISSL_METHOD_CFD) exit_now = tot_cfd > p.maximum_sum;
-                if (exit_now) { stop = true; break; }
-            }
+        auto accumulate = [&](double mit_term, double cfd_term, uint32_t cnt) {
+            stop = accumulate_chunk(mit_term, cfd_term, cnt, p, lane, tot_mit, tot_cfd, kept);
         };
-        if (threadIdx.x < 64) {
-            for (uint32_t base = 0; base < lazy && !stop; base += 64) {
-                const uint32_t idx = base + lane;
+        for (uint32_t s2 = 0; s2 < v.n_slices; ++s2) {
+            const uint32_t off = slice_off[s2], len = slice_cnt[s2];
+            if (len == 0) continue; // uniform over the workgroup
+            if (st && threadIdx.x == 0 && s2 == 0) { st[3] = __builtin_amdgcn_s_memrealtime(); st[4] = len; }
+            uint64_t *dst = seg + off;
+            if (len <= kBigLds) {
+                for (uint32_t i = threadIdx.x; i < ((len + 3u) & ~3u); i += blockDim.x)
+                    pos_lds[i] = i < len ? static_cast<uint32_t>(tmp[off + i]) : 0xFFFFFFFFu;
+                __syncthreads();
+                const uint64_t high_bits = (static_cast<uint64_t>(g) << 35) | (static_cast<uint64_t>(s2) << 32);
+                if (dbg & 1u) { for (uint32_t i = threadIdx.x; i < len; i += blockDim.x) dst[i] = high_bits | pos_lds[i]; }
+                else if (len <= 1024u) rank_sort_slice<1>(pos_lds, len, high_bits, dst);
+                else rank_sort_slice_grouped(pos_lds, grouped, group_at, group_cur, &max_pos, len, high_bits, dst);
+            } else {
+                for (uint32_t i = threadIdx.x; i < len; i += blockDim.x) dst[i] = tmp[off + i];
+                __syncthreads();
+                wave_sort(dst, len);
+            }
+            __syncthreads();
+            if (st && threadIdx.x == 0 && s2 == 0) st[5] = __builtin_amdgcn_s_memrealtime();
+            // terms of the slice's hits by the whole workgroup, then wave 0 adds them up in key order
+            for (uint32_t i = threadIdx.x; i < len && !(dbg & 2u); i += blockDim.x) {
                 HitTerms t;
-                t.mit = 0.0; t.cfd = 0.0;
-                if (idx < lazy) t = hit_terms(v, gsig, g, seg[idx], calc_mit, calc_cfd);
-                accumulate(t.mit, t.cfd, (lazy - base < 64u) ? lazy - base : 64u);
+                if (dbg & 16u) { t.mit = 1000.0; t.cfd = 1000.0; }
+                else t = hit_terms(v, gsig, g, dst[i], calc_mit, calc_cfd);
+                ws.terms[2ull * (h0 + off + i)] = t.mit;
+                ws.terms[2ull * (h0 + off + i) + 1] = t.cfd;
+                if (out_hits) out_hits[h0 + off + i] = t.rec;
             }
-            if (lane == 0) walk_stopped = stop ? 1u : 0u;
+            __syncthreads();
+            if (st && threadIdx.x == 0 && s2 == 0) st[6] = __builtin_amdgcn_s_memrealtime();
+            if (threadIdx.x < 64) {
+                if (dbg & 32u) stop = true;
+                for (uint32_t base = 0; base < len && !stop && !(dbg & 4u); base += 64) {
+                    const uint32_t idx = base + lane;
+                    const double mit_term = idx < len ? ws.terms[2ull * (h0 + off + idx)] : 0.0;
+                    const double cfd_term = idx < len ? ws.terms[2ull * (h0 + off + idx) + 1] : 0.0;
+                    accumulate(mit_term, cfd_term, (len - base < 64u) ? len - base : 64u);
+                }
+                if (lane == 0) walk_stopped = stop ? 1u : 0u;
+            }
+            __syncthreads();
+            if (walk_stopped != 0u) break; // uniform: the slices behind the exit are never sorted
         }
-        __syncthreads();
-        const bool rest = walk_stopped == 0u && lazy < h; // uniform over the workgroup
-        if (rest) {
-            for (uint32_t i = lazy + threadIdx.x; i < h; i += blockDim.x) {
-                const HitTerms t = hit_terms(v, gsig, g, seg[i], calc_mit, calc_cfd);
-                ws.terms[2ull * (h0 + i)] = t.mit;
-                ws.terms[2ull * (h0 + i) + 1] = t.cfd;
-                if (out_hits) out_hits[h0 + i] = t.rec;
-            }
-        }
-        __syncthreads();
-        if (threadIdx.x < 64) {
-            for (uint32_t base = lazy; rest && base < h && !stop; base += 64) {
-                const uint32_t idx = base + lane;
-                const double mit_term = idx < h ? ws.terms[2ull * (h0 + idx)] : 0.0;
-                const double cfd_term = idx < h ? ws.terms[2ull * (h0 + idx) + 1] : 0.0;
-                accumulate(mit_term, cfd_term, (h - base < 64u) ? h - base : 64u);
-            }
-            if (lane == 0) {
-                out_mit[g] = 10000.0 / (100.0 + tot_mit); // :505
-                out_cfd[g] = 10000.0 / (100.0 + tot_cfd); // :506
-                if (out_kept) out_kept[g] = kept;
-            }
+        if (threadIdx.x == 0) {
+            out_mit[g] = 10000.0 / (100.0 + tot_mit); // :505
+            out_cfd[g] = 10000.0 / (100.0 + tot_cfd); // :506
+            if (out_kept) out_kept[g] = kept;
+            if (st) { st[7] = __builtin_amdgcn_s_memrealtime(); st[8] = kept; }
         }
         __syncthreads();
     }
@@ -1161,8 +1300,9 @@ void launch_replay(const ImageView &v, const Workspace &ws, const uint64_t *d_gu
     const uint32_t grid = n < 65536u ? n : 65536u;
     hipLaunchKernelGGL(k_replay, dim3(grid), dim3(64), 0, static_cast<hipStream_t>(stream), v, ws, d_guides, n, p,
                        d_mit, d_cfd, d_kept, d_hitrec);
+    const char *dbg_env = getenv("ISSL_REPLAY_DEBUG");
     hipLaunchKernelGGL(k_replay_big, dim3(512), dim3(1024), 0, static_cast<hipStream_t>(stream), v, ws, d_guides, p,
-                       d_mit, d_cfd, d_kept, d_hitrec);
+                       d_mit, d_cfd, d_kept, d_hitrec, dbg_env ? static_cast<uint32_t>(atoi(dbg_env)) : 0u);
 }
 
 } // namespace issl
