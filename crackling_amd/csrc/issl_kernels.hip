@@ -658,13 +658,13 @@ __global__ __launch_bounds__(kChunkRecs) void k_verify(ImageView v, Workspace ws
         uint64_t *recs = ws.raw + static_cast<uint64_t>(chunk) * kChunkRecs;
         const uint32_t used = static_cast<uint32_t>(recs[0]);
         const uint32_t t = threadIdx.x + 1u;
-        if (t >= used || t >= kChunkRecs) continue;
-        const uint64_t rec = recs[t];
+        const bool in_use = t < used && t < kChunkRecs; // every lane stays: the counting below is done by the wave
+        const uint64_t rec = in_use ? recs[t] : 0ull;
         uint64_t key = kDeadKey;
         const uint32_t offset = static_cast<uint32_t>(rec) & (kTileCands - 1u);
         const uint32_t tile = static_cast<uint32_t>(rec >> 11) & 0x3FFFFFFu;
         const uint32_t gslot = static_cast<uint32_t>(rec >> 37);
-        const uint32_t guide = ws.gidx[gslot];
+        const uint32_t guide = in_use ? ws.gidx[gslot] : kNoGuide;
         if (guide != kNoGuide) {
             const uint32_t bucket = ws.gbucket[gslot]; // the guide slot knows its bucket: no search for the tile's
             const uint32_t slice = bucket >> v.slice_width;
@@ -684,14 +684,36 @@ __global__ __launch_bounds__(kChunkRecs) void k_verify(ImageView v, Workspace ws
                         if (((x >> (v.slice_width * j)) & low) == 0) earlier = true;
                     if (!earlier) {
                         key = (static_cast<uint64_t>(guide) << 35) | (static_cast<uint64_t>(slice) << 32) | pos;
-                        // the count doubles as the hit's place in its guide's segment: the grouping pass scatters
-                        // without a second atomic (the ranks borrow the not-yet-used `terms` buffer)
-                        reinterpret_cast<uint32_t *>(ws.terms)[static_cast<uint64_t>(chunk) * kChunkRecs + t] =
-                            atomicAdd(&ws.gcount[guide], 1u);
+
                     }
                 }
             }
         }
+        // Count the hit for its guide.  The count doubles as the hit's place in the guide's segment, so that the grouping
+        // pass scatters without a second atomic (the ranks borrow the not-yet-used `terms` buffer).  A dense guide's hits
+        // come in runs (one scan wave, consecutive tiles): lanes that share the guide of the first live lane take ONE
+        // atomic together while such runs are at least 4 lanes long; everybody else adds for itself.
+        const bool live = key != kDeadKey;
+        const uint32_t lane = threadIdx.x & 63u;
+        uint32_t rank = 0;
+        uint64_t todo = __ballot(live);
+        while (todo != 0ull) {
+            const int leader = __builtin_ctzll(todo);
+            const uint32_t g0 = __builtin_amdgcn_readlane(guide, leader);
+            const uint64_t same = __ballot(live && guide == g0) & todo;
+            const uint32_t cnt = static_cast<uint32_t>(__builtin_popcountll(same));
+            if (cnt < 4u) break;
+            uint32_t base = 0;
+            if (static_cast<int>(lane) == leader) base = atomicAdd(&ws.gcount[g0], cnt);
+            base = __builtin_amdgcn_readlane(base, leader);
+            if ((same >> lane) & 1ull)
+                rank = base + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(same >> 32),
+                                                        __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(same), 0u));
+            todo &= ~same;
+        }
+        if ((todo >> lane) & 1ull) rank = atomicAdd(&ws.gcount[guide], 1u);
+        if (live) reinterpret_cast<uint32_t *>(ws.terms)[static_cast<uint64_t>(chunk) * kChunkRecs + t] = rank;
+        if (!in_use) continue;
         recs[t] = key;
     }
 }
@@ -1169,7 +1191,7 @@ __device__ __forceinline__ void rank_sort_slice_grouped(const uint32_t *pos_lds,
 __global__ __launch_bounds__(1024, 8) void k_replay_big(ImageView v, Workspace ws, const uint64_t *__restrict__ guides,
                                                      ScoreParams p, double *__restrict__ out_mit,
                                                      double *__restrict__ out_cfd, uint32_t *__restrict__ out_kept,
-                                                     issl_hit *__restrict__ out_hits, uint32_t dbg)
+                                                     issl_hit *__restrict__ out_hits)
 {
     short_kernel_priority();
     __shared__ __attribute__((aligned(16))) uint32_t pos_lds[kBigLds];
@@ -1190,6 +1212,7 @@ __global__ __launch_bounds__(1024, 8) void k_replay_big(ImageView v, Workspace w
         const uint64_t gsig = guides[g];
         uint64_t *seg = ws.sorted + h0;
         uint64_t *tmp = ws.raw + h0; // the raw records are dead once they are grouped; the buffer holds >= all hits
+        // diagnostics (ISSL_SCAN_STAMPS, tools/replay_stamps.py): phase clocks of the first 4096 big guides
         unsigned long long *st = (ws.stamps && b < 4096u) ? ws.stamps + 65536u + 16u * b : nullptr;
         if (st && threadIdx.x == 0) { st[0] = __builtin_amdgcn_s_memrealtime(); st[1] = h; st[15] = blockIdx.x; }
 
@@ -1248,8 +1271,7 @@ __global__ __launch_bounds__(1024, 8) void k_replay_big(ImageView v, Workspace w
                     pos_lds[i] = i < len ? static_cast<uint32_t>(tmp[off + i]) : 0xFFFFFFFFu;
                 __syncthreads();
                 const uint64_t high_bits = (static_cast<uint64_t>(g) << 35) | (static_cast<uint64_t>(s2) << 32);
-                if (dbg & 1u) { for (uint32_t i = threadIdx.x; i < len; i += blockDim.x) dst[i] = high_bits | pos_lds[i]; }
-                else if (len <= 1024u) rank_sort_slice<1>(pos_lds, len, high_bits, dst);
+                if (len <= 1024u) rank_sort_slice<1>(pos_lds, len, high_bits, dst);
                 else rank_sort_slice_grouped(pos_lds, grouped, group_at, group_cur, &max_pos, len, high_bits, dst);
             } else {
                 for (uint32_t i = threadIdx.x; i < len; i += blockDim.x) dst[i] = tmp[off + i];
@@ -1259,10 +1281,8 @@ __global__ __launch_bounds__(1024, 8) void k_replay_big(ImageView v, Workspace w
             __syncthreads();
             if (st && threadIdx.x == 0 && s2 == 0) st[5] = __builtin_amdgcn_s_memrealtime();
             // terms of the slice's hits by the whole workgroup, then wave 0 adds them up in key order
-            for (uint32_t i = threadIdx.x; i < len && !(dbg & 2u); i += blockDim.x) {
-                HitTerms t;
-                if (dbg & 16u) { t.mit = 1000.0; t.cfd = 1000.0; }
-                else t = hit_terms(v, gsig, g, dst[i], calc_mit, calc_cfd);
+            for (uint32_t i = threadIdx.x; i < len; i += blockDim.x) {
+                const HitTerms t = hit_terms(v, gsig, g, dst[i], calc_mit, calc_cfd);
                 ws.terms[2ull * (h0 + off + i)] = t.mit;
                 ws.terms[2ull * (h0 + off + i) + 1] = t.cfd;
                 if (out_hits) out_hits[h0 + off + i] = t.rec;
@@ -1270,8 +1290,7 @@ __global__ __launch_bounds__(1024, 8) void k_replay_big(ImageView v, Workspace w
             __syncthreads();
             if (st && threadIdx.x == 0 && s2 == 0) st[6] = __builtin_amdgcn_s_memrealtime();
             if (threadIdx.x < 64) {
-                if (dbg & 32u) stop = true;
-                for (uint32_t base = 0; base < len && !stop && !(dbg & 4u); base += 64) {
+                for (uint32_t base = 0; base < len && !stop; base += 64) {
                     const uint32_t idx = base + lane;
                     const double mit_term = idx < len ? ws.terms[2ull * (h0 + off + idx)] : 0.0;
                     const double cfd_term = idx < len ? ws.terms[2ull * (h0 + off + idx) + 1] : 0.0;
@@ -1300,9 +1319,8 @@ void launch_replay(const ImageView &v, const Workspace &ws, const uint64_t *d_gu
     const uint32_t grid = n < 65536u ? n : 65536u;
     hipLaunchKernelGGL(k_replay, dim3(grid), dim3(64), 0, static_cast<hipStream_t>(stream), v, ws, d_guides, n, p,
                        d_mit, d_cfd, d_kept, d_hitrec);
-    const char *dbg_env = getenv("ISSL_REPLAY_DEBUG");
     hipLaunchKernelGGL(k_replay_big, dim3(512), dim3(1024), 0, static_cast<hipStream_t>(stream), v, ws, d_guides, p,
-                       d_mit, d_cfd, d_kept, d_hitrec, dbg_env ? static_cast<uint32_t>(atoi(dbg_env)) : 0u);
+                       d_mit, d_cfd, d_kept, d_hitrec);
 }
 
 } // namespace issl
