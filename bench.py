@@ -30,6 +30,7 @@ sys.path.insert(0, str(ROOT / "tests"))
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s HBM3E spec peak
+VALU_BOUND_CMP_PER_S = 1024 * 2.1e9 / 2 / 62 * 2048  # 35.5 T comparisons/s, see DESIGN.md section 3
 
 
 def log(*a):
@@ -260,6 +261,10 @@ def main():
                 "algorithmic_bytes_per_launch": algo_bytes,
                 "avg_launch_ms": scan_avg_ms,
                 "comparisons_per_launch": st["candidates"],
+                # the bound that actually applies at this batch size: 62 VALU wave-instructions per 2048 comparisons,
+                # 2 cycles each on a SIMD-32, 1024 SIMDs at the 2.1 GHz the chip holds under this load
+                "valu_bound_comparisons_per_s": VALU_BOUND_CMP_PER_S,
+                "valu_frac": st["candidates"] / (scan_avg_ms * 1e-3) / VALU_BOUND_CMP_PER_S,
                 "note": "algorithmic bytes = 8 B x (guide,candidate) comparisons, no credit for cross-guide reuse; "
                         "the kernel streams each bucket tile once for all guides of the bucket (4 B/candidate), so "
                         "achieved can exceed the HBM peak: then the scan is VALU-bound, see DESIGN.md",
