@@ -230,18 +230,6 @@ __device__ __forceinline__ RangeStart range_start_of(const ScanItem *__restrict_
     return out;
 }
 
-// First tile of every cost range: range r owns the tiles whose start cost lies in [lo(r), lo(r+1)).
-// Done once here so that the scan waves neither divide nor search.
-__global__ __launch_bounds__(256) void k_ranges(const PlanInfo *__restrict__ plan, const ScanItem *__restrict__ items,
-                                                RangeStart *__restrict__ starts)
-{
-    short_kernel_priority();
-    const uint32_t n_ranges = plan->n_ranges;
-    const uint32_t r = blockIdx.x * 256 + threadIdx.x;
-    if (r > n_ranges || n_ranges == 0) return;
-    starts[r] = range_start_of(items, plan->n_items, plan->total_cost, n_ranges, r);
-}
-
 // One block: lay out the bucket-sorted guide arrays and the list of scan items.
 __global__ __launch_bounds__(256) void k_plan(ImageView v, uint32_t *__restrict__ ng, uint32_t *__restrict__ gfill,
                                               uint32_t *__restrict__ gstart, ScanItem *__restrict__ items,
@@ -323,9 +311,21 @@ __global__ __launch_bounds__(256) void k_guide_scatter(const uint64_t *__restric
                                                        uint32_t slice_width, uint32_t n_slices,
                                                        uint32_t n_buckets, const uint32_t *__restrict__ gstart,
                                                        uint32_t *__restrict__ gfill, uint32_t *__restrict__ gword,
-                                                       uint32_t *__restrict__ gidx, uint32_t *__restrict__ gbucket)
+                                                       uint32_t *__restrict__ gidx, uint32_t *__restrict__ gbucket,
+                                                       uint32_t guide_blocks, const PlanInfo *__restrict__ plan,
+                                                       const ScanItem *__restrict__ items,
+                                                       RangeStart *__restrict__ starts)
 {
     short_kernel_priority();
+    if (blockIdx.x >= guide_blocks) {
+        // the workgroups behind the guides resolve the cost ranges of the scan (independent of the scatter; one launch
+        // less).  First tile of every range: range r owns the tiles whose start cost lies in [lo(r), lo(r+1)); done
+        // once here so that the scan waves neither divide nor search.
+        const uint32_t n_ranges = plan->n_ranges;
+        const uint32_t r = (blockIdx.x - guide_blocks) * 256 + threadIdx.x;
+        if (r <= n_ranges && n_ranges != 0) starts[r] = range_start_of(items, plan->n_items, plan->total_cost, n_ranges, r);
+        return;
+    }
     __shared__ uint32_t hist[kMaxBuckets];
     __shared__ uint32_t base[kMaxBuckets];
     for (uint32_t b = threadIdx.x; b < n_buckets; b += 256) hist[b] = 0;
@@ -381,7 +381,7 @@ void launch_bin_guides(const ImageView &v, const Workspace &ws, const uint64_t *
     // slots in use: 8-padded guides per bucket, at most n * slices + 8 * buckets
     const uint32_t n_slots = static_cast<uint32_t>(
         std::min<size_t>(ws.cap_gslots, static_cast<size_t>(n) * v.n_slices + static_cast<size_t>(kGuideGroup) * nb));
-    // four launches: histogram (+ resets), plan, scatter, ranges
+    // three launches: histogram (+ resets), plan, scatter (+ ranges)
     const uint32_t blocks = (n + 255u) / 256u;
     const uint32_t reset_blocks = std::min<uint32_t>(1024u, (std::max(n_slots, nb) + 255u) / 256u);
     hipLaunchKernelGGL(k_guide_hist, dim3(std::max(blocks, reset_blocks)), dim3(256), 0, stream, ws, d_guides, n,
@@ -394,9 +394,9 @@ void launch_bin_guides(const ImageView &v, const Workspace &ws, const uint64_t *
     }
     hipLaunchKernelGGL(k_plan, dim3(1), dim3(256), 0, stream, v, ws.ng, ws.gfill, ws.gstart, ws.items,
                        static_cast<uint32_t>(ws.cap_items), ws.plan, item_guides, scan_blocks());
-    hipLaunchKernelGGL(k_guide_scatter, dim3(blocks), dim3(256), 0, stream, d_guides, n, v.slice_width, v.n_slices,
-                       nb, ws.gstart, ws.gfill, ws.gword, ws.gidx, ws.gbucket);
-    hipLaunchKernelGGL(k_ranges, dim3((scan_blocks() + 1 + 255) / 256), dim3(256), 0, stream, ws.plan, ws.items,
+    const uint32_t range_blocks = (scan_blocks() + 1u + 255u) / 256u;
+    hipLaunchKernelGGL(k_guide_scatter, dim3(blocks + range_blocks), dim3(256), 0, stream, d_guides, n, v.slice_width,
+                       v.n_slices, nb, ws.gstart, ws.gfill, ws.gword, ws.gidx, ws.gbucket, blocks, ws.plan, ws.items,
                        ws.range_start);
 }
 
