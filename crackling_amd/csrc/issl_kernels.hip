@@ -173,22 +173,34 @@ __global__ __launch_bounds__(256) void k_guide_hist(Workspace ws, const uint64_t
             if (hist[b]) atomicAdd(&ws.ng[b], hist[b]);
 }
 
-// Exclusive scan of one uint64 per thread over a 256-thread block.
-__device__ inline uint64_t block_exclusive_scan(uint64_t v, uint64_t *lds /*[256]*/, uint64_t *total)
+// Exclusive scan of one uint64 per thread over a 256-thread block: shuffles inside the four waves, one LDS
+// exchange across them (two barriers instead of the seventeen of a Hillis-Steele scan through LDS).
+__device__ inline uint64_t wave_inclusive_scan_u64(uint64_t x)
 {
-    const uint32_t t = threadIdx.x;
-    lds[t] = v;
-    __syncthreads();
-    for (uint32_t d = 1; d < 256; d <<= 1) {
-        const uint64_t add = (t >= d) ? lds[t - d] : 0;
-        __syncthreads();
-        lds[t] += add;
-        __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint32_t d = 1; d < 64; d <<= 1) {
+        const uint32_t lo = __shfl_up(static_cast<uint32_t>(x), d, 64);
+        const uint32_t hi = __shfl_up(static_cast<uint32_t>(x >> 32), d, 64);
+        if (lane >= d) x += (static_cast<uint64_t>(hi) << 32) | lo;
     }
-    const uint64_t incl = lds[t];
-    if (total) *total = lds[255];
+    return x;
+}
+
+__device__ inline uint64_t block_exclusive_scan(uint64_t v, uint64_t *lds /*[256], 4 used*/, uint64_t *total)
+{
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint64_t incl = wave_inclusive_scan_u64(v);
+    if (lane == 63) lds[wave] = incl;
     __syncthreads();
-    return incl - v;
+    uint64_t before = 0, all = 0;
+    for (uint32_t w = 0; w < 4; ++w) {
+        const uint64_t s = lds[w];
+        if (w < wave) before += s;
+        all += s;
+    }
+    if (total) *total = all;
+    __syncthreads();
+    return before + incl - v;
 }
 
 // Start of cost range r of n_ranges (r == n_ranges: the end marker).
