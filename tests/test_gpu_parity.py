@@ -307,9 +307,18 @@ def test_guides_with_thousands_of_hits(tmp_path):
     sites = neighbours(centres[0], 6000, 4) | neighbours(centres[1], 1500, 3) | neighbours(centres[2], 40, 2)
     centres = np.append(centres, rng.integers(0, 1 << 40, dtype=np.uint64))
     sites |= neighbours(centres[3], 300, 3)  # 64 < hits <= 512: the LDS sort
+    # one guide whose hits almost all sit in ONE slice list (substitutions outside the first four bases only):
+    # more than 7680 in slice 0, the length beyond which k_replay_big sorts in HBM instead of LDS
+    centres = np.append(centres, rng.integers(0, 1 << 40, dtype=np.uint64))
+    wide = set()
+    while len(wide) < 9000:
+        s = int(centres[4])
+        for p in rng.choice(16, size=int(rng.integers(1, 5)), replace=False):
+            s ^= int(rng.integers(1, 4)) << (2 * (4 + int(p)))
+        wide.add(s)
+    sites |= wide
     sites |= set(int(x) for x in rng.integers(0, 1 << 40, size=20000, dtype=np.uint64))
     sig = np.array(sorted(sites), dtype=np.uint64)
-    from synth import text_order_key
     sig = sig[np.argsort(text_order_key(sig), kind="stable")]
     occ = rng.integers(1, 4, size=len(sig)).astype(np.uint32)
     ix = ca.IsslIndex.build_from_sites(sig, occ)
@@ -329,6 +338,7 @@ def test_guides_with_thousands_of_hits(tmp_path):
     assert np.array_equal(hits, ohits)
     per_guide = np.bincount(hits[:, 0], minlength=len(guides))
     assert per_guide.max() > 2048 and per_guide[1] > 512 and 64 < per_guide[3] <= 512 and per_guide[2] <= 64
+    assert np.count_nonzero((hits[:, 0] == 4) & (hits[:, 1] == 0)) > 7680  # the HBM sort of one slice
     ix.close()
 
 
