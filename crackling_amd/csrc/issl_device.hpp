@@ -81,7 +81,7 @@ constexpr uint32_t kItemGuides = 512;  // guides per scan item (bounds one tile'
 constexpr uint32_t kTileFixedCost = 4; // cost of fetching a tile, in guide-comparisons of that tile
 constexpr uint32_t kNoGuide = 0xFFFFFFFFu;
 constexpr uint32_t kPadGuideWord = 0xFFFFFFFFu; // scan word of padding guide slots: 16 x T, distance 16 from tile padding
-constexpr uint32_t kScanGridBlocks = 256u * 2u; // scan launch: 256 CUs x 2 workgroups of 16 waves
+constexpr uint32_t kScanGridBlocks = 256u * 4u; // scan launch: 256 CUs x 2 resident workgroups of 16 waves, two rounds
 constexpr uint32_t kScanMaxBlocks = 8192u;       // upper bound of the ISSL_SCAN_BLOCKS knob
 constexpr uint32_t kScanWaves = kScanMaxBlocks * 16u;
 constexpr uint32_t kMaxRanges = kScanMaxBlocks;  // one equal-cost range per workgroup
@@ -139,7 +139,7 @@ struct Workspace {
     uint64_t *raw = nullptr;     // [(cap_chunks+1) * kChunkRecs] raw records of the scan, chunked
     size_t cap_chunks = 0;
     Counters *counters = nullptr;
-    unsigned long long *stamps = nullptr; // [2 * kScanWaves] wave start/end ticks (ISSL_SCAN_STAMPS diagnostics)
+    unsigned long long *stamps = nullptr; // [4 * kScanWaves] scan wave clocks, then replay phase clocks (ISSL_SCAN_STAMPS diagnostics)
     uint32_t *sticky = nullptr;  // [4] survives the per-batch resets: [0] raw overflow seen, [1] max chunks asked, [2] plan errors
     uint64_t *sorted = nullptr;  // [hit_cap] keys guide<<35 | slice<<32 | pos, grouped by guide
     uint32_t *gcount = nullptr;  // [G+1] hits per guide

@@ -375,7 +375,7 @@ __global__ __launch_bounds__(256) void k_guide_scatter(const uint64_t *__restric
     }
 }
 
-// Workgroups of the scan launch: two 16-wave workgroups per CU by default.  ISSL_SCAN_BLOCKS=<n> (<= kScanMaxBlocks)
+// Workgroups of the scan launch: 1024 by default (two 16-wave workgroups resident per CU).  ISSL_SCAN_BLOCKS=<n> (<= kScanMaxBlocks)
 // is a tuning knob.
 uint32_t scan_blocks()
 {
