@@ -651,6 +651,10 @@ __global__ __launch_bounds__(1024, 8) void k_scan(const uint32_t *__restrict__ s
     }
 }
 
+// Workgroups of the two passes over the raw chunks (one chunk per workgroup and step): enough of them that the
+// ~16 k first chunks of the scan waves are all in flight at once -- the passes are chains of dependent loads.
+constexpr uint32_t kTailGrid = 16384;
+
 // Exact check of the raw records, IN PLACE: one thread per record, one chunk per 128-thread workgroup.
 // A record that survives is overwritten by its final key guide<<35 | slice<<32 | position-in-bucket,
 // every other slot by kDeadKey; the per-guide hit counts are accumulated for the grouping pass.
@@ -759,7 +763,7 @@ void launch_scan(const ImageView &v, const Workspace &ws, const uint64_t *d_guid
 void launch_verify(const ImageView &v, const Workspace &ws, const uint64_t *d_guides, int max_dist, void *stream)
 {
     if (max_dist < 0) return;
-    hipLaunchKernelGGL(k_verify, dim3(4096), dim3(kChunkRecs), 0, static_cast<hipStream_t>(stream), v, ws, d_guides,
+    hipLaunchKernelGGL(k_verify, dim3(kTailGrid), dim3(kChunkRecs), 0, static_cast<hipStream_t>(stream), v, ws, d_guides,
                        max_dist);
 }
 
@@ -897,7 +901,7 @@ void launch_group_hits(const Workspace &ws, uint32_t n, void *stream_)
         hipLaunchKernelGGL(k_prefix_apply, dim3(blocks), dim3(256), 0, stream, ws.gcount, m, ws.blocksum, ws.goff,
                            ws.gcur_big, ws.counters);
     }
-    hipLaunchKernelGGL(k_group_scatter, dim3(4096), dim3(kChunkRecs), 0, stream, ws.raw, ws.counters,
+    hipLaunchKernelGGL(k_group_scatter, dim3(kTailGrid), dim3(kChunkRecs), 0, stream, ws.raw, ws.counters,
                        static_cast<uint32_t>(ws.cap_chunks), ws.goff, reinterpret_cast<const uint32_t *>(ws.terms),
                        ws.sorted);
 }
