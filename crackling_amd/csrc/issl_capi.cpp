@@ -960,10 +960,10 @@ int issl_score(issl_index *idx, const uint64_t *guides, size_t n, int max_dist, 
     // that up front, which saves the first large batch on an index its grow-and-rerun round, and a piece ends
     // early when its estimate would not fit a quarter of the free HBM.  Denser data still grows the buffers.
     const size_t piece = size_t(1) << 22;
-    const bool presize = !std::getenv("ISSL_RAW_CHUNKS");
+    const bool presize = !std::getenv("ISSL_RAW_CHUNKS") && n >= (size_t(1) << 15); // small pages: the default buffers do
     const double records_per_comparison = 8e-5;
     size_t free_b = 0, total_b = 0;
-    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    if (presize) HIP_TRY(hipMemGetInfo(&free_b, &total_b));
     const double budget_slots = std::max<double>(static_cast<double>(idx->lanes[0].ws.cap_chunks) * (kChunkRecs - 1),
                                                  static_cast<double>(std::min<size_t>(free_b / 4, size_t(32) << 30)) / 32.0);
     const uint64_t per = idx->geo.buckets_per_slice();
@@ -971,7 +971,8 @@ int issl_score(issl_index *idx, const uint64_t *guides, size_t n, int max_dist, 
     for (size_t at = 0; at < n;) {
         uint64_t cand = 0;
         size_t cnt = 0;
-        while (at + cnt < n && cnt < piece) {
+        if (!presize) cnt = std::min(piece, n - at);
+        while (presize && at + cnt < n && cnt < piece) {
             uint64_t c = 0;
             for (uint64_t sl = 0; sl < idx->geo.n_slices; ++sl)
                 c += idx->bucket_sizes[sl * per + ((guides[at + cnt] >> (idx->geo.slice_width * sl)) & (per - 1))];
