@@ -95,6 +95,7 @@ struct Lane {
     bool ready = false;         // events and stream created
     uint32_t last_n = 0;
     uint32_t pending = 0;       // batches enqueued on this lane since the last finish
+    bool staged = true;         // the lane's last batch recorded its stage events
 };
 
 struct issl_index {
@@ -430,8 +431,12 @@ static int new_index_from_host(std::unique_ptr<HostIndex> h, issl_index **out)
 // The scoring pipeline.  Guides and outputs are device pointers on ix->device.
 // enqueue_batch() only launches (no host round trip); finish_batches() synchronises, checks the sticky overflow
 // words the pipelines leave behind, and fills the statistics.
+// `staged`: record an event at every stage boundary (bin / scan / verify / group / replay times in issl_stats).  An event
+// record costs ~4 us of stream time on MI355X -- 5 % of a 10 k-guide batch for the six of them -- so the asynchronous
+// back-to-back path records only the pair around the scan and the end of the batch unless ISSL_STAGE_TIMING=1.
 static int enqueue_batch(issl_index *ix, Lane &lane, hipStream_t stream, const uint64_t *d_guides, size_t n,
-                         int max_dist, double threshold, int method, double *d_mit, double *d_cfd, bool dump)
+                         int max_dist, double threshold, int method, double *d_mit, double *d_cfd, bool dump,
+                         bool staged)
 {
     if (!ix->d_image) {
         set_error("index has no device image: call issl_index_upload first");
@@ -461,10 +466,12 @@ static int enqueue_batch(issl_index *ix, Lane &lane, hipStream_t stream, const u
     p.maximum_sum = (10000.0 - threshold * 100) / threshold; // isslScoreOfftargets.cpp:326
     const uint32_t n32 = static_cast<uint32_t>(n);
     const uint32_t slot = ix->n_pending % kRing;
-    HIP_TRY(hipEventRecord(lane.ev[0], stream));
+    const bool other_stream_scan = ix->scan_stream && stream == lane.stream;
+    lane.staged = staged;
+    if (staged) HIP_TRY(hipEventRecord(lane.ev[0], stream));
     launch_bin_guides(ix->view, ws, d_guides, n32, stream);
-    HIP_TRY(hipEventRecord(lane.ev[1], stream));
-    if (ix->scan_stream && stream == lane.stream) {
+    if (staged || other_stream_scan) HIP_TRY(hipEventRecord(lane.ev[1], stream));
+    if (other_stream_scan) {
         // scans of both lanes run one after the other on the high-priority stream
         HIP_TRY(hipStreamWaitEvent(ix->scan_stream, lane.ev[1], 0));
         HIP_TRY(hipEventRecord(ix->ring[2 * slot], ix->scan_stream));
@@ -476,16 +483,15 @@ static int enqueue_batch(issl_index *ix, Lane &lane, hipStream_t stream, const u
         HIP_TRY(hipEventRecord(ix->ring[2 * slot], stream));
         launch_scan(ix->view, ws, d_guides, n32, max_dist, stream);
         HIP_TRY(hipEventRecord(ix->ring[2 * slot + 1], stream));
-        HIP_TRY(hipEventRecord(lane.scan_done, stream));
     }
-    HIP_TRY(hipEventRecord(lane.ev[2], stream));
+    if (staged) HIP_TRY(hipEventRecord(lane.ev[2], stream));
     launch_verify(ix->view, ws, d_guides, max_dist, stream);
-    HIP_TRY(hipEventRecord(lane.ev[3], stream));
+    if (staged) HIP_TRY(hipEventRecord(lane.ev[3], stream));
     launch_group_hits(ws, n32, stream);
-    HIP_TRY(hipEventRecord(lane.ev[4], stream));
+    if (staged) HIP_TRY(hipEventRecord(lane.ev[4], stream));
     launch_replay(ix->view, ws, d_guides, n32, p, d_mit, d_cfd, dump ? ws.d_kept : nullptr,
                   dump ? ws.d_hitrec : nullptr, stream);
-    HIP_TRY(hipEventRecord(lane.ev[5], stream));
+    if (staged) HIP_TRY(hipEventRecord(lane.ev[5], stream));
     HIP_TRY(hipEventRecord(lane.done, stream));
     ix->n_pending += 1;
     lane.pending += 1;
@@ -539,7 +545,8 @@ static int finish_batches(issl_index *ix, hipStream_t stream)
     HIP_TRY(hipMemcpy(&pl, last.ws.plan, sizeof pl, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(&total_hits, last.ws.goff + last.last_n, sizeof total_hits, hipMemcpyDeviceToHost));
     float ms[5] = {0, 0, 0, 0, 0};
-    for (int i = 0; i < 5; ++i) (void)hipEventElapsedTime(&ms[i], last.ev[i], last.ev[i + 1]);
+    if (last.staged)
+        for (int i = 0; i < 5; ++i) (void)hipEventElapsedTime(&ms[i], last.ev[i], last.ev[i + 1]);
     double scan_sum = 0.0;
     const uint32_t have = batches < kRing ? batches : kRing;
     for (uint32_t i = 0; i < have; ++i) {
@@ -581,7 +588,7 @@ static int score_core(issl_index *ix, const uint64_t *d_guides, size_t n, int ma
     ix->stats.n_guides = n;
     if (n == 0) return ISSL_OK;
     for (int attempt = 0;; ++attempt) {
-        rc = enqueue_batch(ix, ix->lanes[0], stream, d_guides, n, max_dist, threshold, method, d_mit, d_cfd, dump);
+        rc = enqueue_batch(ix, ix->lanes[0], stream, d_guides, n, max_dist, threshold, method, d_mit, d_cfd, dump, true);
         if (rc) return rc;
         rc = finish_batches(ix, stream);
         if (rc == ISSL_OK) {
@@ -928,7 +935,9 @@ int issl_score_device_async(issl_index *idx, const uint64_t *d_guides, size_t n,
         HIP_TRY(hipEventRecord(lane.ev[0], static_cast<hipStream_t>(stream)));
         HIP_TRY(hipStreamWaitEvent(lane.stream, lane.ev[0], 0));
     }
-    return enqueue_batch(idx, lane, lane.stream, d_guides, n, max_dist, threshold, method, d_mit, d_cfd, false);
+    const char *st_env = std::getenv("ISSL_STAGE_TIMING");
+    return enqueue_batch(idx, lane, lane.stream, d_guides, n, max_dist, threshold, method, d_mit, d_cfd, false,
+                         st_env && st_env[0] == '1');
 }
 
 int issl_score_wait(issl_index *idx, void *stream)

@@ -69,7 +69,10 @@ typedef struct {
     uint32_t occ;   /* occurrences = high 32 bits of the entry, :348 */
 } issl_hit;
 
-/* Timings and counters of the last issl_score* call on an index (milliseconds, GPU events). */
+/* Timings and counters of the last issl_score* call on an index (milliseconds, GPU events).  ms_scan is always
+ * measured (mean over the batches since the last finish); the other stage times and ms_total are filled by the
+ * synchronous entry points, and by issl_score_device_async only when ISSL_STAGE_TIMING=1 is set (every event record
+ * costs ~4 us of stream time, which back-to-back batches should not pay). */
 typedef struct {
     uint64_t n_guides;
     uint64_t candidates;    /* sum over guides of the 5 bucket lengths = comparisons done */
