@@ -925,9 +925,9 @@ int issl_score_device_async(issl_index *idx, const uint64_t *d_guides, size_t n,
     HIP_TRY(hipSetDevice(idx->device));
     // One lane by default: batches run back to back on one internal stream.  ISSL_LANES=2|3 rotates through several
     // lanes (workspace + low-priority stream each, every scan on one shared high-priority stream) so that the short
-    // kernels of a batch run in the shadow of the next scan.  Measured on MI355X at 10 k guides per batch: 0.52-0.55 ms
-    // per step against 0.55-0.56 with one lane -- the scan it shadows slows from 0.40 to 0.50 ms, which eats most of
-    // the hidden 0.15 ms -- so one lane stays the default and this an experiment switch.
+    // kernels of a batch run in the shadow of the next scan.  Measured on MI355X at 10 k guides per batch: 0.54 ms per
+    // step against 0.50 with one lane -- the scan it shadows slows from 0.39 to 0.52 ms, more than the 0.11 ms that are
+    // hidden -- so one lane stays the default and this an experiment switch.
     Lane &lane = idx->lanes[idx->n_pending % lane_count()];
     int rc = ensure_workspace(idx, lane, n); // creates the lane's stream on first use
     if (rc) return rc;
