@@ -28,13 +28,16 @@ def _torch_first():
         torch.cuda.synchronize()
 
 
-@pytest.fixture(scope="session", autouse=True)
-def _built():
-    """Product library + oracle (checker) must exist; build them if the tree is fresh."""
+def _ensure_built():
+    """Product library + oracle (checker) must exist; build them if the tree is fresh.  Runs when conftest is imported,
+    i.e. before the test modules (which import crackling_amd at their top) are collected."""
     if not (ROOT / "crackling_amd" / "libissl_hip.so").exists() or not (ROOT / "bin" / "isslScoreOfftargets").exists():
         subprocess.run(["make", "-C", str(ROOT)], check=True, capture_output=True)
     if not (ROOT / "oracle" / "_build" / "liboracle.so").exists():
         subprocess.run(["make", "-C", str(ROOT / "oracle"), "all"], check=True, capture_output=True)
+
+
+_ensure_built()
 
 
 GOLDEN_SETS = ["uniform", "clustered", "edge"]
