@@ -23,7 +23,8 @@ namespace issl {
 
 static uint64_t align256(uint64_t x) { return (x + 255ull) & ~255ull; }
 
-void layout_image(ImageHeader &h, const Geometry &g, uint64_t n_scores_unique, uint64_t n_tiles, bool dense_mit)
+void layout_image(ImageHeader &h, const Geometry &g, uint64_t n_scores_unique, uint64_t n_tiles, bool dense_mit,
+                  bool inline_sigs)
 {
     std::memset(&h, 0, sizeof h);
     h.magic = kImageMagic;
@@ -48,6 +49,7 @@ void layout_image(ImageHeader &h, const Geometry &g, uint64_t n_scores_unique, u
     h.off_sites = off;        off = align256(off + 8 * g.n_sites);
     h.off_entries = off;      off = align256(off + 8 * g.n_sites * g.n_slices);
     h.off_scan = off;         off = align256(off + 4ull * kTileCands * n_tiles);
+    if (inline_sigs) { h.off_esig = off; off = align256(off + 8 * g.n_sites * g.n_slices); }
     h.total_bytes = off;
 }
 
@@ -62,6 +64,7 @@ ImageView make_view(const ImageHeader &h, void *base)
     v.mit_dense = h.off_mit_dense ? reinterpret_cast<const double *>(p + h.off_mit_dense) : nullptr;
     v.sites = reinterpret_cast<const uint64_t *>(p + h.off_sites);
     v.entries = reinterpret_cast<const uint64_t *>(p + h.off_entries);
+    v.esig = h.off_esig ? reinterpret_cast<const uint64_t *>(p + h.off_esig) : nullptr;
     v.scan = reinterpret_cast<const uint32_t *>(p + h.off_scan);
     v.n_sites = h.n_sites;
     v.n_buckets = static_cast<uint32_t>(h.n_buckets);
@@ -363,7 +366,8 @@ static int finish_upload(issl_index *ix, const DeviceBuildInput *dbi = nullptr)
     uint32_t *flag = nullptr;
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&flag), 4));
     HIP_TRY(hipMemset(flag, 0, 4));
-    launch_pack_scan_stream(ix->view, reinterpret_cast<uint32_t *>(base + ix->hdr.off_scan), flag, nullptr);
+    launch_pack_scan_stream(ix->view, reinterpret_cast<uint32_t *>(base + ix->hdr.off_scan),
+                            ix->hdr.off_esig ? reinterpret_cast<uint64_t *>(base + ix->hdr.off_esig) : nullptr, flag, nullptr);
     HIP_TRY(hipGetLastError());
     uint32_t err = 0;
     HIP_TRY(hipMemcpy(&err, flag, 4, hipMemcpyDeviceToHost));
@@ -374,6 +378,14 @@ static int finish_upload(issl_index *ix, const DeviceBuildInput *dbi = nullptr)
         return ISSL_E_FORMAT;
     }
     return ISSL_OK;
+}
+
+// The optional in-list signatures cost 8 B per list entry (40 B per site next to the 68 B of the rest): worth it while
+// the image stays a modest part of the HBM (ISSL_INLINE_SIGS=0/1 overrides).
+static bool want_inline_sigs(const Geometry &g)
+{
+    if (const char *e = std::getenv("ISSL_INLINE_SIGS")) return e[0] == '1';
+    return g.n_sites <= 600000000ull;
 }
 
 static uint64_t count_tiles(const HostIndex &h)
@@ -724,7 +736,7 @@ int issl_index_device_bytes(const issl_index *idx, size_t *out)
     std::vector<double> v;
     idx->host->unique_scores(m, v);
     ImageHeader h;
-    layout_image(h, idx->geo, m.size(), count_tiles(*idx->host), masks_are_dense(m));
+    layout_image(h, idx->geo, m.size(), count_tiles(*idx->host), masks_are_dense(m), want_inline_sigs(idx->geo));
     *out = h.total_bytes;
     return ISSL_OK;
 }
@@ -752,7 +764,7 @@ static int upload_common(issl_index *idx, int device, void *buf, size_t bytes, c
     std::vector<uint64_t> m;
     std::vector<double> v;
     idx->host->unique_scores(m, v);
-    layout_image(idx->hdr, idx->geo, m.size(), count_tiles(*idx->host), masks_are_dense(m));
+    layout_image(idx->hdr, idx->geo, m.size(), count_tiles(*idx->host), masks_are_dense(m), want_inline_sigs(idx->geo));
     idx->device = device;
     if (buf) {
         if (bytes < idx->hdr.total_bytes || (reinterpret_cast<uintptr_t>(buf) & 255u)) {

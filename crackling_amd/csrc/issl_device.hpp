@@ -22,12 +22,15 @@ namespace issl {
 //   sites          u64[N]      packed signatures                (:200-204)
 //   entries        u64[N*S]    bucket contents occ<<32|id       (:235-240)
 //   mit_dense      f64[2^20]   local MIT scores indexed by the 20 mismatch flags (when the table allows it)
+//   esig           u64[N*S]    (optional) the signature of the site behind every list entry, in list order: the
+//                              exact check and the replay then need one HBM access per hit instead of two
+//                              dependent ones (entries -> sites); written while the scan stream is packed
 //   scan           u32[tiles*kTileCands]  the scan stream: for every bucket, in bucket order, the
 //                              candidate signature with its own slice removed, 16 positions, even
 //                              bits in the low half-word and odd bits in the high half-word;
 //                              each bucket zero-padded to a whole number of tiles.
 constexpr uint64_t kImageMagic = 0x314C535349444D41ull; // "AMDISSL1"
-constexpr uint32_t kImageVersion = 2;
+constexpr uint32_t kImageVersion = 3;
 constexpr uint32_t kTileCands = 2048; // candidates per scan tile: one wave, 64 lanes x 32 registers
 constexpr uint32_t kHeaderBytes = 4096;
 
@@ -44,6 +47,7 @@ struct ImageHeader {
     uint64_t off_bucket_start, off_tile_first, off_score_mask, off_score_val, off_sites, off_entries,
         off_scan;
     uint64_t off_mit_dense; // 0: absent (table holds masks outside the 20 even bits)
+    uint64_t off_esig;      // 0: absent (large indexes: +8 B per list entry do not pay for themselves in HBM)
 };
 static_assert(sizeof(ImageHeader) <= kHeaderBytes, "header must fit its block");
 
@@ -56,6 +60,7 @@ struct ImageView {
     const double *mit_dense; // 2^20 doubles indexed by the 20 mismatch flags, or null
     const uint64_t *sites;
     const uint64_t *entries;
+    const uint64_t *esig; // signature of the site behind every list entry, in list order, or null
     const uint32_t *scan;
     uint64_t n_sites;
     uint32_t n_buckets;
@@ -67,7 +72,8 @@ struct ImageView {
 
 // Layout computation shared by upload and attach.  Fills every field of `h` from the geometry,
 // the number of unique scores and the bucket sizes (sizes may be null when n_tiles is given).
-void layout_image(ImageHeader &h, const Geometry &g, uint64_t n_scores_unique, uint64_t n_tiles, bool dense_mit);
+void layout_image(ImageHeader &h, const Geometry &g, uint64_t n_scores_unique, uint64_t n_tiles, bool dense_mit,
+                  bool inline_sigs);
 ImageView make_view(const ImageHeader &h, void *base);
 
 // Slice lists built on the device (issl_build.hip): d_entries[s * n_sites + k] for the n_slices slices, from the site
@@ -166,7 +172,7 @@ struct ScoreParams {
 };
 
 // Launchers (issl_kernels.hip).  All asynchronous on `stream`.
-void launch_pack_scan_stream(const ImageView &v, uint32_t *scan_out, uint32_t *error_flag, void *stream);
+void launch_pack_scan_stream(const ImageView &v, uint32_t *scan_out, uint64_t *esig_out, uint32_t *error_flag, void *stream);
 void launch_bin_guides(const ImageView &v, const Workspace &ws, const uint64_t *d_guides, uint32_t n, void *stream);
 void launch_scan(const ImageView &v, const Workspace &ws, const uint64_t *d_guides, uint32_t n, int max_dist,
                  void *stream);

@@ -80,6 +80,7 @@ __host__ __device__ inline uint32_t plane_word(uint32_t r, uint32_t group)
 // ------------------------------------------------------------------------------------------------
 
 __global__ __launch_bounds__(256) void k_pack_scan_stream(ImageView v, uint32_t *__restrict__ scan_out,
+                                                          uint64_t *__restrict__ esig_out,
                                                           uint32_t *__restrict__ error_flag)
 {
     for (uint32_t t = blockIdx.x; t < v.n_tiles; t += gridDim.x) {
@@ -106,8 +107,13 @@ __global__ __launch_bounds__(256) void k_pack_scan_stream(ImageView v, uint32_t 
             if (pos < len) {
                 const uint64_t e = v.entries[start + pos];
                 const uint64_t id = e & 0xFFFFFFFFull;
-                if (id < v.n_sites) w = scan_word(v.sites[id], slice);
-                else atomicOr(error_flag, 1u);
+                if (id < v.n_sites) {
+                    const uint64_t sig = v.sites[id];
+                    w = scan_word(sig, slice);
+                    if (esig_out) esig_out[start + pos] = sig;
+                } else {
+                    atomicOr(error_flag, 1u);
+                }
             }
             uint32_t mine_lo = 0, mine_hi = 0;
             for (uint32_t r = 0; r < 32; ++r) {
@@ -123,12 +129,13 @@ __global__ __launch_bounds__(256) void k_pack_scan_stream(ImageView v, uint32_t 
     }
 }
 
-void launch_pack_scan_stream(const ImageView &v, uint32_t *scan_out, uint32_t *error_flag, void *stream)
+void launch_pack_scan_stream(const ImageView &v, uint32_t *scan_out, uint64_t *esig_out, uint32_t *error_flag,
+                             void *stream)
 {
     if (v.n_tiles == 0) return;
     const uint32_t grid = v.n_tiles < 65536u ? v.n_tiles : 65536u;
     hipLaunchKernelGGL(k_pack_scan_stream, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), v,
-                       scan_out, error_flag);
+                       scan_out, esig_out, error_flag);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -689,8 +696,7 @@ __global__ __launch_bounds__(kChunkRecs) void k_verify(ImageView v, Workspace ws
             const uint64_t pos = static_cast<uint64_t>(tile - v.tile_first[bucket]) * kTileCands + offset;
             if (pos < len) { // else: zero padding of the bucket's last tile
                 const uint64_t gsig = guides[guide];
-                const uint64_t entry = v.entries[start + pos];
-                const uint64_t ot = v.sites[entry & 0xFFFFFFFFull];
+                const uint64_t ot = v.esig ? v.esig[start + pos] : v.sites[v.entries[start + pos] & 0xFFFFFFFFull];
                 if (__builtin_popcountll(mismatch_mask(gsig, ot)) <= max_dist) { // exact, full signatures (:376-382)
                     // First-matching-slice rule (equivalent of the seen bitmap, isslScoreOfftargets.cpp:385-390,463):
                     // the site was already met iff an earlier slice of the XOR is all zero.
@@ -1016,10 +1022,11 @@ __device__ inline HitTerms hit_terms(const ImageView &v, uint64_t gsig, uint32_t
     const uint32_t slice = static_cast<uint32_t>(key >> 32) & 7u;
     const uint32_t pos = static_cast<uint32_t>(key);
     const uint32_t bucket = (slice << v.slice_width) + static_cast<uint32_t>((gsig >> (v.slice_width * slice)) & low);
-    const uint64_t e = v.entries[v.bucket_start[bucket] + pos];
+    const uint64_t at = v.bucket_start[bucket] + pos;
+    const uint64_t e = v.entries[at];
     const uint32_t id = static_cast<uint32_t>(e);
     const uint32_t occ = static_cast<uint32_t>(e >> 32);
-    const uint64_t ot = v.sites[id];
+    const uint64_t ot = v.esig ? v.esig[at] : v.sites[id]; // independent of `e` when the in-list copy exists
     const uint64_t mm = mismatch_mask(gsig, ot);
     const int dist = __builtin_popcountll(mm);
     if (calc_mit && dist > 0) t.mit = mit_lookup(v, mm) * static_cast<double>(occ); // :394
