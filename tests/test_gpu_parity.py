@@ -606,3 +606,29 @@ def test_random_small_indexes_differential():
                 assert np.array_equal(cfd.view(np.uint64), ocfd.view(np.uint64)), (trial, method, thr, dist)
             oracle.close()
             ix.close()
+
+
+def test_image_without_inline_signatures(golden, monkeypatch):
+    """Indexes above 600 M sites leave the optional in-list signature section out of the image (verify and replay then
+    go entries -> sites); force that layout on the golden indexes: smaller image, same stdout, same hit lists."""
+    guides = ca.encode_guides(golden.guides)
+    with_sigs = ca.IsslIndex.open(golden.issl)
+    n_with = with_sigs.device_bytes()
+    with_sigs.close()
+    monkeypatch.setenv("ISSL_INLINE_SIGS", "0")
+    ix = ca.IsslIndex.open(golden.issl)
+    assert ix.device_bytes() < n_with
+    ix.upload(0)
+    for key in ("and|75|4", "or|0|4", "cfd|75|2"):
+        if key not in golden.expected:
+            continue
+        method, thr, dist = key.split("|")
+        mit, cfd = ix.score(guides, int(dist), float(thr), method)
+        assert ca.format_scores(guides, mit, cfd, method) == golden.expected[key], key
+    hits = ix.dump_hits(guides, 4, 0.0, "and")
+    ix.close()
+    monkeypatch.setenv("ISSL_INLINE_SIGS", "1")
+    ix = ca.IsslIndex.open(golden.issl).upload(0)
+    assert ix.device_bytes() == n_with
+    assert np.array_equal(ix.dump_hits(guides, 4, 0.0, "and"), hits)
+    ix.close()
