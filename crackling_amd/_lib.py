@@ -56,6 +56,7 @@ class Stats(C.Structure):
         ("n_guides", C.c_uint64), ("candidates", C.c_uint64), ("hits", C.c_uint64), ("scan_tiles", C.c_uint64),
         ("ms_bin", C.c_double), ("ms_scan", C.c_double), ("ms_verify", C.c_double), ("ms_group", C.c_double),
         ("ms_replay", C.c_double), ("ms_total", C.c_double), ("scan_launches", C.c_uint64), ("raw_records", C.c_uint64), ("n_batches", C.c_uint64),
+        ("planned_comparisons", C.c_uint64),
     ]
 
 
@@ -85,6 +86,10 @@ _protos = {
     "issl_index_upload_into": (C.c_int, [_P, C.c_int, _P, C.c_size_t]),
     "issl_index_attach_image": (C.c_int, [C.c_int, _P, C.c_size_t, C.POINTER(_P)]),
     "issl_index_image": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_size_t)]),
+    "issl_index_cold": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_size_t)]),
+    "issl_index_attach_image_cold": (C.c_int, [C.c_int, _P, C.c_size_t, _P, C.c_size_t, C.POINTER(_P)]),
+    "issl_index_set_option": (C.c_int, [_P, C.c_char_p, C.c_char_p]),
+    "issl_index_get_option": (C.c_int, [_P, C.c_char_p, C.POINTER(C.c_longlong)]),
     "issl_encode_guides": (C.c_int, [C.c_char_p, C.c_size_t, C.c_size_t, C.c_size_t, _P]),
     "issl_decode_guide": (C.c_int, [C.c_uint64, C.c_size_t, C.c_char_p]),
     "issl_read_query_file": (C.c_int, [C.c_char_p, C.c_size_t, C.POINTER(_P), C.POINTER(C.c_size_t)]),

@@ -27,8 +27,8 @@ struct SliceEntry {
 
 } // namespace
 
-int launch_build_entries(const uint64_t *d_sites, const uint32_t *d_occ, uint64_t n_sites, uint32_t n_slices,
-                         uint32_t slice_width, uint64_t *d_entries)
+int launch_build_entries(const uint64_t *d_sites, const uint32_t *d_occ, uint64_t n_sites, uint32_t slice_begin,
+                         uint32_t slice_end, uint32_t slice_width, uint64_t *d_entries)
 {
     if (slice_width != 8) { // one pass = one byte of the signature
         set_error("the device-side builder handles 8-bit slices only");
@@ -41,12 +41,12 @@ int launch_build_entries(const uint64_t *d_sites, const uint32_t *d_occ, uint64_
         set_error(std::string("HIP error: ") + hipGetErrorString(e) + " (histograms of the device-side builder)");
         return ISSL_E_DEVICE;
     }
-    for (uint32_t s = 0; s < n_slices; ++s) {
+    for (uint32_t s = slice_begin; s < slice_end; ++s) {
         const uint32_t shift = slice_width * s;
         hipLaunchKernelGGL(k_radix_hist, dim3(n_blocks), dim3(256), 0, nullptr, d_sites, n_sites, shift, d_hist, n_blocks);
         hipLaunchKernelGGL(k_radix_scan, dim3(1), dim3(1024), 0, nullptr, d_hist, 256ull * n_blocks);
         hipLaunchKernelGGL(k_radix_scatter<SliceEntry>, dim3(n_blocks), dim3(256), 0, nullptr, d_sites,
-                           d_entries + static_cast<uint64_t>(s) * n_sites, n_sites, shift, d_hist, n_blocks,
+                           d_entries + static_cast<uint64_t>(s - slice_begin) * n_sites, n_sites, shift, d_hist, n_blocks,
                            SliceEntry{d_occ});
     }
     e = hipDeviceSynchronize();

@@ -24,7 +24,7 @@ namespace issl {
 static uint64_t align256(uint64_t x) { return (x + 255ull) & ~255ull; }
 
 void layout_image(ImageHeader &h, const Geometry &g, uint64_t n_scores_unique, uint64_t n_tiles, bool dense_mit,
-                  bool inline_sigs)
+                  bool inline_sigs, bool cold_on_host)
 {
     std::memset(&h, 0, sizeof h);
     h.magic = kImageMagic;
@@ -40,30 +40,40 @@ void layout_image(ImageHeader &h, const Geometry &g, uint64_t n_scores_unique, u
     h.n_scores_unique = n_scores_unique;
     h.n_tiles = n_tiles;
     h.tile_cands = kTileCands;
+    const uint64_t sites_b = align256(8 * g.n_sites), lists_b = align256(8 * g.n_sites * g.n_slices);
     uint64_t off = kHeaderBytes;
     h.off_bucket_start = off; off = align256(off + 8 * (h.n_buckets + 1));
     h.off_tile_first = off;   off = align256(off + 4 * (h.n_buckets + 1));
     h.off_score_mask = off;   off = align256(off + 8 * n_scores_unique);
     h.off_score_val = off;    off = align256(off + 8 * n_scores_unique);
     if (dense_mit) { h.off_mit_dense = off; off = align256(off + 8ull * (1u << 20)); }
-    h.off_sites = off;        off = align256(off + 8 * g.n_sites);
-    h.off_entries = off;      off = align256(off + 8 * g.n_sites * g.n_slices);
+    if (cold_on_host) { // the cold sections form a buffer of their own (pinned host memory); no in-list signatures there
+        h.cold_on_host = 1;
+        h.off_sites = 0;
+        h.off_entries = sites_b;
+        h.cold_bytes = sites_b + lists_b;
+    } else {
+        h.off_sites = off;    off += sites_b;
+        h.off_entries = off;  off += lists_b;
+        h.cold_bytes = sites_b + lists_b + (inline_sigs ? lists_b : 0);
+    }
     h.off_scan = off;         off = align256(off + 4ull * kTileCands * n_tiles);
-    if (inline_sigs) { h.off_esig = off; off = align256(off + 8 * g.n_sites * g.n_slices); }
+    if (inline_sigs && !cold_on_host) { h.off_esig = off; off += lists_b; }
     h.total_bytes = off;
 }
 
-ImageView make_view(const ImageHeader &h, void *base)
+ImageView make_view(const ImageHeader &h, void *base, void *cold)
 {
     uint8_t *p = static_cast<uint8_t *>(base);
+    uint8_t *c = h.cold_on_host ? static_cast<uint8_t *>(cold) : p;
     ImageView v;
     v.bucket_start = reinterpret_cast<const uint64_t *>(p + h.off_bucket_start);
     v.tile_first = reinterpret_cast<const uint32_t *>(p + h.off_tile_first);
     v.score_mask = reinterpret_cast<const uint64_t *>(p + h.off_score_mask);
     v.score_val = reinterpret_cast<const double *>(p + h.off_score_val);
     v.mit_dense = h.off_mit_dense ? reinterpret_cast<const double *>(p + h.off_mit_dense) : nullptr;
-    v.sites = reinterpret_cast<const uint64_t *>(p + h.off_sites);
-    v.entries = reinterpret_cast<const uint64_t *>(p + h.off_entries);
+    v.sites = reinterpret_cast<const uint64_t *>(c + h.off_sites);
+    v.entries = reinterpret_cast<const uint64_t *>(c + h.off_entries);
     v.esig = h.off_esig ? reinterpret_cast<const uint64_t *>(p + h.off_esig) : nullptr;
     v.scan = reinterpret_cast<const uint32_t *>(p + h.off_scan);
     v.n_sites = h.n_sites;
@@ -75,51 +85,89 @@ ImageView make_view(const ImageHeader &h, void *base)
     return v;
 }
 
+static bool env_flag(const char *name) { const char *e = std::getenv(name); return e && e[0] == '1'; }
+
+Tuning Tuning::from_env()
+{
+    Tuning t;
+    t.scan_blocks = kScanGridBlocks;
+    t.item_guides = kItemGuides;
+    t.scan_tiles = kDefaultScanTiles;
+    t.scan_generic = false;
+    t.stage_timing = false;
+    t.upload_timing = env_flag("ISSL_UPLOAD_TIMING");
+    t.raw_chunks = 0;
+    t.inline_sigs = -1;
+    t.host_cold = -1;
+    static const char *const keys[][2] = {
+        {"ISSL_SCAN_BLOCKS", "scan_blocks"}, {"ISSL_ITEM_GUIDES", "item_guides"}, {"ISSL_SCAN_TILES", "scan_tiles"},
+        {"ISSL_SCAN_GENERIC", "scan_generic"}, {"ISSL_STAGE_TIMING", "stage_timing"}, {"ISSL_RAW_CHUNKS", "raw_chunks"},
+        {"ISSL_INLINE_SIGS", "inline_sigs"}, {"ISSL_FORCE_HOST_COLD", "host_cold"}, {"ISSL_SCAN_STAMPS", "scan_stamps"},
+    };
+    for (const auto &k : keys)
+        if (const char *e = std::getenv(k[0])) (void)t.set(k[1], e); // values out of range leave the default
+    return t;
+}
+
+bool Tuning::set(const char *key, const char *value)
+{
+    if (!key || !value) return false;
+    const std::string k(key);
+    char *end = nullptr;
+    const long long n = std::strtoll(value, &end, 10);
+    const bool is_int = end != value && *end == 0;
+    if (k == "scan_blocks") { if (!is_int || n < 1 || n > static_cast<long long>(kScanMaxBlocks)) return false; scan_blocks = static_cast<uint32_t>(n); }
+    else if (k == "item_guides") { if (!is_int || n < 8 || n > static_cast<long long>(kItemGuides)) return false; item_guides = static_cast<uint32_t>(n) & ~7u; }
+    else if (k == "scan_tiles") { if (!is_int || (n != 1 && n != 2)) return false; scan_tiles = static_cast<uint32_t>(n); }
+    else if (k == "scan_generic") { if (!is_int || (n != 0 && n != 1)) return false; scan_generic = n == 1; }
+    else if (k == "stage_timing") { if (!is_int || (n != 0 && n != 1)) return false; stage_timing = n == 1; }
+    else if (k == "raw_chunks") { if (!is_int || n < 0) return false; raw_chunks = static_cast<size_t>(n); }
+    else if (k == "inline_sigs") { if (!is_int || n < -1 || n > 1) return false; inline_sigs = static_cast<int>(n); }
+    else if (k == "host_cold") { if (!is_int || n < -1 || n > 1) return false; host_cold = static_cast<int>(n); }
+    else if (k == "scan_stamps") stamps_path = value;
+    else return false;
+    return true;
+}
+
 } // namespace issl
 
 constexpr uint32_t kRing = 64;
 constexpr size_t kMaxBatch = size_t(1) << 24; // guides per pipeline launch
-constexpr uint32_t kMaxLanes = 3;
 
-// ISSL_LANES=<1..3>: workspaces/streams that consecutive asynchronous batches rotate through (default 1)
-static uint32_t lane_count()
-{
-    const char *e = std::getenv("ISSL_LANES");
-    if (e && e[0] >= '1' && e[0] <= '0' + static_cast<int>(kMaxLanes) && e[1] == 0) return static_cast<uint32_t>(e[0] - '0');
-    return 1;
-}
-
+// One complete workspace + the internal stream that asynchronous batches run on.  (Rotating consecutive batches through
+// several of these so that the short kernels of one batch run in the shadow of the next scan was measured in round 1
+// -- 0.54 ms per step against 0.50 -- and removed: a scan fills every wave slot of the chip)
 struct Lane {
     Workspace ws;
-    hipEvent_t ev[6] = {};      // stage boundaries of the lane's last batch
-    hipEvent_t done = nullptr;  // end of the lane's last batch
-    hipEvent_t scan_done = nullptr; // end of the scan of the lane's last batch
+    hipEvent_t ev[6] = {};      // stage boundaries of the last batch
+    hipEvent_t done = nullptr;  // end of the last batch
     hipStream_t stream = nullptr; // internal stream of asynchronous batches
     bool ready = false;         // events and stream created
     uint32_t last_n = 0;
-    uint32_t pending = 0;       // batches enqueued on this lane since the last finish
-    bool staged = true;         // the lane's last batch recorded its stage events
+    uint32_t pending = 0;       // batches enqueued since the last finish
+    bool staged = true;         // the last batch recorded its stage events
+    int last_max_dist = 0;
 };
 
 struct issl_index {
     std::unique_ptr<HostIndex> host; // absent for attached images
     Geometry geo;
     std::vector<uint64_t> bucket_sizes;
+    Tuning tuning = Tuning::from_env(); // the environment is read here, once per handle
     // device state
     int device = -1;
     void *d_image = nullptr;
     bool owns_image = false;
+    void *h_cold = nullptr;   // pinned host buffer of the cold sections (hdr.cold_on_host), else null
+    void *d_cold = nullptr;   // the same buffer as the device addresses it
+    bool owns_cold = false;
     ImageHeader hdr{};
     ImageView view{};
-    // A lane = one complete workspace + an internal stream.  Synchronous calls use lane 0 on the caller's stream;
-    // asynchronous batches run on lane 0's internal stream (and rotate through more lanes only under ISSL_LANES).
-    Lane lanes[kMaxLanes];
-    hipStream_t scan_stream = nullptr; // ISSL_LANES>1: high-priority stream that carries every scan
+    Lane lane;
     hipEvent_t ring[2 * kRing] = {}; // scan begin/end of the batches enqueued since the last finish
     bool have_events = false;
     issl_stats stats{};
     uint32_t n_pending = 0;  // batches enqueued and not yet finished
-    uint32_t last_lane = 0;
 };
 
 #define HIP_TRY(expr)                                                                              \
@@ -158,7 +206,7 @@ static int select_device(int device)
 
 static void free_workspace(Workspace &w)
 {
-    void *ptrs[] = {w.ng, w.gfill, w.gstart, w.gword, w.gidx, w.gbucket, w.items, w.plan, w.range_start, w.counters, w.sticky, w.stamps, w.gcur_big, w.terms, w.sorted, w.gcount,
+    void *ptrs[] = {w.ng, w.gfill, w.gstart, w.gword, w.gidx, w.gbucket, w.items, w.plan, w.range_start, w.counters, w.scan_count, w.sticky, w.stamps, w.gcur_big, w.terms, w.sorted, w.gcount,
                     w.goff, w.blocksum, w.d_guides, w.d_mit, w.d_cfd, w.d_kept, w.d_hitrec};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -195,9 +243,13 @@ static int ensure_raw_capacity(Workspace &w, size_t chunks)
     return ISSL_OK;
 }
 
-static int ensure_workspace(issl_index *ix, Lane &lane, size_t n)
+static uint32_t scan_waves(const Tuning &tn) { return tn.scan_blocks * (tn.scan_tiles == 2 ? 8u : 16u); }
+
+static int ensure_workspace(issl_index *ix, size_t n)
 {
+    Lane &lane = ix->lane;
     Workspace &w = lane.ws;
+    const Tuning &tn = ix->tuning;
     const size_t nb = ix->hdr.n_buckets;
     int rc;
     if (w.n_buckets != nb) {
@@ -209,13 +261,14 @@ static int ensure_workspace(issl_index *ix, Lane &lane, size_t n)
         if ((rc = dev_alloc(w.counters, 1))) return rc;
         if ((rc = dev_alloc(w.plan, 1))) return rc;
         if ((rc = dev_alloc(w.range_start, kMaxRanges + 2))) return rc;
-
+        if ((rc = dev_alloc(w.scan_count, kScanMaxBlocks))) return rc;
+        HIP_TRY(hipMemset(w.scan_count, 0, 8 * kScanMaxBlocks));
         w.n_buckets = static_cast<uint32_t>(nb);
     }
     if (n > w.cap_guides) {
         const size_t cap = std::max<size_t>(n, 1024);
         const size_t slots = cap * ix->hdr.n_slices + kGuideGroup * nb;
-        const size_t items = nb + cap * ix->hdr.n_slices / 8 + 2; // item sizes down to 8 guides (ISSL_ITEM_GUIDES)
+        const size_t items = nb + cap * ix->hdr.n_slices / 8 + 2; // item sizes down to 8 guides (item_guides knob)
         if ((rc = dev_alloc(w.gword, slots))) return rc;
         if ((rc = dev_alloc(w.gidx, slots))) return rc;
         if ((rc = dev_alloc(w.gbucket, slots))) return rc;
@@ -233,10 +286,9 @@ static int ensure_workspace(issl_index *ix, Lane &lane, size_t n)
         w.cap_items = items;
     }
     if (w.cap_chunks == 0) {
-        // every scan wave may hold one partly filled chunk; beyond that ~1 record per 50k comparisons
-        size_t want = std::max<size_t>(size_t(scan_blocks()) * 16 * 4, n);
-        // ISSL_RAW_CHUNKS=<n>: start with a small raw buffer (tests of the grow-and-rerun path)
-        if (const char *e = std::getenv("ISSL_RAW_CHUNKS")) want = std::max<size_t>(1, std::strtoull(e, nullptr, 10));
+        // every scan wave may hold one partly filled chunk; beyond that ~1 record per 50k comparisons.
+        // raw_chunks knob: start with a small raw buffer (tests of the grow-and-rerun path)
+        const size_t want = tn.raw_chunks ? tn.raw_chunks : std::max<size_t>(size_t(scan_waves(tn)) * 4, n);
         if ((rc = ensure_raw_capacity(w, want))) return rc;
     }
     if (!ix->have_events) {
@@ -246,20 +298,10 @@ static int ensure_workspace(issl_index *ix, Lane &lane, size_t n)
     if (!lane.ready) {
         for (auto &e : lane.ev) HIP_TRY(hipEventCreate(&e));
         HIP_TRY(hipEventCreate(&lane.done));
-        HIP_TRY(hipEventCreate(&lane.scan_done));
-        if (lane_count() > 1) {
-            // two lanes: the scans of both go to one high-priority stream, everything else to low-priority streams,
-            // so that the workgroups of a scan are placed before the small kernels of the other lane
-            int lo = 0, hi = 0;
-            HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi)); // lo = lowest priority (largest number)
-            HIP_TRY(hipStreamCreateWithPriority(&lane.stream, hipStreamNonBlocking, lo));
-            if (!ix->scan_stream) HIP_TRY(hipStreamCreateWithPriority(&ix->scan_stream, hipStreamNonBlocking, hi));
-        } else {
-            HIP_TRY(hipStreamCreateWithFlags(&lane.stream, hipStreamNonBlocking));
-        }
+        HIP_TRY(hipStreamCreateWithFlags(&lane.stream, hipStreamNonBlocking));
         lane.ready = true;
     }
-    if (!w.stamps && std::getenv("ISSL_SCAN_STAMPS")) { // diagnostics: per-wave start/end times of the scan
+    if (!w.stamps && !tn.stamps_path.empty()) { // diagnostics: per-wave start/end times of the scan
         if ((rc = dev_alloc(w.stamps, 4 * kScanWaves))) return rc;
         HIP_TRY(hipMemset(w.stamps, 0, 32 * kScanWaves));
     }
@@ -292,16 +334,21 @@ static double wall_ms()
     return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
 }
 
-// ISSL_UPLOAD_TIMING=1: one diagnostic line per upload on stderr (where the time of an upload goes)
-static void upload_note(const char *what, double t0)
+// upload_timing knob (ISSL_UPLOAD_TIMING=1): one diagnostic line per upload stage on stderr
+static void upload_note(const issl_index *ix, const char *what, double t0)
 {
-    if (std::getenv("ISSL_UPLOAD_TIMING")) std::fprintf(stderr, "[issl upload] %s %.1f ms\n", what, wall_ms() - t0);
+    if (ix->tuning.upload_timing) std::fprintf(stderr, "[issl upload] %s %.1f ms\n", what, wall_ms() - t0);
 }
 
 // Non-null when the slice lists are to be built on the device (the host index then has no arrays).
 struct DeviceBuildInput {
     const uint64_t *sigs;
     const uint32_t *occ;
+};
+
+struct DevTemp { // device allocation freed on every path out of a function
+    void *p = nullptr;
+    ~DevTemp() { if (p) (void)hipFree(p); }
 };
 
 static int finish_upload(issl_index *ix, const DeviceBuildInput *dbi = nullptr)
@@ -334,45 +381,78 @@ static int finish_upload(issl_index *ix, const DeviceBuildInput *dbi = nullptr)
         for (size_t i = 0; i < masks.size(); ++i) dense[dense_index(masks[i])] = vals[i];
         HIP_TRY(hipMemcpy(base + ix->hdr.off_mit_dense, dense.data(), 8 * dense.size(), hipMemcpyHostToDevice));
     }
-    double t0 = wall_ms();
-    // Plain copies from the (file-mapped) host arrays: measured 48 GB/s on a 14 GB index, where a 12-thread pipeline
-    // through pinned staging buffers reached 24 GB/s.
-    HIP_TRY(hipMemcpy(base + ix->hdr.off_sites, dbi ? dbi->sigs : h.sites, 8 * g.n_sites, hipMemcpyHostToDevice));
-    upload_note("sites", t0);
-    t0 = wall_ms();
-    if (dbi) { // isslCreateIndex.cpp:218-234 on the device
-        uint32_t *d_occ = nullptr;
-        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_occ), 4 * g.n_sites));
-        hipError_t ce = hipMemcpy(d_occ, dbi->occ, 4 * g.n_sites, hipMemcpyHostToDevice);
-        int brc = ISSL_OK;
-        if (ce != hipSuccess) {
-            set_error(std::string("HIP error: ") + hipGetErrorString(ce) + " (occurrence counts)");
-            brc = ISSL_E_DEVICE;
-        } else {
-            brc = launch_build_entries(reinterpret_cast<const uint64_t *>(base + ix->hdr.off_sites), d_occ, g.n_sites,
-                                       static_cast<uint32_t>(g.n_slices), static_cast<uint32_t>(g.slice_width),
-                                       reinterpret_cast<uint64_t *>(base + ix->hdr.off_entries));
-        }
-        (void)hipFree(d_occ);
-        if (brc) return brc;
-        upload_note("slice lists built on the device", t0);
-    } else {
-        HIP_TRY(hipMemcpy(base + ix->hdr.off_entries, h.entries, 8 * g.n_sites * g.n_slices, hipMemcpyHostToDevice));
-        upload_note("entries", t0);
-    }
-    t0 = wall_ms();
-    ix->view = make_view(ix->hdr, ix->d_image);
-    // scan stream: built on the device from sites + entries
-    uint32_t *flag = nullptr;
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&flag), 4));
+    ix->view = make_view(ix->hdr, ix->d_image, ix->d_cold);
+    DevTemp flag_mem, occ_mem;
+    HIP_TRY(hipMalloc(&flag_mem.p, 4));
+    uint32_t *flag = static_cast<uint32_t *>(flag_mem.p);
     HIP_TRY(hipMemset(flag, 0, 4));
-    launch_pack_scan_stream(ix->view, reinterpret_cast<uint32_t *>(base + ix->hdr.off_scan),
-                            ix->hdr.off_esig ? reinterpret_cast<uint64_t *>(base + ix->hdr.off_esig) : nullptr, flag, nullptr);
-    HIP_TRY(hipGetLastError());
+    uint32_t *scan_out = reinterpret_cast<uint32_t *>(base + ix->hdr.off_scan);
+    if (dbi) {
+        HIP_TRY(hipMalloc(&occ_mem.p, 4 * g.n_sites));
+        HIP_TRY(hipMemcpy(occ_mem.p, dbi->occ, 4 * g.n_sites, hipMemcpyHostToDevice));
+    }
+    const uint32_t *d_occ = static_cast<const uint32_t *>(occ_mem.p);
+    double t0 = wall_ms();
+    if (!ix->hdr.cold_on_host) {
+        // Plain copies from the (file-mapped) host arrays: measured 48 GB/s on a 14 GB index, where a 12-thread
+        // pipeline through pinned staging buffers reached 24 GB/s.
+        HIP_TRY(hipMemcpy(base + ix->hdr.off_sites, dbi ? dbi->sigs : h.sites, 8 * g.n_sites, hipMemcpyHostToDevice));
+        upload_note(ix, "sites", t0);
+        t0 = wall_ms();
+        if (dbi) { // isslCreateIndex.cpp:218-234 on the device
+            int brc = launch_build_entries(reinterpret_cast<const uint64_t *>(base + ix->hdr.off_sites), d_occ, g.n_sites,
+                                           0, static_cast<uint32_t>(g.n_slices), static_cast<uint32_t>(g.slice_width),
+                                           reinterpret_cast<uint64_t *>(base + ix->hdr.off_entries));
+            if (brc) return brc;
+            upload_note(ix, "slice lists built on the device", t0);
+        } else {
+            HIP_TRY(hipMemcpy(base + ix->hdr.off_entries, h.entries, 8 * g.n_sites * g.n_slices, hipMemcpyHostToDevice));
+            upload_note(ix, "entries", t0);
+        }
+        t0 = wall_ms();
+        // scan stream: built on the device from sites + entries
+        launch_pack_scan_stream(ix->view, scan_out,
+                                ix->hdr.off_esig ? reinterpret_cast<uint64_t *>(base + ix->hdr.off_esig) : nullptr, flag, nullptr);
+        HIP_TRY(hipGetLastError());
+    } else {
+        // Cold sections in pinned host memory: the scan stream is packed one slice at a time from temporary device
+        // copies of the signatures (8 B/site) and of that slice's list (8 B/site); random reads of the site table
+        // across PCIe would take minutes.  With a device-side build the lists are made here and copied out.
+        uint8_t *cold = static_cast<uint8_t *>(ix->h_cold);
+        uint64_t *c_sites = reinterpret_cast<uint64_t *>(cold + ix->hdr.off_sites);
+        uint64_t *c_entries = reinterpret_cast<uint64_t *>(cold + ix->hdr.off_entries);
+        const uint64_t n = g.n_sites;
+        DevTemp sites_mem, list_mem;
+        HIP_TRY(hipMalloc(&sites_mem.p, std::max<uint64_t>(8 * n, 8)));
+        HIP_TRY(hipMalloc(&list_mem.p, std::max<uint64_t>(8 * n, 8)));
+        uint64_t *t_sites = static_cast<uint64_t *>(sites_mem.p), *t_list = static_cast<uint64_t *>(list_mem.p);
+        std::memcpy(c_sites, dbi ? dbi->sigs : h.sites, 8 * n);
+        HIP_TRY(hipMemcpy(t_sites, c_sites, 8 * n, hipMemcpyHostToDevice));
+        upload_note(ix, "sites (pinned host copy + temporary device copy)", t0);
+        t0 = wall_ms();
+        for (uint64_t sl = 0; sl < g.n_slices; ++sl) {
+            if (dbi) {
+                int brc = launch_build_entries(t_sites, d_occ, n, static_cast<uint32_t>(sl), static_cast<uint32_t>(sl + 1),
+                                               static_cast<uint32_t>(g.slice_width), t_list);
+                if (brc) return brc;
+                HIP_TRY(hipMemcpy(c_entries + sl * n, t_list, 8 * n, hipMemcpyDeviceToHost));
+            } else {
+                std::memcpy(c_entries + sl * n, h.entries + sl * n, 8 * n);
+                HIP_TRY(hipMemcpy(t_list, c_entries + sl * n, 8 * n, hipMemcpyHostToDevice));
+            }
+            ImageView pv = ix->view;
+            pv.sites = t_sites;
+            pv.entries = t_list - sl * n; // bucket_start of the slice's first bucket is sl * n: every site sits in one bucket per slice
+            launch_pack_scan_range(pv, scan_out, nullptr, flag, tfirst[sl << g.slice_width], tfirst[(sl + 1) << g.slice_width], nullptr);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipDeviceSynchronize());
+        }
+        upload_note(ix, "slice lists into pinned host memory", t0);
+        t0 = wall_ms();
+    }
     uint32_t err = 0;
     HIP_TRY(hipMemcpy(&err, flag, 4, hipMemcpyDeviceToHost));
-    (void)hipFree(flag);
-    upload_note("scan stream", t0);
+    upload_note(ix, "scan stream", t0);
     if (err) {
         set_error("Error reading index: a slice entry refers to an off-target id beyond the site table");
         return ISSL_E_FORMAT;
@@ -381,10 +461,10 @@ static int finish_upload(issl_index *ix, const DeviceBuildInput *dbi = nullptr)
 }
 
 // The optional in-list signatures cost 8 B per list entry (40 B per site next to the 68 B of the rest): worth it while
-// the image stays a modest part of the HBM (ISSL_INLINE_SIGS=0/1 overrides).
-static bool want_inline_sigs(const Geometry &g)
+// the image stays a modest part of the HBM (inline_sigs knob / ISSL_INLINE_SIGS=0/1 overrides).
+static bool want_inline_sigs(const Tuning &tn, const Geometry &g)
 {
-    if (const char *e = std::getenv("ISSL_INLINE_SIGS")) return e[0] == '1';
+    if (tn.inline_sigs >= 0) return tn.inline_sigs == 1;
     return g.n_sites <= 600000000ull;
 }
 
@@ -398,24 +478,17 @@ static uint64_t count_tiles(const HostIndex &h)
 static void release_device(issl_index *ix)
 {
     if (ix->device >= 0) (void)hipSetDevice(ix->device);
-    for (Lane &lane : ix->lanes) {
-        if (lane.ready) {
-            (void)hipStreamSynchronize(lane.stream);
-            for (auto &e : lane.ev) (void)hipEventDestroy(e);
-            (void)hipEventDestroy(lane.done);
-            (void)hipEventDestroy(lane.scan_done);
-            (void)hipStreamDestroy(lane.stream);
-            lane.ready = false;
-        }
-        free_workspace(lane.ws);
-        lane.last_n = 0;
-        lane.pending = 0;
+    Lane &lane = ix->lane;
+    if (lane.ready) {
+        (void)hipStreamSynchronize(lane.stream);
+        for (auto &e : lane.ev) (void)hipEventDestroy(e);
+        (void)hipEventDestroy(lane.done);
+        (void)hipStreamDestroy(lane.stream);
+        lane.ready = false;
     }
-    if (ix->scan_stream) {
-        (void)hipStreamSynchronize(ix->scan_stream);
-        (void)hipStreamDestroy(ix->scan_stream);
-        ix->scan_stream = nullptr;
-    }
+    free_workspace(lane.ws);
+    lane.last_n = 0;
+    lane.pending = 0;
     if (ix->have_events) {
         for (auto &e : ix->ring) (void)hipEventDestroy(e);
         ix->have_events = false;
@@ -424,6 +497,10 @@ static void release_device(issl_index *ix)
     if (ix->d_image && ix->owns_image) (void)hipFree(ix->d_image);
     ix->d_image = nullptr;
     ix->owns_image = false;
+    if (ix->h_cold && ix->owns_cold) (void)hipHostFree(ix->h_cold);
+    ix->h_cold = nullptr;
+    ix->d_cold = nullptr;
+    ix->owns_cold = false;
 }
 
 static int new_index_from_host(std::unique_ptr<HostIndex> h, issl_index **out)
@@ -445,10 +522,9 @@ static int new_index_from_host(std::unique_ptr<HostIndex> h, issl_index **out)
 // words the pipelines leave behind, and fills the statistics.
 // `staged`: record an event at every stage boundary (bin / scan / verify / group / replay times in issl_stats).  An event
 // record costs ~4 us of stream time on MI355X -- 5 % of a 10 k-guide batch for the six of them -- so the asynchronous
-// back-to-back path records only the pair around the scan and the end of the batch unless ISSL_STAGE_TIMING=1.
-static int enqueue_batch(issl_index *ix, Lane &lane, hipStream_t stream, const uint64_t *d_guides, size_t n,
-                         int max_dist, double threshold, int method, double *d_mit, double *d_cfd, bool dump,
-                         bool staged)
+// back-to-back path records only the pair around the scan and the end of the batch unless the stage_timing knob is set.
+static int enqueue_batch(issl_index *ix, hipStream_t stream, const uint64_t *d_guides, size_t n, int max_dist,
+                         double threshold, int method, double *d_mit, double *d_cfd, bool dump, bool staged)
 {
     if (!ix->d_image) {
         set_error("index has no device image: call issl_index_upload first");
@@ -460,9 +536,11 @@ static int enqueue_batch(issl_index *ix, Lane &lane, hipStream_t stream, const u
     }
     HIP_TRY(hipSetDevice(ix->device));
     if (n == 0) return ISSL_OK;
-    int rc = ensure_workspace(ix, lane, n);
+    int rc = ensure_workspace(ix, n);
     if (rc) return rc;
+    Lane &lane = ix->lane;
     Workspace &ws = lane.ws;
+    const Tuning &tn = ix->tuning;
     // `sorted` always has room for every raw slot, so the whole pipeline runs without a host round trip;
     // an exhausted raw buffer is detected in finish_batches() and the batch is re-run with a larger one.
     rc = ensure_hit_capacity(ws, ws.cap_chunks * (kChunkRecs - 1));
@@ -478,24 +556,13 @@ static int enqueue_batch(issl_index *ix, Lane &lane, hipStream_t stream, const u
     p.maximum_sum = (10000.0 - threshold * 100) / threshold; // isslScoreOfftargets.cpp:326
     const uint32_t n32 = static_cast<uint32_t>(n);
     const uint32_t slot = ix->n_pending % kRing;
-    const bool other_stream_scan = ix->scan_stream && stream == lane.stream;
     lane.staged = staged;
     if (staged) HIP_TRY(hipEventRecord(lane.ev[0], stream));
-    launch_bin_guides(ix->view, ws, d_guides, n32, stream);
-    if (staged || other_stream_scan) HIP_TRY(hipEventRecord(lane.ev[1], stream));
-    if (other_stream_scan) {
-        // scans of both lanes run one after the other on the high-priority stream
-        HIP_TRY(hipStreamWaitEvent(ix->scan_stream, lane.ev[1], 0));
-        HIP_TRY(hipEventRecord(ix->ring[2 * slot], ix->scan_stream));
-        launch_scan(ix->view, ws, d_guides, n32, max_dist, ix->scan_stream);
-        HIP_TRY(hipEventRecord(ix->ring[2 * slot + 1], ix->scan_stream));
-        HIP_TRY(hipEventRecord(lane.scan_done, ix->scan_stream));
-        HIP_TRY(hipStreamWaitEvent(stream, lane.scan_done, 0));
-    } else {
-        HIP_TRY(hipEventRecord(ix->ring[2 * slot], stream));
-        launch_scan(ix->view, ws, d_guides, n32, max_dist, stream);
-        HIP_TRY(hipEventRecord(ix->ring[2 * slot + 1], stream));
-    }
+    launch_bin_guides(ix->view, ws, tn, d_guides, n32, stream);
+    if (staged) HIP_TRY(hipEventRecord(lane.ev[1], stream));
+    HIP_TRY(hipEventRecord(ix->ring[2 * slot], stream));
+    launch_scan(ix->view, ws, tn, d_guides, n32, max_dist, stream);
+    HIP_TRY(hipEventRecord(ix->ring[2 * slot + 1], stream));
     if (staged) HIP_TRY(hipEventRecord(lane.ev[2], stream));
     launch_verify(ix->view, ws, d_guides, max_dist, stream);
     if (staged) HIP_TRY(hipEventRecord(lane.ev[3], stream));
@@ -508,57 +575,52 @@ static int enqueue_batch(issl_index *ix, Lane &lane, hipStream_t stream, const u
     ix->n_pending += 1;
     lane.pending += 1;
     lane.last_n = n32;
-    ix->last_lane = static_cast<uint32_t>(&lane - ix->lanes);
+    lane.last_max_dist = max_dist;
     return ISSL_OK;
 }
 
-// Synchronises everything that was enqueued (lane streams and, for synchronous calls, `stream`).  Returns ISSL_OK,
-// or ISSL_E_RETRY when a batch since the last finish ran out of raw-record space (the buffers have been enlarged;
-// the caller enqueues those batches again).
+// Synchronises everything that was enqueued (the internal stream and, for synchronous calls, `stream`).  Returns
+// ISSL_OK, or ISSL_E_RETRY when a batch since the last finish ran out of raw-record space (the buffers have been
+// enlarged; the caller enqueues those batches again).
 static int finish_batches(issl_index *ix, hipStream_t stream)
 {
     if (!ix->d_image || ix->n_pending == 0) return ISSL_OK;
     HIP_TRY(hipSetDevice(ix->device));
     HIP_TRY(hipStreamSynchronize(stream));
-    for (Lane &lane : ix->lanes)
-        if (lane.ready && lane.pending) HIP_TRY(hipStreamSynchronize(lane.stream));
+    Lane &lane = ix->lane;
+    if (lane.ready && lane.pending) HIP_TRY(hipStreamSynchronize(lane.stream));
     HIP_TRY(hipGetLastError());
     const uint32_t batches = ix->n_pending;
     ix->n_pending = 0;
-    bool retry = false;
-    uint32_t max_chunks = 0;
-    for (Lane &lane : ix->lanes) {
-        if (!lane.pending) continue;
-        lane.pending = 0;
-        uint32_t sticky[4] = {0, 0, 0, 0};
-        HIP_TRY(hipMemcpy(sticky, lane.ws.sticky, sizeof sticky, hipMemcpyDeviceToHost));
-        max_chunks = std::max(max_chunks, sticky[1]);
-        if (sticky[2] & 2u) {
-            HIP_TRY(hipMemset(lane.ws.sticky, 0, 16));
-            set_error("internal error: scan item list overflow");
-            return ISSL_E_DEVICE;
-        }
-        if (sticky[0]) retry = true;
+    lane.pending = 0;
+    uint32_t sticky[4] = {0, 0, 0, 0};
+    HIP_TRY(hipMemcpy(sticky, lane.ws.sticky, sizeof sticky, hipMemcpyDeviceToHost));
+    const uint32_t max_chunks = sticky[1];
+    if (sticky[2] & 2u) {
+        HIP_TRY(hipMemset(lane.ws.sticky, 0, 16));
+        set_error("internal error: scan item list overflow");
+        return ISSL_E_DEVICE;
     }
-    if (retry) {
-        // max_chunks = largest number of chunks any batch asked for; both lanes get the room
-        for (Lane &lane : ix->lanes) {
-            if (!lane.ready) continue;
-            HIP_TRY(hipMemset(lane.ws.sticky, 0, 16));
-            int rc = ensure_raw_capacity(lane.ws, static_cast<size_t>(max_chunks) + max_chunks / 8 + 1024);
-            if (rc) return rc;
-        }
+    if (sticky[0]) {
+        // max_chunks = largest number of chunks any batch asked for
+        HIP_TRY(hipMemset(lane.ws.sticky, 0, 16));
+        int rc = ensure_raw_capacity(lane.ws, static_cast<size_t>(max_chunks) + max_chunks / 8 + 1024);
+        if (rc) return rc;
         set_error("raw record buffer was too small for a batch; it has been enlarged, score the batch again");
         return ISSL_E_RETRY;
     }
-    Lane &last = ix->lanes[ix->last_lane];
     PlanInfo pl{};
     uint32_t total_hits = 0;
-    HIP_TRY(hipMemcpy(&pl, last.ws.plan, sizeof pl, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(&total_hits, last.ws.goff + last.last_n, sizeof total_hits, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&pl, lane.ws.plan, sizeof pl, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&total_hits, lane.ws.goff + lane.last_n, sizeof total_hits, hipMemcpyDeviceToHost));
+    // comparisons the scan workgroups of the last batch counted while they made them
+    std::vector<uint64_t> counted(ix->tuning.scan_blocks);
+    HIP_TRY(hipMemcpy(counted.data(), lane.ws.scan_count, 8 * counted.size(), hipMemcpyDeviceToHost));
+    uint64_t compared = 0;
+    for (uint64_t c : counted) compared += c;
     float ms[5] = {0, 0, 0, 0, 0};
-    if (last.staged)
-        for (int i = 0; i < 5; ++i) (void)hipEventElapsedTime(&ms[i], last.ev[i], last.ev[i + 1]);
+    if (lane.staged)
+        for (int i = 0; i < 5; ++i) (void)hipEventElapsedTime(&ms[i], lane.ev[i], lane.ev[i + 1]);
     double scan_sum = 0.0;
     const uint32_t have = batches < kRing ? batches : kRing;
     for (uint32_t i = 0; i < have; ++i) {
@@ -567,7 +629,7 @@ static int finish_batches(issl_index *ix, hipStream_t stream)
         scan_sum += t;
     }
     ix->stats = issl_stats{};
-    ix->stats.n_guides = last.last_n;
+    ix->stats.n_guides = lane.last_n;
     ix->stats.ms_bin = ms[0];
     ix->stats.ms_scan = have ? scan_sum / have : ms[1]; // mean over the batches since the last finish
     ix->stats.ms_verify = ms[2];
@@ -575,14 +637,15 @@ static int finish_batches(issl_index *ix, hipStream_t stream)
     ix->stats.ms_replay = ms[4];
     ix->stats.ms_total = ms[0] + ms[1] + ms[2] + ms[3] + ms[4];
     ix->stats.raw_records = static_cast<uint64_t>(max_chunks) * (kChunkRecs - 1);
-    ix->stats.candidates = pl.candidates;
+    ix->stats.candidates = compared;
+    ix->stats.planned_comparisons = lane.last_max_dist < 0 ? 0 : pl.candidates;
     ix->stats.hits = total_hits;
     ix->stats.scan_tiles = pl.tiles;
     ix->stats.n_batches = batches;
-    if (last.ws.stamps) { // ISSL_SCAN_STAMPS=<file>: dump the wave stamps of the last scan (4 u64 per wave)
+    if (lane.ws.stamps) { // scan_stamps knob: dump the wave stamps of the last scan (4 u64 per wave)
         std::vector<unsigned long long> st(4 * kScanWaves);
-        HIP_TRY(hipMemcpy(st.data(), last.ws.stamps, 32 * kScanWaves, hipMemcpyDeviceToHost));
-        if (FILE *f = std::fopen(std::getenv("ISSL_SCAN_STAMPS"), "wb")) {
+        HIP_TRY(hipMemcpy(st.data(), lane.ws.stamps, 32 * kScanWaves, hipMemcpyDeviceToHost));
+        if (FILE *f = std::fopen(ix->tuning.stamps_path.c_str(), "wb")) {
             std::fwrite(st.data(), 8, st.size(), f);
             std::fclose(f);
         }
@@ -590,7 +653,7 @@ static int finish_batches(issl_index *ix, hipStream_t stream)
     return ISSL_OK;
 }
 
-// Synchronous batch on lane 0 and the caller's stream.
+// Synchronous batch on the caller's stream.
 static int score_core(issl_index *ix, const uint64_t *d_guides, size_t n, int max_dist, double threshold, int method,
                       double *d_mit, double *d_cfd, hipStream_t stream, bool dump)
 {
@@ -600,7 +663,7 @@ static int score_core(issl_index *ix, const uint64_t *d_guides, size_t n, int ma
     ix->stats.n_guides = n;
     if (n == 0) return ISSL_OK;
     for (int attempt = 0;; ++attempt) {
-        rc = enqueue_batch(ix, ix->lanes[0], stream, d_guides, n, max_dist, threshold, method, d_mit, d_cfd, dump, true);
+        rc = enqueue_batch(ix, stream, d_guides, n, max_dist, threshold, method, d_mit, d_cfd, dump, true);
         if (rc) return rc;
         rc = finish_batches(ix, stream);
         if (rc == ISSL_OK) {
@@ -678,8 +741,14 @@ int issl_index_write(const issl_index *idx, const char *path)
     }
     bool ok = idx->host->write_leading_sections(fp) == ISSL_OK;
     const uint8_t *base = static_cast<const uint8_t *>(idx->d_image);
-    std::vector<uint8_t> stage(size_t(64) << 20);
+    const uint8_t *cold = static_cast<const uint8_t *>(idx->h_cold);
+    std::vector<uint8_t> stage;
     auto stream_out = [&](uint64_t off, uint64_t bytes) {
+        if (idx->hdr.cold_on_host) { // the section already sits in host memory
+            ok = ok && std::fwrite(cold + off, 1, bytes, fp) == bytes;
+            return;
+        }
+        stage.resize(size_t(64) << 20);
         for (uint64_t at = 0; ok && at < bytes; at += stage.size()) {
             const size_t len = static_cast<size_t>(std::min<uint64_t>(stage.size(), bytes - at));
             ok = hipMemcpy(stage.data(), base + off + at, len, hipMemcpyDeviceToHost) == hipSuccess &&
@@ -736,10 +805,58 @@ int issl_index_device_bytes(const issl_index *idx, size_t *out)
     std::vector<double> v;
     idx->host->unique_scores(m, v);
     ImageHeader h;
-    layout_image(h, idx->geo, m.size(), count_tiles(*idx->host), masks_are_dense(m), want_inline_sigs(idx->geo));
+    // the layout an upload tries first (issl_index_upload falls back to smaller ones when the HBM is short)
+    const bool cold = idx->tuning.host_cold == 1;
+    layout_image(h, idx->geo, m.size(), count_tiles(*idx->host), masks_are_dense(m),
+                 !cold && want_inline_sigs(idx->tuning, idx->geo), cold);
     *out = h.total_bytes;
     return ISSL_OK;
 }
+
+int issl_index_set_option(issl_index *idx, const char *key, const char *value)
+{
+    if (!idx || !key || !value) { set_error("null argument"); return ISSL_E_ARG; }
+    if (idx->n_pending) { set_error("issl_index_set_option: batches are in flight, call issl_score_finish first"); return ISSL_E_STATE; }
+    Tuning t = idx->tuning;
+    if (!t.set(key, value)) {
+        set_error(std::string("unknown option or value out of range: ") + key + "=" + value);
+        return ISSL_E_ARG;
+    }
+    if (idx->d_image && (t.scan_blocks != idx->tuning.scan_blocks || t.scan_tiles != idx->tuning.scan_tiles)) {
+        // every scan wave owns the raw chunk with its own number: keep at least that many
+        HIP_TRY(hipSetDevice(idx->device));
+        if (idx->lane.ws.cap_chunks && idx->lane.ws.cap_chunks < size_t(scan_waves(t)) * 2) {
+            int rc = ensure_raw_capacity(idx->lane.ws, size_t(scan_waves(t)) * 4);
+            if (rc) return rc;
+        }
+    }
+    idx->tuning = t;
+    return ISSL_OK;
+}
+
+int issl_index_get_option(const issl_index *idx, const char *key, long long *value)
+{
+    if (!idx || !key || !value) { set_error("null argument"); return ISSL_E_ARG; }
+    const Tuning &t = idx->tuning;
+    const std::string k(key);
+    if (k == "scan_blocks") *value = t.scan_blocks;
+    else if (k == "item_guides") *value = t.item_guides;
+    else if (k == "scan_tiles") *value = t.scan_tiles;
+    else if (k == "scan_generic") *value = t.scan_generic;
+    else if (k == "stage_timing") *value = t.stage_timing;
+    else if (k == "raw_chunks") *value = static_cast<long long>(t.raw_chunks);
+    else if (k == "inline_sigs") *value = t.inline_sigs;
+    else if (k == "host_cold") *value = t.host_cold;
+    else if (k == "cold_on_host") *value = idx->d_image ? static_cast<long long>(idx->hdr.cold_on_host) : -1; // read-only: layout in use
+    else if (k == "has_inline_sigs") *value = idx->d_image ? (idx->hdr.off_esig ? 1 : 0) : -1;            // read-only
+    else { set_error(std::string("unknown option: ") + key); return ISSL_E_ARG; }
+    return ISSL_OK;
+}
+
+// Layouts an upload tries in turn: with the in-list signatures, without them, with the cold sections in host memory.
+struct LayoutChoice {
+    bool inline_sigs, cold;
+};
 
 static int upload_common(issl_index *idx, int device, void *buf, size_t bytes, const DeviceBuildInput *dbi = nullptr)
 {
@@ -759,25 +876,76 @@ static int upload_common(issl_index *idx, int device, void *buf, size_t bytes, c
     if (rc) return rc;
     release_device(idx);
     (void)hipFree(nullptr); // creates the context
-    upload_note("device runtime start", t0);
+    upload_note(idx, "device runtime start", t0);
     t0 = wall_ms();
     std::vector<uint64_t> m;
     std::vector<double> v;
     idx->host->unique_scores(m, v);
-    layout_image(idx->hdr, idx->geo, m.size(), count_tiles(*idx->host), masks_are_dense(m), want_inline_sigs(idx->geo));
-    idx->device = device;
-    if (buf) {
-        if (bytes < idx->hdr.total_bytes || (reinterpret_cast<uintptr_t>(buf) & 255u)) {
-            set_error("device buffer too small or not 256-byte aligned");
-            return ISSL_E_ARG;
-        }
-        idx->d_image = buf;
-        idx->owns_image = false;
+    const Tuning &tn = idx->tuning;
+    std::vector<LayoutChoice> choices;
+    if (tn.host_cold == 1) {
+        choices.push_back({false, true});
     } else {
-        HIP_TRY(hipMalloc(&idx->d_image, idx->hdr.total_bytes));
-        idx->owns_image = true;
+        if (want_inline_sigs(tn, idx->geo)) choices.push_back({true, false});
+        if (tn.inline_sigs != 1) choices.push_back({false, false}); // an explicit inline_sigs=1 is honoured or fails
+        if (tn.host_cold == -1 && tn.inline_sigs != 1) choices.push_back({false, true});
     }
-    upload_note("layout + allocation", t0);
+    idx->device = device;
+    const uint64_t n_tiles = count_tiles(*idx->host);
+    const bool dense = masks_are_dense(m);
+    std::string why;
+    bool placed = false;
+    for (const LayoutChoice &c : choices) {
+        layout_image(idx->hdr, idx->geo, m.size(), n_tiles, dense, c.inline_sigs, c.cold);
+        // temporary device copies while a host-cold image is packed: signatures + one slice list
+        const uint64_t temp = c.cold ? 16 * idx->geo.n_sites : 0;
+        if (buf) {
+            if (bytes < idx->hdr.total_bytes || (reinterpret_cast<uintptr_t>(buf) & 255u)) {
+                why = "device buffer too small or not 256-byte aligned";
+                continue;
+            }
+            idx->d_image = buf;
+            idx->owns_image = false;
+        } else {
+            // leave room for the scoring workspace: the larger of 2 GiB and 3 % of the device
+            size_t free_b = 0, total_b = 0;
+            HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+            const uint64_t reserve = std::max<uint64_t>(uint64_t(2) << 30, total_b / 32);
+            if (idx->hdr.total_bytes + temp + reserve > free_b) {
+                why = "the image (" + std::to_string(idx->hdr.total_bytes >> 20) + " MiB) does not fit the free device memory (" +
+                      std::to_string(free_b >> 20) + " MiB)";
+                continue;
+            }
+            if (hipMalloc(&idx->d_image, idx->hdr.total_bytes) != hipSuccess) {
+                (void)hipGetLastError();
+                idx->d_image = nullptr;
+                why = "hipMalloc of the image failed";
+                continue;
+            }
+            idx->owns_image = true;
+        }
+        if (c.cold) {
+            // portable + mapped: every device of the node can read the one host copy (issl_node)
+            if (hipHostMalloc(&idx->h_cold, std::max<uint64_t>(idx->hdr.cold_bytes, 256), hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) {
+                (void)hipGetLastError();
+                idx->h_cold = nullptr;
+                if (idx->owns_image) (void)hipFree(idx->d_image);
+                idx->d_image = nullptr;
+                idx->owns_image = false;
+                why = "cannot pin " + std::to_string(idx->hdr.cold_bytes >> 20) + " MiB of host memory for the cold sections";
+                continue;
+            }
+            idx->owns_cold = true;
+            HIP_TRY(hipHostGetDevicePointer(&idx->d_cold, idx->h_cold, 0));
+        }
+        placed = true;
+        break;
+    }
+    if (!placed) {
+        set_error("cannot place the index image: " + why);
+        return buf ? ISSL_E_ARG : ISSL_E_DEVICE;
+    }
+    upload_note(idx, idx->hdr.cold_on_host ? "layout + allocation (cold sections in pinned host memory)" : "layout + allocation", t0);
     rc = finish_upload(idx, dbi);
     if (rc) release_device(idx);
     return rc;
@@ -812,7 +980,7 @@ int issl_index_upload_into(issl_index *idx, int device, void *dev_buf, size_t by
     return upload_common(idx, device, dev_buf, bytes);
 }
 
-int issl_index_attach_image(int device, void *dev_buf, size_t bytes, issl_index **out)
+static int attach_common(int device, void *dev_buf, size_t bytes, void *cold_host, size_t cold_bytes, issl_index **out)
 {
     if (!dev_buf || !out) { set_error("null argument"); return ISSL_E_ARG; }
     int rc = select_device(device);
@@ -828,6 +996,15 @@ int issl_index_attach_image(int device, void *dev_buf, size_t bytes, issl_index 
         set_error("device buffer does not hold an ISSL image of this library version");
         return ISSL_E_FORMAT;
     }
+    void *d_cold = nullptr;
+    if (h.cold_on_host) {
+        if (!cold_host || cold_bytes < h.cold_bytes) {
+            set_error("this image keeps its cold sections (sites, slice lists) in pinned host memory: attach it with "
+                      "issl_index_attach_image_cold and the buffer of issl_index_cold");
+            return ISSL_E_STATE;
+        }
+        HIP_TRY(hipHostGetDevicePointer(&d_cold, cold_host, 0));
+    }
     issl_index *ix = new (std::nothrow) issl_index();
     if (!ix) { set_error("out of memory"); return ISSL_E_NOMEM; }
     ix->geo.n_sites = h.n_sites;
@@ -840,7 +1017,10 @@ int issl_index_attach_image(int device, void *dev_buf, size_t bytes, issl_index 
     ix->device = device;
     ix->d_image = dev_buf;
     ix->owns_image = false;
-    ix->view = make_view(h, dev_buf);
+    ix->h_cold = h.cold_on_host ? cold_host : nullptr;
+    ix->d_cold = d_cold;
+    ix->owns_cold = false;
+    ix->view = make_view(h, dev_buf, d_cold);
     std::vector<uint64_t> bstart(h.n_buckets + 1);
     hipError_t e = hipMemcpy(bstart.data(), static_cast<uint8_t *>(dev_buf) + h.off_bucket_start,
                              8 * (h.n_buckets + 1), hipMemcpyDeviceToHost);
@@ -852,6 +1032,26 @@ int issl_index_attach_image(int device, void *dev_buf, size_t bytes, issl_index 
     ix->bucket_sizes.resize(h.n_buckets);
     for (uint64_t b = 0; b < h.n_buckets; ++b) ix->bucket_sizes[b] = bstart[b + 1] - bstart[b];
     *out = ix;
+    return ISSL_OK;
+}
+
+int issl_index_attach_image(int device, void *dev_buf, size_t bytes, issl_index **out)
+{
+    return attach_common(device, dev_buf, bytes, nullptr, 0, out);
+}
+
+int issl_index_attach_image_cold(int device, void *dev_buf, size_t bytes, void *cold_host, size_t cold_bytes,
+                                 issl_index **out)
+{
+    return attach_common(device, dev_buf, bytes, cold_host, cold_bytes, out);
+}
+
+int issl_index_cold(const issl_index *idx, void **host_ptr, size_t *bytes)
+{
+    if (!idx || !host_ptr || !bytes) { set_error("null argument"); return ISSL_E_ARG; }
+    if (!idx->d_image) { set_error("index has no device image"); return ISSL_E_STATE; }
+    *host_ptr = idx->hdr.cold_on_host ? idx->h_cold : nullptr;
+    *bytes = idx->hdr.cold_on_host ? idx->hdr.cold_bytes : 0;
     return ISSL_OK;
 }
 
@@ -934,30 +1134,28 @@ int issl_score_device_async(issl_index *idx, const uint64_t *d_guides, size_t n,
     if (!idx || (n && (!d_guides || !d_mit || !d_cfd))) { set_error("null argument"); return ISSL_E_ARG; }
     if (!idx->d_image) { set_error("index has no device image: call issl_index_upload first"); return ISSL_E_STATE; }
     if (n == 0) return ISSL_OK;
+    if (n > kMaxBatch) { // before any workspace is sized for it
+        set_error("at most 2^24 guides per device batch (issl_score splits larger batches itself)");
+        return ISSL_E_ARG;
+    }
     HIP_TRY(hipSetDevice(idx->device));
-    // One lane by default: batches run back to back on one internal stream.  ISSL_LANES=2|3 rotates through several
-    // lanes (workspace + low-priority stream each, every scan on one shared high-priority stream) so that the short
-    // kernels of a batch run in the shadow of the next scan.  Measured on MI355X at 10 k guides per batch: 0.54 ms per
-    // step against 0.50 with one lane -- the scan it shadows slows from 0.39 to 0.52 ms, more than the 0.11 ms that are
-    // hidden -- so one lane stays the default and this an experiment switch.
-    Lane &lane = idx->lanes[idx->n_pending % lane_count()];
-    int rc = ensure_workspace(idx, lane, n); // creates the lane's stream on first use
+    int rc = ensure_workspace(idx, n); // creates the internal stream on first use
     if (rc) return rc;
+    Lane &lane = idx->lane;
     if (stream) { // inputs are produced on the caller's stream: the batch starts after what is enqueued there now
         HIP_TRY(hipEventRecord(lane.ev[0], static_cast<hipStream_t>(stream)));
         HIP_TRY(hipStreamWaitEvent(lane.stream, lane.ev[0], 0));
     }
-    const char *st_env = std::getenv("ISSL_STAGE_TIMING");
-    return enqueue_batch(idx, lane, lane.stream, d_guides, n, max_dist, threshold, method, d_mit, d_cfd, false,
-                         st_env && st_env[0] == '1');
+    return enqueue_batch(idx, lane.stream, d_guides, n, max_dist, threshold, method, d_mit, d_cfd, false,
+                         idx->tuning.stage_timing);
 }
 
 int issl_score_wait(issl_index *idx, void *stream)
 {
     if (!idx) { set_error("null argument"); return ISSL_E_ARG; }
     if (idx->device >= 0) HIP_TRY(hipSetDevice(idx->device));
-    for (Lane &lane : idx->lanes)
-        if (lane.ready && lane.pending) HIP_TRY(hipStreamWaitEvent(static_cast<hipStream_t>(stream), lane.done, 0));
+    if (idx->lane.ready && idx->lane.pending)
+        HIP_TRY(hipStreamWaitEvent(static_cast<hipStream_t>(stream), idx->lane.done, 0));
     return ISSL_OK;
 }
 
@@ -981,11 +1179,11 @@ int issl_score(issl_index *idx, const uint64_t *guides, size_t n, int max_dist, 
     // that up front, which saves the first large batch on an index its grow-and-rerun round, and a piece ends
     // early when its estimate would not fit a quarter of the free HBM.  Denser data still grows the buffers.
     const size_t piece = size_t(1) << 22;
-    const bool presize = !std::getenv("ISSL_RAW_CHUNKS") && n >= (size_t(1) << 15); // small pages: the default buffers do
+    const bool presize = !idx->tuning.raw_chunks && n >= (size_t(1) << 15); // small pages: the default buffers do
     const double records_per_comparison = 8e-5;
     size_t free_b = 0, total_b = 0;
     if (presize) HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-    const double budget_slots = std::max<double>(static_cast<double>(idx->lanes[0].ws.cap_chunks) * (kChunkRecs - 1),
+    const double budget_slots = std::max<double>(static_cast<double>(idx->lane.ws.cap_chunks) * (kChunkRecs - 1),
                                                  static_cast<double>(std::min<size_t>(free_b / 4, size_t(32) << 30)) / 32.0);
     const uint64_t per = idx->geo.buckets_per_slice();
     issl_stats total{};
@@ -1001,14 +1199,14 @@ int issl_score(issl_index *idx, const uint64_t *guides, size_t n, int max_dist, 
             cand += c;
             ++cnt;
         }
-        Workspace &ws = idx->lanes[0].ws;
+        Workspace &ws = idx->lane.ws;
         int rc = finish_batches(idx, nullptr); // asynchronous batches may still use the staging buffers
         if (rc) return rc;
-        rc = ensure_workspace(idx, idx->lanes[0], cnt);
+        rc = ensure_workspace(idx, cnt);
         if (rc) return rc;
         if (presize) {
             const double slots = std::min(static_cast<double>(cand) * records_per_comparison, budget_slots);
-            rc = ensure_raw_capacity(ws, static_cast<size_t>(slots / (kChunkRecs - 1)) + size_t(scan_blocks()) * 16 * 2);
+            rc = ensure_raw_capacity(ws, static_cast<size_t>(slots / (kChunkRecs - 1)) + size_t(scan_waves(idx->tuning)) * 2);
             if (rc) return rc;
         }
         HIP_TRY(hipMemcpy(ws.d_guides, guides + at, 8 * cnt, hipMemcpyHostToDevice));
@@ -1018,6 +1216,7 @@ int issl_score(issl_index *idx, const uint64_t *guides, size_t n, int max_dist, 
         HIP_TRY(hipMemcpy(cfd + at, ws.d_cfd, 8 * cnt, hipMemcpyDeviceToHost));
         const issl_stats &s = idx->stats;
         total.n_guides += s.n_guides; total.candidates += s.candidates; total.hits += s.hits;
+        total.planned_comparisons += s.planned_comparisons;
         total.scan_tiles += s.scan_tiles; total.ms_bin += s.ms_bin; total.ms_scan += s.ms_scan;
         total.ms_verify += s.ms_verify; total.ms_group += s.ms_group; total.ms_replay += s.ms_replay;
         total.ms_total += s.ms_total; total.scan_launches += s.scan_launches;
@@ -1039,8 +1238,8 @@ int issl_dump_hits(issl_index *idx, const uint64_t *guides, size_t n, int max_di
     HIP_TRY(hipSetDevice(idx->device));
     int rc = finish_batches(idx, nullptr);
     if (rc) return rc;
-    Workspace &ws = idx->lanes[0].ws;
-    rc = ensure_workspace(idx, idx->lanes[0], n);
+    Workspace &ws = idx->lane.ws;
+    rc = ensure_workspace(idx, n);
     if (rc) return rc;
     HIP_TRY(hipMemcpy(ws.d_guides, guides, 8 * n, hipMemcpyHostToDevice));
     rc = score_core(idx, ws.d_guides, n, max_dist, threshold, method, ws.d_mit, ws.d_cfd, nullptr, true);

@@ -3,6 +3,7 @@
 #pragma once
 #include <cstddef>
 #include <cstdint>
+#include <string>
 
 #include "issl_host.hpp"
 
@@ -29,8 +30,15 @@ namespace issl {
 //                              candidate signature with its own slice removed, 16 positions, even
 //                              bits in the low half-word and odd bits in the high half-word;
 //                              each bucket zero-padded to a whole number of tiles.
+//
+// Hot and cold.  The scan reads ONLY `scan` (20 B per site); `sites` / `entries` / `esig` (48-88 B per site) are read
+// for the ~2e-5 of the comparisons that come within max_dist (k_verify, k_replay).  When the whole image does not
+// fit the free HBM (the format's 32-bit ids allow 4.29 G sites = 292 GB, and a resident server keeps several
+// indexes) the cold sections live in mapped, pinned HOST memory instead (`cold_on_host`): their offsets are then
+// relative to that second buffer, `total_bytes` covers the hot part only, and the kernels read them across PCIe
+// through the same ImageView pointers.
 constexpr uint64_t kImageMagic = 0x314C535349444D41ull; // "AMDISSL1"
-constexpr uint32_t kImageVersion = 3;
+constexpr uint32_t kImageVersion = 4;
 constexpr uint32_t kTileCands = 2048; // candidates per scan tile: one wave, 64 lanes x 32 registers
 constexpr uint32_t kHeaderBytes = 4096;
 
@@ -48,6 +56,8 @@ struct ImageHeader {
         off_scan;
     uint64_t off_mit_dense; // 0: absent (table holds masks outside the 20 even bits)
     uint64_t off_esig;      // 0: absent (large indexes: +8 B per list entry do not pay for themselves in HBM)
+    uint64_t cold_on_host;  // 1: off_sites / off_entries are offsets into the pinned host buffer of cold_bytes bytes
+    uint64_t cold_bytes;    // bytes of sites + entries (+ esig) wherever they live
 };
 static_assert(sizeof(ImageHeader) <= kHeaderBytes, "header must fit its block");
 
@@ -73,17 +83,39 @@ struct ImageView {
 // Layout computation shared by upload and attach.  Fills every field of `h` from the geometry,
 // the number of unique scores and the bucket sizes (sizes may be null when n_tiles is given).
 void layout_image(ImageHeader &h, const Geometry &g, uint64_t n_scores_unique, uint64_t n_tiles, bool dense_mit,
-                  bool inline_sigs);
-ImageView make_view(const ImageHeader &h, void *base);
+                  bool inline_sigs, bool cold_on_host);
+// `cold`: device-visible address of the pinned host buffer when h.cold_on_host, else ignored.
+ImageView make_view(const ImageHeader &h, void *base, void *cold);
 
-// Slice lists built on the device (issl_build.hip): d_entries[s * n_sites + k] for the n_slices slices, from the site
-// signatures and their occurrence counts, both already in device memory.  Synchronous.
-int launch_build_entries(const uint64_t *d_sites, const uint32_t *d_occ, uint64_t n_sites, uint32_t n_slices,
-                         uint32_t slice_width, uint64_t *d_entries);
+// ---- tuning knobs ------------------------------------------------------------------------------
+// Read from the environment ONCE, when an index handle is created (never inside a scoring call: several scoring
+// threads share the process environment), and changed afterwards only through issl_index_set_option().
+struct Tuning {
+    uint32_t scan_blocks;   // ISSL_SCAN_BLOCKS   workgroups of the scan launch
+    uint32_t item_guides;   // ISSL_ITEM_GUIDES   guides per scan item (multiple of 8, <= kItemGuides)
+    uint32_t scan_tiles;    // ISSL_SCAN_TILES    candidate tiles a scan wave keeps in registers per guide pass (1 or 2)
+    bool scan_generic;      // ISSL_SCAN_GENERIC  force the runtime-threshold build of the scan kernel
+    bool stage_timing;      // ISSL_STAGE_TIMING  asynchronous batches record an event at every stage boundary
+    bool upload_timing;     // ISSL_UPLOAD_TIMING one stderr line per upload stage
+    size_t raw_chunks;      // ISSL_RAW_CHUNKS    initial raw-record buffer in chunks (0: sized from the launch)
+    int inline_sigs;        // ISSL_INLINE_SIGS   -1 automatic, 0 never, 1 always
+    int host_cold;          // ISSL_FORCE_HOST_COLD  -1 automatic (image larger than the free HBM), 0 never, 1 always
+    std::string stamps_path; // ISSL_SCAN_STAMPS  dump per-wave clocks of the scan here (diagnostics)
+    static Tuning from_env();
+    // Returns false when the key is unknown or the value out of range.
+    bool set(const char *key, const char *value);
+};
+
+// Slice lists built on the device (issl_build.hip): d_entries[(s - slice_begin) * n_sites + k] for the slices
+// [slice_begin, slice_end), from the site signatures and their occurrence counts, both already in device memory.
+// Synchronous.
+int launch_build_entries(const uint64_t *d_sites, const uint32_t *d_occ, uint64_t n_sites, uint32_t slice_begin,
+                         uint32_t slice_end, uint32_t slice_width, uint64_t *d_entries);
 
 // ---- scoring workspace -------------------------------------------------------------------------
 constexpr uint32_t kGuideGroup = 8;    // guide words fetched per scalar load
 constexpr uint32_t kItemGuides = 512;  // guides per scan item (bounds one tile's work)
+constexpr uint32_t kDefaultScanTiles = 1; // tiles a scan wave keeps in registers (Tuning::scan_tiles)
 constexpr uint32_t kTileFixedCost = 4; // cost of fetching a tile, in guide-comparisons of that tile
 constexpr uint32_t kNoGuide = 0xFFFFFFFFu;
 constexpr uint32_t kPadGuideWord = 0xFFFFFFFFu; // scan word of padding guide slots: 16 x T, distance 16 from tile padding
@@ -91,7 +123,6 @@ constexpr uint32_t kScanGridBlocks = 256u * 4u; // scan launch: 256 CUs x 2 resi
 constexpr uint32_t kScanMaxBlocks = 8192u;       // upper bound of the ISSL_SCAN_BLOCKS knob
 constexpr uint32_t kScanWaves = kScanMaxBlocks * 16u;
 constexpr uint32_t kMaxRanges = kScanMaxBlocks;  // one equal-cost range per workgroup
-uint32_t scan_blocks();                          // workgroups of the scan launch (kScanGridBlocks unless ISSL_SCAN_BLOCKS)
 constexpr uint32_t kChunkRecs = 128;            // raw-record chunk: 1 KiB, slot 0 is the fill count
 constexpr uint64_t kDeadKey = ~0ull;            // raw slot that did not survive the exact check
 
@@ -100,16 +131,16 @@ struct ScanItem {
     uint32_t bucket;
     uint32_t g0, g1; // range in the bucket-sorted guide arrays, g0 % kGuideGroup == 0
     uint32_t n_tiles;
-    uint64_t cost0;  // sum of costs of all earlier items; tile cost = (g1-g0)+kTileFixedCost
-    uint32_t tile0;  // sum of n_tiles of all earlier items (tiles are numbered in item order)
-    uint32_t pad;
+    uint64_t cost0;  // sum of costs of all earlier items; a unit of tp tiles costs tp * ((g1-g0) + kTileFixedCost)
+    uint32_t unit0;  // sum of the unit counts of all earlier items (units are numbered in item order)
+    uint32_t last_cands; // candidates in the bucket's last tile (1..kTileCands): the other tiles are full
 };
 
-// Start of a cost range of the scan: (item, tile inside the item, guide offset); item == n_items marks the end.
+// Start of a cost range of the scan: (item, unit inside the item, guide offset); item == n_items marks the end.
 struct RangeStart {
     uint32_t item;
-    uint32_t tile;
-    uint32_t goff; // guide offset inside the item (multiple of 8): a tile may be shared by two ranges
+    uint32_t unit;
+    uint32_t goff; // guide offset inside the item (multiple of 8): a unit may be shared by two ranges
     uint32_t pad;
 };
 
@@ -120,7 +151,7 @@ struct PlanInfo {
     uint32_t n_ranges;    // equal-cost ranges of the scan, one per workgroup
     uint32_t pad;
     uint64_t total_cost;
-    uint64_t candidates;  // sum over guides of their bucket lengths
+    uint64_t candidates;  // sum over guides of their bucket lengths (what the plan EXPECTS the scan to compare)
     uint64_t tiles;       // (tile, item) pairs the scan works through
 };
 
@@ -145,6 +176,7 @@ struct Workspace {
     uint64_t *raw = nullptr;     // [(cap_chunks+1) * kChunkRecs] raw records of the scan, chunked
     size_t cap_chunks = 0;
     Counters *counters = nullptr;
+    uint64_t *scan_count = nullptr; // [kScanMaxBlocks] comparisons every scan workgroup actually made (real candidates x real guides)
     unsigned long long *stamps = nullptr; // [4 * kScanWaves] scan wave clocks, then replay phase clocks (ISSL_SCAN_STAMPS diagnostics)
     uint32_t *sticky = nullptr;  // [4] survives the per-batch resets: [0] raw overflow seen, [1] max chunks asked, [2] plan errors
     uint64_t *sorted = nullptr;  // [hit_cap] keys guide<<35 | slice<<32 | pos, grouped by guide
@@ -173,9 +205,12 @@ struct ScoreParams {
 
 // Launchers (issl_kernels.hip).  All asynchronous on `stream`.
 void launch_pack_scan_stream(const ImageView &v, uint32_t *scan_out, uint64_t *esig_out, uint32_t *error_flag, void *stream);
-void launch_bin_guides(const ImageView &v, const Workspace &ws, const uint64_t *d_guides, uint32_t n, void *stream);
-void launch_scan(const ImageView &v, const Workspace &ws, const uint64_t *d_guides, uint32_t n, int max_dist,
-                 void *stream);
+void launch_pack_scan_range(const ImageView &v, uint32_t *scan_out, uint64_t *esig_out, uint32_t *error_flag,
+                            uint32_t tile_begin, uint32_t tile_end, void *stream);
+void launch_bin_guides(const ImageView &v, const Workspace &ws, const Tuning &tn, const uint64_t *d_guides, uint32_t n,
+                       void *stream);
+void launch_scan(const ImageView &v, const Workspace &ws, const Tuning &tn, const uint64_t *d_guides, uint32_t n,
+                 int max_dist, void *stream);
 void launch_verify(const ImageView &v, const Workspace &ws, const uint64_t *d_guides, int max_dist, void *stream);
 void launch_group_hits(const Workspace &ws, uint32_t n, void *stream);
 void launch_replay(const ImageView &v, const Workspace &ws, const uint64_t *d_guides, uint32_t n,

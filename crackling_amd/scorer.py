@@ -153,6 +153,23 @@ class IsslIndex:
         self._keep = tensor
         return self
 
+    def set_option(self, key, value):
+        """Tuning knob of this handle (include/issl_hip.h: issl_index_set_option); no batches may be in flight."""
+        check(lib.issl_index_set_option(self._h, str(key).encode(), str(value).encode()))
+        return self
+
+    def get_option(self, key):
+        v = C.c_longlong()
+        check(lib.issl_index_get_option(self._h, str(key).encode(), C.byref(v)))
+        return v.value
+
+    def cold(self):
+        """(host pointer, bytes) of the pinned host buffer holding the cold sections, (None, 0) when all is in HBM."""
+        p = C.c_void_p()
+        n = C.c_size_t()
+        check(lib.issl_index_cold(self._h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
     def image(self):
         p = C.c_void_p()
         n = C.c_size_t()

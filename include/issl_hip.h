@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define ISSL_ABI_VERSION 1
+#define ISSL_ABI_VERSION 2
 
 enum {
     ISSL_OK = 0,
@@ -71,11 +71,14 @@ typedef struct {
 
 /* Timings and counters of the last issl_score* call on an index (milliseconds, GPU events).  ms_scan is always
  * measured (mean over the batches since the last finish); the other stage times and ms_total are filled by the
- * synchronous entry points, and by issl_score_device_async only when ISSL_STAGE_TIMING=1 is set (every event record
- * costs ~4 us of stream time, which back-to-back batches should not pay). */
+ * synchronous entry points, and by issl_score_device_async only when the stage_timing option is set (every event
+ * record costs ~4 us of stream time, which back-to-back batches should not pay). */
 typedef struct {
     uint64_t n_guides;
-    uint64_t candidates;    /* sum over guides of the 5 bucket lengths = comparisons done */
+    uint64_t candidates;    /* (guide, candidate) comparisons the scan kernel COUNTED while making them: real
+                               candidates of every tile it fetched x real guides it ran past it (isslScoreOfftargets.cpp
+                               :344 iterations without early exit) -- equals issl_count_candidates() when every
+                               bucket of every guide was scanned */
     uint64_t hits;          /* candidates within max_dist, first matching slice only */
     uint64_t scan_tiles;    /* candidate tiles x guide groups processed by the scan kernel */
     double ms_bin;          /* guide binning kernels */
@@ -87,6 +90,8 @@ typedef struct {
     uint64_t scan_launches; /* >1 when a hit buffer had to grow and the scan was repeated */
     uint64_t raw_records;   /* upper bound of candidates noted by the scan (chunks handed out x chunk size) */
     uint64_t n_batches;     /* batches covered by these statistics (ms_scan is their mean) */
+    uint64_t planned_comparisons; /* what the planning kernel expected from the bucket-length table (host arithmetic
+                                     equivalent: issl_count_candidates) */
 } issl_stats;
 
 const char *issl_last_error(void);
@@ -152,6 +157,32 @@ int issl_index_attach_image(int device, void *dev_buf, size_t bytes, issl_index 
 
 /* Device pointer/size of the current image (for the broadcast on the producing rank). */
 int issl_index_image(const issl_index *idx, void **dev_ptr, size_t *bytes);
+
+/* Index larger than the free HBM (BASELINE configs[4]; the format's 32-bit ids, isslScoreOfftargets.cpp:347, allow
+ * 4.29 G sites = 292 GB of image).  Only the scan stream (20 B/site) is read by the scan; the site table and the slice
+ * lists (isslScoreOfftargets.cpp:200-204,235-240; 48 B/site) are touched for the ~2e-5 of the comparisons that come
+ * within max_dist.  issl_index_upload / issl_index_build_on_device therefore fall back, in this order, to an image
+ * without the optional in-list signatures and to an image whose cold sections stay in pinned, mapped HOST memory and
+ * are read across PCIe by the verify and replay kernels (option host_cold / ISSL_FORCE_HOST_COLD=1 forces that layout;
+ * results are identical).  issl_index_cold() returns that host buffer (NULL / 0 when everything is in HBM); another
+ * device of the same process adopts a copy of the hot image plus the SAME host buffer with
+ * issl_index_attach_image_cold (issl_node does this).  Images with host-resident cold sections cannot be attached in
+ * another process. */
+int issl_index_cold(const issl_index *idx, void **host_ptr, size_t *bytes);
+int issl_index_attach_image_cold(int device, void *dev_buf, size_t bytes, void *cold_host, size_t cold_bytes,
+                                 issl_index **out);
+
+/* Tuning knobs.  Every knob has an environment variable that is read ONCE, when the handle is created (open / build /
+ * attach), never inside a scoring call; afterwards this call changes it (no batches may be in flight).  Keys (env):
+ *   scan_blocks (ISSL_SCAN_BLOCKS) workgroups of the scan launch      item_guides (ISSL_ITEM_GUIDES) guides per scan item
+ *   scan_tiles (ISSL_SCAN_TILES) 1|2 tiles per scan wave              scan_generic (ISSL_SCAN_GENERIC) 0|1 runtime-threshold scan
+ *   stage_timing (ISSL_STAGE_TIMING) 0|1 events at every stage        raw_chunks (ISSL_RAW_CHUNKS) initial raw-record buffer
+ *   inline_sigs (ISSL_INLINE_SIGS) -1|0|1, host_cold (ISSL_FORCE_HOST_COLD) -1|0|1: image layout, read at upload
+ *   scan_stamps (ISSL_SCAN_STAMPS) file for per-wave clocks (diagnostics) */
+int issl_index_set_option(issl_index *idx, const char *key, const char *value);
+/* Current value of an integer knob; also the read-only keys cold_on_host and has_inline_sigs (layout of the uploaded
+ * image: 0/1, -1 before an upload). */
+int issl_index_get_option(const issl_index *idx, const char *key, long long *value);
 
 /* ---- guides (A2, isslScoreOfftargets.cpp:63-71,82-89,275-305) ---------------------------- */
 

@@ -150,40 +150,61 @@ def test_large_max_dist_and_single_guide(config0):
     assert mit[0] == omit[0] and cfd[0] == ocfd[0]
 
 
-def test_runtime_threshold_build_of_the_scan_kernel(config0, monkeypatch):
+@pytest.mark.parametrize("scan_tiles", [1, 2])
+def test_runtime_threshold_build_of_the_scan_kernel(config0, scan_tiles):
     """The scan kernel is compiled with max_dist 0..4 as constants and once with a runtime threshold (used for
-    max_dist > 4).  Force the runtime-threshold build for small distances too and compare."""
+    max_dist > 4), each holding one or two tiles per wave.  Force the runtime-threshold build for small distances too
+    and compare."""
     ix, oracle, sigs, guides = config0
-    monkeypatch.setenv("ISSL_SCAN_GENERIC", "1")
-    for dist in (0, 1, 2, 3, 4, 5, 16):
-        mit, cfd = ix.score(guides[:256], dist, 0.0, "and")
-        omit, ocfd = oracle.score(guides[:256], dist, 0.0, "and")
-        assert np.array_equal(mit.view(np.uint64), omit.view(np.uint64)), dist
-        assert np.array_equal(cfd.view(np.uint64), ocfd.view(np.uint64)), dist
-    monkeypatch.delenv("ISSL_SCAN_GENERIC")
-    for dist in (1, 2, 3):
-        mit, cfd = ix.score(guides[:256], dist, 0.0, "and")
-        omit, ocfd = oracle.score(guides[:256], dist, 0.0, "and")
-        assert np.array_equal(mit.view(np.uint64), omit.view(np.uint64)), dist
-        assert np.array_equal(cfd.view(np.uint64), ocfd.view(np.uint64)), dist
+    default_tiles = ix.get_option("scan_tiles")
+    ix.set_option("scan_tiles", scan_tiles).set_option("scan_generic", 1)
+    try:
+        for dist in (0, 1, 2, 3, 4, 5, 16):
+            mit, cfd = ix.score(guides[:256], dist, 0.0, "and")
+            omit, ocfd = oracle.score(guides[:256], dist, 0.0, "and")
+            assert np.array_equal(mit.view(np.uint64), omit.view(np.uint64)), dist
+            assert np.array_equal(cfd.view(np.uint64), ocfd.view(np.uint64)), dist
+    finally:
+        ix.set_option("scan_generic", 0)
+    try:
+        for dist in (0, 1, 2, 3, 4):
+            mit, cfd = ix.score(guides[:256], dist, 0.0, "and")
+            assert ix.stats()["candidates"] == ix.stats()["planned_comparisons"] == ix.count_candidates(guides[:256])
+            omit, ocfd = oracle.score(guides[:256], dist, 0.0, "and")
+            assert np.array_equal(mit.view(np.uint64), omit.view(np.uint64)), dist
+            assert np.array_equal(cfd.view(np.uint64), ocfd.view(np.uint64)), dist
+    finally:
+        ix.set_option("scan_tiles", default_tiles)
 
 
-def test_scheduling_knobs_do_not_change_results(config0, monkeypatch):
-    """Smaller scan items (more, finer work units; tiles re-read per item): same hit lists and scores."""
+def test_scheduling_knobs_do_not_change_results(config0):
+    """Smaller scan items (more, finer work units; tiles re-read per item), other launch sizes, one or two tiles per
+    scan wave: same hit lists and scores, and the scan counts exactly the comparisons the bucket table predicts."""
     ix, oracle, sigs, guides = config0
     rng = np.random.default_rng(5)
     batch = np.concatenate([guides, guides[:1].repeat(700) ^ (rng.integers(0, 1 << 14, size=700, dtype=np.uint64) << np.uint64(20))])
     want = ix.dump_hits(batch, 4, 0.0, "and")
     wm, wc = ix.score(batch, 4, 75.0, "and")
-    for sched in ("64", "8", "200"):
-        monkeypatch.setenv("ISSL_ITEM_GUIDES", sched)
-        got = ix.dump_hits(batch, 4, 0.0, "and")
-        assert np.array_equal(got, want), sched
-        gm, gc = ix.score(batch, 4, 75.0, "and")
-        assert np.array_equal(gm, wm) and np.array_equal(gc, wc), sched
-    monkeypatch.delenv("ISSL_ITEM_GUIDES")
+    expected = ix.count_candidates(batch)
+    default_tiles = ix.get_option("scan_tiles")
+    try:
+        for tiles in (1, 2):
+            for sched, blocks in (("64", 1024), ("8", 1024), ("200", 77), ("512", 4096)):
+                ix.set_option("scan_tiles", tiles).set_option("item_guides", sched).set_option("scan_blocks", blocks)
+                got = ix.dump_hits(batch, 4, 0.0, "and")
+                assert np.array_equal(got, want), (tiles, sched, blocks)
+                gm, gc = ix.score(batch, 4, 75.0, "and")
+                assert np.array_equal(gm, wm) and np.array_equal(gc, wc), (tiles, sched, blocks)
+                st = ix.stats()
+                assert st["candidates"] == expected == st["planned_comparisons"], (tiles, sched, blocks)
+    finally:
+        ix.set_option("scan_tiles", default_tiles).set_option("item_guides", 512).set_option("scan_blocks", 1024)
     _, _, ohits = oracle.score(batch, 4, 0.0, "and", want_hits=True)
     assert np.array_equal(want, ohits)
+    with pytest.raises(ca.IsslError):
+        ix.set_option("scan_tiles", 3)
+    with pytest.raises(ca.IsslError):
+        ix.set_option("no_such_knob", 1)
 
 
 def test_skewed_batch_and_poly_a(config0):
@@ -256,12 +277,9 @@ def test_one_site_index(tmp_path):
     ix.close()
 
 
-@pytest.mark.parametrize("lanes", ["1", "2", "3"])
-def test_async_batches(config0, monkeypatch, lanes):
-    """issl_score_device_async / issl_score_wait / issl_score_finish: several batches in flight, on one internal
-    lane (default) and rotating through two or three (ISSL_LANES, scans on a shared high-priority stream)."""
+def test_async_batches(config0):
+    """issl_score_device_async / issl_score_wait / issl_score_finish: several batches in flight on the internal stream."""
     import torch
-    monkeypatch.setenv("ISSL_LANES", lanes)
     ix, oracle, sigs, guides = config0
     stream = torch.cuda.current_stream().cuda_stream
     parts = [guides[:300], guides[300:301], guides[301:]]

@@ -5,32 +5,42 @@ import numpy as np
 ROOT = pathlib.Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
 import crackling_amd as ca
-from synth import random_sites, random_guides
+from synth import random_sites, random_sites_fast, markov_sites, random_guides
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--sites", type=int, default=5_000_000)
 ap.add_argument("--guides", type=int, default=10_000)
 ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--thr", type=float, default=0.0)
-ap.add_argument("--variants", default="512", help="ISSL_SCAN_BLOCKS settings to compare, separated by /")
+ap.add_argument("--variants", default="", help="option settings to compare, separated by / (each a comma list of key=value, "
+                "see issl_index_set_option), e.g. scan_tiles=1/scan_tiles=2,scan_blocks=2048")
+ap.add_argument("--fast-synth", action="store_true", help="random_sites_fast + index built on the device (large indexes)")
+ap.add_argument("--dist", default="uniform", choices=["uniform", "markov"])
 ap.add_argument("--json", default=None, help="write the best repetition (by scan time) of the last variant here")
 ap.add_argument("--write-issl", default=None)
 ap.add_argument("--write-guides", default=None)
 a = ap.parse_args()
-t = time.time(); sigs, occ = random_sites(a.sites, seed=1); guides = random_guides(sigs, a.guides, seed=2)
+gen = markov_sites if a.dist == "markov" else (random_sites_fast if a.fast_synth else random_sites)
+t = time.time(); sigs, occ = gen(a.sites, seed=1); guides = random_guides(sigs, a.guides, seed=2)
 print(f"synth {time.time()-t:.1f}s  distinct={len(sigs)}", flush=True)
-t = time.time(); ix = ca.IsslIndex.build_from_sites(sigs, occ); t_build = time.time() - t; print(f"build {t_build:.1f}s", flush=True)
+t = time.time()
+ix = ca.IsslIndex.build_on_device(sigs, occ, device=0) if a.fast_synth else ca.IsslIndex.build_from_sites(sigs, occ)
+t_build = time.time() - t; print(f"build {t_build:.1f}s", flush=True)
 if a.write_issl:
     t = time.time(); ix.write(a.write_issl); print(f"write issl {time.time()-t:.1f}s", flush=True)
 if a.write_guides:
     open(a.write_guides, "w").write("".join(s + "\n" for s in ca.decode_guides(guides)))
-t = time.time(); ix.upload(0); t_upload = time.time() - t
+t = time.time()
+if not a.fast_synth:
+    ix.upload(0)
+t_upload = time.time() - t
 print(f"upload {t_upload:.1f}s  image={ix.device_bytes()/1e9:.2f} GB", flush=True)
 import os, json
 best = None
 for variant in a.variants.split("/"):
-  os.environ["ISSL_SCAN_BLOCKS"] = variant
-  print(f"-- scan blocks {variant}", flush=True)
+  for kv in filter(None, variant.split(",")):
+    ix.set_option(*kv.split("="))
+  print(f"-- {variant or 'defaults'}", flush=True)
   for r in range(a.reps):
     t = time.time(); mit, cfd = ix.score(guides, 4, a.thr, "and"); dt = time.time() - t
     st = ix.stats()
