@@ -86,6 +86,7 @@ _protos = {
     "issl_index_upload_into": (C.c_int, [_P, C.c_int, _P, C.c_size_t]),
     "issl_index_attach_image": (C.c_int, [C.c_int, _P, C.c_size_t, C.POINTER(_P)]),
     "issl_index_image": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_size_t)]),
+    "issl_index_copy_image_to": (C.c_int, [_P, _P, C.c_size_t]),
     "issl_index_cold": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_size_t)]),
     "issl_index_attach_image_cold": (C.c_int, [C.c_int, _P, C.c_size_t, _P, C.c_size_t, C.POINTER(_P)]),
     "issl_index_set_option": (C.c_int, [_P, C.c_char_p, C.c_char_p]),
@@ -110,6 +111,7 @@ _protos = {
     "issl_node_create": (C.c_int, [_P, C.POINTER(C.c_int), C.c_int, C.POINTER(_P)]),
     "issl_node_score": (C.c_int, [_P, _P, C.c_size_t, C.c_int, C.c_double, C.c_int, _P, _P]),
     "issl_node_get_info": (C.c_int, [_P, C.POINTER(NodeInfo)]),
+    "issl_node_shard_times": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]),
     "issl_node_close": (C.c_int, [_P]),
 }
 for _name, (_res, _args) in _protos.items():

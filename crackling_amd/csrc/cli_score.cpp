@@ -7,8 +7,9 @@
 // that was not requested); diagnostics go to stderr; exit status 1 on any error.
 // Optional environment (the five positionals stay untouched so that Crackling needs no change):
 //   ISSL_DEVICE=<n>   HIP device to use (default 0)
-//   ISSL_DEVICES=all | <a,b,...>   several GPUs of the node: index image broadcast over RCCL/xGMI, guides sharded
-//                     (default: one device; all visible devices when the query file holds >= 2^20 guides)
+//   ISSL_DEVICES=all | <a,b,...>   several GPUs of the node: index image broadcast over RCCL/xGMI, guides handed out
+//                     in chunks (opt-in only: by default one device is used, whatever the size of the query file --
+//                     a page process must not fail because a neighbour GPU is busy or RCCL cannot start)
 //   ISSL_TIMING=1     one JSON line with load/upload/score timings on stderr
 //   ISSL_SERVER=<unix socket path>   resident mode, see below
 //   ISSL_VERDICTS=<file>   also write "<20-mer>\t<0|1>\n" per guide: the accept/reject decision Crackling derives
@@ -22,6 +23,7 @@
 #include <cerrno>
 #include <chrono>
 #include <climits>
+#include <csignal>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -88,9 +90,11 @@ struct Resident {
     issl_header hdr{};
     double load_ms = 0, upload_ms = 0, broadcast_ms = 0;
     int n_devices = 1, used_rccl = 0;
-    // identity of the file it was loaded from
+    // identity of the file it was loaded from (a rebuilt index must not be served stale from HBM)
     off_t size = 0;
-    time_t mtime = 0;
+    struct timespec mtime{};
+    ino_t ino = 0;
+    dev_t dev = 0;
 };
 
 void release(Resident &r)
@@ -100,14 +104,14 @@ void release(Resident &r)
     r = Resident{};
 }
 
-// Open + upload.  n_guides_hint decides whether all devices are worth setting up when nothing was asked for.
-bool make_resident(const char *issl_path, const DeviceChoice &dc, size_t n_guides_hint, Resident &r, std::string &err)
+// Open + upload.  Several devices only when ISSL_DEVICES asks for them.
+bool make_resident(const char *issl_path, const DeviceChoice &dc, Resident &r, std::string &err)
 {
     const double t0 = now_ms();
     if (issl_index_open(issl_path, &r.idx)) { err = last_error("cannot open index"); return false; }
     issl_index_header(r.idx, &r.hdr);
     r.load_ms = now_ms() - t0;
-    const bool all = dc.all || (!dc.single_given && dc.list.empty() && n_guides_hint >= (size_t(1) << 20));
+    const bool all = dc.all;
     const double t1 = now_ms();
     if (all || dc.list.size() > 1) {
         if (issl_node_create(r.idx, all ? nullptr : dc.list.data(), static_cast<int>(dc.list.size()), &r.node)) {
@@ -241,10 +245,11 @@ bool score_request(Resident &r, const Request &q, std::string &out, std::string 
 //   request : "SCORE\t<issl>\t<query>\t<maxDist>\t<threshold>\t<method>[\t<verdict file>]\n"   |  "QUIT\n"
 //   response: "OK <nbytes> <timing json>\n" + nbytes of TSV               |  "ERR <message>\n"
 
+// Sockets only: a peer that went away gives EPIPE instead of a signal (the server must outlive its clients).
 bool write_all(int fd, const char *p, size_t n)
 {
     while (n) {
-        const ssize_t k = ::write(fd, p, n);
+        const ssize_t k = ::send(fd, p, n, MSG_NOSIGNAL);
         if (k < 0) {
             if (errno == EINTR) continue;
             return false;
@@ -288,8 +293,19 @@ int serve(const char *sock_path)
     sockaddr_un addr;
     const int lfd = unix_socket(sock_path, addr);
     if (lfd < 0) { std::fprintf(stderr, "cannot create socket %s\n", sock_path); return 1; }
-    ::unlink(sock_path);
-    if (::bind(lfd, reinterpret_cast<sockaddr *>(&addr), sizeof addr) != 0 || ::listen(lfd, 16) != 0) {
+    std::signal(SIGPIPE, SIG_IGN); // a client killed mid-answer must not take the server (and its resident indexes) down
+    struct stat old;
+    if (::lstat(sock_path, &old) == 0) { // a stale socket of an earlier server may be replaced, nothing else
+        if (!S_ISSOCK(old.st_mode)) {
+            std::fprintf(stderr, "%s exists and is not a socket: not touching it\n", sock_path);
+            return 1;
+        }
+        ::unlink(sock_path);
+    }
+    const mode_t mask = ::umask(0177); // the socket is created 0600: only this user may send requests
+    const bool bound = ::bind(lfd, reinterpret_cast<sockaddr *>(&addr), sizeof addr) == 0;
+    ::umask(mask);
+    if (!bound || ::listen(lfd, 16) != 0) {
         std::fprintf(stderr, "cannot listen on %s: %s\n", sock_path, std::strerror(errno));
         return 1;
     }
@@ -303,6 +319,11 @@ int serve(const char *sock_path)
             if (errno == EINTR) continue;
             break;
         }
+        // one client at a time: a client that connects and then says nothing may hold the server for 10 s, no longer;
+        // one that stops reading its answer, for 60 s
+        const struct timeval rcv_to = {10, 0}, snd_to = {60, 0};
+        ::setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &rcv_to, sizeof rcv_to);
+        ::setsockopt(fd, SOL_SOCKET, SO_SNDTIMEO, &snd_to, sizeof snd_to);
         std::string line;
         if (read_line(fd, line)) {
             if (line == "QUIT") {
@@ -329,13 +350,17 @@ int serve(const char *sock_path)
                         err = "cannot open index file '" + q.issl + "': " + std::strerror(errno);
                     } else {
                         auto it = cache.find(q.issl);
-                        bool hit = it != cache.end() && it->second.size == st.st_size && it->second.mtime == st.st_mtime;
+                        bool hit = it != cache.end() && it->second.size == st.st_size && it->second.ino == st.st_ino &&
+                                   it->second.dev == st.st_dev && it->second.mtime.tv_sec == st.st_mtim.tv_sec &&
+                                   it->second.mtime.tv_nsec == st.st_mtim.tv_nsec;
                         if (it != cache.end() && !hit) { release(it->second); cache.erase(it); it = cache.end(); }
                         if (it == cache.end()) {
                             Resident r;
-                            if (make_resident(q.issl.c_str(), dc, 0, r, err)) {
+                            if (make_resident(q.issl.c_str(), dc, r, err)) {
                                 r.size = st.st_size;
-                                r.mtime = st.st_mtime;
+                                r.mtime = st.st_mtim;
+                                r.ino = st.st_ino;
+                                r.dev = st.st_dev;
                                 it = cache.emplace(q.issl, r).first;
                             }
                         }
@@ -449,10 +474,6 @@ int main(int argc, char **argv)
     q.threshold = std::atof(argv[4]);    // :112
     q.method_arg = argv[5];
     if (const char *vp = std::getenv("ISSL_VERDICTS")) q.verdict_path = vp;
-    // size of the query file decides whether a lone process spreads over all GPUs
-    size_t n_hint = 0;
-    struct stat st;
-    if (::stat(argv[2], &st) == 0) n_hint = static_cast<size_t>(st.st_size) / 21;
     Resident r;
     std::string err, out, tj;
     {   // same order of checks as the reference: index file first, then the query file (:152-294), before any
@@ -474,7 +495,7 @@ int main(int argc, char **argv)
             return 1;
         }
     }
-    if (!make_resident(argv[1], device_choice_from_env(), n_hint, r, err)) {
+    if (!make_resident(argv[1], device_choice_from_env(), r, err)) {
         std::fprintf(stderr, "%s\n", err.c_str());
         return 1;
     }

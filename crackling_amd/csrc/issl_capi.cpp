@@ -92,7 +92,6 @@ Tuning Tuning::from_env()
     Tuning t;
     t.scan_blocks = kScanGridBlocks;
     t.item_guides = kItemGuides;
-    t.scan_tiles = kDefaultScanTiles;
     t.scan_generic = false;
     t.stage_timing = false;
     t.upload_timing = env_flag("ISSL_UPLOAD_TIMING");
@@ -100,7 +99,7 @@ Tuning Tuning::from_env()
     t.inline_sigs = -1;
     t.host_cold = -1;
     static const char *const keys[][2] = {
-        {"ISSL_SCAN_BLOCKS", "scan_blocks"}, {"ISSL_ITEM_GUIDES", "item_guides"}, {"ISSL_SCAN_TILES", "scan_tiles"},
+        {"ISSL_SCAN_BLOCKS", "scan_blocks"}, {"ISSL_ITEM_GUIDES", "item_guides"},
         {"ISSL_SCAN_GENERIC", "scan_generic"}, {"ISSL_STAGE_TIMING", "stage_timing"}, {"ISSL_RAW_CHUNKS", "raw_chunks"},
         {"ISSL_INLINE_SIGS", "inline_sigs"}, {"ISSL_FORCE_HOST_COLD", "host_cold"}, {"ISSL_SCAN_STAMPS", "scan_stamps"},
     };
@@ -118,7 +117,6 @@ bool Tuning::set(const char *key, const char *value)
     const bool is_int = end != value && *end == 0;
     if (k == "scan_blocks") { if (!is_int || n < 1 || n > static_cast<long long>(kScanMaxBlocks)) return false; scan_blocks = static_cast<uint32_t>(n); }
     else if (k == "item_guides") { if (!is_int || n < 8 || n > static_cast<long long>(kItemGuides)) return false; item_guides = static_cast<uint32_t>(n) & ~7u; }
-    else if (k == "scan_tiles") { if (!is_int || (n != 1 && n != 2)) return false; scan_tiles = static_cast<uint32_t>(n); }
     else if (k == "scan_generic") { if (!is_int || (n != 0 && n != 1)) return false; scan_generic = n == 1; }
     else if (k == "stage_timing") { if (!is_int || (n != 0 && n != 1)) return false; stage_timing = n == 1; }
     else if (k == "raw_chunks") { if (!is_int || n < 0) return false; raw_chunks = static_cast<size_t>(n); }
@@ -243,7 +241,7 @@ static int ensure_raw_capacity(Workspace &w, size_t chunks)
     return ISSL_OK;
 }
 
-static uint32_t scan_waves(const Tuning &tn) { return tn.scan_blocks * (tn.scan_tiles == 2 ? 8u : 16u); }
+static uint32_t scan_waves(const Tuning &tn) { return tn.scan_blocks * 16u; }
 
 static int ensure_workspace(issl_index *ix, size_t n)
 {
@@ -822,7 +820,7 @@ int issl_index_set_option(issl_index *idx, const char *key, const char *value)
         set_error(std::string("unknown option or value out of range: ") + key + "=" + value);
         return ISSL_E_ARG;
     }
-    if (idx->d_image && (t.scan_blocks != idx->tuning.scan_blocks || t.scan_tiles != idx->tuning.scan_tiles)) {
+    if (idx->d_image && t.scan_blocks != idx->tuning.scan_blocks) {
         // every scan wave owns the raw chunk with its own number: keep at least that many
         HIP_TRY(hipSetDevice(idx->device));
         if (idx->lane.ws.cap_chunks && idx->lane.ws.cap_chunks < size_t(scan_waves(t)) * 2) {
@@ -841,13 +839,13 @@ int issl_index_get_option(const issl_index *idx, const char *key, long long *val
     const std::string k(key);
     if (k == "scan_blocks") *value = t.scan_blocks;
     else if (k == "item_guides") *value = t.item_guides;
-    else if (k == "scan_tiles") *value = t.scan_tiles;
     else if (k == "scan_generic") *value = t.scan_generic;
     else if (k == "stage_timing") *value = t.stage_timing;
     else if (k == "raw_chunks") *value = static_cast<long long>(t.raw_chunks);
     else if (k == "inline_sigs") *value = t.inline_sigs;
     else if (k == "host_cold") *value = t.host_cold;
     else if (k == "cold_on_host") *value = idx->d_image ? static_cast<long long>(idx->hdr.cold_on_host) : -1; // read-only: layout in use
+    else if (k == "dense_mit") *value = idx->d_image ? (idx->hdr.off_mit_dense ? 1 : 0) : -1;              // read-only
     else if (k == "has_inline_sigs") *value = idx->d_image ? (idx->hdr.off_esig ? 1 : 0) : -1;            // read-only
     else { set_error(std::string("unknown option: ") + key); return ISSL_E_ARG; }
     return ISSL_OK;
@@ -1061,6 +1059,19 @@ int issl_index_image(const issl_index *idx, void **dev_ptr, size_t *bytes)
     if (!idx->d_image) { set_error("index has no device image"); return ISSL_E_STATE; }
     *dev_ptr = idx->d_image;
     *bytes = idx->hdr.total_bytes;
+    return ISSL_OK;
+}
+
+int issl_index_copy_image_to(const issl_index *idx, void *dev_dst, size_t bytes)
+{
+    if (!idx || !dev_dst) { set_error("null argument"); return ISSL_E_ARG; }
+    if (!idx->d_image) { set_error("index has no device image"); return ISSL_E_STATE; }
+    if (bytes < idx->hdr.total_bytes || (reinterpret_cast<uintptr_t>(dev_dst) & 255u)) {
+        set_error("destination too small or not 256-byte aligned");
+        return ISSL_E_ARG;
+    }
+    HIP_TRY(hipSetDevice(idx->device));
+    HIP_TRY(hipMemcpy(dev_dst, idx->d_image, idx->hdr.total_bytes, hipMemcpyDeviceToDevice));
     return ISSL_OK;
 }
 

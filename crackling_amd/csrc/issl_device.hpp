@@ -93,7 +93,6 @@ ImageView make_view(const ImageHeader &h, void *base, void *cold);
 struct Tuning {
     uint32_t scan_blocks;   // ISSL_SCAN_BLOCKS   workgroups of the scan launch
     uint32_t item_guides;   // ISSL_ITEM_GUIDES   guides per scan item (multiple of 8, <= kItemGuides)
-    uint32_t scan_tiles;    // ISSL_SCAN_TILES    candidate tiles a scan wave keeps in registers per guide pass (1 or 2)
     bool scan_generic;      // ISSL_SCAN_GENERIC  force the runtime-threshold build of the scan kernel
     bool stage_timing;      // ISSL_STAGE_TIMING  asynchronous batches record an event at every stage boundary
     bool upload_timing;     // ISSL_UPLOAD_TIMING one stderr line per upload stage
@@ -115,7 +114,6 @@ int launch_build_entries(const uint64_t *d_sites, const uint32_t *d_occ, uint64_
 // ---- scoring workspace -------------------------------------------------------------------------
 constexpr uint32_t kGuideGroup = 8;    // guide words fetched per scalar load
 constexpr uint32_t kItemGuides = 512;  // guides per scan item (bounds one tile's work)
-constexpr uint32_t kDefaultScanTiles = 1; // tiles a scan wave keeps in registers (Tuning::scan_tiles)
 constexpr uint32_t kTileFixedCost = 4; // cost of fetching a tile, in guide-comparisons of that tile
 constexpr uint32_t kNoGuide = 0xFFFFFFFFu;
 constexpr uint32_t kPadGuideWord = 0xFFFFFFFFu; // scan word of padding guide slots: 16 x T, distance 16 from tile padding
@@ -131,16 +129,16 @@ struct ScanItem {
     uint32_t bucket;
     uint32_t g0, g1; // range in the bucket-sorted guide arrays, g0 % kGuideGroup == 0
     uint32_t n_tiles;
-    uint64_t cost0;  // sum of costs of all earlier items; a unit of tp tiles costs tp * ((g1-g0) + kTileFixedCost)
-    uint32_t unit0;  // sum of the unit counts of all earlier items (units are numbered in item order)
+    uint64_t cost0;  // sum of costs of all earlier items; tile cost = (g1-g0)+kTileFixedCost
+    uint32_t tile0;  // sum of n_tiles of all earlier items (tiles are numbered in item order)
     uint32_t last_cands; // candidates in the bucket's last tile (1..kTileCands): the other tiles are full
 };
 
-// Start of a cost range of the scan: (item, unit inside the item, guide offset); item == n_items marks the end.
+// Start of a cost range of the scan: (item, tile inside the item, guide offset); item == n_items marks the end.
 struct RangeStart {
     uint32_t item;
-    uint32_t unit;
-    uint32_t goff; // guide offset inside the item (multiple of 8): a unit may be shared by two ranges
+    uint32_t tile;
+    uint32_t goff; // guide offset inside the item (multiple of 8): a tile may be shared by two ranges
     uint32_t pad;
 };
 

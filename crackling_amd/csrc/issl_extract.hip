@@ -206,57 +206,58 @@ int extract_sorted_text(const std::string &seq, int device, char **out_text, siz
         *out_text = static_cast<char *>(std::malloc(1));
         return ISSL_OK;
     }
-    uint8_t *d_seq = nullptr;
-    unsigned long long *d_ctr = nullptr;
-    EX_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_seq), len));
-    EX_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_ctr), 16));
+    // device buffers are released on every path out of this function
+    struct DevBuf {
+        void *p = nullptr;
+        ~DevBuf() { release(); }
+        void release() { if (p) (void)hipFree(p); p = nullptr; }
+    } seq_buf, ctr_buf, keys_buf, tmp_buf, text_buf;
+    EX_HIP_TRY(hipMalloc(&seq_buf.p, len));
+    EX_HIP_TRY(hipMalloc(&ctr_buf.p, 16));
+    uint8_t *d_seq = static_cast<uint8_t *>(seq_buf.p);
+    unsigned long long *d_ctr = static_cast<unsigned long long *>(ctr_buf.p);
     EX_HIP_TRY(hipMemcpy(d_seq, seq.data(), len, hipMemcpyHostToDevice));
     EX_HIP_TRY(hipMemset(d_ctr, 0, 16));
     const uint32_t blocks = static_cast<uint32_t>((len + kPosPerBlock - 1) / kPosPerBlock);
     hipLaunchKernelGGL(k_match_count, dim3(blocks), dim3(256), 0, nullptr, d_seq, len, d_ctr);
     unsigned long long total = 0;
     EX_HIP_TRY(hipMemcpy(&total, d_ctr, 8, hipMemcpyDeviceToHost));
-    uint64_t *d_keys = nullptr, *d_tmp = nullptr;
-    char *d_text = nullptr;
-    int rc = ISSL_OK;
-    if (total) {
-        EX_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_keys), 8 * total));
-        EX_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_tmp), 8 * total));
-        hipLaunchKernelGGL(k_match_emit, dim3(blocks), dim3(256), 0, nullptr, d_seq, len, d_ctr + 1, d_keys, total);
-        EX_HIP_TRY(hipDeviceSynchronize());
-        (void)hipFree(d_seq);
-        d_seq = nullptr;
-        rc = radix_sort(d_keys, d_tmp, total, 40);
-        (void)hipFree(d_tmp);
-        if (rc == ISSL_OK) {
-            EX_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_text), 21 * total));
-            hipLaunchKernelGGL(k_keys_to_text, dim3(static_cast<uint32_t>((total + 255) / 256)), dim3(256), 0, nullptr,
-                               d_keys, total, d_text);
-            char *host = static_cast<char *>(std::malloc(21 * total));
-            if (!host) {
-                set_error("out of memory");
-                rc = ISSL_E_NOMEM;
-            } else {
-                hipError_t e = hipMemcpy(host, d_text, 21 * total, hipMemcpyDeviceToHost);
-                if (e != hipSuccess) {
-                    std::free(host);
-                    set_error(std::string("HIP error: ") + hipGetErrorString(e));
-                    rc = ISSL_E_DEVICE;
-                } else {
-                    *out_text = host;
-                    *out_len = 21 * total;
-                    *n_sites = total;
-                }
-            }
-            (void)hipFree(d_text);
-        }
-        (void)hipFree(d_keys);
-    } else {
-        *out_text = static_cast<char *>(std::malloc(1));
+    if (total > 0xFFFFFFFFull) { // the radix passes count and place with 32-bit offsets (issl_radix.hpp)
+        set_error("more than 2^32 - 1 sites in one extraction (" + std::to_string(total) + "): split the input");
+        return ISSL_E_UNSUPPORTED;
     }
-    if (d_seq) (void)hipFree(d_seq);
-    (void)hipFree(d_ctr);
-    return rc;
+    if (total == 0) {
+        *out_text = static_cast<char *>(std::malloc(1));
+        return ISSL_OK;
+    }
+    EX_HIP_TRY(hipMalloc(&keys_buf.p, 8 * total));
+    EX_HIP_TRY(hipMalloc(&tmp_buf.p, 8 * total));
+    uint64_t *d_keys = static_cast<uint64_t *>(keys_buf.p), *d_tmp = static_cast<uint64_t *>(tmp_buf.p);
+    hipLaunchKernelGGL(k_match_emit, dim3(blocks), dim3(256), 0, nullptr, d_seq, len, d_ctr + 1, d_keys, total);
+    EX_HIP_TRY(hipDeviceSynchronize());
+    seq_buf.release();
+    int rc = radix_sort(d_keys, d_tmp, total, 40);
+    tmp_buf.release();
+    if (rc) return rc;
+    EX_HIP_TRY(hipMalloc(&text_buf.p, 21 * total));
+    char *d_text = static_cast<char *>(text_buf.p);
+    hipLaunchKernelGGL(k_keys_to_text, dim3(static_cast<uint32_t>((total + 255) / 256)), dim3(256), 0, nullptr, d_keys,
+                       total, d_text);
+    char *host = static_cast<char *>(std::malloc(21 * total));
+    if (!host) {
+        set_error("out of memory");
+        return ISSL_E_NOMEM;
+    }
+    hipError_t e = hipMemcpy(host, d_text, 21 * total, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) {
+        std::free(host);
+        set_error(std::string("HIP error: ") + hipGetErrorString(e));
+        return ISSL_E_DEVICE;
+    }
+    *out_text = host;
+    *out_len = 21 * total;
+    *n_sites = total;
+    return ISSL_OK;
 }
 
 } // namespace

@@ -220,14 +220,13 @@ __device__ inline uint64_t block_exclusive_scan(uint64_t v, uint64_t *lds /*[256
     return before + incl - v;
 }
 
-// Start of cost range r of n_ranges (r == n_ranges: the end marker).  `tp` = tiles per scan unit (a scan wave keeps
-// tp consecutive tiles of an item in registers while the item's guides stream past).
+// Start of cost range r of n_ranges (r == n_ranges: the end marker).
 __device__ __forceinline__ RangeStart range_start_of(const ScanItem *__restrict__ items, uint32_t n_items, uint64_t total,
-                                                     uint32_t n_ranges, uint32_t r, uint32_t tp)
+                                                     uint32_t n_ranges, uint32_t r)
 {
     RangeStart out;
     out.item = n_items;
-    out.unit = 0;
+    out.tile = 0;
     out.goff = 0;
     out.pad = 0;
     if (r < n_ranges) {
@@ -238,24 +237,22 @@ __device__ __forceinline__ RangeStart range_start_of(const ScanItem *__restrict_
             const uint32_t mid = (a + z) >> 1;
             if (items[mid].cost0 <= lo) a = mid; else z = mid;
         }
-        // A unit of an item costs tp * kTileFixedCost (fetching its tiles) + tp per guide.  A boundary may fall between
-        // two groups of 8 guides INSIDE a unit: then two waves share that unit (both fetch it), which makes the ranges
-        // equal to within 8 guides instead of within one unit.
+        // A tile of an item costs kTileFixedCost (fetching it) + one unit per guide.  A boundary may fall between two
+        // groups of 8 guides INSIDE a tile: then two waves share that tile (both fetch it), which makes the ranges
+        // equal to within 8 guides instead of within one tile.
         const ScanItem it = items[a];
         const uint32_t len = it.g1 - it.g0;
-        const uint64_t fetch = static_cast<uint64_t>(tp) * kTileFixedCost;
-        const uint64_t unit_cost = static_cast<uint64_t>(tp) * len + fetch;
+        const uint64_t tile_cost = static_cast<uint64_t>(len) + kTileFixedCost;
         const uint64_t rel = lo - it.cost0;
-        uint64_t k = rel / unit_cost;
-        const uint64_t rem = rel % unit_cost;
+        uint64_t k = rel / tile_cost;
+        const uint64_t rem = rel % tile_cost;
         uint32_t goff = 0;
-        if (rem > fetch) { // (inside the fetch part the unit starts the range: positions stay monotone in r)
-            goff = (static_cast<uint32_t>((rem - fetch + tp - 1u) / tp) + kGuideGroup - 1u) & ~(kGuideGroup - 1u);
+        if (rem > kTileFixedCost) { // (inside the fetch part the tile starts the range: positions stay monotone in r)
+            goff = (static_cast<uint32_t>(rem - kTileFixedCost) + kGuideGroup - 1u) & ~(kGuideGroup - 1u);
             if (goff >= len) { goff = 0; ++k; }
         }
-        const uint32_t n_units = (it.n_tiles + tp - 1u) / tp;
-        if (k >= n_units) { out.item = a + 1; out.unit = 0; out.goff = 0; }
-        else { out.item = a; out.unit = static_cast<uint32_t>(k); out.goff = goff; }
+        if (k >= it.n_tiles) { out.item = a + 1; out.tile = 0; out.goff = 0; }
+        else { out.item = a; out.tile = static_cast<uint32_t>(k); out.goff = goff; }
     }
     return out;
 }
@@ -264,7 +261,7 @@ __device__ __forceinline__ RangeStart range_start_of(const ScanItem *__restrict_
 __global__ __launch_bounds__(256) void k_plan(ImageView v, uint32_t *__restrict__ ng, uint32_t *__restrict__ gfill,
                                               uint32_t *__restrict__ gstart, ScanItem *__restrict__ items,
                                               uint32_t cap_items, PlanInfo *__restrict__ plan, uint32_t item_guides,
-                                              uint32_t scan_blocks, uint32_t tp)
+                                              uint32_t scan_blocks)
 {
     short_kernel_priority();
     __shared__ uint64_t lds[256];
@@ -273,26 +270,25 @@ __global__ __launch_bounds__(256) void k_plan(ImageView v, uint32_t *__restrict_
     const uint32_t b0 = threadIdx.x * per;
     const uint32_t b1 = (b0 + per < nb) ? b0 + per : nb;
 
-    uint64_t slots = 0, n_it = 0, cost = 0, cand = 0, wunits = 0;
+    uint64_t slots = 0, n_it = 0, cost = 0, cand = 0, wtiles = 0;
     for (uint32_t b = b0; b < b1; ++b) {
         const uint32_t g = ng[b];
         const uint32_t nt = v.tile_first[b + 1] - v.tile_first[b];
         slots += (g + kGuideGroup - 1u) / kGuideGroup * kGuideGroup;
         if (g && nt) {
             const uint32_t k = (g + item_guides - 1u) / item_guides;
-            const uint32_t nu = (nt + tp - 1u) / tp;
             n_it += k;
-            cost += static_cast<uint64_t>(nu) * tp * (static_cast<uint64_t>(g) + static_cast<uint64_t>(k) * kTileFixedCost);
+            cost += static_cast<uint64_t>(nt) * (static_cast<uint64_t>(g) + static_cast<uint64_t>(k) * kTileFixedCost);
             cand += (v.bucket_start[b + 1] - v.bucket_start[b]) * g;
-            wunits += static_cast<uint64_t>(nu) * k;
+            wtiles += static_cast<uint64_t>(nt) * k;
         }
     }
-    uint64_t tot_slots, tot_items, tot_cost, tot_cand, tot_units;
+    uint64_t tot_slots, tot_items, tot_cost, tot_cand, tot_tiles;
     uint64_t slot_at = block_exclusive_scan(slots, lds, &tot_slots);
     uint64_t item_at = block_exclusive_scan(n_it, lds, &tot_items);
     uint64_t cost_at = block_exclusive_scan(cost, lds, &tot_cost);
     (void)block_exclusive_scan(cand, lds, &tot_cand);
-    uint64_t unit_at = block_exclusive_scan(wunits, lds, &tot_units);
+    uint64_t tile_at = block_exclusive_scan(wtiles, lds, &tot_tiles);
 
     const bool overflow = tot_items > cap_items;
     for (uint32_t b = b0; b < b1; ++b) {
@@ -300,7 +296,6 @@ __global__ __launch_bounds__(256) void k_plan(ImageView v, uint32_t *__restrict_
         const uint32_t nt = v.tile_first[b + 1] - v.tile_first[b];
         gstart[b] = static_cast<uint32_t>(slot_at);
         if (g && nt && !overflow) {
-            const uint32_t nu = (nt + tp - 1u) / tp;
             const uint64_t blen = v.bucket_start[b + 1] - v.bucket_start[b];
             for (uint32_t done = 0; done < g; done += item_guides) {
                 const uint32_t len = (g - done < item_guides) ? g - done : item_guides;
@@ -310,11 +305,11 @@ __global__ __launch_bounds__(256) void k_plan(ImageView v, uint32_t *__restrict_
                 it.g1 = it.g0 + len;
                 it.n_tiles = nt;
                 it.cost0 = cost_at;
-                it.unit0 = static_cast<uint32_t>(unit_at);
+                it.tile0 = static_cast<uint32_t>(tile_at);
                 it.last_cands = static_cast<uint32_t>(blen - static_cast<uint64_t>(nt - 1u) * kTileCands);
                 items[item_at++] = it;
-                cost_at += static_cast<uint64_t>(nu) * tp * (len + kTileFixedCost);
-                unit_at += nu;
+                cost_at += static_cast<uint64_t>(nt) * (len + kTileFixedCost);
+                tile_at += nt;
             }
         }
         slot_at += (g + kGuideGroup - 1u) / kGuideGroup * kGuideGroup;
@@ -326,15 +321,15 @@ __global__ __launch_bounds__(256) void k_plan(ImageView v, uint32_t *__restrict_
         if (!overflow) {
             ScanItem end;
             end.bucket = 0; end.g0 = 0; end.g1 = 0; end.n_tiles = 0; end.cost0 = tot_cost;
-            end.unit0 = static_cast<uint32_t>(tot_units); end.last_cands = 0;
+            end.tile0 = static_cast<uint32_t>(tot_tiles); end.last_cands = 0;
             items[tot_items] = end;
         }
         plan->n_items = overflow ? 0u : static_cast<uint32_t>(tot_items);
         plan->total_cost = overflow ? 0ull : tot_cost;
         plan->candidates = tot_cand;
-        plan->tiles = tot_units;
-        // one equal-cost range per scan workgroup; inside a workgroup the waves share the units dynamically
-        plan->n_ranges = (overflow || tot_units == 0) ? 0u : scan_blocks;
+        plan->tiles = tot_tiles;
+        // one equal-cost range per scan workgroup; inside a workgroup the waves share the tiles dynamically
+        plan->n_ranges = (overflow || tot_tiles == 0) ? 0u : scan_blocks;
         plan->error = overflow ? 2u : 0u;
     }
 }
@@ -347,7 +342,7 @@ __global__ __launch_bounds__(256) void k_guide_scatter(const uint64_t *__restric
                                                        uint32_t *__restrict__ gidx, uint32_t *__restrict__ gbucket,
                                                        uint32_t guide_blocks, const PlanInfo *__restrict__ plan,
                                                        const ScanItem *__restrict__ items,
-                                                       RangeStart *__restrict__ starts, uint32_t tp)
+                                                       RangeStart *__restrict__ starts)
 {
     short_kernel_priority();
     if (blockIdx.x >= guide_blocks) {
@@ -356,7 +351,7 @@ __global__ __launch_bounds__(256) void k_guide_scatter(const uint64_t *__restric
         // once here so that the scan waves neither divide nor search.
         const uint32_t n_ranges = plan->n_ranges;
         const uint32_t r = (blockIdx.x - guide_blocks) * 256 + threadIdx.x;
-        if (r <= n_ranges && n_ranges != 0) starts[r] = range_start_of(items, plan->n_items, plan->total_cost, n_ranges, r, tp);
+        if (r <= n_ranges && n_ranges != 0) starts[r] = range_start_of(items, plan->n_items, plan->total_cost, n_ranges, r);
         return;
     }
     __shared__ uint32_t hist[kMaxBuckets];
@@ -396,10 +391,6 @@ __global__ __launch_bounds__(256) void k_guide_scatter(const uint64_t *__restric
     }
 }
 
-// Waves per scan workgroup: 16 (1024 threads, 8 waves per SIMD with two workgroups per CU) when a wave holds one
-// tile, 8 (512 threads, 4 waves per SIMD) when it holds two.
-static uint32_t scan_waves_per_block(const Tuning &tn) { return tn.scan_tiles == 2 ? 8u : 16u; }
-
 void launch_bin_guides(const ImageView &v, const Workspace &ws, const Tuning &tn, const uint64_t *d_guides, uint32_t n,
                        void *stream_)
 {
@@ -412,13 +403,13 @@ void launch_bin_guides(const ImageView &v, const Workspace &ws, const Tuning &tn
     const uint32_t blocks = (n + 255u) / 256u;
     const uint32_t reset_blocks = std::min<uint32_t>(1024u, (std::max(n_slots, nb) + 255u) / 256u);
     hipLaunchKernelGGL(k_guide_hist, dim3(std::max(blocks, reset_blocks)), dim3(256), 0, stream, ws, d_guides, n,
-                       v.slice_width, v.n_slices, nb, n_slots, tn.scan_blocks * scan_waves_per_block(tn));
+                       v.slice_width, v.n_slices, nb, n_slots, tn.scan_blocks * 16u);
     hipLaunchKernelGGL(k_plan, dim3(1), dim3(256), 0, stream, v, ws.ng, ws.gfill, ws.gstart, ws.items,
-                       static_cast<uint32_t>(ws.cap_items), ws.plan, tn.item_guides, tn.scan_blocks, tn.scan_tiles);
+                       static_cast<uint32_t>(ws.cap_items), ws.plan, tn.item_guides, tn.scan_blocks);
     const uint32_t range_blocks = (tn.scan_blocks + 1u + 255u) / 256u;
     hipLaunchKernelGGL(k_guide_scatter, dim3(blocks + range_blocks), dim3(256), 0, stream, d_guides, n, v.slice_width,
                        v.n_slices, nb, ws.gstart, ws.gfill, ws.gword, ws.gidx, ws.gbucket, blocks, ws.plan, ws.items,
-                       ws.range_start, tn.scan_tiles);
+                       ws.range_start);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -561,76 +552,34 @@ __device__ __forceinline__ void note_candidates(uint32_t ok, uint32_t gslot, uin
     }
 }
 
-// One pass of the guide slots [g_begin, g_end) over the NT tiles (2048 candidates each, 32 bit planes per lane) a
-// wave holds in registers.  The guide words arrive through scalar registers, 8 per scalar load; the 32 all-zero /
-// all-one masks of a guide are derived once (scalar unit) and serve all NT tiles.
-template <int THR, int NT>
-__device__ __forceinline__ void scan_guides(const uint32_t (&c)[NT][kPlanes], uint32_t g_begin, uint32_t g_end,
-                                            const uint32_t *__restrict__ gword_stream, uint32_t tile, uint32_t lane,
-                                            uint32_t thr, RawWriter &w, uint64_t *raw, uint32_t max_chunks,
-                                            Counters *counters, bool &own_chunk)
-{
-    // Guide slots are padded to groups of 8 with a word (all T) that is far from the zero padding of the tiles;
-    // a padding slot that does come near a real candidate is dropped by k_verify.
-    for (uint32_t g = g_begin; g < g_end; g += kGuideGroup) {
-        const GuideGroup gg = *reinterpret_cast<const GuideGroup *>(gword_stream + g);
-#pragma unroll
-        for (uint32_t uu = 0; uu < kGuideGroup; ++uu) {
-            uint32_t ok[NT];
-#pragma unroll
-            for (int t = 0; t < NT; ++t) ok[t] = near_plane<THR>(c[t], gg.w[uu], thr);
-            uint32_t any = ok[0];
-            if (NT == 2) any |= ok[NT - 1];
-            if (__ballot(any != 0u) != 0ull) { // ~4 % of the (guide, tile) pairs on random data
-#pragma unroll
-                for (int t = 0; t < NT; ++t)
-                    note_candidates(ok[t], g + uu, tile + static_cast<uint32_t>(t), lane, w, raw, max_chunks, counters);
-                own_chunk = true;
-            }
-        }
-    }
-}
-
-template <int NT>
-__device__ __forceinline__ void load_planes(uint32_t (&c)[NT][kPlanes], int t, const uint32_t *__restrict__ scan_stream,
-                                            uint32_t tile, uint32_t lane)
-{
-    const uint4 *__restrict__ src = reinterpret_cast<const uint4 *>(scan_stream + static_cast<uint64_t>(tile) * kTileCands);
-#pragma unroll
-    for (int q = 0; q < kPlanes / 4; ++q) {
-        const uint4 t4 = src[q * 64 + lane];
-        c[t][4 * q + 0] = t4.x; c[t][4 * q + 1] = t4.y; c[t][4 * q + 2] = t4.z; c[t][4 * q + 3] = t4.w;
-    }
-}
-
-// Scan kernel.  A workgroup owns one equal-cost range of the work and its waves share the UNITS of that range (a
-// unit = TP consecutive tiles of one item) through a ticket counter in LDS: the hardware favours the older waves of
-// a SIMD, so waves with equal static shares finish anywhere between 30 % and 100 % of the kernel time (measured with
-// ISSL_SCAN_STAMPS) and the SIMDs run half empty for the second half; with the LDS tickets all waves of a workgroup
-// stop within one unit of each other.  (A device-wide ticket counter would serialise at ~12 ns per ticket, see
-// DESIGN.md; an LDS atomic costs a few hundred cycles and no global traffic.)
-// Per unit a wave keeps TP x 2048 candidates in registers (32 bit planes per lane and tile) while the guide words of
-// the item stream through scalar registers, 8 per scalar load.
-//   TP = 1: 16 waves per workgroup, two workgroups per CU = 8 waves per SIMD (<= 64 VGPRs);
-//   TP = 2:  8 waves per workgroup, two workgroups per CU = 4 waves per SIMD (<= 128 VGPRs): the scalar work per
-//            guide (32 mask extractions, loop control, the hit branch) is shared by two tiles.  The CU's single
-//            scalar pipe is what saturates together with the vector ALUs at TP = 1 (31 SALU per 62 VALU instructions,
-//            one scalar issue per cycle and CU against one vector issue per two cycles and SIMD).
+// Scan kernel.  A workgroup of 16 waves (two per CU = 8 waves per SIMD) owns one equal-cost range of the work
+// and its waves share the tiles of that range through a ticket counter in LDS: the hardware favours the older
+// waves of a SIMD, so waves with equal static shares finish anywhere between 30 % and 100 % of the kernel time
+// (measured with the scan_stamps knob) and the SIMDs run half empty for the second half; with the LDS tickets all
+// waves of a workgroup stop within one tile of each other.  (A device-wide ticket counter would serialise at ~12 ns
+// per ticket; an LDS atomic costs a few hundred cycles and no global traffic.)
+// Per tile a wave keeps the 2048 candidates in registers (32 bit planes per lane) while the guide words of the
+// item stream through scalar registers, 8 per scalar load.  (Two tiles per wave -- the scalar work of a guide shared by
+// 4096 candidates, 4 waves per SIMD -- was measured in round 2: 15 % slower, profiles/r02_ab_scan_tiles_*.log; the
+// scalar pipe is not what limits the loop, tools/ubench_issue.hip.)
 // The streams the hot loop reads (scan planes, tile table, items, guide words, plan) are separate
 // `const __restrict__` kernel arguments: they are never written by this kernel, which lets the compiler fetch the
 // wave-uniform ones through the scalar cache.
-template <int THR, int TP>
-__global__ __launch_bounds__(TP == 1 ? 1024 : 512, TP == 1 ? 8 : 4) void k_scan(
-    const uint32_t *__restrict__ scan_stream, const uint32_t *__restrict__ tile_first, const ScanItem *__restrict__ items,
-    const PlanInfo *__restrict__ plan, const RangeStart *__restrict__ range_start,
-    const uint32_t *__restrict__ gword_stream, uint64_t *raw, uint32_t max_chunks, Counters *counters, uint32_t thr,
-    unsigned long long *stamps, uint64_t *__restrict__ scan_count)
+template <int THR>
+__global__ __launch_bounds__(1024, 8) void k_scan(const uint32_t *__restrict__ scan_stream,
+                                                  const uint32_t *__restrict__ tile_first,
+                                                  const ScanItem *__restrict__ items,
+                                                  const PlanInfo *__restrict__ plan,
+                                                  const RangeStart *__restrict__ range_start,
+                                                  const uint32_t *__restrict__ gword_stream, uint64_t *raw,
+                                                  uint32_t max_chunks, Counters *counters, uint32_t thr,
+                                                  unsigned long long *stamps, uint64_t *__restrict__ scan_count)
 {
     __shared__ uint32_t next_unit;
     __shared__ uint32_t waves_done;
     __shared__ unsigned long long wg_compared;
     // stamps (diagnostics, normally null): per wave {start, end} in 100 MHz ticks, {XCC_ID, HW_ID} and the number of
-    // units it took; nothing else reads them
+    // tiles it took; nothing else reads them
     const unsigned long long t_start = stamps ? __builtin_amdgcn_s_memrealtime() : 0ull;
     uint32_t units_done = 0;
     if (threadIdx.x == 0) { next_unit = 0; waves_done = 0; wg_compared = 0ull; }
@@ -650,14 +599,14 @@ __global__ __launch_bounds__(TP == 1 ? 1024 : 512, TP == 1 ? 8 : 4) void k_scan(
     bool own_chunk = false;
     unsigned long long compared = 0ull; // (real candidate, real guide) pairs this wave has compared; wave-uniform
 
-    // Work of this workgroup: from `first` up to (not including) `last`; a position is (item, unit of the item,
-    // guide offset inside the item in multiples of 8).  Units are numbered from the first one; the first and the last
-    // unit may be shared with the neighbouring workgroups (guide offsets).
+    // Work of this workgroup: from `first` up to (not including) `last`; a position is (item, tile of the item,
+    // guide offset inside the item in multiples of 8).  Units = tiles, numbered from the first one; the first and
+    // the last tile may be shared with the neighbouring workgroups (guide offsets).
     const RangeStart first = range_start[blockIdx.x];
     const RangeStart last = range_start[blockIdx.x + 1];
-    const uint32_t unit_begin = items[first.item].unit0 + first.unit;
-    const uint32_t unit_last = items[last.item].unit0 + last.unit; // partly ours when last.goff > 0
-    const uint32_t n_units = unit_last - unit_begin + (last.goff ? 1u : 0u);
+    const uint32_t tile_begin = items[first.item].tile0 + first.tile;
+    const uint32_t tile_last = items[last.item].tile0 + last.tile; // partly ours when last.goff > 0
+    const uint32_t n_units = tile_last - tile_begin + (last.goff ? 1u : 0u);
     uint32_t it = first.item;
     ScanItem cur = items[it];
 
@@ -667,27 +616,36 @@ __global__ __launch_bounds__(TP == 1 ? 1024 : 512, TP == 1 ? 8 : 4) void k_scan(
         u = __builtin_amdgcn_readfirstlane(u);
         if (u >= n_units) break;
         ++units_done;
-        const uint32_t gu = unit_begin + u;            // unit number in item order
-        while (gu >= cur.unit0 + (cur.n_tiles + TP - 1u) / TP) cur = items[++it]; // tickets only grow: the cursor moves forward
-        const uint32_t k = (gu - cur.unit0) * TP;      // first tile of the unit inside the item's bucket
+        const uint32_t gt = tile_begin + u;            // tile number in item order
+        while (gt >= cur.tile0 + cur.n_tiles) cur = items[++it]; // tickets only grow: the cursor moves forward
+        const uint32_t k = gt - cur.tile0;
         const uint32_t g_begin = cur.g0 + (u == 0 ? first.goff : 0u);
-        const uint32_t g_end = (gu == unit_last) ? cur.g0 + last.goff : cur.g1;
-        const uint32_t tile = tile_first[cur.bucket] + k;
-        const bool two = TP == 2 && k + 1u < cur.n_tiles;
+        const uint32_t g_end = (gt == tile_last) ? cur.g0 + last.goff : cur.g1;
 
-        // ---- one unit: candidates of bucket cur.bucket, tiles k (and k + 1), guide slots [g_begin, g_end) ----------
-        uint32_t cands = (k + 1u == cur.n_tiles) ? cur.last_cands : kTileCands;
-        if (two) cands += (k + 2u == cur.n_tiles) ? cur.last_cands : kTileCands;
-        compared += static_cast<unsigned long long>(cands) * (g_end - g_begin);
-        if (TP == 2 && two) {
-            uint32_t c[2][kPlanes];
-            load_planes<2>(c, 0, scan_stream, tile, lane);
-            load_planes<2>(c, 1, scan_stream, tile + 1u, lane);
-            scan_guides<THR, 2>(c, g_begin, g_end, gword_stream, tile, lane, thr, w, raw, max_chunks, counters, own_chunk);
-        } else { // one tile per wave, or the odd last tile of a bucket
-            uint32_t c[1][kPlanes];
-            load_planes<1>(c, 0, scan_stream, tile, lane);
-            scan_guides<THR, 1>(c, g_begin, g_end, gword_stream, tile, lane, thr, w, raw, max_chunks, counters, own_chunk);
+        // ---- one tile: 2048 candidates of bucket cur.bucket, tile k, guide slots [g_begin, g_end) -----------
+        const uint32_t tile = tile_first[cur.bucket] + k;
+        // comparisons made here: the tile's real candidates (only a bucket's last tile is padded) x the real guides
+        compared += static_cast<unsigned long long>((k + 1u == cur.n_tiles) ? cur.last_cands : kTileCands) * (g_end - g_begin);
+        const uint4 *__restrict__ src =
+            reinterpret_cast<const uint4 *>(scan_stream + static_cast<uint64_t>(tile) * kTileCands);
+        uint32_t c[kPlanes];
+#pragma unroll
+        for (int q = 0; q < kPlanes / 4; ++q) {
+            const uint4 t4 = src[q * 64 + lane];
+            c[4 * q + 0] = t4.x; c[4 * q + 1] = t4.y; c[4 * q + 2] = t4.z; c[4 * q + 3] = t4.w;
+        }
+        // Guide slots are padded to groups of 8 with a word (all T) that is far from the zero padding of the tiles;
+        // a padding slot that does come near a real candidate is dropped by k_verify.
+        for (uint32_t g = g_begin; g < g_end; g += kGuideGroup) {
+            const GuideGroup gg = *reinterpret_cast<const GuideGroup *>(gword_stream + g);
+#pragma unroll
+            for (uint32_t uu = 0; uu < kGuideGroup; ++uu) {
+                const uint32_t ok = near_plane<THR>(c, gg.w[uu], thr);
+                if (__ballot(ok != 0u) != 0ull) { // ~4 % of the (guide, tile) pairs on random data
+                    note_candidates(ok, g + uu, tile, lane, w, raw, max_chunks, counters);
+                    own_chunk = true;
+                }
+            }
         }
     }
     if (own_chunk) {
@@ -790,24 +748,12 @@ __global__ __launch_bounds__(kChunkRecs) void k_verify(ImageView v, Workspace ws
     }
 }
 
-template <int THR, int TP>
+template <int THR>
 static void launch_scan_thr(const ImageView &v, const Workspace &ws, const Tuning &tn, uint32_t thr, hipStream_t stream)
 {
-    hipLaunchKernelGGL((k_scan<THR, TP>), dim3(tn.scan_blocks), dim3(TP == 1 ? 1024 : 512), 0, stream, v.scan, v.tile_first,
-                       ws.items, ws.plan, ws.range_start, ws.gword, ws.raw, static_cast<uint32_t>(ws.cap_chunks),
-                       ws.counters, thr, ws.stamps, ws.scan_count);
-}
-
-template <int TP>
-static void launch_scan_tp(const ImageView &v, const Workspace &ws, const Tuning &tn, uint32_t thr, hipStream_t stream)
-{
-    // the runtime-threshold build serves max_dist > 4 (and, forced by the scan_generic knob, the tests of that build)
-    if (tn.scan_generic || thr > 4) launch_scan_thr<-1, TP>(v, ws, tn, thr, stream);
-    else if (thr == 0) launch_scan_thr<0, TP>(v, ws, tn, thr, stream);
-    else if (thr == 1) launch_scan_thr<1, TP>(v, ws, tn, thr, stream);
-    else if (thr == 2) launch_scan_thr<2, TP>(v, ws, tn, thr, stream);
-    else if (thr == 3) launch_scan_thr<3, TP>(v, ws, tn, thr, stream);
-    else launch_scan_thr<4, TP>(v, ws, tn, thr, stream);
+    hipLaunchKernelGGL(k_scan<THR>, dim3(tn.scan_blocks), dim3(1024), 0, stream, v.scan, v.tile_first, ws.items, ws.plan,
+                       ws.range_start, ws.gword, ws.raw, static_cast<uint32_t>(ws.cap_chunks), ws.counters, thr, ws.stamps,
+                       ws.scan_count);
 }
 
 void launch_scan(const ImageView &v, const Workspace &ws, const Tuning &tn, const uint64_t *d_guides, uint32_t n,
@@ -821,8 +767,13 @@ void launch_scan(const ImageView &v, const Workspace &ws, const Tuning &tn, cons
         return;
     }
     const uint32_t thr = max_dist > 31 ? 31u : static_cast<uint32_t>(max_dist);
-    if (tn.scan_tiles == 2) launch_scan_tp<2>(v, ws, tn, thr, stream);
-    else launch_scan_tp<1>(v, ws, tn, thr, stream);
+    // the runtime-threshold build serves max_dist > 4 (and, forced by the scan_generic knob, the tests of that build)
+    if (tn.scan_generic || thr > 4) launch_scan_thr<-1>(v, ws, tn, thr, stream);
+    else if (thr == 0) launch_scan_thr<0>(v, ws, tn, thr, stream);
+    else if (thr == 1) launch_scan_thr<1>(v, ws, tn, thr, stream);
+    else if (thr == 2) launch_scan_thr<2>(v, ws, tn, thr, stream);
+    else if (thr == 3) launch_scan_thr<3>(v, ws, tn, thr, stream);
+    else launch_scan_thr<4>(v, ws, tn, thr, stream);
 }
 
 void launch_verify(const ImageView &v, const Workspace &ws, const uint64_t *d_guides, int max_dist, void *stream)

@@ -3,7 +3,10 @@
 #include <hip/hip_runtime_api.h>
 #include <rccl/rccl.h>
 
+#include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <cstdlib>
 #include <dlfcn.h>
 #include <set>
 #include <string>
@@ -63,6 +66,9 @@ struct issl_node {
     std::vector<int> devices;
     std::vector<void *> images;            // images[0] belongs to root; the others are owned here
     std::vector<issl_index *> replicas;    // replicas[0] == root
+    std::vector<double> busy_ms;           // per device: time spent scoring in the last issl_node_score call
+    std::vector<uint64_t> guides_done;     // per device: guides it scored in that call
+    bool force_rccl = false, no_rccl = false; // ISSL_FORCE_RCCL / ISSL_NO_RCCL, read once at creation
     issl_node_info info{};
 };
 
@@ -80,14 +86,9 @@ static int broadcast_image(issl_node *nd, size_t bytes, int *used_rccl)
 {
     const int n = static_cast<int>(nd->devices.size());
     *used_rccl = 0;
-    if (n <= 1) {
-        // a single device has nothing to receive; ISSL_FORCE_RCCL=1 still runs the collective (test aid)
-        const char *force = std::getenv("ISSL_FORCE_RCCL");
-        if (!(force && force[0] == '1')) return ISSL_OK;
-    }
+    if (n <= 1 && !nd->force_rccl) return ISSL_OK; // a single device has nothing to receive; ISSL_FORCE_RCCL=1 still runs the collective (test aid)
     std::set<int> distinct(nd->devices.begin(), nd->devices.end());
-    const char *no = std::getenv("ISSL_NO_RCCL");
-    const bool want_rccl = distinct.size() == nd->devices.size() && !(no && no[0] == '1');
+    const bool want_rccl = distinct.size() == nd->devices.size() && !nd->no_rccl;
     if (want_rccl && g_rccl.load()) {
         std::vector<ncclComm_t> comms(n);
         std::vector<hipStream_t> streams(n);
@@ -170,6 +171,11 @@ int issl_node_create(issl_index *idx, const int *devices, int n_devices, issl_no
     const int n = static_cast<int>(nd->devices.size());
     nd->root = idx;
     nd->info.n_devices = n;
+    const char *force = std::getenv("ISSL_FORCE_RCCL"), *no = std::getenv("ISSL_NO_RCCL");
+    nd->force_rccl = force && force[0] == '1';
+    nd->no_rccl = no && no[0] == '1';
+    nd->busy_ms.assign(n, 0.0);
+    nd->guides_done.assign(n, 0);
     double t0 = now_ms();
     int rc = issl_index_upload(idx, nd->devices[0]);
     if (rc) { delete nd; return rc; }
@@ -195,8 +201,15 @@ int issl_node_create(issl_index *idx, const int *devices, int n_devices, issl_no
     if (rc) { issl_node_close(nd); return rc; }
     nd->info.ms_broadcast = now_ms() - t0;
     nd->info.used_rccl = used;
+    // An image whose cold sections (site table, slice lists) live in pinned host memory is replicated hot part only:
+    // every device reads the ONE host copy (BASELINE configs[4]: index larger than the HBM).
+    void *cold = nullptr;
+    size_t cold_bytes = 0;
+    rc = issl_index_cold(idx, &cold, &cold_bytes);
+    if (rc) { issl_node_close(nd); return rc; }
     for (int i = 1; i < n; ++i) {
-        rc = issl_index_attach_image(nd->devices[i], nd->images[i], bytes, &nd->replicas[i]);
+        rc = cold ? issl_index_attach_image_cold(nd->devices[i], nd->images[i], bytes, cold, cold_bytes, &nd->replicas[i])
+                  : issl_index_attach_image(nd->devices[i], nd->images[i], bytes, &nd->replicas[i]);
         if (rc) { issl_node_close(nd); return rc; }
     }
     *out = nd;
@@ -211,13 +224,30 @@ int issl_node_score(issl_node *nd, const uint64_t *guides, size_t n, int max_dis
     const double t0 = now_ms();
     std::vector<int> rcs(world, ISSL_OK);
     std::vector<std::string> errs(world);
+    // The reference cuts its guide loop statically (OpenMP, isslScoreOfftargets.cpp:316); Crackling emits guides in
+    // genome order, so contiguous eighths would give the GPU with the repeat-dense region the longest shard.  The
+    // batch is a queue of chunks instead: every device thread takes the next one when it is done with its last
+    // (scores land at the chunk's place in the caller's arrays, so input order is kept).
+    const size_t chunk = std::min<size_t>(262144, std::max<size_t>(16384, (n + world * 4 - 1) / (world * 4)));
+    std::atomic<size_t> next{0};
+    std::atomic<bool> failed{false};
     auto work = [&](size_t r) {
-        // contiguous shard r of `world`: sizes differ by at most one, input order preserved
-        const size_t base = n / world, extra = n % world;
-        const size_t lo = r * base + (r < extra ? r : extra);
-        const size_t cnt = base + (r < extra ? 1 : 0);
-        rcs[r] = issl_score(nd->replicas[r], guides + lo, cnt, max_dist, threshold, method, mit + lo, cfd + lo);
-        if (rcs[r]) errs[r] = issl_last_error();
+        nd->busy_ms[r] = 0.0;
+        nd->guides_done[r] = 0;
+        while (!failed.load(std::memory_order_relaxed)) {
+            const size_t lo = next.fetch_add(chunk);
+            if (lo >= n) break;
+            const size_t cnt = std::min(chunk, n - lo);
+            const double t1 = now_ms();
+            rcs[r] = issl_score(nd->replicas[r], guides + lo, cnt, max_dist, threshold, method, mit + lo, cfd + lo);
+            nd->busy_ms[r] += now_ms() - t1;
+            nd->guides_done[r] += cnt;
+            if (rcs[r]) {
+                errs[r] = issl_last_error();
+                failed.store(true);
+                break;
+            }
+        }
     };
     std::vector<std::thread> pool;
     for (size_t r = 1; r < world; ++r) pool.emplace_back(work, r);
@@ -230,6 +260,14 @@ int issl_node_score(issl_node *nd, const uint64_t *guides, size_t n, int max_dis
             return rcs[r];
         }
     }
+    return ISSL_OK;
+}
+
+int issl_node_shard_times(const issl_node *nd, double *busy_ms, uint64_t *guides, int n)
+{
+    if (!nd || !busy_ms || !guides) { set_error("null argument"); return ISSL_E_ARG; }
+    if (n < static_cast<int>(nd->replicas.size())) { set_error("buffer too small"); return ISSL_E_ARG; }
+    for (size_t r = 0; r < nd->replicas.size(); ++r) { busy_ms[r] = nd->busy_ms[r]; guides[r] = nd->guides_done[r]; }
     return ISSL_OK;
 }
 

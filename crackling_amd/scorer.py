@@ -170,6 +170,14 @@ class IsslIndex:
         check(lib.issl_index_cold(self._h, C.byref(p), C.byref(n)))
         return p.value, n.value
 
+    def copy_image_to_tensor(self, tensor):
+        """Device-to-device copy of the HBM image into a torch uint8 CUDA tensor (256-byte aligned data pointer)."""
+        check(lib.issl_index_copy_image_to(self._h, tensor.data_ptr(), tensor.numel()))
+        return tensor
+
+    def has_device_image(self):
+        return self.get_option("cold_on_host") >= 0
+
     def image(self):
         p = C.c_void_p()
         n = C.c_size_t()
@@ -278,6 +286,14 @@ class IsslNode:
         check(lib.issl_node_score(self._h, sigs.ctypes.data, len(sigs), int(max_dist), float(threshold),
                                   _method_code(method), mit.ctypes.data, cfd.ctypes.data))
         return mit, cfd
+
+    def shard_times(self):
+        """Per device, for the last score(): (milliseconds spent scoring, guides scored)."""
+        n = self.info()["n_devices"]
+        ms = (C.c_double * n)()
+        g = (C.c_uint64 * n)()
+        check(lib.issl_node_shard_times(self._h, ms, g, n))
+        return list(ms), list(g)
 
     def info(self):
         inf = _lib.NodeInfo()

@@ -1,13 +1,18 @@
 """Multi-GPU orchestration of the scoring step: one process per GPU, `torch.distributed`.
 
-Guides are independent (isslScoreOfftargets.cpp:316-509 touches only the read-only index), so the batch
-is cut into `world` contiguous shards with no data-path collective.  The only communication is
+Guides are independent (isslScoreOfftargets.cpp:316-509 touches only the read-only index), so a batch is cut into
+per-rank shards with no data-path collective.  The only communication is
   * start-up: the HBM index image is produced by rank 0 and broadcast (RCCL over xGMI on GPUs),
   * end: a gather of 16 B per guide (MIT, CFD) to rank 0, which prints in input order (:514-527).
-The functions take the process group functions from `torch.distributed`, so the same code runs on the
-`gloo` backend in the CPU tests (tests/test_sharding_gloo.py) and on `nccl` (= RCCL) on the GPU node.
+The reference splits its guide loop statically over OpenMP threads (:316); Crackling emits guides in genome order, so
+contiguous eighths would put a repeat-dense region on one GPU.  Shards are therefore INTERLEAVED chunks: chunk k (of
+`chunk` guides) belongs to rank k mod world, which spreads every region over all ranks (SURVEY 8e "finer chunks").
+The functions take the process-group functions from `torch.distributed`, so the same code runs on the `gloo` backend
+in the CPU tests (tests/test_sharding_gloo.py) and on `nccl` (= RCCL) on the GPU node; bench.py uses them as they are.
 """
 import numpy as np
+
+DEFAULT_CHUNK = 4096
 
 
 def shard_bounds(n, world, rank):
@@ -17,11 +22,36 @@ def shard_bounds(n, world, rank):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-def broadcast_image(dist, torch, index, device, src=0):
-    """Rank `src` holds an uploaded IsslIndex; every other rank receives the image and attaches to it.
+def shard_indices(n, world, rank, chunk=DEFAULT_CHUNK):
+    """Indices (ascending) of the guides rank `rank` scores: chunks of `chunk` guides dealt round-robin.
 
-    Returns the IsslIndex usable on this rank."""
-    from .scorer import IsslIndex
+    chunk=None gives the contiguous split of shard_bounds()."""
+    if chunk is None:
+        lo, hi = shard_bounds(n, world, rank)
+        return np.arange(lo, hi, dtype=np.int64)
+    idx = np.arange(n, dtype=np.int64)
+    return idx[(idx // chunk) % world == rank]
+
+
+def shard_size(n, world, rank, chunk=DEFAULT_CHUNK):
+    if chunk is None:
+        lo, hi = shard_bounds(n, world, rank)
+        return hi - lo
+    full, rest = divmod(n, chunk)            # `full` whole chunks, then one of `rest` guides
+    mine = full // world + (1 if rank < full % world else 0)
+    return mine * chunk + (rest if full % world == rank else 0)
+
+
+def broadcast_image(dist, torch, index, device, src=0, index_cls=None):
+    """Rank `src` holds an IsslIndex (host arrays, or an image already on `device`); every rank ends up with an
+    IsslIndex attached to its own copy of the image.  Returns (index, seconds spent in the broadcast proper).
+
+    The image travels as ONE uint8 tensor: rank `src` builds it straight into the tensor (host arrays) or copies its
+    device-built image there; the others receive and attach (issl_index_attach_image).  `index_cls` (default
+    IsslIndex) provides attach_tensor(); the CPU tests pass a host-memory stand-in with the same methods."""
+    import time
+    if index_cls is None:
+        from .scorer import IsslIndex as index_cls
     rank = dist.get_rank()
     nbytes = torch.zeros(1, dtype=torch.int64, device=device)
     if rank == src:
@@ -31,35 +61,69 @@ def broadcast_image(dist, torch, index, device, src=0):
     raw = torch.empty(n + 256, dtype=torch.uint8, device=device)
     off = (-raw.data_ptr()) % 256
     image = raw[off:off + n]
+    attach = True
     if rank == src:
-        index.upload_into_tensor(image)
+        if index.has_device_image():           # built on the device: move the image into the tensor, then attach like
+            index.copy_image_to_tensor(image)  # everybody else (the library-owned copy is released)
+            index.close()
+        else:                                  # host arrays: build the image straight into the tensor
+            index.upload_into_tensor(image)
+            attach = False
+    _sync(torch, device)
+    t0 = time.perf_counter()
     dist.broadcast(image, src)
-    return index if rank == src else IsslIndex.attach_tensor(image)
+    _sync(torch, device)
+    seconds = time.perf_counter() - t0
+    return (index_cls.attach_tensor(image) if attach else index), seconds
 
 
-def score_sharded(dist, torch, score_fn, guides, device="cpu", dst=0):
+def _sync(torch, device):
+    if getattr(device, "type", str(device)) != "cpu" and torch.cuda.is_available():
+        torch.cuda.synchronize()
+
+
+class ShardLayout:
+    """Who scores which guide of an n-guide batch, and how the gathered pieces go back into input order.
+    Built once per batch shape (the index tensors live on `device`), reused for every gather."""
+
+    def __init__(self, torch, n, world, chunk=DEFAULT_CHUNK, device="cpu"):
+        self.n, self.world, self.chunk = n, world, chunk
+        self.sizes = [shard_size(n, world, r, chunk) for r in range(world)]
+        self.width = max(self.sizes) if self.sizes else 0
+        self.indices = [shard_indices(n, world, r, chunk) for r in range(world)]
+        self.index_tensors = [torch.from_numpy(i).to(device) for i in self.indices]
+
+
+def score_sharded(dist, torch, score_fn, guides, device="cpu", dst=0, chunk=DEFAULT_CHUNK):
     """Score `guides` (uint64 signatures, identical on every rank) shard-wise and gather on `dst`.
 
-    score_fn(sigs) -> (mit, cfd) float64 arrays for the local shard.  Returns (mit, cfd) in input order on
-    rank `dst`, (None, None) elsewhere."""
+    score_fn(sigs) -> (mit, cfd) float64 arrays for the local shard.  Returns (mit, cfd) numpy arrays in input order
+    on rank `dst`, (None, None) elsewhere."""
     world, rank = dist.get_world_size(), dist.get_rank()
-    n = len(guides)
-    lo, hi = shard_bounds(n, world, rank)
-    mit, cfd = score_fn(guides[lo:hi])
-    width = max(shard_bounds(n, world, r)[1] - shard_bounds(n, world, r)[0] for r in range(world))
-    local = torch.zeros(2, width, dtype=torch.float64, device=device)
-    if hi > lo:
-        local[0, :hi - lo] = torch.from_numpy(np.ascontiguousarray(mit)).to(device)
-        local[1, :hi - lo] = torch.from_numpy(np.ascontiguousarray(cfd)).to(device)
+    layout = ShardLayout(torch, len(guides), world, chunk, device)
+    mit, cfd = score_fn(guides[layout.indices[rank]])
+    out_m, out_c = gather_scores(dist, torch, layout, mit, cfd, device=device, dst=dst)
+    if out_m is None:
+        return None, None
+    return out_m.cpu().numpy(), out_c.cpu().numpy()
+
+
+def gather_scores(dist, torch, layout, mit, cfd, device="cpu", dst=0):
+    """Gather the per-rank score arrays (any leading shape, last axis = this rank's shard; numpy or torch) to `dst` and
+    put them back in input order THERE, on `device`: returns two float64 tensors of shape (..., n) on `dst`,
+    (None, None) elsewhere.  One collective: dist.gather of a (2, ..., width) tensor per rank."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    mit_t = mit if isinstance(mit, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(mit))
+    cfd_t = cfd if isinstance(cfd, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(cfd))
+    lead = tuple(mit_t.shape[:-1])
+    local = torch.zeros((2,) + lead + (layout.width,), dtype=torch.float64, device=device)
+    local[0, ..., :layout.sizes[rank]] = mit_t.to(device)
+    local[1, ..., :layout.sizes[rank]] = cfd_t.to(device)
     parts = [torch.empty_like(local) for _ in range(world)] if rank == dst else None
     dist.gather(local, parts, dst=dst)
     if rank != dst:
         return None, None
-    out_m = np.empty(n, dtype=np.float64)
-    out_c = np.empty(n, dtype=np.float64)
+    out = torch.empty((2,) + lead + (layout.n,), dtype=torch.float64, device=device)
     for r in range(world):
-        a, b = shard_bounds(n, world, r)
-        part = parts[r].cpu().numpy()
-        out_m[a:b] = part[0, :b - a]
-        out_c[a:b] = part[1, :b - a]
-    return out_m, out_c
+        out[..., layout.index_tensors[r]] = parts[r][..., :layout.sizes[r]]
+    return out[0], out[1]

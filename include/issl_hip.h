@@ -158,6 +158,10 @@ int issl_index_attach_image(int device, void *dev_buf, size_t bytes, issl_index 
 /* Device pointer/size of the current image (for the broadcast on the producing rank). */
 int issl_index_image(const issl_index *idx, void **dev_ptr, size_t *bytes);
 
+/* Copy the image into caller-owned device memory of the same device (256-byte aligned, >= issl_index_image bytes):
+ * how an index that was built on the device gets into the tensor a framework broadcasts. */
+int issl_index_copy_image_to(const issl_index *idx, void *dev_dst, size_t bytes);
+
 /* Index larger than the free HBM (BASELINE configs[4]; the format's 32-bit ids, isslScoreOfftargets.cpp:347, allow
  * 4.29 G sites = 292 GB of image).  Only the scan stream (20 B/site) is read by the scan; the site table and the slice
  * lists (isslScoreOfftargets.cpp:200-204,235-240; 48 B/site) are touched for the ~2e-5 of the comparisons that come
@@ -175,13 +179,13 @@ int issl_index_attach_image_cold(int device, void *dev_buf, size_t bytes, void *
 /* Tuning knobs.  Every knob has an environment variable that is read ONCE, when the handle is created (open / build /
  * attach), never inside a scoring call; afterwards this call changes it (no batches may be in flight).  Keys (env):
  *   scan_blocks (ISSL_SCAN_BLOCKS) workgroups of the scan launch      item_guides (ISSL_ITEM_GUIDES) guides per scan item
- *   scan_tiles (ISSL_SCAN_TILES) 1|2 tiles per scan wave              scan_generic (ISSL_SCAN_GENERIC) 0|1 runtime-threshold scan
- *   stage_timing (ISSL_STAGE_TIMING) 0|1 events at every stage        raw_chunks (ISSL_RAW_CHUNKS) initial raw-record buffer
+ *   scan_generic (ISSL_SCAN_GENERIC) 0|1 runtime-threshold scan       stage_timing (ISSL_STAGE_TIMING) 0|1 events at every stage
+ *   raw_chunks (ISSL_RAW_CHUNKS) initial raw-record buffer
  *   inline_sigs (ISSL_INLINE_SIGS) -1|0|1, host_cold (ISSL_FORCE_HOST_COLD) -1|0|1: image layout, read at upload
  *   scan_stamps (ISSL_SCAN_STAMPS) file for per-wave clocks (diagnostics) */
 int issl_index_set_option(issl_index *idx, const char *key, const char *value);
-/* Current value of an integer knob; also the read-only keys cold_on_host and has_inline_sigs (layout of the uploaded
- * image: 0/1, -1 before an upload). */
+/* Current value of an integer knob; also the read-only keys cold_on_host, has_inline_sigs and dense_mit (layout of
+ * the uploaded image: 0/1, -1 before an upload). */
 int issl_index_get_option(const issl_index *idx, const char *key, long long *value);
 
 /* ---- guides (A2, isslScoreOfftargets.cpp:63-71,82-89,275-305) ---------------------------- */
@@ -252,8 +256,11 @@ int issl_verdicts(const double *mit, const double *cfd, size_t n, double thresho
 /* The reference's outer loop is data-parallel over guides (isslScoreOfftargets.cpp:316-509 reads only the
  * index): a node replicates the HBM image on every listed device -- uploaded once on devices[0], then broadcast
  * with RCCL (ncclBroadcast over xGMI; peer copies when RCCL cannot be used, e.g. a device listed twice) -- and
- * cuts every batch into contiguous shards, one host thread per device.  bin/isslScoreOfftargets uses it when
- * ISSL_DEVICES names more than one device (or for very large query files). */
+ * scores every batch as a QUEUE OF CHUNKS (16 k - 256 k guides), one host thread per device taking the next chunk
+ * when it has finished its last: the reference's static OpenMP split (:316) would leave the device that holds a
+ * repeat-dense stretch of Crackling's genome-ordered guides working long after the others.  Scores land in input
+ * order.  An image whose cold sections live in pinned host memory (issl_index_cold) is replicated hot part only, all
+ * devices read the one host copy.  bin/isslScoreOfftargets uses a node when ISSL_DEVICES names several devices. */
 typedef struct issl_node issl_node;
 
 typedef struct {
@@ -264,12 +271,14 @@ typedef struct {
     double ms_last_score;  /* wall time of the last issl_node_score call */
 } issl_node_info;
 
-/* idx must have host arrays (opened from a file or built); it stays owned by the caller and must outlive the
- * node.  devices may be NULL: then all visible devices are used. */
+/* idx has host arrays (opened from a file or built) or was built on devices[0] (issl_index_build_on_device); it stays
+ * owned by the caller and must outlive the node.  devices may be NULL: then all visible devices are used. */
 int issl_node_create(issl_index *idx, const int *devices, int n_devices, issl_node **out);
 int issl_node_score(issl_node *node, const uint64_t *guides, size_t n, int max_dist, double threshold,
                     int method, double *mit, double *cfd);
 int issl_node_get_info(const issl_node *node, issl_node_info *out);
+/* Per device, for the last issl_node_score call: milliseconds spent scoring and guides scored (n >= n_devices). */
+int issl_node_shard_times(const issl_node *node, double *busy_ms, uint64_t *guides, int n);
 int issl_node_close(issl_node *node);
 
 /* ---- off-target site extraction (the step before the index builder) ------------------------------ */

@@ -71,3 +71,10 @@ def golden(request):
 @pytest.fixture(scope="session")
 def golden_uniform():
     return Golden("uniform")
+
+
+@pytest.fixture(scope="session")
+def golden_oddtable():
+    """The clustered index with a rewritten local-MIT table: duplicate masks (first pair wins), masks with odd bits,
+    patterns missing from the table -- outputs of the compiled reference (oracle/make_golden_oddtable.py)."""
+    return Golden("oddtable")

@@ -72,6 +72,26 @@ def random_guides(sigs, n_guides, seed, seq_len=20):
     return g
 
 
+def random_guides_fast(sigs, n_guides, seed, seq_len=20):
+    """Same recipe as random_guides (80 % = a site with 0-4 substitutions at distinct positions, 20 % random 20-mers),
+    vectorised for the 100k-1M guide batches of bench.py; not the same random stream."""
+    rng = np.random.default_rng(seed)
+    g = sigs[rng.integers(0, len(sigs), size=n_guides)].astype(np.uint64)
+    nsub = rng.integers(0, 5, size=n_guides)
+    # four distinct positions per guide: the first columns of a random permutation of the positions
+    pos = np.argsort(rng.random((n_guides, seq_len)), axis=1)[:, :4].astype(np.uint64)
+    delta = rng.integers(1, 4, size=(n_guides, 4), dtype=np.uint64)   # old base + 1..3 (mod 4) is never the old base
+    for k in range(4):
+        use = nsub > k
+        sh = np.uint64(2) * pos[:, k]
+        old = (g >> sh) & np.uint64(3)
+        new = (old + delta[:, k]) & np.uint64(3)
+        g = np.where(use, (g & ~(np.uint64(3) << sh)) | (new << sh), g)
+    is_rand = (np.arange(n_guides) % 5) == 4
+    rnd = rng.integers(0, 1 << (2 * seq_len), size=n_guides, dtype=np.uint64)
+    return np.where(is_rand, rnd, g).astype(np.uint64)
+
+
 def sigs_to_text(sigs, occ=None, seq_len=20):
     """Sorted site list text for the index builders (occurrences expanded)."""
     letters = np.frombuffer(b"ACGT", dtype=np.uint8)

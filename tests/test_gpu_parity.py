@@ -54,6 +54,27 @@ def test_hit_lists_match_reference(golden, dev_index_cache):
         assert np.array_equal(hits, want), thr
 
 
+def test_score_table_with_duplicate_odd_and_missing_masks(golden_oddtable):
+    """A local-MIT table no builder writes (duplicate masks: the first pair wins, isslScoreOfftargets.cpp:188-197; masks
+    with odd bits; patterns that are missing: 0.0, :394).  The image then carries no dense 2^20-entry table and the
+    replay looks the masks up by binary search (mit_lookup) -- stdout and hit lists of the compiled reference."""
+    g = golden_oddtable
+    ix = ca.IsslIndex.open(g.issl).upload(0)
+    assert ix.get_option("dense_mit") == 0
+    sigs = ca.encode_guides([s.encode() for s in g.guides])
+    for key, want in g.expected.items():
+        method, thr, dist = key.split("|")
+        mit, cfd = ix.score(sigs, int(dist), float(thr), method)
+        assert ca.format_scores(sigs, mit, cfd, method) == want, key
+    for thr in g.hit_thresholds():
+        assert np.array_equal(ix.dump_hits(sigs, 4, float(thr), "and"), g.hits(thr)), thr
+    ix.close()
+    # the same bytes through the CLI
+    exe = ROOT / "bin" / "isslScoreOfftargets"
+    r = subprocess.run([str(exe), str(g.issl), str(g.guides_txt), "4", "75", "mit"], capture_output=True)
+    assert r.returncode == 0 and r.stdout.decode() == g.expected["mit|75|4"]
+
+
 def test_cli_stdout_is_byte_identical(golden):
     exe = ROOT / "bin" / "isslScoreOfftargets"
     for key in ("and|75|4", "mit|0|4", "cfd|75|4", "xyz|0|4"):
@@ -150,14 +171,11 @@ def test_large_max_dist_and_single_guide(config0):
     assert mit[0] == omit[0] and cfd[0] == ocfd[0]
 
 
-@pytest.mark.parametrize("scan_tiles", [1, 2])
-def test_runtime_threshold_build_of_the_scan_kernel(config0, scan_tiles):
+def test_runtime_threshold_build_of_the_scan_kernel(config0):
     """The scan kernel is compiled with max_dist 0..4 as constants and once with a runtime threshold (used for
-    max_dist > 4), each holding one or two tiles per wave.  Force the runtime-threshold build for small distances too
-    and compare."""
+    max_dist > 4).  Force the runtime-threshold build for small distances too and compare."""
     ix, oracle, sigs, guides = config0
-    default_tiles = ix.get_option("scan_tiles")
-    ix.set_option("scan_tiles", scan_tiles).set_option("scan_generic", 1)
+    ix.set_option("scan_generic", 1)
     try:
         for dist in (0, 1, 2, 3, 4, 5, 16):
             mit, cfd = ix.score(guides[:256], dist, 0.0, "and")
@@ -166,43 +184,39 @@ def test_runtime_threshold_build_of_the_scan_kernel(config0, scan_tiles):
             assert np.array_equal(cfd.view(np.uint64), ocfd.view(np.uint64)), dist
     finally:
         ix.set_option("scan_generic", 0)
-    try:
-        for dist in (0, 1, 2, 3, 4):
-            mit, cfd = ix.score(guides[:256], dist, 0.0, "and")
-            assert ix.stats()["candidates"] == ix.stats()["planned_comparisons"] == ix.count_candidates(guides[:256])
-            omit, ocfd = oracle.score(guides[:256], dist, 0.0, "and")
-            assert np.array_equal(mit.view(np.uint64), omit.view(np.uint64)), dist
-            assert np.array_equal(cfd.view(np.uint64), ocfd.view(np.uint64)), dist
-    finally:
-        ix.set_option("scan_tiles", default_tiles)
+    assert ix.get_option("scan_generic") == 0
+    for dist in (0, 1, 2, 3, 4):
+        mit, cfd = ix.score(guides[:256], dist, 0.0, "and")
+        assert ix.stats()["candidates"] == ix.stats()["planned_comparisons"] == ix.count_candidates(guides[:256])
+        omit, ocfd = oracle.score(guides[:256], dist, 0.0, "and")
+        assert np.array_equal(mit.view(np.uint64), omit.view(np.uint64)), dist
+        assert np.array_equal(cfd.view(np.uint64), ocfd.view(np.uint64)), dist
 
 
 def test_scheduling_knobs_do_not_change_results(config0):
-    """Smaller scan items (more, finer work units; tiles re-read per item), other launch sizes, one or two tiles per
-    scan wave: same hit lists and scores, and the scan counts exactly the comparisons the bucket table predicts."""
+    """Smaller scan items (more, finer work units; tiles re-read per item) and other launch sizes: same hit lists and
+    scores, and the scan counts exactly the comparisons the bucket table predicts."""
     ix, oracle, sigs, guides = config0
     rng = np.random.default_rng(5)
     batch = np.concatenate([guides, guides[:1].repeat(700) ^ (rng.integers(0, 1 << 14, size=700, dtype=np.uint64) << np.uint64(20))])
     want = ix.dump_hits(batch, 4, 0.0, "and")
     wm, wc = ix.score(batch, 4, 75.0, "and")
     expected = ix.count_candidates(batch)
-    default_tiles = ix.get_option("scan_tiles")
     try:
-        for tiles in (1, 2):
-            for sched, blocks in (("64", 1024), ("8", 1024), ("200", 77), ("512", 4096)):
-                ix.set_option("scan_tiles", tiles).set_option("item_guides", sched).set_option("scan_blocks", blocks)
-                got = ix.dump_hits(batch, 4, 0.0, "and")
-                assert np.array_equal(got, want), (tiles, sched, blocks)
-                gm, gc = ix.score(batch, 4, 75.0, "and")
-                assert np.array_equal(gm, wm) and np.array_equal(gc, wc), (tiles, sched, blocks)
-                st = ix.stats()
-                assert st["candidates"] == expected == st["planned_comparisons"], (tiles, sched, blocks)
+        for sched, blocks in (("64", 1024), ("8", 1024), ("200", 77), ("512", 4096)):
+            ix.set_option("item_guides", sched).set_option("scan_blocks", blocks)
+            got = ix.dump_hits(batch, 4, 0.0, "and")
+            assert np.array_equal(got, want), (sched, blocks)
+            gm, gc = ix.score(batch, 4, 75.0, "and")
+            assert np.array_equal(gm, wm) and np.array_equal(gc, wc), (sched, blocks)
+            st = ix.stats()
+            assert st["candidates"] == expected == st["planned_comparisons"], (sched, blocks)
     finally:
-        ix.set_option("scan_tiles", default_tiles).set_option("item_guides", 512).set_option("scan_blocks", 1024)
+        ix.set_option("item_guides", 512).set_option("scan_blocks", 1024)
     _, _, ohits = oracle.score(batch, 4, 0.0, "and", want_hits=True)
     assert np.array_equal(want, ohits)
     with pytest.raises(ca.IsslError):
-        ix.set_option("scan_tiles", 3)
+        ix.set_option("scan_blocks", 0)
     with pytest.raises(ca.IsslError):
         ix.set_option("no_such_knob", 1)
 

@@ -36,6 +36,21 @@ def test_oracle_builder_bytes_match_reference(golden):
     assert hashlib.sha256(data).hexdigest() == (golden.dir / "index.sha256").read_text().strip()
 
 
+def test_oracle_matches_reference_on_a_table_with_duplicate_odd_and_missing_masks(golden_oddtable):
+    """isslScoreOfftargets.cpp:188-197 (insert: the first pair of a mask wins) and :394 (operator[]: a missing mask
+    scores 0.0) on a table no builder writes; one thread, like the golden run."""
+    g = golden_oddtable
+    ix = ou.OracleIndex(g.issl)
+    sigs = ou.encode(g.guides)
+    for key, want in g.expected.items():
+        method, thr, dist = key.split("|")
+        mit, cfd = ix.score(sigs, int(dist), float(thr), method, threads=1)
+        assert ou.format_tsv([l.split("\t")[0] for l in want.splitlines()], mit, cfd, method) == want, key
+    for thr in g.hit_thresholds():
+        _, _, hits = ix.score(sigs, 4, float(thr), "and", threads=1, want_hits=True)
+        assert np.array_equal(hits, g.hits(thr)), thr
+
+
 def test_oracle_thread_count_invariance(golden_uniform):
     ix = ou.OracleIndex(golden_uniform.issl)
     sigs = ou.encode(golden_uniform.guides)

@@ -1,6 +1,9 @@
-"""CPU, world_size 2, gloo: the N>1 orchestration (contiguous guide shards, gather in input order).
-The per-rank scorer is the oracle here (the checker) -- the HIP path needs a GPU; what is under test is the
-sharding/gather logic that bench.py and multi-GPU callers use with index.score on `nccl`."""
+"""CPU, world_size 2 and 3, gloo: the N>1 orchestration bench.py and multi-GPU callers run on `nccl`.
+
+Under test is crackling_amd/sharding.py -- every collective call site of bench.py: the broadcast of the image size and
+of the image, the interleaved guide shards, the one gather of the scores and their return to input order.  The HIP
+path needs a GPU, so the per-rank scorer here is the oracle (the checker) behind a host-memory stand-in for IsslIndex:
+its "image" is the .issl bytes in a CPU tensor, attach_tensor() loads them into the oracle."""
 import os
 import socket
 import sys
@@ -19,32 +22,86 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _worker(rank, world, port, issl, guides_path, out_path):
+class HostImageIndex:
+    """IsslIndex stand-in with a host-memory image: the methods sharding.broadcast_image() uses."""
+
+    def __init__(self, issl_bytes=None, oracle=None, device_built=False):
+        self.bytes, self.oracle, self.device_built, self.closed = issl_bytes, oracle, device_built, False
+
+    def device_bytes(self):
+        return len(self.bytes)
+
+    def has_device_image(self):
+        return self.device_built
+
+    def _fill(self, tensor):
+        tensor[:len(self.bytes)] = torch.frombuffer(bytearray(self.bytes), dtype=torch.uint8)
+
+    def upload_into_tensor(self, tensor):      # index with host arrays: the image is built straight into the tensor
+        self._fill(tensor)
+        self.oracle = self._load(self.bytes)
+
+    def copy_image_to_tensor(self, tensor):    # index built on the device: its image is copied into the tensor
+        self._fill(tensor)
+
+    def close(self):
+        self.closed = True
+
+    @staticmethod
+    def _load(data):
+        import tempfile
+        import oracle_util as ou
+        with tempfile.NamedTemporaryFile(suffix=".issl") as f:
+            f.write(data); f.flush()
+            return ou.OracleIndex(f.name)
+
+    @classmethod
+    def attach_tensor(cls, tensor):
+        return cls(oracle=cls._load(tensor.numpy().tobytes()))
+
+    def score(self, g):
+        return self.oracle.score(g, 4, 75.0, "and", threads=1)
+
+
+def _worker(rank, world, port, issl, guides_path, out_path, device_built, chunk):
     sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    import oracle_util as ou
-    from crackling_amd.sharding import score_sharded
+    from crackling_amd import sharding
     guides = np.load(guides_path)
-    ix = ou.OracleIndex(issl)
-    mit, cfd = score_sharded(dist, torch, lambda g: ix.score(g, 4, 75.0, "and", threads=1), guides)
+    # only rank 0 has the index; everybody else receives the image (same calls as bench.py)
+    index = HostImageIndex(open(issl, "rb").read(), device_built=device_built) if rank == 0 else None
+    index, seconds = sharding.broadcast_image(dist, torch, index, torch.device("cpu"), index_cls=HostImageIndex)
+    assert seconds >= 0 and index.oracle is not None and not index.closed
+    # one batch through score_sharded ...
+    mit, cfd = sharding.score_sharded(dist, torch, index.score, guides, chunk=chunk)
+    # ... and bench.py's shape: K steps of the local shard, ONE gather of (steps, shard) arrays
+    layout = sharding.ShardLayout(torch, len(guides), world, chunk, "cpu")
+    m1, c1 = index.score(guides[layout.indices[rank]])
+    steps_m, steps_c = torch.from_numpy(np.stack([m1, m1])), torch.from_numpy(np.stack([c1, c1]))
+    gm, gc = sharding.gather_scores(dist, torch, layout, steps_m, steps_c, device="cpu")
     if rank == 0:
-        np.savez(out_path, mit=mit, cfd=cfd)
+        assert gm.shape == (2, len(guides))
+        np.savez(out_path, mit=mit, cfd=cfd, gm=gm.numpy(), gc=gc.numpy())
+    else:
+        assert mit is None and gm is None
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_scores_equal_single_process(golden_uniform, tmp_path, world):
+@pytest.mark.parametrize("world,device_built,chunk", [(2, False, 16), (3, True, 16), (2, True, None), (3, False, 4096)])
+def test_broadcast_shard_gather_equal_single_process(golden_uniform, tmp_path, world, device_built, chunk):
     import oracle_util as ou
-    sigs = ou.encode(golden_uniform.guides)[:101]  # odd count: ragged shards
+    sigs = ou.encode(golden_uniform.guides)[:101]  # odd count: ragged shards, a last chunk of 5
     gp = tmp_path / "g.npy"; np.save(gp, sigs)
     out = tmp_path / "out.npz"
-    mp.spawn(_worker, args=(world, _free_port(), str(golden_uniform.issl), str(gp), str(out)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), str(golden_uniform.issl), str(gp), str(out), device_built, chunk),
+             nprocs=world, join=True)
     got = np.load(out)
     ix = ou.OracleIndex(golden_uniform.issl)
     mit, cfd = ix.score(sigs, 4, 75.0, "and")
     assert np.array_equal(got["mit"], mit) and np.array_equal(got["cfd"], cfd)
+    assert np.array_equal(got["gm"], np.stack([mit, mit])) and np.array_equal(got["gc"], np.stack([cfd, cfd]))
 
 
 def test_shard_bounds_cover_and_order():
@@ -56,3 +113,18 @@ def test_shard_bounds_cover_and_order():
             assert all(cuts[i][1] == cuts[i + 1][0] for i in range(w - 1))
             sizes = [b - a for a, b in cuts]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_interleaved_shards_partition_the_batch():
+    from crackling_amd.sharding import shard_indices, shard_size
+    for n in (0, 1, 5, 4096, 4097, 100_001):
+        for w in (1, 2, 3, 8):
+            for chunk in (None, 1, 7, 4096):
+                parts = [shard_indices(n, w, r, chunk) for r in range(w)]
+                assert [len(p) for p in parts] == [shard_size(n, w, r, chunk) for r in range(w)]
+                allidx = np.concatenate(parts) if parts else np.empty(0, dtype=np.int64)
+                assert np.array_equal(np.sort(allidx), np.arange(n))
+                assert all((np.diff(p) > 0).all() for p in parts)       # input order kept inside a shard
+                if chunk is not None and n >= w * chunk * 4:             # a region of the batch is spread over all ranks
+                    region = np.arange(n // 2, n // 2 + w * chunk)
+                    assert all(np.intersect1d(p, region).size > 0 for p in parts)
