@@ -52,10 +52,15 @@ def log(*a):
 
 def host_description():
     info = {"nproc": os.cpu_count(), "affinity": len(os.sched_getaffinity(0))}
+    info["cgroup_cpu_max"] = None
+    info["effective_cores"] = info["affinity"]
     try:
         info["cgroup_cpu_max"] = open("/sys/fs/cgroup/cpu.max").read().strip()
-    except OSError:
-        info["cgroup_cpu_max"] = None
+        quota, period = info["cgroup_cpu_max"].split()
+        if quota != "max":  # CPU time the job may use per period: more runnable threads than this only queue
+            info["effective_cores"] = max(1, min(info["affinity"], int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
     try:
         for line in open("/proc/cpuinfo"):
             if line.startswith("model name"):
@@ -74,8 +79,10 @@ def cpu_baseline(issl_path, guides, gpu_scores, max_dist, thr, method, budget_s)
     t0 = time.perf_counter()
     ix = ou.OracleIndex(issl_path)
     load_s = time.perf_counter() - t0
-    affinity = host["affinity"]
-    sweep_threads = sorted({t for t in (8, 16, 32, 64, 128, affinity) if t <= affinity})
+    affinity, cores = host["affinity"], host["effective_cores"]
+    # thread counts up to 4x the CPU share of the job (beyond that the cgroup quota only queues threads: 256 threads on a
+    # 16-core share measured half the rate of 32), always including the share itself and a 2x oversubscription
+    sweep_threads = sorted({t for t in (8, 16, 32, 64, 128, cores, 2 * cores, affinity) if t <= min(affinity, 4 * cores)})
     # one guide on one thread: what a guide costs (sizes the samples)
     t0 = time.perf_counter()
     ix.score(guides[:1], max_dist, 0.0, method, threads=1)
@@ -88,7 +95,7 @@ def cpu_baseline(issl_path, guides, gpu_scores, max_dist, thr, method, budget_s)
     for label, t_val in (("thr0", 0.0), (f"thr{thr:g}", thr)):
         sweep[label] = {}
         for threads in sweep_threads:
-            n = int(min(len(guides) - at, max(threads, threads * per_point_s / per_guide_s)))
+            n = int(min(len(guides) - at, max(threads, min(threads, cores) * per_point_s / per_guide_s)))
             if n <= 0:
                 break
             sample = guides[at:at + n]

@@ -228,7 +228,7 @@ int issl_node_score(issl_node *nd, const uint64_t *guides, size_t n, int max_dis
     // genome order, so contiguous eighths would give the GPU with the repeat-dense region the longest shard.  The
     // batch is a queue of chunks instead: every device thread takes the next one when it is done with its last
     // (scores land at the chunk's place in the caller's arrays, so input order is kept).
-    const size_t chunk = std::min<size_t>(262144, std::max<size_t>(16384, (n + world * 4 - 1) / (world * 4)));
+    const size_t chunk = std::min<size_t>(262144, std::max<size_t>(16384, (n + world * 8 - 1) / (world * 8)));
     std::atomic<size_t> next{0};
     std::atomic<bool> failed{false};
     auto work = [&](size_t r) {

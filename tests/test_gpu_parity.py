@@ -75,6 +75,33 @@ def test_score_table_with_duplicate_odd_and_missing_masks(golden_oddtable):
     assert r.returncode == 0 and r.stdout.decode() == g.expected["mit|75|4"]
 
 
+def test_cold_sections_in_host_memory(golden, monkeypatch):
+    """The layout for an index larger than the free HBM, forced on the golden indexes: scan stream and tables in HBM,
+    site table and slice lists in pinned host memory read across PCIe by k_verify / k_replay.  Same stdout and hit
+    lists as the reference; a node of two replicas shares the one host copy."""
+    monkeypatch.setenv("ISSL_FORCE_HOST_COLD", "1")      # read when the handle is created
+    ix = ca.IsslIndex.open(golden.issl)
+    all_hbm = ix.device_bytes()
+    ix.upload(0)
+    assert ix.get_option("cold_on_host") == 1 and ix.get_option("has_inline_sigs") == 0
+    host_ptr, cold_bytes = ix.cold()
+    assert host_ptr and cold_bytes >= 48 * ix.header["n_sites"] and ix.device_bytes() <= all_hbm
+    sigs = ca.encode_guides([g.encode() for g in golden.guides])
+    for key, want in golden.expected.items():
+        method, thr, dist = key.split("|")
+        mit, cfd = ix.score(sigs, int(dist), float(thr), method)
+        assert ca.format_scores(sigs, mit, cfd, method) == want, key
+    for thr in golden.hit_thresholds():
+        assert np.array_equal(ix.dump_hits(sigs, 4, float(thr), "and"), golden.hits(thr)), thr
+    node = ca.IsslNode(ix, devices=[0, 0])
+    mit, cfd = node.score(sigs, 4, 75.0, "and")
+    assert ca.format_scores(sigs, mit, cfd, "and") == golden.expected["and|75|4"]
+    node.close()
+    ix.close()
+    # an image with host-resident cold sections cannot be adopted without them
+    monkeypatch.delenv("ISSL_FORCE_HOST_COLD")
+
+
 def test_cli_stdout_is_byte_identical(golden):
     exe = ROOT / "bin" / "isslScoreOfftargets"
     for key in ("and|75|4", "mit|0|4", "cfd|75|4", "xyz|0|4"):

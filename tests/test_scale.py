@@ -1,9 +1,11 @@
-"""Scale point: one large index on one GPU, scores of a guide sample bit-identical to the oracle on the same index.
+"""Scale points: BASELINE configs[2] (100 k guides x 300 M-line index, one GPU), configs[3]'s shape on one GPU (1 M
+guides over three replicas of that index) and hit lists at that size, checked against the CPU oracle.
 
-Default size keeps the suite fast; the big points of profiles/ are the same test with
-ISSL_SCALE_SITES / ISSL_SCALE_GUIDES / ISSL_SCALE_JSON set (e.g. 3 000 000 000 sites = BASELINE configs[4]'s index,
-a 204 GB image, on ONE MI355X).  The .issl for the oracle goes to ISSL_SCALE_TMP (default: pytest's tmp dir; use
-/dev/shm for files larger than the disk)."""
+The device-built tests run at configs[2]'s full size whenever the GPU has >= 40 GB of free HBM and the host has the
+memory for the site table (else at 20 M lines x 20 k guides); the host-built test keeps 20 M lines (it writes the
+.issl for the oracle).  The bigger points of profiles/ are the same tests with ISSL_SCALE_SITES / ISSL_SCALE_GUIDES /
+ISSL_SCALE_JSON set (e.g. 3 000 000 000 sites = BASELINE configs[4]'s index on ONE MI355X).  The .issl for the
+oracle goes to ISSL_SCALE_TMP (default: pytest's tmp dir; use /dev/shm for files larger than the disk)."""
 import json
 import os
 import pathlib
@@ -14,7 +16,7 @@ import pytest
 
 import crackling_amd as ca
 import oracle_util as ou
-from synth import random_sites_fast, random_guides, text_order_key
+from synth import random_sites_fast, random_guides, random_guides_fast, text_order_key
 
 
 def test_fast_generator_is_sorted_and_distinct():
@@ -111,64 +113,165 @@ def _neighbours(sigs, guide, max_dist, chunk=1 << 26):
     return np.concatenate(found) if found else np.empty(0, dtype=np.int64)
 
 
+def _free_hbm_bytes():
+    import torch
+    free, _total = torch.cuda.mem_get_info(0)
+    return free
+
+
+class ScalePoint:
+    """One device-built index shared by the tests below (built once per module: synthesis dominates the cost)."""
+
+    def __init__(self):
+        from concurrent.futures import ThreadPoolExecutor
+        self.threads = min(32, os.cpu_count() or 8)
+        want_lines = int(os.environ.get("ISSL_SCALE_SITES", 300_000_000))
+        want_guides = int(os.environ.get("ISSL_SCALE_GUIDES", 100_000))
+        # 12 B/site generated (twice while the chunks are concatenated) + brute-force temporaries; image 68-108 B/site
+        fits = want_lines * 40 <= 0.7 * _memory_limit_bytes() and _free_hbm_bytes() >= max(40e9, want_lines * 125)
+        if not fits and "ISSL_SCALE_SITES" in os.environ:
+            pytest.skip(f"{want_lines} lines need ~{want_lines * 40 / 1e9:.0f} GB of host memory and ~{want_lines * 125 / 1e9:.0f} GB of HBM")
+        self.n_lines, self.n_guides = (want_lines, want_guides) if fits else (20_000_000, 20_000)
+        t = time.time(); self.sigs, self.occ = random_sites_fast(self.n_lines, seed=11, threads=self.threads); self.t_synth = time.time() - t
+        self.guides = random_guides_fast(self.sigs, self.n_guides, seed=12)
+        t = time.time(); self.ix = ca.IsslIndex.build_on_device(self.sigs, self.occ, device=0); self.t_build = time.time() - t
+        print(f"scale point: {self.n_lines} lines, {len(self.sigs)} distinct sites, synth {self.t_synth:.1f}s, built on the "
+              f"device in {self.t_build:.1f}s, image {self.ix.device_bytes() / 1e9:.1f} GB", flush=True)
+        # the checker: for a sample of guides every site within 4 mismatches, by brute force over the site table; those
+        # sites (+ bystanders), with their occurrences and in the same relative order, form a small index for the oracle
+        self.n_check = int(os.environ.get("ISSL_SCALE_CHECK", 64))
+        self.pick = np.linspace(0, self.n_guides - 1, self.n_check).astype(np.int64)
+        t = time.time()
+        with ThreadPoolExecutor(max_workers=min(self.threads, 16)) as pool:
+            near = list(pool.map(lambda g: _neighbours(self.sigs, g, 4), self.guides[self.pick]))
+        self.t_brute = time.time() - t
+        self.keep = np.unique(np.concatenate(near + [np.arange(0, len(self.sigs), max(1, len(self.sigs) // 5000))]))
+        print(f"brute force for {self.n_check} guides: {self.t_brute:.1f}s, {sum(len(x) for x in near)} sites within 4 mismatches", flush=True)
+
+    def oracle_on_neighbourhoods(self, tmp_path, thr, want_hits=False):
+        mini = ca.IsslIndex.build_from_sites(self.sigs[self.keep], self.occ[self.keep])
+        path = tmp_path / "mini.issl"
+        mini.write(path)
+        mini.close()
+        oracle = ou.OracleIndex(path)
+        out = oracle.score(self.guides[self.pick], 4, thr, "and", want_hits=want_hits)
+        oracle.close()
+        return out
+
+
+@pytest.fixture(scope="module")
+def scale():
+    sp = ScalePoint()
+    yield sp
+    sp.ix.close()
+
+
 @pytest.mark.gpu
-def test_device_built_scale_point(tmp_path):
-    """Index built ON the GPU (issl_index_build_on_device: no 48 B/site host arrays), so the size is bounded by HBM.
-    Checker without the full .issl: for a sample of guides every site within 4 mismatches is found by brute force over
-    the site table; those sites (with their occurrences, in the same relative order) form a small index on which the
-    CPU oracle must give bit-identical scores -- sites farther away contribute nothing, and the scoring order
-    (slice, position in bucket) of the survivors is unchanged.  ISSL_SCALE_SITES=3000000000 is BASELINE configs[4]'s
-    index on ONE MI355X (204 GB image)."""
-    from concurrent.futures import ThreadPoolExecutor
-    n_lines = int(os.environ.get("ISSL_SCALE_SITES", 20_000_000))
-    n_guides = int(os.environ.get("ISSL_SCALE_GUIDES", 20_000))
-    n_check = int(os.environ.get("ISSL_SCALE_CHECK", 24))
-    threads = min(32, os.cpu_count() or 8)
-    need = n_lines * 40  # 12 B/site generated, twice while the chunks are concatenated, brute-force temporaries
-    if need > 0.7 * _memory_limit_bytes():
-        pytest.skip(f"needs ~{need / 1e9:.0f} GB of host memory, limit is {_memory_limit_bytes() / 1e9:.0f} GB")
-    t = time.time(); sigs, occ = random_sites_fast(n_lines, seed=11, threads=threads); t_synth = time.time() - t
-    guides = random_guides(sigs, n_guides, seed=12)
-    print(f"synth {t_synth:.1f}s distinct={len(sigs)}", flush=True)
-    t = time.time(); ix = ca.IsslIndex.build_on_device(sigs, occ, device=0); t_build = time.time() - t
-    print(f"built on the device in {t_build:.1f}s, image {ix.device_bytes() / 1e9:.1f} GB", flush=True)
+def test_device_built_scale_point(scale, tmp_path):
+    """BASELINE configs[2] on one MI355X: index built ON the GPU (issl_index_build_on_device: no 48 B/site host arrays),
+    100 k guides scored; a sample is bit-identical to the CPU oracle on the index of its brute-force neighbourhoods --
+    sites farther away contribute nothing, and the scoring order (slice, position in bucket) of the survivors is
+    unchanged.  The scan's own comparison counter must equal the bucket-table arithmetic: every bucket was scanned."""
+    ix, guides = scale.ix, scale.guides
     best = None
-    for rep in range(4):
+    for rep in range(3):
         t = time.time(); mit, cfd = ix.score(guides, 4, 75.0, "and"); wall = time.time() - t
         st = ix.stats()
         print(f"rep{rep} wall {wall * 1e3:.1f} ms scan {st['ms_scan']:.2f} ms", flush=True)
         if rep and (best is None or st["ms_scan"] < best[1]["ms_scan"]):
             best = (wall, st)
     wall, st = best
-    assert st["candidates"] == ix.count_candidates(guides)
-    pick = np.linspace(0, n_guides - 1, n_check).astype(np.int64)
-    t = time.time()
-    with ThreadPoolExecutor(max_workers=min(threads, 8)) as pool:
-        near = list(pool.map(lambda g: _neighbours(sigs, g, 4), guides[pick]))
-    t_brute = time.time() - t
-    print(f"brute force for {n_check} guides: {t_brute:.1f}s, {sum(len(x) for x in near)} sites within 4 mismatches", flush=True)
-    keep = np.unique(np.concatenate(near + [np.arange(0, len(sigs), max(1, len(sigs) // 5000))]))  # + some bystanders
-    mini = ca.IsslIndex.build_from_sites(sigs[keep], occ[keep])
-    path = tmp_path / "mini.issl"
-    mini.write(path)
-    oracle = ou.OracleIndex(path)
-    omit, ocfd = oracle.score(guides[pick], 4, 75.0, "and")
-    oracle.close()
-    assert np.array_equal(mit[pick].view(np.uint64), omit.view(np.uint64))
-    assert np.array_equal(cfd[pick].view(np.uint64), ocfd.view(np.uint64))
+    assert st["candidates"] == ix.count_candidates(guides) == st["planned_comparisons"]
+    omit, ocfd = scale.oracle_on_neighbourhoods(tmp_path, 75.0)
+    assert np.array_equal(mit[scale.pick].view(np.uint64), omit.view(np.uint64))
+    assert np.array_equal(cfd[scale.pick].view(np.uint64), ocfd.view(np.uint64))
     assert (omit < 100).any()  # the sample does meet off-targets
     summary = {
-        "what": f"tests/test_scale.py::test_device_built_scale_point: {n_guides} guides vs a {n_lines}-line synthetic index "
-                f"built on one MI355X (issl_index_build_on_device), 'and' thr 75 max_dist 4; {n_check} guides checked "
+        "what": f"tests/test_scale.py::test_device_built_scale_point: {scale.n_guides} guides vs a {scale.n_lines}-line synthetic "
+                f"index built on one MI355X (issl_index_build_on_device), 'and' thr 75 max_dist 4; {scale.n_check} guides checked "
                 f"bit-for-bit against the CPU oracle on the index of their brute-force neighbourhoods",
-        "distinct_sites": int(len(sigs)), "image_GB": ix.device_bytes() / 1e9, "synth_s": t_synth,
-        "device_build_s": t_build, "wall_ms": wall * 1e3, "scan_ms": st["ms_scan"], "verify_ms": st["ms_verify"],
+        "distinct_sites": int(len(scale.sigs)), "image_GB": ix.device_bytes() / 1e9, "synth_s": scale.t_synth,
+        "device_build_s": scale.t_build, "wall_ms": wall * 1e3, "scan_ms": st["ms_scan"], "verify_ms": st["ms_verify"],
         "group_ms": st["ms_group"], "replay_ms": st["ms_replay"], "pipeline_ms": st["ms_total"],
         "comparisons": st["candidates"], "hits": st["hits"], "scan_launches": st["scan_launches"],
         "scan_Tcmp_per_s": st["candidates"] / st["ms_scan"] / 1e9,
         "algorithmic_TBps": 8.0 * st["candidates"] / st["ms_scan"] / 1e9,
-        "guides_per_s_kernels": n_guides / st["ms_total"] * 1e3, "brute_force_check_s": t_brute,
+        "guides_per_s_kernels": scale.n_guides / st["ms_total"] * 1e3, "brute_force_check_s": scale.t_brute,
+        "cold_on_host": ix.get_option("cold_on_host"),
     }
     print(json.dumps(summary), flush=True)
     if os.environ.get("ISSL_SCALE_JSON"):
         json.dump(summary, open(os.environ["ISSL_SCALE_JSON"], "w"), indent=1)
+
+
+@pytest.mark.gpu
+def test_hit_lists_at_scale(scale, tmp_path):
+    """Bit-exact hit lists at configs[2]'s size: for the sampled guides, (slice, site, distance, occurrences) of every
+    scored off-target in scoring order, without and with early exit, against the oracle on the neighbourhood index
+    (site ids and bucket positions differ between the two indexes; the sites and their order do not)."""
+    for thr in (0.0, 75.0):
+        got = scale.ix.dump_hits(scale.guides[scale.pick], 4, thr, "and")
+        _, _, want = scale.oracle_on_neighbourhoods(tmp_path, thr, want_hits=True)
+        assert len(got) == len(want) and len(got) > scale.n_check // 2, (thr, len(got), len(want))
+        assert np.array_equal(got[:, [0, 1, 4, 5]], want[:, [0, 1, 4, 5]]), thr           # guide, slice, dist, occ
+        assert np.array_equal(scale.sigs[got[:, 3]], scale.sigs[scale.keep][want[:, 3]]), thr  # the same sites
+
+
+@pytest.mark.gpu
+def test_config3_shape_on_one_gpu(scale):
+    """BASELINE configs[3]'s shape (1 M guides against replicas of the 300 M-site index, results gathered in input
+    order) on the one GPU of the test box: three replicas on device 0 (peer-copy path), the batch handed out as a queue
+    of chunks.  The first third of the batch is a 'repeat region' (near-copies of a few sites: many hits, slow replay),
+    the way Crackling's genome-ordered pages are skewed: contiguous thirds would leave replica 0 with all of it."""
+    n = 1_000_000 if scale.n_lines >= 100_000_000 else 120_000
+    guides = random_guides_fast(scale.sigs, n, seed=99)
+    rng = np.random.default_rng(5)
+    dense = scale.sigs[rng.integers(0, len(scale.sigs), size=8)]
+    third = n // 3
+    guides[:third] = dense[rng.integers(0, 8, size=third)] ^ (rng.integers(0, 4, size=third, dtype=np.uint64) << np.uint64(2 * 19))
+    want_m, want_c = scale.ix.score(guides, 4, 75.0, "and")
+    node = ca.IsslNode(scale.ix, devices=[0, 0, 0])
+    try:
+        assert node.info()["n_devices"] == 3
+        node.score(guides[:50_000], 4, 75.0, "and")           # sizes the replicas' scratch buffers
+        t = time.time(); mit, cfd = node.score(guides, 4, 75.0, "and"); wall = time.time() - t
+        busy, done = node.shard_times()
+    finally:
+        node.close()
+    assert np.array_equal(mit.view(np.uint64), want_m.view(np.uint64)) and np.array_equal(cfd.view(np.uint64), want_c.view(np.uint64))
+    assert sum(done) == n and min(done) > 0
+    print(f"node of 3 replicas: {n} guides in {wall * 1e3:.1f} ms, busy ms per replica {[round(b, 1) for b in busy]}, guides {done}", flush=True)
+    assert max(busy) / min(busy) <= 1.2, busy
+
+
+@pytest.mark.gpu
+def test_cold_sections_in_host_memory_at_scale(monkeypatch, tmp_path):
+    """The layout for indexes larger than the HBM (sites and slice lists in pinned host memory, scan stream in HBM),
+    forced at 20 M lines: same bits as the all-HBM image of the same index, device-built and from host arrays."""
+    sigs, occ = random_sites_fast(20_000_000, seed=21, threads=min(32, os.cpu_count() or 8))
+    guides = random_guides_fast(sigs, 20_000, seed=22)
+    hot = ca.IsslIndex.build_on_device(sigs, occ, device=0)
+    assert hot.get_option("cold_on_host") == 0
+    want = hot.score(guides, 4, 75.0, "and")
+    want_hits = hot.dump_hits(guides[:200], 4, 0.0, "and")
+    hot_bytes = hot.device_bytes()
+    hot.close()
+    monkeypatch.setenv("ISSL_FORCE_HOST_COLD", "1")      # read when a handle is created
+    t = time.time(); cold = ca.IsslIndex.build_on_device(sigs, occ, device=0); t_build = time.time() - t
+    assert cold.get_option("cold_on_host") == 1 and cold.cold()[1] >= 48 * len(sigs) and cold.device_bytes() < 0.4 * hot_bytes
+    for rep in range(2):
+        t = time.time(); got = cold.score(guides, 4, 75.0, "and"); wall = time.time() - t
+    st = cold.stats()
+    print(f"host-cold image: built in {t_build:.1f}s, {cold.device_bytes() / 1e9:.2f} GB in HBM + {cold.cold()[1] / 1e9:.2f} GB pinned; "
+          f"20k guides in {wall * 1e3:.1f} ms (scan {st['ms_scan']:.2f}, verify {st['ms_verify']:.2f}, replay {st['ms_replay']:.2f})", flush=True)
+    assert np.array_equal(got[0].view(np.uint64), want[0].view(np.uint64)) and np.array_equal(got[1].view(np.uint64), want[1].view(np.uint64))
+    assert np.array_equal(cold.dump_hits(guides[:200], 4, 0.0, "and"), want_hits)
+    # written back out (the lists come from the pinned host copy) and uploaded again from that file's host arrays
+    path = tmp_path / "cold.issl"
+    cold.write(path)
+    cold.close()
+    again = ca.IsslIndex.open(path).upload(0)
+    assert again.get_option("cold_on_host") == 1
+    got2 = again.score(guides[:5000], 4, 75.0, "and")
+    assert np.array_equal(got2[0].view(np.uint64), want[0][:5000].view(np.uint64))
+    again.close()
