@@ -3,8 +3,10 @@
 Follows /root/reference/src/crackling/Crackling.py:780-835 (Constants.py:1-2: CODE_ACCEPTED = 1, CODE_REJECTED = 0):
 lines are split on tabs, only 3-field lines are used, fields 2 and 3 go through float(); the decision uses the
 configured method lower-cased and stripped.  The reference has this logic inline in one 800-line function, so there is
-no callable unit to pin it against: it is pinned by reading, and its inputs by the golden stdout files of tests/golden
-(which come from the compiled reference scorer).  Only tests/ may import this module.
+no callable unit to import.  PINNED by tests/golden/verdicts/: oracle/make_golden_verdicts.py lifts those statements
+out of the reference source at run time (AST slice, nothing stored), executes them on the golden stdout files of the
+compiled reference scorer and on borderline score sets, and tests/test_verdicts.py checks this restatement (and the
+product's issl_verdicts) against the recorded verdicts.  Only tests/ may import this module.
 """
 
 ACCEPTED, REJECTED = 1, 0

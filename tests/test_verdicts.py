@@ -1,5 +1,10 @@
-"""Caller-side thresholding fused into the scorer: issl_verdicts / ISSL_VERDICTS against the
-restatement of Crackling.py:780-835 in oracle/caller_thresholds.py."""
+"""Caller-side thresholding fused into the scorer: issl_verdicts / ISSL_VERDICTS.
+
+Pinned by tests/golden/verdicts/: the verdicts the reference caller's OWN loop (Crackling.py:780-835, lifted out of the
+reference source at run time by oracle/make_golden_verdicts.py) produced on the reference scorer's stdout and on
+borderline score sets.  Both the product (issl_verdicts) and the restatement used elsewhere in this file
+(oracle/caller_thresholds.py) are checked against them."""
+import json
 import os
 import pathlib
 import subprocess
@@ -28,6 +33,56 @@ def _check(sigs, mit, cfd, thr, method):
         return 0
     assert [int(v) for v in got] == [want[s] for s in seqs], (thr, method)
     return int((got == 0).sum())
+
+
+GOLD = ROOT / "tests" / "golden"
+CHAR = {1: "1", 0: "0", 255: "-"}
+
+
+def test_golden_verdicts_of_the_reference_caller_on_reference_stdout():
+    """tests/golden/verdicts/reference_stdout.json: every stdout of the compiled reference scorer, fed to the lifted
+    caller loop under the configured method string and three other spellings of it."""
+    rec = json.loads((GOLD / "verdicts" / "reference_stdout.json").read_text())
+    assert rec["source_lines"] == [780, 835]
+    expected = {name: json.loads((GOLD / name / "expected.json").read_text()) for name in ("uniform", "clustered", "edge")}
+    spellings = set()
+    for case in rec["cases"]:
+        text = expected[case["golden"]][case["key"]]
+        thr, method = case["threshold"], case["config_method"]
+        seqs = [line.split("\t")[0] for line in text.splitlines()]
+        # the restatement, from the text
+        want = caller_verdicts(text, seqs, thr, method)
+        assert "".join(CHAR[want[s]] if s in want else "-" for s in seqs) == case["verdicts"], (case["golden"], case["key"], method)
+        # the product, from the scores.  issl_verdicts takes ONE method string -- the one the scorer was started with --
+        # so it is comparable where the caller's configured string is that string (a sequence that occurs twice is keyed
+        # once by the caller: its last line wins, which parse_scorer_output mirrors)
+        printed = case["key"].split("|")[0]
+        if method == printed:
+            parsed = ca.parse_scorer_output(text)
+            got = ca.verdicts([parsed[s]["mit"] for s in seqs], [parsed[s]["cfd"] for s in seqs], float(thr), method)
+            assert "".join(CHAR[int(v)] for v in got) == case["verdicts"], (case["golden"], case["key"], method)
+        spellings.add(method == printed)
+    assert spellings == {True, False} and len(rec["cases"]) >= 700
+
+
+def test_golden_verdicts_of_the_reference_caller_on_borderline_scores():
+    """tests/golden/verdicts/borderline.json: score pairs whose 6-decimal text lands on either side of the threshold;
+    scorer and caller configured with the same string (as Crackling does), incl. strings the scorer does not know."""
+    rec = json.loads((GOLD / "verdicts" / "borderline.json").read_text())
+    checked = 0
+    for case in rec["cases"]:
+        thr = case["threshold"]
+        mit = np.array([float.fromhex(h) for h in case["mit_hex"]])
+        cfd = np.array([float.fromhex(h) for h in case["cfd_hex"]])
+        sigs = ca.encode_guides(case["seqs"])
+        for method, want in case["verdicts_by_config_method"].items():
+            got = ca.verdicts(mit, cfd, float(thr), method)
+            assert "".join(CHAR[int(v)] for v in got) == want, (thr, method)
+            text = ca.format_scores(sigs, mit, cfd, method)
+            rest = caller_verdicts(text, case["seqs"], thr, method)
+            assert "".join(CHAR[rest[s]] if s in rest else "-" for s in case["seqs"]) == want, (thr, method)
+            checked += len(want)
+    assert checked >= 10_000
 
 
 def test_verdicts_follow_the_caller_on_random_and_borderline_scores():
