@@ -3,10 +3,11 @@
 #   tools/profile_scan.sh <outdir-under-gpurun_out> [bench.py args...]
 # Pass 1: --kernel-trace --stats (per-kernel durations).  Passes 2-5: PMC counters, each in its own run
 # (never combined with tracing domains; FETCH_SIZE and WRITE_SIZE do not fit one pass).
-# The program after `--` is python3 itself (no env/bash wrappers under the profiler).
+# The program after `--` is python3 itself (no env/bash wrappers under the profiler).  bench.py runs without the CPU
+# baseline and without its extra measurement points, so that every k_scan launch of a pass has the same batch size.
 set -u
 OUT=gpurun_out/${1:-prof}; shift || true
-ARGS="bench.py --no-cpu-baseline $*"
+ARGS="bench.py --no-cpu-baseline --no-extras $*"
 mkdir -p "$OUT"
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp

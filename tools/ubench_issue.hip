@@ -144,6 +144,44 @@ __device__ __forceinline__ uint32_t step_le4(const uint32_t (&c)[32], const uint
     return ok;
 }
 
+#define XK(p) const uint32_t x##p = op_xor_s(mk[p], c[p])
+#define MK(p) n[p] = op_or_xor_s(x##p, c[16 + p], mk[16 + p])
+__device__ __forceinline__ uint32_t step_le4_masks(const uint32_t (&c)[32], const uint32_t (&m)[16], uint32_t (&n)[16], const uint32_t (&mk)[32])
+{
+    XK(0); const uint32_t s0 = SUM3(m[0], m[1], m[2]); SB;
+    MK(0);  const uint32_t k0 = MAJ3(m[0], m[1], m[2]); SB;
+    XK(1); const uint32_t s1 = SUM3(m[3], m[4], m[5]); SB;
+    MK(1);  const uint32_t k1 = MAJ3(m[3], m[4], m[5]); SB;
+    XK(2); const uint32_t s2 = SUM3(m[6], m[7], m[8]); SB;
+    MK(2);  const uint32_t k2 = MAJ3(m[6], m[7], m[8]); SB;
+    XK(3); const uint32_t s3 = SUM3(m[9], m[10], m[11]); SB;
+    MK(3);  const uint32_t k3 = MAJ3(m[9], m[10], m[11]); SB;
+    XK(4); const uint32_t s4 = SUM3(m[12], m[13], m[14]); SB;
+    MK(4);  const uint32_t k4 = MAJ3(m[12], m[13], m[14]); SB;
+    XK(5); const uint32_t t = SUM3(s0, s1, s2); SB;
+    MK(5);  const uint32_t k5 = MAJ3(s0, s1, s2); SB;
+    XK(6); const uint32_t u = SUM3(s3, s4, m[15]); SB;
+    MK(6);  const uint32_t k6 = MAJ3(s3, s4, m[15]); SB;
+    XK(7); const uint32_t a2 = SUM3(k0, k1, k2); SB;
+    MK(7);  const uint32_t q0 = MAJ3(k0, k1, k2); SB;
+    XK(8); const uint32_t n0 = op_xor(t, u); SB;
+    MK(8);  const uint32_t k7 = op_and(t, u); SB;
+    XK(9); const uint32_t b2 = SUM3(k3, k4, k5); SB;
+    MK(9);  const uint32_t q1 = MAJ3(k3, k4, k5); SB;
+    XK(10); const uint32_t c2 = SUM3(k6, k7, a2); SB;
+    MK(10); const uint32_t q2 = MAJ3(k6, k7, a2); SB;
+    XK(11); const uint32_t n1 = op_xor(b2, c2); SB;
+    MK(11); const uint32_t q3 = op_and(b2, c2); SB;
+    XK(12); const uint32_t a4 = SUM3(q0, q1, q2); SB;
+    MK(12); const uint32_t k8a = MAJ3(q0, q1, q2); SB;
+    XK(13); const uint32_t n2 = op_xor(a4, q3); SB;
+    MK(13); const uint32_t k8b = op_and(a4, q3); SB;
+    XK(14); const uint32_t w = op_and_or(n2, n1, n0); SB;
+    MK(14); const uint32_t ok = op_nor3(k8a, k8b, w); SB;
+    XK(15); MK(15);
+    return ok;
+}
+
 struct Stamp {
     unsigned long long c0, r0;
     __device__ void start() { c0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
@@ -158,7 +196,7 @@ struct Stamp {
     }
 };
 
-enum { VOP2 = 0, VOP3 = 1, VOP2LIT = 2, SL_BFE = 3, SL_BFE_SGPR = 4, SL_CONST = 5, SL_SLOAD = 6, VOP2VV = 7, VOP3VVV = 8, VOP2INL = 9, VOP2MIX = 10, VOP3_2S = 11, VOP2_WAVES4 = 12, SL_PIPE = 13 };
+enum { VOP2 = 0, VOP3 = 1, VOP2LIT = 2, SL_BFE = 3, SL_BFE_SGPR = 4, SL_CONST = 5, SL_SLOAD = 6, VOP2VV = 7, VOP3VVV = 8, VOP2INL = 9, VOP2MIX = 10, VOP3_2S = 11, VOP2_WAVES4 = 12, SL_PIPE = 13, SL_PIPE_SLOAD = 14 };
 
 template <int MODE>
 __global__ __launch_bounds__(1024, 8) void k(uint32_t *out, unsigned long long *stamps, const uint32_t *__restrict__ table,
@@ -166,7 +204,7 @@ __global__ __launch_bounds__(1024, 8) void k(uint32_t *out, unsigned long long *
 {
     Stamp st;
     uint32_t keep = 0;
-    if (MODE <= VOP2LIT || (MODE >= VOP2VV && MODE != SL_PIPE)) {
+    if (MODE <= VOP2LIT || (MODE >= VOP2VV && MODE < SL_PIPE)) {
         uint32_t a[8];
         for (int i = 0; i < 8; ++i) a[i] = seed * (threadIdx.x + 1) + i * 0x9E3779B9u + blockIdx.x;
         uint32_t g = seed;
@@ -196,16 +234,26 @@ __global__ __launch_bounds__(1024, 8) void k(uint32_t *out, unsigned long long *
         uint32_t desc[32];
         if (MODE == SL_BFE_SGPR)
             for (int p = 0; p < 32; ++p) desc[p] = __builtin_amdgcn_readfirstlane((0x10000u | p) + (seed & 0u));
-        if (MODE == SL_PIPE) {
+        if (MODE == SL_PIPE || MODE == SL_PIPE_SLOAD) {
             uint32_t m[16];
             for (int p = 0; p < 16; ++p) m[p] = ~0u;
             st.start();
             for (int it = 0; it < iters; ++it) {
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    gg = gg * 1664525u + 1013904223u;
                     uint32_t n[16];
-                    keep |= step_le4(pl, m, n, gg);
+                    if (MODE == SL_PIPE) {
+                        gg = gg * 1664525u + 1013904223u;
+                        keep |= step_le4(pl, m, n, gg);
+                    } else {
+                        struct alignas(64) M16 { uint32_t w[16]; };
+                        const M16 *src = reinterpret_cast<const M16 *>(table + (((it * 8 + u) & 511) * 32));
+                        const M16 lo = src[0], hi = src[1];
+                        uint32_t mk[32];
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) { mk[q] = lo.w[q]; mk[16 + q] = hi.w[q]; }
+                        keep |= step_le4_masks(pl, m, n, mk);
+                    }
 #pragma unroll
                     for (int p = 0; p < 16; ++p) m[p] = n[p];
                 }
@@ -311,5 +359,6 @@ int main()
     run<SL_CONST>("sliced_const", 8 * 62, 8 * 432, d_out, d_st, d_table, 3000);
     run<SL_SLOAD>("sliced_sload", 8 * 62, 8 * (432 + 16), d_out, d_st, d_table, 3000);
     run<SL_PIPE>("sliced_pipelined", 8 * 62, 8 * (432 + 256 + 12), d_out, d_st, d_table, 3000);
+    run<SL_PIPE_SLOAD>("sliced_pipe_sload", 8 * 62, 8 * (432 + 16), d_out, d_st, d_table, 3000);
     return 0;
 }
