@@ -59,6 +59,7 @@ void layout_image(ImageHeader &h, const Geometry &g, uint64_t n_scores_unique, u
     }
     h.off_scan = off;         off = align256(off + 4ull * kTileCands * n_tiles);
     if (inline_sigs && !cold_on_host) { h.off_esig = off; off += lists_b; }
+    if (cold_on_host) { h.off_occ8 = off; off = align256(off + g.n_sites * g.n_slices); }
     h.total_bytes = off;
 }
 
@@ -75,6 +76,7 @@ ImageView make_view(const ImageHeader &h, void *base, void *cold)
     v.sites = reinterpret_cast<const uint64_t *>(c + h.off_sites);
     v.entries = reinterpret_cast<const uint64_t *>(c + h.off_entries);
     v.esig = h.off_esig ? reinterpret_cast<const uint64_t *>(p + h.off_esig) : nullptr;
+    v.occ8 = h.off_occ8 ? reinterpret_cast<const uint8_t *>(p + h.off_occ8) : nullptr;
     v.scan = reinterpret_cast<const uint32_t *>(p + h.off_scan);
     v.n_sites = h.n_sites;
     v.n_buckets = static_cast<uint32_t>(h.n_buckets);
@@ -410,7 +412,8 @@ static int finish_upload(issl_index *ix, const DeviceBuildInput *dbi = nullptr)
         t0 = wall_ms();
         // scan stream: built on the device from sites + entries
         launch_pack_scan_stream(ix->view, scan_out,
-                                ix->hdr.off_esig ? reinterpret_cast<uint64_t *>(base + ix->hdr.off_esig) : nullptr, flag, nullptr);
+                                ix->hdr.off_esig ? reinterpret_cast<uint64_t *>(base + ix->hdr.off_esig) : nullptr, nullptr, flag,
+                                nullptr);
         HIP_TRY(hipGetLastError());
     } else {
         // Cold sections in pinned host memory: the scan stream is packed one slice at a time from temporary device
@@ -441,7 +444,8 @@ static int finish_upload(issl_index *ix, const DeviceBuildInput *dbi = nullptr)
             ImageView pv = ix->view;
             pv.sites = t_sites;
             pv.entries = t_list - sl * n; // bucket_start of the slice's first bucket is sl * n: every site sits in one bucket per slice
-            launch_pack_scan_range(pv, scan_out, nullptr, flag, tfirst[sl << g.slice_width], tfirst[(sl + 1) << g.slice_width], nullptr);
+            launch_pack_scan_range(pv, scan_out, nullptr, reinterpret_cast<uint8_t *>(base + ix->hdr.off_occ8), flag,
+                                   tfirst[sl << g.slice_width], tfirst[(sl + 1) << g.slice_width], nullptr);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipDeviceSynchronize());
         }

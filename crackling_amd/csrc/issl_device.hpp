@@ -35,8 +35,11 @@ namespace issl {
 // for the ~2e-5 of the comparisons that come within max_dist (k_verify, k_replay).  When the whole image does not
 // fit the free HBM (the format's 32-bit ids allow 4.29 G sites = 292 GB, and a resident server keeps several
 // indexes) the cold sections live in mapped, pinned HOST memory instead (`cold_on_host`): their offsets are then
-// relative to that second buffer, `total_bytes` covers the hot part only, and the kernels read them across PCIe
-// through the same ImageView pointers.
+// relative to that second buffer, `total_bytes` covers the hot part only, and the kernels reach them across PCIe
+// through the same ImageView pointers -- but rarely: the candidate's signature is rebuilt from its 32 bit planes in
+// the scan stream (8 loads of 16 B from HBM; the slice's own byte is the bucket number), and the occurrence count comes
+// from `occ8`, one saturating byte per list entry kept in HBM with the hot part (5 B per site).  Host memory is read
+// only for occurrence counts >= 255 and for the site ids of issl_dump_hits.
 constexpr uint64_t kImageMagic = 0x314C535349444D41ull; // "AMDISSL1"
 constexpr uint32_t kImageVersion = 4;
 constexpr uint32_t kTileCands = 2048; // candidates per scan tile: one wave, 64 lanes x 32 registers
@@ -58,6 +61,7 @@ struct ImageHeader {
     uint64_t off_esig;      // 0: absent (large indexes: +8 B per list entry do not pay for themselves in HBM)
     uint64_t cold_on_host;  // 1: off_sites / off_entries are offsets into the pinned host buffer of cold_bytes bytes
     uint64_t cold_bytes;    // bytes of sites + entries (+ esig) wherever they live
+    uint64_t off_occ8;      // u8[N*S]: min(occurrences, 255) per list entry; present (in HBM) only when cold_on_host
 };
 static_assert(sizeof(ImageHeader) <= kHeaderBytes, "header must fit its block");
 
@@ -71,6 +75,7 @@ struct ImageView {
     const uint64_t *sites;
     const uint64_t *entries;
     const uint64_t *esig; // signature of the site behind every list entry, in list order, or null
+    const uint8_t *occ8;  // min(occurrences, 255) of every list entry, or null (only with host-resident cold sections)
     const uint32_t *scan;
     uint64_t n_sites;
     uint32_t n_buckets;
@@ -202,9 +207,10 @@ struct ScoreParams {
 };
 
 // Launchers (issl_kernels.hip).  All asynchronous on `stream`.
-void launch_pack_scan_stream(const ImageView &v, uint32_t *scan_out, uint64_t *esig_out, uint32_t *error_flag, void *stream);
-void launch_pack_scan_range(const ImageView &v, uint32_t *scan_out, uint64_t *esig_out, uint32_t *error_flag,
-                            uint32_t tile_begin, uint32_t tile_end, void *stream);
+void launch_pack_scan_stream(const ImageView &v, uint32_t *scan_out, uint64_t *esig_out, uint8_t *occ8_out,
+                             uint32_t *error_flag, void *stream);
+void launch_pack_scan_range(const ImageView &v, uint32_t *scan_out, uint64_t *esig_out, uint8_t *occ8_out,
+                            uint32_t *error_flag, uint32_t tile_begin, uint32_t tile_end, void *stream);
 void launch_bin_guides(const ImageView &v, const Workspace &ws, const Tuning &tn, const uint64_t *d_guides, uint32_t n,
                        void *stream);
 void launch_scan(const ImageView &v, const Workspace &ws, const Tuning &tn, const uint64_t *d_guides, uint32_t n,

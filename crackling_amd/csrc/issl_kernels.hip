@@ -70,6 +70,8 @@ __host__ __device__ inline uint64_t mismatch_mask(uint64_t a, uint64_t b)
 // candidate at tile offset 32 G + j), the low bit of the 2-bit code at position r of the scan word;
 // plane 16 + r the high bit.  The word of (plane r, group G) sits at index ((r / 4) * 64 + G) * 4 + r % 4,
 // so the scanning wave fetches its 32 planes with 8 coalesced 16-byte loads per lane.
+constexpr int kPlanes = 32; // planes per lane = VGPRs holding the lane's 32 candidates
+
 __host__ __device__ inline uint32_t plane_word(uint32_t r, uint32_t group)
 {
     return ((r >> 2) * 64u + group) * 4u + (r & 3u);
@@ -81,6 +83,7 @@ __host__ __device__ inline uint32_t plane_word(uint32_t r, uint32_t group)
 
 __global__ __launch_bounds__(256) void k_pack_scan_stream(ImageView v, uint32_t *__restrict__ scan_out,
                                                           uint64_t *__restrict__ esig_out,
+                                                          uint8_t *__restrict__ occ8_out,
                                                           uint32_t *__restrict__ error_flag, uint32_t tile_begin,
                                                           uint32_t tile_end)
 {
@@ -112,6 +115,7 @@ __global__ __launch_bounds__(256) void k_pack_scan_stream(ImageView v, uint32_t 
                     const uint64_t sig = v.sites[id];
                     w = scan_word(sig, slice);
                     if (esig_out) esig_out[start + pos] = sig;
+                    if (occ8_out) occ8_out[start + pos] = static_cast<uint8_t>((e >> 32) < 255ull ? (e >> 32) : 255ull);
                 } else {
                     atomicOr(error_flag, 1u);
                 }
@@ -132,20 +136,45 @@ __global__ __launch_bounds__(256) void k_pack_scan_stream(ImageView v, uint32_t 
 
 // Tiles [tile_begin, tile_end) only: the upload of an image whose cold sections stay in host memory packs one slice
 // at a time from temporary device copies (v.entries then points at the slice's list minus the slice's offset).
-void launch_pack_scan_range(const ImageView &v, uint32_t *scan_out, uint64_t *esig_out, uint32_t *error_flag,
-                            uint32_t tile_begin, uint32_t tile_end, void *stream)
+void launch_pack_scan_range(const ImageView &v, uint32_t *scan_out, uint64_t *esig_out, uint8_t *occ8_out,
+                            uint32_t *error_flag, uint32_t tile_begin, uint32_t tile_end, void *stream)
 {
     if (tile_end <= tile_begin) return;
     const uint32_t n = tile_end - tile_begin;
     const uint32_t grid = n < 65536u ? n : 65536u;
     hipLaunchKernelGGL(k_pack_scan_stream, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), v,
-                       scan_out, esig_out, error_flag, tile_begin, tile_end);
+                       scan_out, esig_out, occ8_out, error_flag, tile_begin, tile_end);
 }
 
-void launch_pack_scan_stream(const ImageView &v, uint32_t *scan_out, uint64_t *esig_out, uint32_t *error_flag,
-                             void *stream)
+void launch_pack_scan_stream(const ImageView &v, uint32_t *scan_out, uint64_t *esig_out, uint8_t *occ8_out,
+                             uint32_t *error_flag, void *stream)
 {
-    launch_pack_scan_range(v, scan_out, esig_out, error_flag, 0u, v.n_tiles, stream);
+    launch_pack_scan_range(v, scan_out, esig_out, occ8_out, error_flag, 0u, v.n_tiles, stream);
+}
+
+// The packed signature of the candidate at offset `offset` of scan tile `tile` of bucket `bucket`, rebuilt from the
+// scan stream: bit (offset % 32) of the 32 plane words of its group gives the 16 remaining positions (inverse of
+// scan_word), the bucket number gives the slice's own byte.  8 loads of 16 B -- HBM, where the site table may be in
+// host memory.
+__device__ inline uint64_t candidate_signature(const ImageView &v, uint32_t bucket, uint32_t tile, uint32_t offset)
+{
+    const uint4 *src = reinterpret_cast<const uint4 *>(v.scan + static_cast<uint64_t>(tile) * kTileCands);
+    const uint32_t group = offset >> 5, bit = offset & 31u;
+    uint32_t w = 0; // plane r of the candidate at bit r: bits 0..15 = low code bits of the 16 positions, 16..31 = high bits
+#pragma unroll
+    for (uint32_t q = 0; q < kPlanes / 4; ++q) {
+        const uint4 t4 = src[q * 64u + group];
+        w |= ((t4.x >> bit) & 1u) << (4 * q) | ((t4.y >> bit) & 1u) << (4 * q + 1) | ((t4.z >> bit) & 1u) << (4 * q + 2) |
+             ((t4.w >> bit) & 1u) << (4 * q + 3);
+    }
+    uint64_t rem = 0; // 16 positions x 2 bits: low bit of position p at bit 2p, high bit at 2p + 1
+#pragma unroll
+    for (uint32_t p = 0; p < 16; ++p)
+        rem |= static_cast<uint64_t>(((w >> p) & 1u) | (((w >> (16 + p)) & 1u) << 1)) << (2 * p);
+    const uint32_t slice = bucket >> v.slice_width;
+    const uint32_t sh = v.slice_width * slice;
+    const uint64_t key = bucket & ((1u << v.slice_width) - 1u);
+    return (rem & ((1ull << sh) - 1ull)) | (key << sh) | ((rem >> sh) << (sh + v.slice_width));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -420,7 +449,6 @@ struct alignas(4 * kGuideGroup) GuideGroup {
     uint32_t w[kGuideGroup];
 };
 
-constexpr int kPlanes = 32; // planes per lane = VGPRs holding the lane's 32 candidates
 
 // ---- raw records ------------------------------------------------------------------------------
 // A candidate that the scan finds within max_dist of a guide is only NOTED by the scan kernel, as an
@@ -704,7 +732,9 @@ __global__ __launch_bounds__(kChunkRecs) void k_verify(ImageView v, Workspace ws
             const uint64_t pos = static_cast<uint64_t>(tile - v.tile_first[bucket]) * kTileCands + offset;
             if (pos < len) { // else: zero padding of the bucket's last tile
                 const uint64_t gsig = guides[guide];
-                const uint64_t ot = v.esig ? v.esig[start + pos] : v.sites[v.entries[start + pos] & 0xFFFFFFFFull];
+                const uint64_t ot = v.esig   ? v.esig[start + pos]
+                                    : v.occ8 ? candidate_signature(v, bucket, tile, offset) // cold sections in host memory
+                                             : v.sites[v.entries[start + pos] & 0xFFFFFFFFull];
                 if (__builtin_popcountll(mismatch_mask(gsig, ot)) <= max_dist) { // exact, full signatures (:376-382)
                     // First-matching-slice rule (equivalent of the seen bitmap, isslScoreOfftargets.cpp:385-390,463):
                     // the site was already met iff an earlier slice of the XOR is all zero.
@@ -1023,7 +1053,7 @@ struct HitTerms {
 };
 
 __device__ inline HitTerms hit_terms(const ImageView &v, uint64_t gsig, uint32_t g, uint64_t key, bool calc_mit,
-                                     bool calc_cfd)
+                                     bool calc_cfd, bool want_id)
 {
     HitTerms t;
     t.mit = 0.0;
@@ -1033,10 +1063,24 @@ __device__ inline HitTerms hit_terms(const ImageView &v, uint64_t gsig, uint32_t
     const uint32_t pos = static_cast<uint32_t>(key);
     const uint32_t bucket = (slice << v.slice_width) + static_cast<uint32_t>((gsig >> (v.slice_width * slice)) & low);
     const uint64_t at = v.bucket_start[bucket] + pos;
-    const uint64_t e = v.entries[at];
-    const uint32_t id = static_cast<uint32_t>(e);
-    const uint32_t occ = static_cast<uint32_t>(e >> 32);
-    const uint64_t ot = v.esig ? v.esig[at] : v.sites[id]; // independent of `e` when the in-list copy exists
+    uint32_t id = 0, occ;
+    uint64_t ot;
+    if (v.occ8) {
+        // cold sections in host memory: signature from the scan planes, occurrences from the byte copy in HBM; the list
+        // entry itself (PCIe) only for counts that do not fit a byte and for the site id of issl_dump_hits
+        ot = candidate_signature(v, bucket, v.tile_first[bucket] + (pos >> 11), pos & (kTileCands - 1u));
+        occ = v.occ8[at];
+        if (occ == 255u || want_id) {
+            const uint64_t e = v.entries[at];
+            id = static_cast<uint32_t>(e);
+            occ = static_cast<uint32_t>(e >> 32);
+        }
+    } else {
+        const uint64_t e = v.entries[at];
+        id = static_cast<uint32_t>(e);
+        occ = static_cast<uint32_t>(e >> 32);
+        ot = v.esig ? v.esig[at] : v.sites[id]; // independent of `e` when the in-list copy exists
+    }
     const uint64_t mm = mismatch_mask(gsig, ot);
     const int dist = __builtin_popcountll(mm);
     if (calc_mit && dist > 0) t.mit = mit_lookup(v, mm) * static_cast<double>(occ); // :394
@@ -1095,7 +1139,7 @@ __global__ __launch_bounds__(64) void k_replay(ImageView v, Workspace ws, const 
             t.mit = 0.0; t.cfd = 0.0;
             if (lane < h) {
                 key = ws.sorted[h0 + lane];
-                t = hit_terms(v, gsig, g, key, calc_mit, calc_cfd);
+                t = hit_terms(v, gsig, g, key, calc_mit, calc_cfd, out_hits != nullptr);
             }
             uint32_t rank = 0;
             for (uint32_t j = 0; j < h; ++j) {
@@ -1124,7 +1168,7 @@ __global__ __launch_bounds__(64) void k_replay(ImageView v, Workspace ws, const 
                 HitTerms t;
                 t.mit = 0.0; t.cfd = 0.0;
                 if (idx < h) {
-                    t = hit_terms(v, gsig, g, data[idx], calc_mit, calc_cfd);
+                    t = hit_terms(v, gsig, g, data[idx], calc_mit, calc_cfd, out_hits != nullptr);
                     if (out_hits) out_hits[h0 + idx] = t.rec;
                 }
                 accumulate(t.mit, t.cfd, (h - base < 64u) ? h - base : 64u);
@@ -1315,7 +1359,7 @@ __global__ __launch_bounds__(1024, 8) void k_replay_big(ImageView v, Workspace w
             if (st && threadIdx.x == 0 && s2 == 0) st[5] = __builtin_amdgcn_s_memrealtime();
             // terms of the slice's hits by the whole workgroup, then wave 0 adds them up in key order
             for (uint32_t i = threadIdx.x; i < len; i += blockDim.x) {
-                const HitTerms t = hit_terms(v, gsig, g, dst[i], calc_mit, calc_cfd);
+                const HitTerms t = hit_terms(v, gsig, g, dst[i], calc_mit, calc_cfd, out_hits != nullptr);
                 ws.terms[2ull * (h0 + off + i)] = t.mit;
                 ws.terms[2ull * (h0 + off + i) + 1] = t.cfd;
                 if (out_hits) out_hits[h0 + off + i] = t.rec;
