@@ -267,7 +267,8 @@ class IsslIndex:
 
 class IsslNode:
     """Several GPUs of this node in one process: the index image is uploaded on devices[0], broadcast (RCCL over
-    xGMI, peer copies as fallback) and every batch is cut into contiguous shards, one host thread per device."""
+    xGMI, peer copies as fallback) and every batch is a queue of chunks, one host thread per device taking the next
+    chunk when it has finished its last (scores land in input order)."""
 
     def __init__(self, index, devices=None):
         self._index = index  # keep the host arrays / root image alive
