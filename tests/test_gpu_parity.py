@@ -102,6 +102,54 @@ def test_cold_sections_in_host_memory(golden, monkeypatch):
     monkeypatch.delenv("ISSL_FORCE_HOST_COLD")
 
 
+def test_image_replication_entry_points(golden_uniform, monkeypatch):
+    """issl_index_copy_image_to (how a device-built index gets into the tensor a framework broadcasts), attach of the
+    copy, option errors, and the refusal to adopt a host-cold image without its cold sections."""
+    import torch
+    g = golden_uniform
+    sigs = ca.encode_guides([s.encode() for s in g.guides])
+    from synth import random_sites
+    ssig, occ = random_sites(30000, seed=3)
+    built = ca.IsslIndex.build_on_device(ssig, occ, device=0)
+    want = built.score(sigs, 4, 75.0, "and")
+    n = built.device_bytes()
+    raw = torch.empty(n + 256, dtype=torch.uint8, device="cuda:0")
+    off = (-raw.data_ptr()) % 256
+    image = built.copy_image_to_tensor(raw[off:off + n])
+    with pytest.raises(ca.IsslError):
+        built.copy_image_to_tensor(raw[off:off + n - 1])          # too small
+    built.close()
+    twin = ca.IsslIndex.attach_tensor(image)
+    got = twin.score(sigs, 4, 75.0, "and")
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    assert twin.get_option("cold_on_host") == 0 and twin.cold() == (None, 0)
+    # options: unknown key, out of range, change while batches are in flight
+    for key, value in (("nope", 1), ("scan_blocks", 0), ("item_guides", 4), ("inline_sigs", 2)):
+        with pytest.raises(ca.IsslError):
+            twin.set_option(key, value)
+    d_g = torch.from_numpy(sigs.view(np.int64)).cuda()
+    d_m = torch.empty(len(sigs), dtype=torch.float64, device="cuda:0"); d_c = torch.empty_like(d_m)
+    twin.score_device_async(d_g, d_m, d_c, 4, 75.0, "and")
+    with pytest.raises(ca.IsslError):
+        twin.set_option("scan_blocks", 512)
+    assert twin.finish()
+    twin.set_option("scan_blocks", 512)
+    assert twin.get_option("scan_blocks") == 512
+    assert np.array_equal(twin.score(sigs, 4, 75.0, "and")[0], want[0])
+    twin.close()
+    # a host-cold image: the hot part alone is not an index
+    monkeypatch.setenv("ISSL_FORCE_HOST_COLD", "1")
+    cold = ca.IsslIndex.open(g.issl).upload(0)
+    n = cold.device_bytes()
+    raw2 = torch.empty(n + 256, dtype=torch.uint8, device="cuda:0")
+    off2 = (-raw2.data_ptr()) % 256
+    hot = cold.copy_image_to_tensor(raw2[off2:off2 + n])
+    with pytest.raises(ca.IsslError) as e:
+        ca.IsslIndex.attach_tensor(hot)
+    assert "cold" in str(e.value)
+    cold.close()
+
+
 def test_cli_stdout_is_byte_identical(golden):
     exe = ROOT / "bin" / "isslScoreOfftargets"
     for key in ("and|75|4", "mit|0|4", "cfd|75|4", "xyz|0|4"):
