@@ -676,12 +676,16 @@ def test_bucket_lengths_around_group_and_tile_boundaries(tmp_path, n_in_bucket):
 
 def test_random_small_indexes_differential():
     """Differential sweep: 12 random small indexes (clustered so that guides have neighbours at every distance), random
-    methods, thresholds and distances, hit lists and scores against the oracle."""
+    image layouts (with / without the in-list signatures, cold sections in host memory), methods, thresholds and
+    distances, hit lists and scores against the oracle.  ISSL_FUZZ_TRIALS / ISSL_FUZZ_SEED run longer campaigns
+    (profiles/r02_fuzz_campaign.txt)."""
     import tempfile
-    rng = np.random.default_rng(424242)
+    trials = int(os.environ.get("ISSL_FUZZ_TRIALS", 12))
+    rng = np.random.default_rng(int(os.environ.get("ISSL_FUZZ_SEED", 424242)))
     methods = ["and", "or", "avg", "mit", "cfd"]
+    layouts = [{"inline_sigs": 1, "host_cold": 0}, {"inline_sigs": 0, "host_cold": 0}, {"inline_sigs": -1, "host_cold": 1}]
     with tempfile.TemporaryDirectory() as tmp:
-        for trial in range(12):
+        for trial in range(trials):
             n_centres = int(rng.integers(1, 40))
             centres = rng.integers(0, 1 << 40, size=n_centres, dtype=np.uint64)
             sites = set(int(c) for c in centres)
@@ -698,7 +702,11 @@ def test_random_small_indexes_differential():
             ix = ca.IsslIndex.build_from_sites(sig, occ)
             path = os.path.join(tmp, f"t{trial}.issl")
             ix.write(path)
+            layout = layouts[int(rng.integers(0, 3))]
+            for key, value in layout.items():
+                ix.set_option(key, value)
             ix.upload(0)
+            assert ix.get_option("cold_on_host") == layout["host_cold"]
             oracle = ou.OracleIndex(path)
             guides = np.concatenate([centres, centres ^ np.uint64(2 << 16), rng.integers(0, 1 << 40, size=5, dtype=np.uint64)])
             for _ in range(4):
@@ -707,10 +715,10 @@ def test_random_small_indexes_differential():
                 dist = int(rng.integers(0, 5))
                 hits = ix.dump_hits(guides, dist, thr, method)
                 omit, ocfd, ohits = oracle.score(guides, dist, thr, method, want_hits=True)
-                assert np.array_equal(hits, ohits), (trial, method, thr, dist)
+                assert np.array_equal(hits, ohits), (trial, layout, method, thr, dist)
                 mit, cfd = ix.score(guides, dist, thr, method)
-                assert np.array_equal(mit.view(np.uint64), omit.view(np.uint64)), (trial, method, thr, dist)
-                assert np.array_equal(cfd.view(np.uint64), ocfd.view(np.uint64)), (trial, method, thr, dist)
+                assert np.array_equal(mit.view(np.uint64), omit.view(np.uint64)), (trial, layout, method, thr, dist)
+                assert np.array_equal(cfd.view(np.uint64), ocfd.view(np.uint64)), (trial, layout, method, thr, dist)
             oracle.close()
             ix.close()
 
