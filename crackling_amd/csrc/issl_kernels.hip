@@ -531,15 +531,25 @@ __device__ __forceinline__ uint32_t near_plane(const uint32_t (&c)[kPlanes], uin
     full_add(k2[3], k2[4], k2[5], b2, k4[1]);
     full_add(k2[6], k2[7], a2, c2, k4[2]);
     half_add(b2, c2, n1, k4[3]);
-    // weight 4: 4 planes
+    // weight 4: 4 planes k4[0..3], S4 = how many of them are set.  count = 4 S4 + 2 n1 + n0, so the compiled thresholds
+    // need S4 only as "none", "at least one", "at least two" -- cheaper than adding the four planes up:
+    //   count <= 3  <=>  S4 == 0;   count <= 4  <=>  S4 == 0 or (S4 == 1 and n1 == n0 == 0)
+    // with o = k4[0] | k4[1] | k4[2] and p = majority(k4[0], k4[1], k4[2]):  S4 >= 1 = o | k4[3],
+    // S4 >= 2 = p | (o & k4[3]), and  S4 >= 2 or (S4 >= 1 and w)  =  p | majority(o, k4[3], w).
+    if (THR >= 0 && THR <= 4) {
+        const uint32_t o = __builtin_amdgcn_bitop3_b32(k4[0], k4[1], k4[2], 0xFE); // a | b | c
+        // (the last operation of each case is ~(a | b) written as one bitop3: table 0x03, third operand unused)
+        if (THR == 0) return __builtin_amdgcn_bitop3_b32(o, __builtin_amdgcn_bitop3_b32(k4[3], n1, n0, 0xFE), o, 0x03);
+        if (THR == 1) return __builtin_amdgcn_bitop3_b32(o, k4[3], n1, 0x01);     // ~(a | b | c)
+        if (THR == 2) return __builtin_amdgcn_bitop3_b32(o, __builtin_amdgcn_bitop3_b32(k4[3], n1, n0, 0xF8), o, 0x03); // a | (b & c)
+        if (THR == 3) return __builtin_amdgcn_bitop3_b32(o, k4[3], o, 0x03);
+        const uint32_t p = __builtin_amdgcn_bitop3_b32(k4[0], k4[1], k4[2], 0xE8);            // majority
+        const uint32_t z = __builtin_amdgcn_bitop3_b32(o, k4[3], n1 | n0, 0xE8);
+        return __builtin_amdgcn_bitop3_b32(p, z, p, 0x03);
+    }
     uint32_t a4;
     full_add(k4[0], k4[1], k4[2], a4, k8a);
     half_add(a4, k4[3], n2, k8b);
-    if (THR == 0) return ~(k8a | k8b | n2 | n1 | n0);
-    if (THR == 1) return ~(k8a | k8b | n2 | n1);
-    if (THR == 2) return ~(k8a | k8b | n2 | (n1 & n0));
-    if (THR == 3) return ~(k8a | k8b | n2);
-    if (THR == 4) return ~(k8a | k8b | (n2 & (n1 | n0)));
     // generic threshold: count = n0 + 2 n1 + 4 n2 + 8 n3 + 16 n4, compared MSB first with the uniform thr
     const uint32_t n[5] = {n0, n1, n2, k8a ^ k8b, k8a & k8b};
     uint32_t gt = 0u, eq = ~0u;

@@ -44,3 +44,14 @@ for x in np.unique(xcc):
 for q in (0.5, 0.7, 0.8, 0.9, 0.95):
     t = e.max() * q
     print(f"  waves still running at {q:.0%} of the kernel ({t:.0f} us): {(e > t).sum()}")
+# wave-slot time lost between a wave's own end and the end of its workgroup (the slots of a 16-wave workgroup are only
+# re-usable by the next workgroup when all of them are free), and between a workgroup's end and the kernel's end
+wg_ids = np.unique(wg)
+wg_end_of = dict(zip(wg_ids, wg_end))
+lost_in_wg = sum((wg_end_of[g] - e[wg == g]).sum() for g in wg_ids)
+busy = (e - s).sum()
+span = e.max() * 8192.0  # wave slots of the chip x kernel duration
+print(f"wave time: busy {busy / span:.1%} of (8192 slots x kernel time); waiting for the workgroup's last wave {lost_in_wg / span:.1%}; "
+      f"rest (ramp, tail, gaps between workgroups) {1 - (busy + lost_in_wg) / span:.1%}")
+per_tile = (e - s) / np.maximum(units, 1)
+print(f"time per tile and wave: p10 {pc(per_tile,10)} p50 {pc(per_tile,50)} p90 {pc(per_tile,90)} us")
