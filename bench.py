@@ -95,9 +95,9 @@ def cpu_baseline(issl_path, guides, gpu_scores, max_dist, thr, method, budget_s)
     for label, t_val in (("thr0", 0.0), (f"thr{thr:g}", thr)):
         sweep[label] = {}
         for threads in sweep_threads:
-            n = int(min(len(guides) - at, max(threads, min(threads, cores) * per_point_s / per_guide_s)))
-            if n <= 0:
-                break
+            n = int(min(len(guides), max(threads, min(threads, cores) * per_point_s / per_guide_s)))
+            if at + n > len(guides):  # small batches: the samples of later points start over at the first guide
+                at = 0
             sample = guides[at:at + n]
             t0 = time.perf_counter()
             mit, cfd = ix.score(sample, max_dist, t_val, method, threads=threads)
