@@ -288,6 +288,28 @@ def main():
                          "comparisons": int(x[3])} for r, x in enumerate(allr)]
 
     extras = {}
+    if world > 1 and not a.no_extras:
+        # the weak-scaling companion of the strong figure above: every rank scores configs[2]'s per-GPU batch (100 000
+        # guides, or its whole shard if that is smaller) for a few steps, no gather; max over ranks
+        n_weak = min(100_000, n_mine)
+        g = d_guides[:n_weak].contiguous()
+        m = torch.empty(n_weak, dtype=torch.float64, device=dev)
+        c = torch.empty_like(m)
+        settle(lambda: step(g, m, c))
+        weak_steps = 10
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(weak_steps):
+            step(g, m, c)
+        index.finish(stream)
+        barrier()
+        tt = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        if rank == 0:
+            dt = float(tt.item())
+            extras["weak_scaling_point"] = {"guides_per_gpu_per_step": n_weak, "steps": weak_steps, "ms_per_step": dt * 1e3 / weak_steps,
+                                            "guides_per_s_all_gpus": world * n_weak * weak_steps / dt,
+                                            "note": "every rank its own batch of this size per step, barrier + max over ranks, no gather"}
     if rank == 0 and world == 1 and not a.no_extras:
         # north_star's point: 10 000 guides per step against the same index
         for label, n_small, reps in (("north_star_10k_guides", 10_000, 30), ("hbm_regime_64_guides", 64, 200)):
