@@ -678,6 +678,7 @@ __global__ __launch_bounds__(1024, 8) void k_scan(const uint32_t *__restrict__ s
             const GuideGroup gg = *reinterpret_cast<const GuideGroup *>(gword_stream + g);
 #pragma unroll
             for (uint32_t uu = 0; uu < kGuideGroup; ++uu) {
+                if (g + uu >= g_end) break; // padding slots of the bucket's last group (scalar test, not taken: free)
                 const uint32_t ok = near_plane<THR>(c, gg.w[uu], thr);
                 if (__ballot(ok != 0u) != 0ull) { // ~4 % of the (guide, tile) pairs on random data
                     note_candidates(ok, g + uu, tile, lane, w, raw, max_chunks, counters);
