@@ -620,6 +620,7 @@ __global__ __launch_bounds__(1024, 8) void k_scan(const uint32_t *__restrict__ s
     // tiles it took; nothing else reads them
     const unsigned long long t_start = stamps ? __builtin_amdgcn_s_memrealtime() : 0ull;
     uint32_t units_done = 0;
+    unsigned long long plane_wait = 0ull; // stamps only: 100 MHz ticks this wave spent waiting for tile planes to arrive
     if (threadIdx.x == 0) { next_unit = 0; waves_done = 0; wg_compared = 0ull; }
     __syncthreads();
     const uint32_t n_ranges = plan->n_ranges;
@@ -672,6 +673,11 @@ __global__ __launch_bounds__(1024, 8) void k_scan(const uint32_t *__restrict__ s
             const uint4 t4 = src[q * 64 + lane];
             c[4 * q + 0] = t4.x; c[4 * q + 1] = t4.y; c[4 * q + 2] = t4.z; c[4 * q + 3] = t4.w;
         }
+        if (stamps) { // diagnostics: how long the planes take to arrive once they are requested
+            const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            plane_wait += __builtin_amdgcn_s_memrealtime() - t1;
+        }
         // Guide slots are padded to groups of 8 with a word (all T) that is far from the zero padding of the tiles;
         // a padding slot that does come near a real candidate is dropped by k_verify.
         for (uint32_t g = g_begin; g < g_end; g += kGuideGroup) {
@@ -701,7 +707,7 @@ __global__ __launch_bounds__(1024, 8) void k_scan(const uint32_t *__restrict__ s
         stamps[4 * wave_id + 1] = __builtin_amdgcn_s_memrealtime();
         stamps[4 * wave_id + 2] = (static_cast<unsigned long long>(__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11))) << 32) |
                                   __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); // XCC_ID, HW_ID
-        stamps[4 * wave_id + 3] = units_done;
+        stamps[4 * wave_id + 3] = units_done | (plane_wait << 32);
     }
 }
 

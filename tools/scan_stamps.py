@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Digest of an ISSL_SCAN_STAMPS dump (4 u64 per scan wave: start, end [100 MHz ticks], XCC_ID<<32|HW_ID, tiles taken).
+"""Digest of an ISSL_SCAN_STAMPS dump (4 u64 per scan wave: start, end [100 MHz ticks], XCC_ID<<32|HW_ID, tiles taken
+in the low half and ticks spent waiting for tile planes in the high half).
 
     ISSL_SCAN_STAMPS=/tmp/st.bin python tools/quick_perf.py ... ; python tools/scan_stamps.py /tmp/st.bin
 """
@@ -19,7 +20,8 @@ cu = (hw >> np.uint64(8)) & np.uint64(0xF)
 sh = (hw >> np.uint64(12)) & np.uint64(1)
 se = (hw >> np.uint64(13)) & np.uint64(7)
 simd = (hw >> np.uint64(4)) & np.uint64(3)
-units = a[:, 3].astype(np.int64)
+units = (a[:, 3] & np.uint64(0xFFFFFFFF)).astype(np.int64)
+plane_wait = (a[:, 3] >> np.uint64(32)).astype(np.float64) / 100.0  # us
 pc = lambda x, q: np.percentile(x, q).round(1)
 print(f"waves {len(a)}  start max {s.max():.1f} us | end min {e.min():.1f} p10 {pc(e,10)} p50 {pc(e,50)} p90 {pc(e,90)} max {e.max():.1f} us")
 print(f"tiles per wave: min {units.min()} p10 {pc(units,10)} p50 {pc(units,50)} p90 {pc(units,90)} max {units.max()}  total {units.sum()}")
@@ -55,3 +57,6 @@ print(f"wave time: busy {busy / span:.1%} of (8192 slots x kernel time); waiting
       f"rest (ramp, tail, gaps between workgroups) {1 - (busy + lost_in_wg) / span:.1%}")
 per_tile = (e - s) / np.maximum(units, 1)
 print(f"time per tile and wave: p10 {pc(per_tile,10)} p50 {pc(per_tile,50)} p90 {pc(per_tile,90)} us")
+wait_per_tile = plane_wait / np.maximum(units, 1)
+print(f"waiting for tile planes, per tile and wave: p10 {pc(wait_per_tile,10)} p50 {pc(wait_per_tile,50)} p90 {pc(wait_per_tile,90)} us; "
+      f"{plane_wait.sum() / busy:.1%} of the waves' busy time")
