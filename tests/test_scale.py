@@ -157,13 +157,14 @@ class ScalePoint:
         self.keep = np.unique(np.concatenate(near + [np.arange(0, len(self.sigs), max(1, len(self.sigs) // 5000))]))
         print(f"brute force for {self.n_check} guides: {self.t_brute:.1f}s, {sum(len(x) for x in near)} sites within 4 mismatches", flush=True)
 
-    def oracle_on_neighbourhoods(self, tmp_path, thr, want_hits=False):
+    def oracle_on_neighbourhoods(self, tmp_path, thr, want_hits=False, method="and", max_dist=4):
+        """max_dist <= 4: the neighbourhood index holds every site within 4 mismatches of the sampled guides."""
         mini = ca.IsslIndex.build_from_sites(self.sigs[self.keep], self.occ[self.keep])
         path = tmp_path / "mini.issl"
         mini.write(path)
         mini.close()
         oracle = ou.OracleIndex(path)
-        out = oracle.score(self.guides[self.pick], 4, thr, "and", want_hits=want_hits)
+        out = oracle.score(self.guides[self.pick], max_dist, thr, method, want_hits=want_hits)
         oracle.close()
         return out
 
@@ -224,6 +225,26 @@ def test_hit_lists_at_scale(scale, tmp_path):
         assert len(got) == len(want) and len(got) > scale.n_check // 2, (thr, len(got), len(want))
         assert np.array_equal(got[:, [0, 1, 4, 5]], want[:, [0, 1, 4, 5]]), thr           # guide, slice, dist, occ
         assert np.array_equal(scale.sigs[got[:, 3]], scale.sigs[scale.keep][want[:, 3]]), thr  # the same sites
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("method,thr,max_dist", [("mit", 0.0, 4), ("cfd", 75.0, 3), ("or", 50.0, 4), ("avg", 90.0, 2),
+                                                 ("and", 100.0, 0), ("xyz", 75.0, 4)])
+def test_methods_thresholds_distances_at_scale(scale, tmp_path, method, thr, max_dist):
+    """The other score methods, exit thresholds and compiled distance tests of the scan at configs[2]'s size: the sampled
+    guides scored alone (a 64-guide batch: the HBM-bound regime of the scan) against the oracle on the neighbourhood
+    index, scores and hit lists."""
+    sample = scale.guides[scale.pick]
+    mit, cfd = scale.ix.score(sample, max_dist, thr, method)
+    omit, ocfd, ohits = scale.oracle_on_neighbourhoods(tmp_path, thr, want_hits=True, method=method, max_dist=max_dist)
+    assert np.array_equal(mit.view(np.uint64), omit.view(np.uint64)), (method, thr, max_dist)
+    assert np.array_equal(cfd.view(np.uint64), ocfd.view(np.uint64)), (method, thr, max_dist)
+    st = scale.ix.stats()
+    assert st["candidates"] == scale.ix.count_candidates(sample) == st["planned_comparisons"]
+    hits = scale.ix.dump_hits(sample, max_dist, thr, method)
+    assert len(hits) == len(ohits)
+    assert np.array_equal(hits[:, [0, 1, 4, 5]], ohits[:, [0, 1, 4, 5]])
+    assert np.array_equal(scale.sigs[hits[:, 3]], scale.sigs[scale.keep][ohits[:, 3]])
 
 
 @pytest.mark.gpu
