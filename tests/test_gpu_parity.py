@@ -150,6 +150,44 @@ def test_image_replication_entry_points(golden_uniform, monkeypatch):
     cold.close()
 
 
+@pytest.mark.parametrize("sites", [["ACGTACGTACGTACGTACGT"], ["ACGTACGTACGTACGTACGT"] * 3 + ["TTTTTTTTTTTTTTTTTTTT"]])
+def test_degenerate_indexes(sites, tmp_path):
+    """One site, one site three times + another: every layout, against the oracle on the same file.  (An index without
+    sites is not one: the reference scorer stops with "loading off-target sequences failed", isslScoreOfftargets.cpp
+    :201-204, and the builder here refuses an empty list.)"""
+    with pytest.raises(ca.IsslError):
+        ca.IsslIndex.build_from_text(b"")
+    text = "".join(s + "\n" for s in sorted(sites)).encode()
+    path = tmp_path / "tiny.issl"
+    host = ca.IsslIndex.build_from_text(text)
+    host.write(path)
+    assert path.read_bytes() == ou.build_issl(text)
+    oracle = ou.OracleIndex(path)
+    guides = ca.encode_guides(["ACGTACGTACGTACGTACGT", "ACGTACGTACGTACGTACGA", "TTTTTTTTTTTTTTTTTTTT", "GGGGGGGGGGGGGGGGGGGG"])
+    for layout in ({"inline_sigs": 1, "host_cold": 0}, {"inline_sigs": 0, "host_cold": 0}, {"host_cold": 1}):
+        ix = ca.IsslIndex.open(path)
+        for key, value in layout.items():
+            ix.set_option(key, value)
+        ix.upload(0)
+        for method, thr, dist in (("and", 75.0, 4), ("mit", 0.0, 0), ("cfd", 100.0, 2)):
+            mit, cfd = ix.score(guides, dist, thr, method)
+            omit, ocfd, ohits = oracle.score(guides, dist, thr, method, want_hits=True)
+            assert np.array_equal(mit.view(np.uint64), omit.view(np.uint64)), (layout, method)
+            assert np.array_equal(cfd.view(np.uint64), ocfd.view(np.uint64)), (layout, method)
+            assert np.array_equal(ix.dump_hits(guides, dist, thr, method), ohits), (layout, method)
+        assert ix.score(guides[:0], 4, 75.0, "and")[0].shape == (0,)
+        ix.close()
+    if sites:
+        sig = ca.encode_guides(sorted(set(sites)))
+        occ = np.array([sites.count(s) for s in sorted(set(sites))], dtype=np.uint32)
+        built = ca.IsslIndex.build_on_device(sig, occ, device=0)
+        mit, cfd = built.score(guides, 4, 75.0, "and")
+        omit, ocfd = oracle.score(guides, 4, 75.0, "and")
+        assert np.array_equal(mit.view(np.uint64), omit.view(np.uint64)) and np.array_equal(cfd.view(np.uint64), ocfd.view(np.uint64))
+        built.close()
+    oracle.close()
+
+
 def test_cli_stdout_is_byte_identical(golden):
     exe = ROOT / "bin" / "isslScoreOfftargets"
     for key in ("and|75|4", "mit|0|4", "cfd|75|4", "xyz|0|4"):
