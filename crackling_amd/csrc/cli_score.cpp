@@ -311,6 +311,8 @@ int serve(const char *sock_path)
     }
     std::fprintf(stderr, "isslScoreOfftargets: serving on %s\n", sock_path);
     const DeviceChoice dc = device_choice_from_env();
+    long request_timeout_s = 10;
+    if (const char *t = std::getenv("ISSL_SERVER_TIMEOUT_S")) request_timeout_s = std::max(1L, std::atol(t));
     std::map<std::string, Resident> cache;
     bool quit = false;
     while (!quit) {
@@ -319,9 +321,9 @@ int serve(const char *sock_path)
             if (errno == EINTR) continue;
             break;
         }
-        // one client at a time: a client that connects and then says nothing may hold the server for 10 s, no longer;
-        // one that stops reading its answer, for 60 s
-        const struct timeval rcv_to = {10, 0}, snd_to = {60, 0};
+        // one client at a time: a client that connects and then says nothing may hold the server for 10 s, no longer
+        // (ISSL_SERVER_TIMEOUT_S, read once at start-up, overrides); one that stops reading its answer, for six times that
+        const struct timeval rcv_to = {request_timeout_s, 0}, snd_to = {6 * request_timeout_s, 0};
         ::setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &rcv_to, sizeof rcv_to);
         ::setsockopt(fd, SOL_SOCKET, SO_SNDTIMEO, &snd_to, sizeof snd_to);
         std::string line;

@@ -565,6 +565,51 @@ def test_resident_server_mode(golden, tmp_path):
     assert r.returncode == 0 and r.stdout.decode() == golden.expected["and|75|4"]
 
 
+def test_resident_server_survives_bad_clients(golden_uniform, tmp_path):
+    """The server outlives its clients: one that connects and says nothing (receive timeout), one that sends a request
+    and hangs up before the answer (SIGPIPE ignored, MSG_NOSIGNAL); its socket is private (0600); an existing path that
+    is not a socket is never replaced."""
+    import socket
+    import stat
+    import time
+    g = golden_uniform
+    exe = str(ROOT / "bin" / "isslScoreOfftargets")
+    precious = tmp_path / "not_a_socket"
+    precious.write_text("keep me")
+    r = subprocess.run([exe, "--serve", str(precious)], capture_output=True, timeout=30)
+    assert r.returncode == 1 and precious.read_text() == "keep me" and b"not a socket" in r.stderr
+    sock = str(tmp_path / "issl.sock")
+    server = subprocess.Popen([exe, "--serve", sock], stderr=subprocess.PIPE, env=dict(os.environ, ISSL_SERVER_TIMEOUT_S="1"))
+    try:
+        for _ in range(100):
+            if os.path.exists(sock):
+                break
+            time.sleep(0.05)
+        assert stat.S_IMODE(os.stat(sock).st_mode) == 0o600
+        env = dict(os.environ, ISSL_SERVER=sock, ISSL_TIMING="1")
+        args = [exe, str(g.issl), str(g.guides_txt), "4", "75", "and"]
+        silent = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+        silent.connect(sock)                                   # says nothing: the server drops it after 1 s
+        t0 = time.time()
+        r = subprocess.run(args, capture_output=True, env=env, timeout=60)
+        assert r.returncode == 0 and r.stdout.decode() == g.expected["and|75|4"] and time.time() - t0 < 20
+        silent.close()
+        rude = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+        rude.connect(sock)
+        rude.sendall(f"SCORE\t{g.issl}\t{g.guides_txt}\t4\t75\tand\n".encode())
+        rude.close()                                           # gone before the answer is written
+        r = subprocess.run(args, capture_output=True, env=env, timeout=60)
+        assert r.returncode == 0 and r.stdout.decode() == g.expected["and|75|4"]
+        assert b'"resident": true' in r.stderr and server.poll() is None
+    finally:
+        subprocess.run([exe, "--stop", sock], capture_output=True)
+        try:
+            server.wait(timeout=20)
+        except subprocess.TimeoutExpired:
+            server.kill()
+    assert server.returncode == 0
+
+
 def test_raw_buffer_growth_reruns_the_batch(golden_uniform, monkeypatch):
     """Start with a raw-record buffer far too small for the batch (fewer chunks than scan waves): the library must
     notice, grow it and re-run, with the golden results."""
