@@ -13,7 +13,7 @@ ap.add_argument("--guides", type=int, default=10_000)
 ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--thr", type=float, default=0.0)
 ap.add_argument("--variants", default="", help="option settings to compare, separated by / (each a comma list of key=value, "
-                "see issl_index_set_option), e.g. scan_tiles=1/scan_tiles=2,scan_blocks=2048")
+                "see issl_index_set_option), e.g. scan_blocks=1024/scan_blocks=2048,item_guides=256")
 ap.add_argument("--fast-synth", action="store_true", help="random_sites_fast + index built on the device (large indexes)")
 ap.add_argument("--dist", default="uniform", choices=["uniform", "markov"])
 ap.add_argument("--json", default=None, help="write the best repetition (by scan time) of the last variant here")
