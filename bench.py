@@ -428,22 +428,27 @@ def main():
             "extras": extras or None,
         }
         if world == 1 and not a.no_cpu_baseline:
+            # the baseline leg must never cost the line itself: on any failure it is reported inside the line
             t1 = time.perf_counter()
-            import shutil
-            need = 48 * hdr["n_sites"] + (1 << 20)  # .issl bytes: 8 B per site + 40 B of slice lists (+ header, tables)
-            tmp = next((d for d in ("/dev/shm", "/tmp", str(ROOT / "gpurun_out"))
-                        if os.path.isdir(d) and os.access(d, os.W_OK) and shutil.disk_usage(d).free > 1.2 * need), None)
-            if tmp is None:
-                raise SystemExit(f"no scratch directory with {need / 1e9:.0f} GB free for the CPU baseline's .issl (use --no-cpu-baseline)")
-            issl_path = f"{tmp}/bench_{os.getpid()}.issl"
+            issl_path = None
             try:
+                import shutil
+                need = 48 * hdr["n_sites"] + (1 << 20)  # .issl bytes: 8 B per site + 40 B of slice lists (+ header, tables)
+                tmp = next((d for d in ("/dev/shm", "/tmp", str(ROOT / "gpurun_out"))
+                            if os.path.isdir(d) and os.access(d, os.W_OK) and shutil.disk_usage(d).free > 1.2 * need), None)
+                if tmp is None:
+                    raise RuntimeError(f"no scratch directory with {need / 1e9:.0f} GB free for the oracle's .issl")
+                issl_path = f"{tmp}/bench_{os.getpid()}.issl"
                 index.write(issl_path)
                 write_s = time.perf_counter() - t1
                 gpu_scores = (out_mit[-1].cpu().numpy(), out_cfd[-1].cpu().numpy())
                 out["cpu_baseline"] = cpu_baseline(issl_path, guides, gpu_scores, a.max_dist, a.threshold, a.method, a.cpu_budget_s)
                 out["cpu_baseline"]["issl_write_s"] = write_s
+            except Exception as e:  # noqa: BLE001
+                out["cpu_baseline"] = {"value": None, "unit": "guides/s", "cores": 0, "kind": "port", "sample": "not measured",
+                                       "error": f"{type(e).__name__}: {e}"}
             finally:
-                if os.path.exists(issl_path):
+                if issl_path and os.path.exists(issl_path):
                     os.unlink(issl_path)
             log(f"[bench] cpu baseline leg took {time.perf_counter()-t1:.1f} s")
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
