@@ -18,6 +18,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "issl_host.hpp"
@@ -166,21 +167,55 @@ int radix_sort(uint64_t *d_keys, uint64_t *d_tmp, uint64_t n, uint32_t bits)
 }
 
 // FASTA bytes -> upper-cased sequence text with '\n' after every record (extractOfftargets.py:27-61,72-88).
-void append_records(const char *fasta, size_t len, std::string &seq)
+// Lines [begin, end) of one piece of a file; `begin` is a line start.  A header line closes the record before it.
+static void parse_fasta_lines(const char *fasta, size_t begin, size_t end, std::string &seq)
 {
-    size_t p = 0;
-    while (p < len) {
+    size_t p = begin;
+    while (p < end) {
         size_t e = p;
-        while (e < len && fasta[e] != '\n') ++e;
+        while (e < end && fasta[e] != '\n') ++e;
         size_t a = p, b = e;
         while (a < b && std::isspace(static_cast<unsigned char>(fasta[a]))) ++a;
         while (b > a && std::isspace(static_cast<unsigned char>(fasta[b - 1]))) --b;
         if (b > a && fasta[a] == '>') {
-            if (!seq.empty() && seq.back() != '\n') seq.push_back('\n');
+            if (seq.empty() || seq.back() != '\n') seq.push_back('\n'); // (a piece's leading separator is settled when it is joined)
         } else {
             for (size_t k = a; k < b; ++k) seq.push_back(static_cast<char>(std::toupper(static_cast<unsigned char>(fasta[k]))));
         }
         p = e + 1;
+    }
+}
+
+// The one host pass of the extraction, on up to 16 threads: the file is cut at line starts, every piece is parsed on
+// its own, and the pieces are joined with the sequential rule for record separators (none at the very start, never two
+// in a row), so the result is byte-for-byte what one thread produces.  (One thread manages ~0.3 GB/s: 10 s for a human
+// genome, against ~0.3 s for everything that follows on the GPU.)
+void append_records(const char *fasta, size_t len, std::string &seq)
+{
+    const size_t want = std::min<size_t>({16, std::max(1u, std::thread::hardware_concurrency()), len / (size_t(4) << 20) + 1});
+    std::vector<size_t> cut(want + 1, len);
+    cut[0] = 0;
+    for (size_t t = 1; t < want; ++t) {
+        size_t at = std::max(cut[t - 1], len / want * t);
+        while (at < len && fasta[at] != '\n') ++at;  // the piece starts behind the next line end
+        cut[t] = at < len ? at + 1 : len;
+    }
+    std::vector<std::string> piece(want);
+    {
+        std::vector<std::thread> pool;
+        for (size_t t = 1; t < want; ++t)
+            pool.emplace_back([&, t] { piece[t].reserve(cut[t + 1] - cut[t]); parse_fasta_lines(fasta, cut[t], cut[t + 1], piece[t]); });
+        piece[0].reserve(cut[1] - cut[0]);
+        parse_fasta_lines(fasta, cut[0], cut[1], piece[0]);
+        for (auto &th : pool) th.join();
+    }
+    size_t total = seq.size() + 1;
+    for (const auto &pc : piece) total += pc.size();
+    seq.reserve(total);
+    for (const auto &pc : piece) {
+        size_t from = 0;
+        if (!pc.empty() && pc[0] == '\n' && (seq.empty() || seq.back() == '\n')) from = 1;
+        seq.append(pc, from, std::string::npos);
     }
     if (!seq.empty() && seq.back() != '\n') seq.push_back('\n');
 }

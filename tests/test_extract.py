@@ -112,6 +112,26 @@ def test_gpu_extraction_matches_oracle_on_random_genomes(tmp_path):
 
 
 @pytest.mark.gpu
+def test_gpu_extraction_of_inputs_parsed_in_several_pieces():
+    """Inputs above 4 MB are parsed by several host threads, cut at line starts and joined with the sequential rule for
+    record separators: wrapped and unwrapped records, CRLF line ends, blank lines, padded lines, many short records (so
+    that pieces start with headers) -- same bytes as the oracle's single pass."""
+    import crackling_amd as ca
+    rng = np.random.default_rng(77)
+    parts = [random_fasta(21, 6, 1_500_000, width=60)]                        # ~4.5 MB, wrapped
+    one = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=5_000_000)].tobytes()
+    parts.append(b">unwrapped one line\n" + one + b"\n")                    # a 5 MB line
+    parts.append(random_fasta(22, 4000, 1200, width=50).replace(b"\n", b"\r\n"))  # CRLF, thousands of headers
+    parts.append(b"\n\n  >padded header\n   acgtacgtacgtacgtacgtagg   \n\n>x\n" + random_fasta(23, 3, 900_000))
+    blob = b"".join(parts)
+    assert len(blob) > 12_000_000
+    want = oracle_extract([blob])
+    assert ca.extract_offtargets([blob]) == want
+    assert ca.extract_offtargets([blob[:6_000_000], blob[6_000_000:]]) == oracle_extract([blob[:6_000_000], blob[6_000_000:]])
+    assert want.count(b"\n") > 1_000_000
+
+
+@pytest.mark.gpu
 def test_gpu_extraction_empty_and_tiny_inputs():
     import crackling_amd as ca
     assert ca.extract_offtargets([b""]) == b""
