@@ -24,7 +24,7 @@ namespace issl {
 static uint64_t align256(uint64_t x) { return (x + 255ull) & ~255ull; }
 
 void layout_image(ImageHeader &h, const Geometry &g, uint64_t n_scores_unique, uint64_t n_tiles, bool dense_mit,
-                  bool inline_sigs, bool cold_on_host)
+                  bool inline_sigs, bool cold_on_host, bool sorted)
 {
     std::memset(&h, 0, sizeof h);
     h.magic = kImageMagic;
@@ -60,6 +60,11 @@ void layout_image(ImageHeader &h, const Geometry &g, uint64_t n_scores_unique, u
     h.off_scan = off;         off = align256(off + 4ull * kTileCands * n_tiles);
     if (inline_sigs && !cold_on_host) { h.off_esig = off; off += lists_b; }
     if (cold_on_host) { h.off_occ8 = off; off = align256(off + g.n_sites * g.n_slices); }
+    if (sorted && !cold_on_host) {
+        h.off_sub_start = off; off = align256(off + 4 * h.n_buckets * 257);
+        h.off_sid = off;       off = align256(off + 4 * g.n_sites * g.n_slices);
+        h.off_pos_of = off;    off = align256(off + 4 * g.n_sites * g.n_slices);
+    }
     h.total_bytes = off;
 }
 
@@ -77,6 +82,9 @@ ImageView make_view(const ImageHeader &h, void *base, void *cold)
     v.entries = reinterpret_cast<const uint64_t *>(c + h.off_entries);
     v.esig = h.off_esig ? reinterpret_cast<const uint64_t *>(p + h.off_esig) : nullptr;
     v.occ8 = h.off_occ8 ? reinterpret_cast<const uint8_t *>(p + h.off_occ8) : nullptr;
+    v.sub_start = h.off_sub_start ? reinterpret_cast<const uint32_t *>(p + h.off_sub_start) : nullptr;
+    v.sid = h.off_sid ? reinterpret_cast<const uint32_t *>(p + h.off_sid) : nullptr;
+    v.pos_of = h.off_pos_of ? reinterpret_cast<const uint32_t *>(p + h.off_pos_of) : nullptr;
     v.scan = reinterpret_cast<const uint32_t *>(p + h.off_scan);
     v.n_sites = h.n_sites;
     v.n_buckets = static_cast<uint32_t>(h.n_buckets);
@@ -100,10 +108,13 @@ Tuning Tuning::from_env()
     t.raw_chunks = 0;
     t.inline_sigs = -1;
     t.host_cold = -1;
+    t.sorted_layout = -1;
+    t.prune = -1;
     static const char *const keys[][2] = {
         {"ISSL_SCAN_BLOCKS", "scan_blocks"}, {"ISSL_ITEM_GUIDES", "item_guides"},
         {"ISSL_SCAN_GENERIC", "scan_generic"}, {"ISSL_STAGE_TIMING", "stage_timing"}, {"ISSL_RAW_CHUNKS", "raw_chunks"},
         {"ISSL_INLINE_SIGS", "inline_sigs"}, {"ISSL_FORCE_HOST_COLD", "host_cold"}, {"ISSL_SCAN_STAMPS", "scan_stamps"},
+        {"ISSL_SORTED_LAYOUT", "sorted_layout"}, {"ISSL_PRUNE", "prune"},
     };
     for (const auto &k : keys)
         if (const char *e = std::getenv(k[0])) (void)t.set(k[1], e); // values out of range leave the default
@@ -124,6 +135,8 @@ bool Tuning::set(const char *key, const char *value)
     else if (k == "raw_chunks") { if (!is_int || n < 0) return false; raw_chunks = static_cast<size_t>(n); }
     else if (k == "inline_sigs") { if (!is_int || n < -1 || n > 1) return false; inline_sigs = static_cast<int>(n); }
     else if (k == "host_cold") { if (!is_int || n < -1 || n > 1) return false; host_cold = static_cast<int>(n); }
+    else if (k == "sorted_layout") { if (!is_int || n < -1 || n > 1) return false; sorted_layout = static_cast<int>(n); }
+    else if (k == "prune") { if (!is_int || n < -1 || n > 1) return false; prune = static_cast<int>(n); }
     else if (k == "scan_stamps") stamps_path = value;
     else return false;
     return true;
@@ -147,6 +160,7 @@ struct Lane {
     uint32_t pending = 0;       // batches enqueued since the last finish
     bool staged = true;         // the last batch recorded its stage events
     int last_max_dist = 0;
+    uint32_t last_prune = 0;
 };
 
 struct issl_index {
@@ -168,6 +182,7 @@ struct issl_index {
     bool have_events = false;
     issl_stats stats{};
     uint32_t n_pending = 0;  // batches enqueued and not yet finished
+    bool list_order_only = false; // the lists of this index cannot be re-ordered (kSortNeedsListOrder)
 };
 
 #define HIP_TRY(expr)                                                                              \
@@ -284,6 +299,21 @@ static int ensure_workspace(issl_index *ix, size_t n)
         w.cap_guides = cap;
         w.cap_gslots = slots;
         w.cap_items = items;
+        if (ix->hdr.off_sid) { // pruned scan: every guide sits in up to 13 successor-byte groups of each of its 5 buckets
+            const size_t m = std::min<size_t>(cap, kPruneMaxGuides);
+            const size_t places = m * ix->hdr.n_slices * kFineWays;
+            const size_t groups = std::min<size_t>(nb * 256, places);
+            const size_t fslots = places + kGuideGroup * groups;
+            const size_t fitems = groups + places / 8 + 2;
+            if ((rc = dev_alloc(w.fword, fslots))) return rc;
+            if ((rc = dev_alloc(w.fidx, fslots))) return rc;
+            if ((rc = dev_alloc(w.fbucket, fslots))) return rc;
+            if ((rc = dev_alloc(w.fitems, fitems + 1))) return rc;
+            if ((rc = dev_alloc(w.fcount, nb * 256))) return rc;
+            if ((rc = dev_alloc(w.fsum, nb))) return rc;
+            w.cap_fslots = fslots;
+            w.cap_fitems = fitems;
+        }
     }
     if (w.cap_chunks == 0) {
         // every scan wave may hold one partly filled chunk; beyond that ~1 record per 50k comparisons.
@@ -409,6 +439,18 @@ static int finish_upload(issl_index *ix, const DeviceBuildInput *dbi = nullptr)
             HIP_TRY(hipMemcpy(base + ix->hdr.off_entries, h.entries, 8 * g.n_sites * g.n_slices, hipMemcpyHostToDevice));
             upload_note(ix, "entries", t0);
         }
+        if (ix->hdr.off_sid) { // order every bucket by the successor slice's byte; the stream is packed in that order
+            t0 = wall_ms();
+            int src = launch_sort_layout(reinterpret_cast<const uint64_t *>(base + ix->hdr.off_sites),
+                                         reinterpret_cast<const uint64_t *>(base + ix->hdr.off_entries),
+                                         reinterpret_cast<const uint64_t *>(base + ix->hdr.off_bucket_start), g.n_sites,
+                                         static_cast<uint32_t>(g.n_slices), static_cast<uint32_t>(nb),
+                                         reinterpret_cast<uint32_t *>(base + ix->hdr.off_sub_start),
+                                         reinterpret_cast<uint32_t *>(base + ix->hdr.off_sid),
+                                         reinterpret_cast<uint32_t *>(base + ix->hdr.off_pos_of), flag);
+            if (src) return src;
+            upload_note(ix, "sorted layout (successor-byte order of every bucket + position maps)", t0);
+        }
         t0 = wall_ms();
         // scan stream: built on the device from sites + entries
         launch_pack_scan_stream(ix->view, scan_out,
@@ -467,6 +509,15 @@ static int finish_upload(issl_index *ix, const DeviceBuildInput *dbi = nullptr)
 static bool want_inline_sigs(const Tuning &tn, const Geometry &g)
 {
     if (tn.inline_sigs >= 0) return tn.inline_sigs == 1;
+    return g.n_sites <= 600000000ull;
+}
+
+// The sorted layout costs 8 B per list entry (40 B per site) and lets the scan skip 243 of every 256 successor-byte groups
+// (sorted_layout option / ISSL_SORTED_LAYOUT=0/1 overrides).
+static bool want_sorted(const Tuning &tn, const Geometry &g, bool list_order_only = false)
+{
+    if (list_order_only) return false;
+    if (tn.sorted_layout >= 0) return tn.sorted_layout == 1;
     return g.n_sites <= 600000000ull;
 }
 
@@ -560,13 +611,14 @@ static int enqueue_batch(issl_index *ix, hipStream_t stream, const uint64_t *d_g
     const uint32_t slot = ix->n_pending % kRing;
     lane.staged = staged;
     if (staged) HIP_TRY(hipEventRecord(lane.ev[0], stream));
-    launch_bin_guides(ix->view, ws, tn, d_guides, n32, stream);
+    const uint32_t prune_mode = prune_mode_for(ix->view, tn, n32, max_dist);
+    launch_bin_guides(ix->view, ws, tn, d_guides, n32, prune_mode, stream);
     if (staged) HIP_TRY(hipEventRecord(lane.ev[1], stream));
     HIP_TRY(hipEventRecord(ix->ring[2 * slot], stream));
-    launch_scan(ix->view, ws, tn, d_guides, n32, max_dist, stream);
+    launch_scan(ix->view, ws, tn, d_guides, n32, max_dist, prune_mode, stream);
     HIP_TRY(hipEventRecord(ix->ring[2 * slot + 1], stream));
     if (staged) HIP_TRY(hipEventRecord(lane.ev[2], stream));
-    launch_verify(ix->view, ws, d_guides, max_dist, stream);
+    launch_verify(ix->view, ws, d_guides, max_dist, prune_mode, stream);
     if (staged) HIP_TRY(hipEventRecord(lane.ev[3], stream));
     launch_group_hits(ws, n32, stream);
     if (staged) HIP_TRY(hipEventRecord(lane.ev[4], stream));
@@ -578,6 +630,7 @@ static int enqueue_batch(issl_index *ix, hipStream_t stream, const uint64_t *d_g
     lane.pending += 1;
     lane.last_n = n32;
     lane.last_max_dist = max_dist;
+    lane.last_prune = prune_mode;
     return ISSL_OK;
 }
 
@@ -641,6 +694,8 @@ static int finish_batches(issl_index *ix, hipStream_t stream)
     ix->stats.raw_records = static_cast<uint64_t>(max_chunks) * (kChunkRecs - 1);
     ix->stats.candidates = compared;
     ix->stats.planned_comparisons = lane.last_max_dist < 0 ? 0 : pl.candidates;
+    ix->stats.reference_comparisons = pl.reference_candidates;
+    ix->stats.pruned = lane.last_prune ? pl.fine : 0;
     ix->stats.hits = total_hits;
     ix->stats.scan_tiles = pl.tiles;
     ix->stats.n_batches = batches;
@@ -810,7 +865,7 @@ int issl_index_device_bytes(const issl_index *idx, size_t *out)
     // the layout an upload tries first (issl_index_upload falls back to smaller ones when the HBM is short)
     const bool cold = idx->tuning.host_cold == 1;
     layout_image(h, idx->geo, m.size(), count_tiles(*idx->host), masks_are_dense(m),
-                 !cold && want_inline_sigs(idx->tuning, idx->geo), cold);
+                 !cold && want_inline_sigs(idx->tuning, idx->geo), cold, !cold && want_sorted(idx->tuning, idx->geo, idx->list_order_only));
     *out = h.total_bytes;
     return ISSL_OK;
 }
@@ -848,6 +903,9 @@ int issl_index_get_option(const issl_index *idx, const char *key, long long *val
     else if (k == "raw_chunks") *value = static_cast<long long>(t.raw_chunks);
     else if (k == "inline_sigs") *value = t.inline_sigs;
     else if (k == "host_cold") *value = t.host_cold;
+    else if (k == "sorted_layout") *value = t.sorted_layout;
+    else if (k == "prune") *value = t.prune;
+    else if (k == "is_sorted") *value = idx->d_image ? (idx->hdr.off_sid ? 1 : 0) : -1;                   // read-only
     else if (k == "cold_on_host") *value = idx->d_image ? static_cast<long long>(idx->hdr.cold_on_host) : -1; // read-only: layout in use
     else if (k == "dense_mit") *value = idx->d_image ? (idx->hdr.off_mit_dense ? 1 : 0) : -1;              // read-only
     else if (k == "has_inline_sigs") *value = idx->d_image ? (idx->hdr.off_esig ? 1 : 0) : -1;            // read-only
@@ -857,7 +915,7 @@ int issl_index_get_option(const issl_index *idx, const char *key, long long *val
 
 // Layouts an upload tries in turn: with the in-list signatures, without them, with the cold sections in host memory.
 struct LayoutChoice {
-    bool inline_sigs, cold;
+    bool inline_sigs, cold, sorted;
 };
 
 static int upload_common(issl_index *idx, int device, void *buf, size_t bytes, const DeviceBuildInput *dbi = nullptr)
@@ -886,11 +944,16 @@ static int upload_common(issl_index *idx, int device, void *buf, size_t bytes, c
     const Tuning &tn = idx->tuning;
     std::vector<LayoutChoice> choices;
     if (tn.host_cold == 1) {
-        choices.push_back({false, true});
+        choices.push_back({false, true, false});
     } else {
-        if (want_inline_sigs(tn, idx->geo)) choices.push_back({true, false});
-        if (tn.inline_sigs != 1) choices.push_back({false, false}); // an explicit inline_sigs=1 is honoured or fails
-        if (tn.host_cold == -1 && tn.inline_sigs != 1) choices.push_back({false, true});
+        const bool sorted = want_sorted(tn, idx->geo, idx->list_order_only); // explicit inline_sigs=1 / sorted_layout=1 are honoured or fail
+        if (want_inline_sigs(tn, idx->geo)) choices.push_back({true, false, sorted});
+        if (tn.inline_sigs != 1) choices.push_back({false, false, sorted});
+        if (sorted && tn.sorted_layout != 1) {
+            if (want_inline_sigs(tn, idx->geo)) choices.push_back({true, false, false});
+            if (tn.inline_sigs != 1) choices.push_back({false, false, false});
+        }
+        if (tn.host_cold == -1 && tn.inline_sigs != 1 && tn.sorted_layout != 1) choices.push_back({false, true, false});
     }
     idx->device = device;
     const uint64_t n_tiles = count_tiles(*idx->host);
@@ -898,9 +961,10 @@ static int upload_common(issl_index *idx, int device, void *buf, size_t bytes, c
     std::string why;
     bool placed = false;
     for (const LayoutChoice &c : choices) {
-        layout_image(idx->hdr, idx->geo, m.size(), n_tiles, dense, c.inline_sigs, c.cold);
-        // temporary device copies while a host-cold image is packed: signatures + one slice list
-        const uint64_t temp = c.cold ? 16 * idx->geo.n_sites : 0;
+        layout_image(idx->hdr, idx->geo, m.size(), n_tiles, dense, c.inline_sigs, c.cold, c.sorted);
+        // temporary device memory: while a host-cold image is packed, signatures + one slice list; for the sorted layout
+        // two arrays of 8 B per list entry
+        const uint64_t temp = c.cold ? 16 * idx->geo.n_sites : c.sorted ? 16 * idx->geo.n_sites * idx->geo.n_slices + (64ull << 20) : 0;
         if (buf) {
             if (bytes < idx->hdr.total_bytes || (reinterpret_cast<uintptr_t>(buf) & 255u)) {
                 why = "device buffer too small or not 256-byte aligned";
@@ -950,6 +1014,10 @@ static int upload_common(issl_index *idx, int device, void *buf, size_t bytes, c
     upload_note(idx, idx->hdr.cold_on_host ? "layout + allocation (cold sections in pinned host memory)" : "layout + allocation", t0);
     rc = finish_upload(idx, dbi);
     if (rc) release_device(idx);
+    if (rc == kSortNeedsListOrder) { // once more, with the stream in list order
+        idx->list_order_only = true;
+        return upload_common(idx, device, buf, bytes, dbi);
+    }
     return rc;
 }
 
@@ -1193,7 +1261,8 @@ int issl_score(issl_index *idx, const uint64_t *guides, size_t n, int max_dist, 
     // mismatches); the record buffers (32 B per slot with the sorted keys and score terms) are sized for twice
     // that up front, which saves the first large batch on an index its grow-and-rerun round, and a piece ends
     // early when its estimate would not fit a quarter of the free HBM.  Denser data still grows the buffers.
-    const size_t piece = size_t(1) << 22;
+    // (the pruned scan places every guide in up to 65 groups: pieces of at most 2^20 guides while it may be chosen)
+    const size_t piece = prune_mode_for(idx->view, idx->tuning, 1, max_dist) ? size_t(kPruneMaxGuides) : size_t(1) << 22;
     const bool presize = !idx->tuning.raw_chunks && n >= (size_t(1) << 15); // small pages: the default buffers do
     const double records_per_comparison = 8e-5;
     size_t free_b = 0, total_b = 0;
@@ -1231,7 +1300,8 @@ int issl_score(issl_index *idx, const uint64_t *guides, size_t n, int max_dist, 
         HIP_TRY(hipMemcpy(cfd + at, ws.d_cfd, 8 * cnt, hipMemcpyDeviceToHost));
         const issl_stats &s = idx->stats;
         total.n_guides += s.n_guides; total.candidates += s.candidates; total.hits += s.hits;
-        total.planned_comparisons += s.planned_comparisons;
+        total.planned_comparisons += s.planned_comparisons; total.reference_comparisons += s.reference_comparisons;
+        total.pruned = std::max(total.pruned, s.pruned);
         total.scan_tiles += s.scan_tiles; total.ms_bin += s.ms_bin; total.ms_scan += s.ms_scan;
         total.ms_verify += s.ms_verify; total.ms_group += s.ms_group; total.ms_replay += s.ms_replay;
         total.ms_total += s.ms_total; total.scan_launches += s.scan_launches;

@@ -41,7 +41,7 @@ namespace issl {
 // from `occ8`, one saturating byte per list entry kept in HBM with the hot part (5 B per site).  Host memory is read
 // only for occurrence counts >= 255 and for the site ids of issl_dump_hits.
 constexpr uint64_t kImageMagic = 0x314C535349444D41ull; // "AMDISSL1"
-constexpr uint32_t kImageVersion = 4;
+constexpr uint32_t kImageVersion = 5;
 constexpr uint32_t kTileCands = 2048; // candidates per scan tile: one wave, 64 lanes x 32 registers
 constexpr uint32_t kHeaderBytes = 4096;
 
@@ -62,6 +62,11 @@ struct ImageHeader {
     uint64_t cold_on_host;  // 1: off_sites / off_entries are offsets into the pinned host buffer of cold_bytes bytes
     uint64_t cold_bytes;    // bytes of sites + entries (+ esig) wherever they live
     uint64_t off_occ8;      // u8[N*S]: min(occurrences, 255) per list entry; present (in HBM) only when cold_on_host
+    // "Sorted" layout (pruned scan, see below): inside every bucket the scan stream holds the candidates ordered by the
+    // byte of the SUCCESSOR slice ((slice + 1) mod n_slices), ties in list order.  0 = absent (stream in list order).
+    uint64_t off_sub_start; // u32[nb * 257]: first stream position (inside the bucket) of every successor-byte value
+    uint64_t off_sid;       // u32[N*S]: stream position (bucket_start[b] + q) -> site id of the candidate there
+    uint64_t off_pos_of;    // u32[N*S]: (slice s, site id) at s * N + id -> position of that site in its bucket of slice s
 };
 static_assert(sizeof(ImageHeader) <= kHeaderBytes, "header must fit its block");
 
@@ -76,6 +81,9 @@ struct ImageView {
     const uint64_t *entries;
     const uint64_t *esig; // signature of the site behind every list entry, in list order, or null
     const uint8_t *occ8;  // min(occurrences, 255) of every list entry, or null (only with host-resident cold sections)
+    const uint32_t *sub_start; // sorted layout: [nb][257] stream offsets of the successor-byte groups, or null
+    const uint32_t *sid;       // sorted layout: stream position -> site id, or null (stream in list order)
+    const uint32_t *pos_of;    // sorted layout: (slice, site id) -> list position in that slice's bucket, or null
     const uint32_t *scan;
     uint64_t n_sites;
     uint32_t n_buckets;
@@ -88,7 +96,7 @@ struct ImageView {
 // Layout computation shared by upload and attach.  Fills every field of `h` from the geometry,
 // the number of unique scores and the bucket sizes (sizes may be null when n_tiles is given).
 void layout_image(ImageHeader &h, const Geometry &g, uint64_t n_scores_unique, uint64_t n_tiles, bool dense_mit,
-                  bool inline_sigs, bool cold_on_host);
+                  bool inline_sigs, bool cold_on_host, bool sorted);
 // `cold`: device-visible address of the pinned host buffer when h.cold_on_host, else ignored.
 ImageView make_view(const ImageHeader &h, void *base, void *cold);
 
@@ -103,6 +111,10 @@ struct Tuning {
     bool upload_timing;     // ISSL_UPLOAD_TIMING one stderr line per upload stage
     size_t raw_chunks;      // ISSL_RAW_CHUNKS    initial raw-record buffer in chunks (0: sized from the launch)
     int inline_sigs;        // ISSL_INLINE_SIGS   -1 automatic, 0 never, 1 always
+    int sorted_layout;      // ISSL_SORTED_LAYOUT -1 automatic (up to 600 M sites, cold sections in HBM), 0 never, 1 always
+    int prune;              // ISSL_PRUNE         scan only the successor-byte groups that can hold a hit (needs the sorted
+                            //                    layout and max_dist <= 4): -1 when the plan estimates it to be faster,
+                            //                    0 never, 1 whenever possible
     int host_cold;          // ISSL_FORCE_HOST_COLD  -1 automatic (image larger than the free HBM), 0 never, 1 always
     std::string stamps_path; // ISSL_SCAN_STAMPS  dump per-wave clocks of the scan here (diagnostics)
     static Tuning from_env();
@@ -115,6 +127,16 @@ struct Tuning {
 // Synchronous.
 int launch_build_entries(const uint64_t *d_sites, const uint32_t *d_occ, uint64_t n_sites, uint32_t slice_begin,
                          uint32_t slice_end, uint32_t slice_width, uint64_t *d_entries);
+
+// Sorted layout (issl_build.hip): orders every bucket's list by the successor slice's byte (three stable radix passes
+// over keys built from the signatures) and writes the three maps of the image; d_sites / d_entries / d_bucket_start are
+// the image's own sections.  Needs 16 B per list entry of temporary device memory.  Synchronous.  d_flag: a zeroed device
+// word.  Returns kSortNeedsListOrder when some entry sits in a bucket its signature does not select (the caller then
+// uploads the list-order layout, which like the reference does not care).
+constexpr int kSortNeedsListOrder = -1000;
+int launch_sort_layout(const uint64_t *d_sites, const uint64_t *d_entries, const uint64_t *d_bucket_start, uint64_t n_sites,
+                       uint32_t n_slices, uint32_t n_buckets, uint32_t *d_sub_start, uint32_t *d_sid, uint32_t *d_pos_of,
+                       uint32_t *d_flag);
 
 // ---- scoring workspace -------------------------------------------------------------------------
 constexpr uint32_t kGuideGroup = 8;    // guide words fetched per scalar load
@@ -129,14 +151,18 @@ constexpr uint32_t kMaxRanges = kScanMaxBlocks;  // one equal-cost range per wor
 constexpr uint32_t kChunkRecs = 128;            // raw-record chunk: 1 KiB, slot 0 is the fill count
 constexpr uint64_t kDeadKey = ~0ull;            // raw slot that did not survive the exact check
 
-// One unit of scan work: all tiles of one bucket against one group of guides of that bucket.
+// One unit of scan work: a run of tiles of one bucket against one group of guides.  Full scan: all tiles of the bucket
+// against <= 512 of the guides whose slice value selects it.  Pruned scan: the tiles that hold one successor-byte group
+// of the bucket against the guides that can have a hit there.
 struct ScanItem {
-    uint32_t bucket;
-    uint32_t g0, g1; // range in the bucket-sorted guide arrays, g0 % kGuideGroup == 0
+    uint32_t bucket; // full scan: bucket; pruned scan: bucket << 8 | successor byte
+    uint32_t g0, g1; // range in the grouped guide arrays, g0 % kGuideGroup == 0
     uint32_t n_tiles;
     uint64_t cost0;  // sum of costs of all earlier items; tile cost = (g1-g0)+kTileFixedCost
     uint32_t tile0;  // sum of n_tiles of all earlier items (tiles are numbered in item order)
-    uint32_t last_cands; // candidates in the bucket's last tile (1..kTileCands): the other tiles are full
+    uint32_t last_cands; // real candidates in the item's last tile (1..kTileCands): its other tiles are full
+    uint32_t tile_abs;   // the item's first tile in the scan stream
+    uint32_t pad;
 };
 
 // Start of a cost range of the scan: (item, tile inside the item, guide offset); item == n_items marks the end.
@@ -152,9 +178,12 @@ struct PlanInfo {
     uint32_t n_items;
     uint32_t error;       // bit 1: item list overflow
     uint32_t n_ranges;    // equal-cost ranges of the scan, one per workgroup
-    uint32_t pad;
+    uint32_t fine;        // 0: the scan works through the bucket-level items; 1 / 2: through the successor-byte groups
+                          // (k_fine_plan decides, per batch, from the two plans' estimated times)
     uint64_t total_cost;
-    uint64_t candidates;  // sum over guides of their bucket lengths (what the plan EXPECTS the scan to compare)
+    uint64_t candidates;  // what the plan EXPECTS the scan to compare: sum over guides of the lengths of the buckets
+                          // (full scan) or successor-byte groups (pruned scan) it visits
+    uint64_t reference_candidates; // sum over guides of their five bucket lengths = what the reference compares
     uint64_t tiles;       // (tile, item) pairs the scan works through
 };
 
@@ -166,6 +195,16 @@ struct Counters {
     uint32_t raw_overflow; // set when the raw buffer was too small
 };
 
+// Per bucket, pruned scan: what its successor-byte groups add to the plan (k_fine_count -> k_fine_plan -> k_fine_scatter).
+struct FineSum {
+    uint64_t cost, cand;  // cost units and planned comparisons of the bucket's items
+    uint32_t slots, items, units, pad;
+};
+
+constexpr uint32_t kFineWays = 13;      // successor bytes within one mismatch of a guide's: itself + 4 positions x 3 bases
+constexpr uint32_t kFetchPairs = 24;    // time of fetching one 8 KiB tile from HBM, in (guide, tile) comparisons of the chip
+constexpr uint32_t kPruneMaxGuides = 1u << 20; // guides per pruned launch: 65 slots per guide + padding must fit the 27-bit slot field
+
 struct Workspace {
     uint32_t *ng = nullptr;      // [nb]   guides per bucket
     uint32_t *gfill = nullptr;   // [nb]
@@ -174,6 +213,12 @@ struct Workspace {
     uint32_t *gidx = nullptr;    // guide index, kNoGuide in padding
     uint32_t *gbucket = nullptr; // bucket of the slot (valid where gidx is a guide)
     ScanItem *items = nullptr;   // [max_items+1]
+    // pruned scan: the same three arrays and the item list once more, grouped by (bucket, successor byte)
+    uint32_t *fword = nullptr, *fidx = nullptr, *fbucket = nullptr;
+    ScanItem *fitems = nullptr;
+    uint32_t *fcount = nullptr;  // [nb * 256] guides per (bucket, successor byte)
+    FineSum *fsum = nullptr;     // [nb] per-bucket totals, then their exclusive prefix
+    size_t cap_fslots = 0, cap_fitems = 0;
     PlanInfo *plan = nullptr;
     RangeStart *range_start = nullptr; // [kMaxRanges + 1]
     uint64_t *raw = nullptr;     // [(cap_chunks+1) * kChunkRecs] raw records of the scan, chunked
@@ -211,11 +256,15 @@ void launch_pack_scan_stream(const ImageView &v, uint32_t *scan_out, uint64_t *e
                              uint32_t *error_flag, void *stream);
 void launch_pack_scan_range(const ImageView &v, uint32_t *scan_out, uint64_t *esig_out, uint8_t *occ8_out,
                             uint32_t *error_flag, uint32_t tile_begin, uint32_t tile_end, void *stream);
+// prune_mode: 0 = full scan of the five buckets of every guide; 1 / 2 = pruned scan over the successor-byte groups equal
+// to / within one mismatch of the guide's own successor byte (enough for max_dist <= 2 / <= 4, see k_fine_count).
+uint32_t prune_mode_for(const ImageView &v, const Tuning &tn, uint32_t n_guides, int max_dist);
 void launch_bin_guides(const ImageView &v, const Workspace &ws, const Tuning &tn, const uint64_t *d_guides, uint32_t n,
-                       void *stream);
+                       uint32_t prune_mode, void *stream);
 void launch_scan(const ImageView &v, const Workspace &ws, const Tuning &tn, const uint64_t *d_guides, uint32_t n,
-                 int max_dist, void *stream);
-void launch_verify(const ImageView &v, const Workspace &ws, const uint64_t *d_guides, int max_dist, void *stream);
+                 int max_dist, uint32_t prune_mode, void *stream);
+void launch_verify(const ImageView &v, const Workspace &ws, const uint64_t *d_guides, int max_dist, uint32_t prune_mode,
+                   void *stream);
 void launch_group_hits(const Workspace &ws, uint32_t n, void *stream);
 void launch_replay(const ImageView &v, const Workspace &ws, const uint64_t *d_guides, uint32_t n,
                    const ScoreParams &p, double *d_mit, double *d_cfd, uint32_t *d_kept, issl_hit *d_hitrec,

@@ -108,7 +108,11 @@ __global__ __launch_bounds__(256) void k_pack_scan_stream(ImageView v, uint32_t 
         for (uint32_t k0 = wave * 64u; k0 < kTileCands; k0 += 256u) {
             const uint64_t pos = tile_pos + k0 + lane;
             uint32_t w = 0;
-            if (pos < len) {
+            if (pos < len && v.sid) {
+                // sorted layout: the stream holds the site v.sid names (ids checked when the maps were built); esig keeps
+                // the list order and is filled by k_fill_esig
+                w = scan_word(v.sites[v.sid[start + pos]], slice);
+            } else if (pos < len) {
                 const uint64_t e = v.entries[start + pos];
                 const uint64_t id = e & 0xFFFFFFFFull;
                 if (id < v.n_sites) {
@@ -134,6 +138,17 @@ __global__ __launch_bounds__(256) void k_pack_scan_stream(ImageView v, uint32_t 
     }
 }
 
+// Sorted layout: the in-list signatures, in list order (the pack kernel walks the stream order there).
+__global__ __launch_bounds__(256) void k_fill_esig(ImageView v, uint64_t *__restrict__ esig_out, uint64_t total,
+                                                   uint32_t *__restrict__ error_flag)
+{
+    for (uint64_t e = static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x; e < total; e += static_cast<uint64_t>(gridDim.x) * 256) {
+        const uint64_t id = v.entries[e] & 0xFFFFFFFFull;
+        if (id < v.n_sites) esig_out[e] = v.sites[id];
+        else atomicOr(error_flag, 1u);
+    }
+}
+
 // Tiles [tile_begin, tile_end) only: the upload of an image whose cold sections stay in host memory packs one slice
 // at a time from temporary device copies (v.entries then points at the slice's list minus the slice's offset).
 void launch_pack_scan_range(const ImageView &v, uint32_t *scan_out, uint64_t *esig_out, uint8_t *occ8_out,
@@ -150,6 +165,11 @@ void launch_pack_scan_stream(const ImageView &v, uint32_t *scan_out, uint64_t *e
                              uint32_t *error_flag, void *stream)
 {
     launch_pack_scan_range(v, scan_out, esig_out, occ8_out, error_flag, 0u, v.n_tiles, stream);
+    if (v.sid && esig_out) {
+        const uint64_t total = v.n_sites * v.n_slices;
+        const uint32_t grid = static_cast<uint32_t>(std::min<uint64_t>((total + 255) / 256, 1u << 20));
+        if (grid) hipLaunchKernelGGL(k_fill_esig, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), v, esig_out, total, error_flag);
+    }
 }
 
 // The packed signature of the candidate at offset `offset` of scan tile `tile` of bucket `bucket`, rebuilt from the
@@ -336,6 +356,8 @@ __global__ __launch_bounds__(256) void k_plan(ImageView v, uint32_t *__restrict_
                 it.cost0 = cost_at;
                 it.tile0 = static_cast<uint32_t>(tile_at);
                 it.last_cands = static_cast<uint32_t>(blen - static_cast<uint64_t>(nt - 1u) * kTileCands);
+                it.tile_abs = v.tile_first[b];
+                it.pad = 0;
                 items[item_at++] = it;
                 cost_at += static_cast<uint64_t>(nt) * (len + kTileFixedCost);
                 tile_at += nt;
@@ -350,12 +372,14 @@ __global__ __launch_bounds__(256) void k_plan(ImageView v, uint32_t *__restrict_
         if (!overflow) {
             ScanItem end;
             end.bucket = 0; end.g0 = 0; end.g1 = 0; end.n_tiles = 0; end.cost0 = tot_cost;
-            end.tile0 = static_cast<uint32_t>(tot_tiles); end.last_cands = 0;
+            end.tile0 = static_cast<uint32_t>(tot_tiles); end.last_cands = 0; end.tile_abs = 0; end.pad = 0;
             items[tot_items] = end;
         }
         plan->n_items = overflow ? 0u : static_cast<uint32_t>(tot_items);
         plan->total_cost = overflow ? 0ull : tot_cost;
         plan->candidates = tot_cand;
+        plan->reference_candidates = tot_cand;
+        plan->fine = 0;
         plan->tiles = tot_tiles;
         // one equal-cost range per scan workgroup; inside a workgroup the waves share the tiles dynamically
         plan->n_ranges = (overflow || tot_tiles == 0) ? 0u : scan_blocks;
@@ -420,8 +444,220 @@ __global__ __launch_bounds__(256) void k_guide_scatter(const uint64_t *__restric
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// pruned scan: guides grouped by (bucket, successor byte)
+// ------------------------------------------------------------------------------------------------
+// A site within max_dist <= 4 mismatches of a guide matches it exactly in some of the five slices (set E), and for at
+// least one slice i of E the NEXT slice (i + 1 mod 5) has at most one mismatch: otherwise every slice of E is followed by
+// a slice with >= 2 mismatches, these followers are distinct and lie outside E, the other slices outside E have >= 1
+// each, and 2|E| + (5 - 2|E|) = 5 > 4 mismatches.  (For max_dist <= 2 the next slice is even exact for some i of E;
+// both facts are checked by enumeration in tests/test_oracle_golden.py.)  With every bucket's candidates ordered by
+// the byte of the successor slice, a guide therefore needs, in each of its five buckets, only the 13 groups whose
+// successor byte is within one mismatch of its own (1 group for max_dist <= 2) instead of all 256 -- the reference
+// scans the whole bucket, isslScoreOfftargets.cpp:344, and finds the same sites.  k_verify re-attributes a hit to the
+// first exactly matching slice and its position there (pos_of), which is what the reference's order is made of.
+
+// The successor bytes a guide with successor byte `gj` visits: way 0 = gj itself, ways 1..12 = one position changed.
+__device__ __forceinline__ uint32_t fine_way(uint32_t gj, uint32_t way)
+{
+    if (way == 0) return gj;
+    const uint32_t q = (way - 1u) / 3u, d = (way - 1u) % 3u + 1u;
+    return gj ^ (d << (2u * q));
+}
+
+// Per bucket: guides per successor byte, and what the bucket's groups add to the plan.
+__global__ __launch_bounds__(256) void k_fine_count(ImageView v, const uint64_t *__restrict__ guides,
+                                                    const uint32_t *__restrict__ gstart, const uint32_t *__restrict__ gfill,
+                                                    const uint32_t *__restrict__ gidx, uint32_t *__restrict__ fcount,
+                                                    FineSum *__restrict__ fsum, uint32_t item_guides, uint32_t ways)
+{
+    short_kernel_priority();
+    __shared__ uint32_t cnt[256];
+    __shared__ uint64_t lds[256];
+    const uint32_t b = blockIdx.x, slice = b >> v.slice_width;
+    const uint32_t succ_shift = v.slice_width * ((slice + 1u) % v.n_slices);
+    cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t g0 = gstart[b], n = gfill[b];
+    for (uint32_t i = threadIdx.x; i < n; i += 256) {
+        const uint32_t gj = static_cast<uint32_t>(guides[gidx[g0 + i]] >> succ_shift) & 0xFFu;
+        for (uint32_t way = 0; way < ways; ++way) atomicAdd(&cnt[fine_way(gj, way)], 1u);
+    }
+    __syncthreads();
+    const uint32_t w = threadIdx.x, c = cnt[w];
+    const uint32_t *ss = v.sub_start + static_cast<uint64_t>(b) * 257u;
+    const uint32_t s0 = ss[w], s1 = ss[w + 1];
+    fcount[static_cast<uint64_t>(b) * 256u + w] = (s1 > s0) ? c : 0u; // a group without candidates takes no guides
+    uint64_t cost = 0, cand = 0, slots = 0, items = 0, units = 0;
+    if (c && s1 > s0) {
+        const uint32_t nt = (s1 - 1u) / kTileCands - s0 / kTileCands + 1u;
+        const uint32_t kk = (c + item_guides - 1u) / item_guides;
+        slots = (c + kGuideGroup - 1u) / kGuideGroup * kGuideGroup;
+        items = kk;
+        units = static_cast<uint64_t>(nt) * kk;
+        cost = static_cast<uint64_t>(nt) * (static_cast<uint64_t>(c) + static_cast<uint64_t>(kk) * kTileFixedCost);
+        cand = static_cast<uint64_t>(s1 - s0) * c;
+    }
+    uint64_t t_cost, t_cand, t_slots, t_items, t_units;
+    (void)block_exclusive_scan(cost, lds, &t_cost);
+    (void)block_exclusive_scan(cand, lds, &t_cand);
+    (void)block_exclusive_scan(slots, lds, &t_slots);
+    (void)block_exclusive_scan(items, lds, &t_items);
+    (void)block_exclusive_scan(units, lds, &t_units);
+    if (threadIdx.x == 0) {
+        FineSum f;
+        f.cost = t_cost; f.cand = t_cand; f.slots = static_cast<uint32_t>(t_slots); f.items = static_cast<uint32_t>(t_items);
+        f.units = static_cast<uint32_t>(t_units); f.pad = 0;
+        fsum[b] = f;
+    }
+}
+
+// One block: exclusive prefix of the per-bucket totals (in place) and the plan of the pruned scan.
+__global__ __launch_bounds__(256) void k_fine_plan(FineSum *__restrict__ fsum, uint32_t nb, ScanItem *__restrict__ fitems,
+                                                   uint32_t cap_items, uint32_t cap_slots, PlanInfo *__restrict__ plan,
+                                                   uint32_t scan_blocks, uint32_t prune_mode, uint32_t always)
+{
+    short_kernel_priority();
+    __shared__ uint64_t lds[256];
+    const uint32_t per = (nb + 255u) / 256u;
+    const uint32_t b0 = threadIdx.x * per, b1 = (b0 + per < nb) ? b0 + per : nb;
+    uint64_t cost = 0, cand = 0, slots = 0, items = 0, units = 0;
+    for (uint32_t b = b0; b < b1; ++b) {
+        cost += fsum[b].cost; cand += fsum[b].cand; slots += fsum[b].slots; items += fsum[b].items; units += fsum[b].units;
+    }
+    uint64_t t_cost, t_cand, t_slots, t_items, t_units;
+    uint64_t cost_at = block_exclusive_scan(cost, lds, &t_cost);
+    (void)block_exclusive_scan(cand, lds, &t_cand);
+    uint64_t slot_at = block_exclusive_scan(slots, lds, &t_slots);
+    uint64_t item_at = block_exclusive_scan(items, lds, &t_items);
+    uint64_t unit_at = block_exclusive_scan(units, lds, &t_units);
+    for (uint32_t b = b0; b < b1; ++b) {
+        const FineSum f = fsum[b];
+        FineSum at;
+        at.cost = cost_at; at.cand = 0; at.slots = static_cast<uint32_t>(slot_at); at.items = static_cast<uint32_t>(item_at);
+        at.units = static_cast<uint32_t>(unit_at); at.pad = 0;
+        fsum[b] = at;
+        cost_at += f.cost; slot_at += f.slots; item_at += f.items; unit_at += f.units;
+    }
+    if (threadIdx.x == 255) {
+        // Which plan is faster?  Comparing and fetching overlap: time ~ max((guide, tile) pairs, kFetchPairs x tile
+        // fetches).  Few guides per successor-byte group make the pruned scan fetch-bound (every group reads its own
+        // tiles, a bucket-level item reads a tile once for up to 512 guides); costs are pairs + kTileFixedCost x fetches.
+        const uint64_t full_fetch = plan->tiles, full_pairs = plan->total_cost - kTileFixedCost * full_fetch;
+        const uint64_t fine_pairs = t_cost - kTileFixedCost * t_units;
+        const uint64_t est_full = full_pairs > kFetchPairs * full_fetch ? full_pairs : kFetchPairs * full_fetch;
+        const uint64_t est_fine = fine_pairs > kFetchPairs * t_units ? fine_pairs : kFetchPairs * t_units;
+        const bool fits = t_items <= cap_items && t_slots <= cap_slots; // (the capacities cover every guide in 13 groups)
+        if (fits && plan->error == 0 && (always || est_fine < est_full)) {
+            ScanItem end;
+            end.bucket = 0; end.g0 = 0; end.g1 = 0; end.n_tiles = 0; end.cost0 = t_cost;
+            end.tile0 = static_cast<uint32_t>(t_units); end.last_cands = 0; end.tile_abs = 0; end.pad = 0;
+            fitems[t_items] = end;
+            plan->n_items = static_cast<uint32_t>(t_items);
+            plan->total_cost = t_cost;
+            plan->candidates = t_cand; // reference_candidates stays what the bucket-level plan counted
+            plan->tiles = t_units;
+            plan->n_ranges = t_units == 0 ? 0u : scan_blocks;
+            plan->fine = prune_mode;
+        }
+    }
+}
+
+// Per bucket: the items of its successor-byte groups and the guides of every group in its slots.
+__global__ __launch_bounds__(256) void k_fine_scatter(ImageView v, const uint64_t *__restrict__ guides,
+                                                      const uint32_t *__restrict__ gstart, const uint32_t *__restrict__ gfill,
+                                                      const uint32_t *__restrict__ gword, const uint32_t *__restrict__ gidx,
+                                                      const uint32_t *__restrict__ fcount, const FineSum *__restrict__ fbase,
+                                                      const PlanInfo *__restrict__ plan, uint32_t *__restrict__ fword,
+                                                      uint32_t *__restrict__ fidx, uint32_t *__restrict__ fbucket,
+                                                      ScanItem *__restrict__ fitems, uint32_t item_guides, uint32_t ways)
+{
+    short_kernel_priority();
+    if (!plan->fine) return; // the bucket-level plan stays
+    __shared__ uint64_t lds[256];
+    __shared__ uint32_t slot_of[256], cursor[256];
+    const uint32_t b = blockIdx.x, slice = b >> v.slice_width;
+    const uint32_t succ_shift = v.slice_width * ((slice + 1u) % v.n_slices);
+    const uint32_t w = threadIdx.x;
+    const uint32_t c = fcount[static_cast<uint64_t>(b) * 256u + w];
+    const uint32_t *ss = v.sub_start + static_cast<uint64_t>(b) * 257u;
+    const uint32_t s0 = ss[w], s1 = ss[w + 1];
+    uint64_t cost = 0, slots = 0, items = 0, units = 0;
+    uint32_t nt = 0, kk = 0;
+    if (c) { // (fcount is zero where the group has no candidates)
+        nt = (s1 - 1u) / kTileCands - s0 / kTileCands + 1u;
+        kk = (c + item_guides - 1u) / item_guides;
+        slots = (c + kGuideGroup - 1u) / kGuideGroup * kGuideGroup;
+        items = kk;
+        units = static_cast<uint64_t>(nt) * kk;
+        cost = static_cast<uint64_t>(nt) * (static_cast<uint64_t>(c) + static_cast<uint64_t>(kk) * kTileFixedCost);
+    }
+    const FineSum base = fbase[b];
+    uint64_t cost_at = base.cost + block_exclusive_scan(cost, lds, nullptr);
+    const uint32_t slot_at = base.slots + static_cast<uint32_t>(block_exclusive_scan(slots, lds, nullptr));
+    uint32_t item_at = base.items + static_cast<uint32_t>(block_exclusive_scan(items, lds, nullptr));
+    uint32_t unit_at = base.units + static_cast<uint32_t>(block_exclusive_scan(units, lds, nullptr));
+    slot_of[w] = slot_at;
+    cursor[w] = 0;
+    if (c) {
+        const uint64_t blen = v.bucket_start[b + 1] - v.bucket_start[b];
+        const uint32_t t_first = s0 / kTileCands, t_last = (s1 - 1u) / kTileCands;
+        const uint64_t after = blen - static_cast<uint64_t>(t_last) * kTileCands; // candidates from the last tile's start on
+        for (uint32_t done = 0; done < c; done += item_guides) {
+            const uint32_t len = (c - done < item_guides) ? c - done : item_guides;
+            ScanItem it;
+            it.bucket = (b << 8) | w;
+            it.g0 = slot_at + done; // item_guides is a multiple of 8
+            it.g1 = it.g0 + len;
+            it.n_tiles = nt;
+            it.cost0 = cost_at;
+            it.tile0 = unit_at;
+            it.last_cands = after < kTileCands ? static_cast<uint32_t>(after) : kTileCands;
+            it.tile_abs = v.tile_first[b] + t_first;
+            it.pad = 0;
+            fitems[item_at++] = it;
+            cost_at += static_cast<uint64_t>(nt) * (len + kTileFixedCost);
+            unit_at += nt;
+        }
+        // padding slots behind the group's guides
+        for (uint32_t k2 = c; k2 < static_cast<uint32_t>(slots); ++k2) { fidx[slot_at + k2] = kNoGuide; fword[slot_at + k2] = kPadGuideWord; }
+    }
+    __syncthreads();
+    const uint32_t g0 = gstart[b], n = gfill[b];
+    for (uint32_t i = threadIdx.x; i < n; i += 256) {
+        const uint32_t guide = gidx[g0 + i], word = gword[g0 + i];
+        const uint32_t gj = static_cast<uint32_t>(guides[guide] >> succ_shift) & 0xFFu;
+        for (uint32_t way = 0; way < ways; ++way) {
+            const uint32_t ww = fine_way(gj, way);
+            if (ss[ww + 1] == ss[ww]) continue; // no candidates there: the group has no slots
+            const uint32_t slot = slot_of[ww] + atomicAdd(&cursor[ww], 1u);
+            fword[slot] = word;
+            fidx[slot] = guide;
+            fbucket[slot] = (b << 8) | ww;
+        }
+    }
+}
+
+// Cost ranges of the pruned scan (the bucket-level ones are resolved by k_guide_scatter's last workgroups).
+__global__ __launch_bounds__(256) void k_fine_ranges(const PlanInfo *__restrict__ plan, const ScanItem *__restrict__ fitems,
+                                                     RangeStart *__restrict__ starts)
+{
+    short_kernel_priority();
+    if (!plan->fine) return;
+    const uint32_t n_ranges = plan->n_ranges;
+    const uint32_t r = blockIdx.x * 256 + threadIdx.x;
+    if (r <= n_ranges && n_ranges != 0) starts[r] = range_start_of(fitems, plan->n_items, plan->total_cost, n_ranges, r);
+}
+
+uint32_t prune_mode_for(const ImageView &v, const Tuning &tn, uint32_t n_guides, int max_dist)
+{
+    if (!v.sid || tn.prune == 0 || max_dist < 0 || max_dist > 4 || n_guides > kPruneMaxGuides || v.n_slices != 5 || v.slice_width != 8)
+        return 0;
+    return max_dist <= 2 ? 1u : 2u;
+}
+
 void launch_bin_guides(const ImageView &v, const Workspace &ws, const Tuning &tn, const uint64_t *d_guides, uint32_t n,
-                       void *stream_)
+                       uint32_t prune_mode, void *stream_)
 {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const uint32_t nb = v.n_buckets;
@@ -439,6 +675,17 @@ void launch_bin_guides(const ImageView &v, const Workspace &ws, const Tuning &tn
     hipLaunchKernelGGL(k_guide_scatter, dim3(blocks + range_blocks), dim3(256), 0, stream, d_guides, n, v.slice_width,
                        v.n_slices, nb, ws.gstart, ws.gfill, ws.gword, ws.gidx, ws.gbucket, blocks, ws.plan, ws.items,
                        ws.range_start);
+    if (prune_mode) { // regroup by (bucket, successor byte); k_fine_plan decides which of the two plans the scan follows
+        const uint32_t ways = prune_mode == 1 ? 1u : kFineWays;
+        hipLaunchKernelGGL(k_fine_count, dim3(nb), dim3(256), 0, stream, v, d_guides, ws.gstart, ws.gfill, ws.gidx, ws.fcount,
+                           ws.fsum, tn.item_guides, ways);
+        hipLaunchKernelGGL(k_fine_plan, dim3(1), dim3(256), 0, stream, ws.fsum, nb, ws.fitems,
+                           static_cast<uint32_t>(ws.cap_fitems), static_cast<uint32_t>(ws.cap_fslots), ws.plan, tn.scan_blocks,
+                           prune_mode, tn.prune == 1 ? 1u : 0u);
+        hipLaunchKernelGGL(k_fine_scatter, dim3(nb), dim3(256), 0, stream, v, d_guides, ws.gstart, ws.gfill, ws.gword, ws.gidx,
+                           ws.fcount, ws.fsum, ws.plan, ws.fword, ws.fidx, ws.fbucket, ws.fitems, tn.item_guides, ways);
+        hipLaunchKernelGGL(k_fine_ranges, dim3(range_blocks), dim3(256), 0, stream, ws.plan, ws.fitems, ws.range_start);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -605,11 +852,12 @@ __device__ __forceinline__ void note_candidates(uint32_t ok, uint32_t gslot, uin
 // wave-uniform ones through the scalar cache.
 template <int THR>
 __global__ __launch_bounds__(1024, 8) void k_scan(const uint32_t *__restrict__ scan_stream,
-                                                  const uint32_t *__restrict__ tile_first,
-                                                  const ScanItem *__restrict__ items,
+                                                  const ScanItem *__restrict__ items_full,
+                                                  const ScanItem *__restrict__ items_fine,
                                                   const PlanInfo *__restrict__ plan,
                                                   const RangeStart *__restrict__ range_start,
-                                                  const uint32_t *__restrict__ gword_stream, uint64_t *raw,
+                                                  const uint32_t *__restrict__ gword_full,
+                                                  const uint32_t *__restrict__ gword_fine, uint64_t *raw,
                                                   uint32_t max_chunks, Counters *counters, uint32_t thr,
                                                   unsigned long long *stamps, uint64_t *__restrict__ scan_count)
 {
@@ -628,6 +876,10 @@ __global__ __launch_bounds__(1024, 8) void k_scan(const uint32_t *__restrict__ s
         if (threadIdx.x == 0) scan_count[blockIdx.x] = 0ull;
         return;
     }
+    // the plan of this batch: bucket-level items, or the successor-byte groups of the pruned scan (k_fine_plan)
+    const bool fine = plan->fine != 0u;
+    const ScanItem *__restrict__ items = fine ? items_fine : items_full;
+    const uint32_t *__restrict__ gword_stream = fine ? gword_fine : gword_full;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave_id = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
     // Raw records: the wave's first chunk is the one with its own number (no atomic); k_guide_hist cleared its header.
@@ -661,8 +913,8 @@ __global__ __launch_bounds__(1024, 8) void k_scan(const uint32_t *__restrict__ s
         const uint32_t g_begin = cur.g0 + (u == 0 ? first.goff : 0u);
         const uint32_t g_end = (gt == tile_last) ? cur.g0 + last.goff : cur.g1;
 
-        // ---- one tile: 2048 candidates of bucket cur.bucket, tile k, guide slots [g_begin, g_end) -----------
-        const uint32_t tile = tile_first[cur.bucket] + k;
+        // ---- one tile: 2048 candidates, tile k of the item, guide slots [g_begin, g_end) -----------
+        const uint32_t tile = cur.tile_abs + k;
         // comparisons made here: the tile's real candidates (only a bucket's last tile is padded) x the real guides
         compared += static_cast<unsigned long long>((k + 1u == cur.n_tiles) ? cur.last_cands : kTileCands) * (g_end - g_begin);
         const uint4 *__restrict__ src =
@@ -722,6 +974,7 @@ __global__ __launch_bounds__(kChunkRecs) void k_verify(ImageView v, Workspace ws
                                                        int max_dist)
 {
     short_kernel_priority();
+    const uint32_t prune_mode = ws.plan->fine; // what the scan of this batch worked through
     uint32_t n_chunks = ws.counters->raw_chunks;
     if (blockIdx.x == 0 && threadIdx.x == 0) { // what the host needs to know after any number of batches
         if (ws.counters->raw_overflow) atomicOr(&ws.sticky[0], 1u);
@@ -730,6 +983,8 @@ __global__ __launch_bounds__(kChunkRecs) void k_verify(ImageView v, Workspace ws
     }
     if (n_chunks > ws.cap_chunks) n_chunks = static_cast<uint32_t>(ws.cap_chunks);
     const uint64_t low = (1ull << v.slice_width) - 1ull;
+    const uint32_t *__restrict__ slot_guide = prune_mode ? ws.fidx : ws.gidx;
+    const uint32_t *__restrict__ slot_bucket = prune_mode ? ws.fbucket : ws.gbucket;
     for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
         uint64_t *recs = ws.raw + static_cast<uint64_t>(chunk) * kChunkRecs;
         const uint32_t used = static_cast<uint32_t>(recs[0]);
@@ -740,28 +995,57 @@ __global__ __launch_bounds__(kChunkRecs) void k_verify(ImageView v, Workspace ws
         const uint32_t offset = static_cast<uint32_t>(rec) & (kTileCands - 1u);
         const uint32_t tile = static_cast<uint32_t>(rec >> 11) & 0x3FFFFFFu;
         const uint32_t gslot = static_cast<uint32_t>(rec >> 37);
-        const uint32_t guide = in_use ? ws.gidx[gslot] : kNoGuide;
+        const uint32_t guide = in_use ? slot_guide[gslot] : kNoGuide;
         if (guide != kNoGuide) {
-            const uint32_t bucket = ws.gbucket[gslot]; // the guide slot knows its bucket: no search for the tile's
+            // the guide slot knows its bucket (pruned scan: and its successor-byte group): no search for the tile's
+            const uint32_t where = slot_bucket[gslot];
+            const uint32_t bucket = prune_mode ? where >> 8 : where;
             const uint32_t slice = bucket >> v.slice_width;
             const uint64_t start = v.bucket_start[bucket];
-            const uint64_t len = v.bucket_start[bucket + 1] - start;
-            const uint64_t pos = static_cast<uint64_t>(tile - v.tile_first[bucket]) * kTileCands + offset;
-            if (pos < len) { // else: zero padding of the bucket's last tile
+            uint64_t lo_pos = 0, hi_pos = v.bucket_start[bucket + 1] - start; // beyond: zero padding of the bucket's last tile
+            if (prune_mode) { // a group's first and last tile also hold candidates of its neighbours: theirs to report
+                const uint32_t *ss = v.sub_start + static_cast<uint64_t>(bucket) * 257u + (where & 0xFFu);
+                lo_pos = ss[0];
+                hi_pos = ss[1];
+            }
+            const uint64_t pos = static_cast<uint64_t>(tile - v.tile_first[bucket]) * kTileCands + offset; // in the stream
+            if (pos >= lo_pos && pos < hi_pos) {
                 const uint64_t gsig = guides[guide];
-                const uint64_t ot = v.esig   ? v.esig[start + pos]
+                // sorted layout: esig is in list order, the candidate's signature is rebuilt from the planes the scan read
+                const uint64_t ot = v.sid    ? candidate_signature(v, bucket, tile, offset)
+                                    : v.esig ? v.esig[start + pos]
                                     : v.occ8 ? candidate_signature(v, bucket, tile, offset) // cold sections in host memory
                                              : v.sites[v.entries[start + pos] & 0xFFFFFFFFull];
                 if (__builtin_popcountll(mismatch_mask(gsig, ot)) <= max_dist) { // exact, full signatures (:376-382)
                     // First-matching-slice rule (equivalent of the seen bitmap, isslScoreOfftargets.cpp:385-390,463):
                     // the site was already met iff an earlier slice of the XOR is all zero.
                     const uint64_t x = gsig ^ ot;
-                    bool earlier = false;
-                    for (uint32_t j = 0; j < slice; ++j)
-                        if (((x >> (v.slice_width * j)) & low) == 0) earlier = true;
-                    if (!earlier) {
-                        key = (static_cast<uint64_t>(guide) << 35) | (static_cast<uint64_t>(slice) << 32) | pos;
-
+                    if (!prune_mode) {
+                        bool earlier = false;
+                        for (uint32_t j = 0; j < slice; ++j)
+                            if (((x >> (v.slice_width * j)) & low) == 0) earlier = true;
+                        if (!earlier) {
+                            // sorted layout: the key carries the position in the bucket's LIST (the reference's order)
+                            const uint64_t p = v.sid ? v.pos_of[static_cast<uint64_t>(slice) * v.n_sites + v.sid[start + pos]] : pos;
+                            key = (static_cast<uint64_t>(guide) << 35) | (static_cast<uint64_t>(slice) << 32) | p;
+                        }
+                    } else {
+                        // Pruned scan: the guide meets this site once in every exactly matching slice whose successor
+                        // slice has at most `tol` mismatches (k_fine_count); the smallest such slice reports it, under
+                        // the slice the reference would meet it in first and its list position there.
+                        const uint32_t tol = prune_mode == 1 ? 0u : 1u;
+                        const uint64_t mm = mismatch_mask(gsig, ot);
+                        uint32_t first = slice, reporter = slice;
+                        for (uint32_t j = slice; j-- > 0;) {
+                            if (((x >> (v.slice_width * j)) & low) != 0) continue;
+                            first = j;
+                            const uint32_t nx = (j + 1u) % v.n_slices;
+                            if (static_cast<uint32_t>(__builtin_popcountll((mm >> (v.slice_width * nx)) & low)) <= tol) reporter = j;
+                        }
+                        if (reporter == slice) {
+                            const uint64_t p = v.pos_of[static_cast<uint64_t>(first) * v.n_sites + v.sid[start + pos]];
+                            key = (static_cast<uint64_t>(guide) << 35) | (static_cast<uint64_t>(first) << 32) | p;
+                        }
                     }
                 }
             }
@@ -796,15 +1080,17 @@ __global__ __launch_bounds__(kChunkRecs) void k_verify(ImageView v, Workspace ws
 }
 
 template <int THR>
-static void launch_scan_thr(const ImageView &v, const Workspace &ws, const Tuning &tn, uint32_t thr, hipStream_t stream)
+static void launch_scan_thr(const ImageView &v, const Workspace &ws, const Tuning &tn, uint32_t thr, uint32_t prune_mode,
+                            hipStream_t stream)
 {
-    hipLaunchKernelGGL(k_scan<THR>, dim3(tn.scan_blocks), dim3(1024), 0, stream, v.scan, v.tile_first, ws.items, ws.plan,
-                       ws.range_start, ws.gword, ws.raw, static_cast<uint32_t>(ws.cap_chunks), ws.counters, thr, ws.stamps,
-                       ws.scan_count);
+    // pruned scan: the items and guide words grouped by (bucket, successor byte); the plan says which list counts
+    hipLaunchKernelGGL(k_scan<THR>, dim3(tn.scan_blocks), dim3(1024), 0, stream, v.scan, ws.items,
+                       prune_mode ? ws.fitems : ws.items, ws.plan, ws.range_start, ws.gword, prune_mode ? ws.fword : ws.gword,
+                       ws.raw, static_cast<uint32_t>(ws.cap_chunks), ws.counters, thr, ws.stamps, ws.scan_count);
 }
 
 void launch_scan(const ImageView &v, const Workspace &ws, const Tuning &tn, const uint64_t *d_guides, uint32_t n,
-                 int max_dist, void *stream_)
+                 int max_dist, uint32_t prune_mode, void *stream_)
 {
     (void)n;
     (void)d_guides;
@@ -815,17 +1101,19 @@ void launch_scan(const ImageView &v, const Workspace &ws, const Tuning &tn, cons
     }
     const uint32_t thr = max_dist > 31 ? 31u : static_cast<uint32_t>(max_dist);
     // the runtime-threshold build serves max_dist > 4 (and, forced by the scan_generic knob, the tests of that build)
-    if (tn.scan_generic || thr > 4) launch_scan_thr<-1>(v, ws, tn, thr, stream);
-    else if (thr == 0) launch_scan_thr<0>(v, ws, tn, thr, stream);
-    else if (thr == 1) launch_scan_thr<1>(v, ws, tn, thr, stream);
-    else if (thr == 2) launch_scan_thr<2>(v, ws, tn, thr, stream);
-    else if (thr == 3) launch_scan_thr<3>(v, ws, tn, thr, stream);
-    else launch_scan_thr<4>(v, ws, tn, thr, stream);
+    if (tn.scan_generic || thr > 4) launch_scan_thr<-1>(v, ws, tn, thr, prune_mode, stream);
+    else if (thr == 0) launch_scan_thr<0>(v, ws, tn, thr, prune_mode, stream);
+    else if (thr == 1) launch_scan_thr<1>(v, ws, tn, thr, prune_mode, stream);
+    else if (thr == 2) launch_scan_thr<2>(v, ws, tn, thr, prune_mode, stream);
+    else if (thr == 3) launch_scan_thr<3>(v, ws, tn, thr, prune_mode, stream);
+    else launch_scan_thr<4>(v, ws, tn, thr, prune_mode, stream);
 }
 
-void launch_verify(const ImageView &v, const Workspace &ws, const uint64_t *d_guides, int max_dist, void *stream)
+void launch_verify(const ImageView &v, const Workspace &ws, const uint64_t *d_guides, int max_dist, uint32_t prune_mode,
+                   void *stream)
 {
     if (max_dist < 0) return;
+    (void)prune_mode; // the kernel reads the mode the planner chose from ws.plan
     hipLaunchKernelGGL(k_verify, dim3(kTailGrid), dim3(kChunkRecs), 0, static_cast<hipStream_t>(stream), v, ws, d_guides,
                        max_dist);
 }

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define ISSL_ABI_VERSION 2
+#define ISSL_ABI_VERSION 3
 
 enum {
     ISSL_OK = 0,
@@ -76,9 +76,10 @@ typedef struct {
 typedef struct {
     uint64_t n_guides;
     uint64_t candidates;    /* (guide, candidate) comparisons the scan kernel COUNTED while making them: real
-                               candidates of every tile it fetched x real guides it ran past it (isslScoreOfftargets.cpp
-                               :344 iterations without early exit) -- equals issl_count_candidates() when every
-                               bucket of every guide was scanned */
+                               candidates of every tile it fetched x real guides it ran past it.  Full scan: equals
+                               reference_comparisons.  Pruned scan: far fewer (only the successor-byte groups of a
+                               bucket that can hold a hit are fetched), and >= planned_comparisons because a group's
+                               first and last tile also hold neighbours' candidates */
     uint64_t hits;          /* candidates within max_dist, first matching slice only */
     uint64_t scan_tiles;    /* candidate tiles x guide groups processed by the scan kernel */
     double ms_bin;          /* guide binning kernels */
@@ -90,8 +91,12 @@ typedef struct {
     uint64_t scan_launches; /* >1 when a hit buffer had to grow and the scan was repeated */
     uint64_t raw_records;   /* upper bound of candidates noted by the scan (chunks handed out x chunk size) */
     uint64_t n_batches;     /* batches covered by these statistics (ms_scan is their mean) */
-    uint64_t planned_comparisons; /* what the planning kernel expected from the bucket-length table (host arithmetic
-                                     equivalent: issl_count_candidates) */
+    uint64_t planned_comparisons; /* what the planning kernel expected the scan to compare: guides x lengths of the
+                                     buckets (full scan) or successor-byte groups (pruned scan) they visit */
+    uint64_t reference_comparisons; /* sum over guides of their five bucket lengths = iterations of the reference's
+                                       loop :344 without early exit (host equivalent: issl_count_candidates) */
+    uint64_t pruned;              /* 0: full scan; 1 / 2: pruned scan over the successor-byte groups equal to / within
+                                     one mismatch of the guide's own (max_dist <= 2 / <= 4, sorted image) */
 } issl_stats;
 
 const char *issl_last_error(void);

@@ -135,3 +135,17 @@ def markov_sites(n_lines, seed, seq_len=20, at_bias=0.62, order=3):
     idx = np.flatnonzero(first)
     occ = np.diff(np.append(idx, len(key))).astype(np.uint32)
     return sig[idx], occ
+
+
+def check_comparisons(ix, guides, prune=None):
+    """Counters of the last call: what the reference would compare, what was planned, what the scan kernel counted."""
+    st = ix.stats()
+    expected = ix.count_candidates(guides)
+    assert st["reference_comparisons"] == expected
+    if prune == 0:
+        assert st["pruned"] == 0
+    if st["pruned"] == 0:
+        assert st["candidates"] == expected == st["planned_comparisons"]
+    else:   # a group's first and last tile also hold its neighbours' candidates
+        assert st["planned_comparisons"] <= st["candidates"]
+    return st

@@ -13,7 +13,7 @@ import pytest
 
 import crackling_amd as ca
 import oracle_util as ou
-from synth import random_sites, random_guides, sigs_to_text, text_order_key
+from synth import random_sites, random_guides, sigs_to_text, text_order_key, check_comparisons
 
 pytestmark = pytest.mark.gpu
 ROOT = pathlib.Path(__file__).resolve().parent.parent
@@ -34,24 +34,44 @@ def _dev(cache, golden):
     return cache[golden.name]
 
 
-def test_scores_match_reference_stdout(golden, dev_index_cache):
-    ix = _dev(dev_index_cache, golden)
-    sigs = ca.encode_guides([g.encode() for g in golden.guides])
-    for key, want in golden.expected.items():
-        method, thr, dist = key.split("|")
-        mit, cfd = ix.score(sigs, int(dist), float(thr), method)
-        got = ca.format_scores(sigs, mit, cfd, method)
-        assert got == want, key
+# The scan either works through whole buckets (what the reference's loop :344 does) or, on the sorted image and for
+# max_dist <= 4, only through the successor-byte groups of a bucket that can hold a hit; by default the planner picks
+# per batch (tiny indexes: whole buckets).  prune=1 forces the pruned scan, prune=0 forbids it.
+PRUNE = pytest.mark.parametrize("prune", [-1, 0, 1], ids=["auto", "full", "pruned"])
 
 
-def test_hit_lists_match_reference(golden, dev_index_cache):
+@PRUNE
+def test_scores_match_reference_stdout(golden, dev_index_cache, prune):
+    ix = _dev(dev_index_cache, golden)
+    assert ix.get_option("is_sorted") == 1
+    sigs = ca.encode_guides([g.encode() for g in golden.guides])
+    ix.set_option("prune", prune)
+    try:
+        for key, want in golden.expected.items():
+            method, thr, dist = key.split("|")
+            mit, cfd = ix.score(sigs, int(dist), float(thr), method)
+            got = ca.format_scores(sigs, mit, cfd, method)
+            assert got == want, key
+            st = check_comparisons(ix, sigs, prune)
+            if prune == 1 and 0 <= int(dist) <= 4:
+                assert st["pruned"] == (1 if int(dist) <= 2 else 2), key
+    finally:
+        ix.set_option("prune", -1)
+
+
+@PRUNE
+def test_hit_lists_match_reference(golden, dev_index_cache, prune):
     ix = _dev(dev_index_cache, golden)
     sigs = ca.encode_guides([g.encode() for g in golden.guides])
-    for thr in golden.hit_thresholds():
-        hits = ix.dump_hits(sigs, 4, float(thr), "and")
-        want = golden.hits(thr)
-        assert hits.shape == want.shape, (thr, hits.shape, want.shape)
-        assert np.array_equal(hits, want), thr
+    ix.set_option("prune", prune)
+    try:
+        for thr in golden.hit_thresholds():
+            hits = ix.dump_hits(sigs, 4, float(thr), "and")
+            want = golden.hits(thr)
+            assert hits.shape == want.shape, (thr, hits.shape, want.shape)
+            assert np.array_equal(hits, want), thr
+    finally:
+        ix.set_option("prune", -1)
 
 
 def test_score_table_with_duplicate_odd_and_missing_masks(golden_oddtable):
@@ -226,25 +246,34 @@ def config0(tmp_path_factory):
 
 @pytest.mark.parametrize("method,thr,dist", [("and", 0.0, 4), ("and", 75.0, 4), ("or", 75.0, 4), ("avg", 50.0, 3),
                                               ("mit", 75.0, 4), ("cfd", 90.0, 2), ("and", 0.0, 0)])
-def test_config0_scores_match_oracle(config0, method, thr, dist):
+@PRUNE
+def test_config0_scores_match_oracle(config0, method, thr, dist, prune):
     ix, oracle, sigs, guides = config0
-    mit, cfd = ix.score(guides, dist, thr, method)
+    ix.set_option("prune", prune)
+    try:
+        mit, cfd = ix.score(guides, dist, thr, method)
+    finally:
+        ix.set_option("prune", -1)
     omit, ocfd = oracle.score(guides, dist, thr, method)
     assert np.allclose(mit, omit, rtol=0, atol=FLOAT_TOL) and np.allclose(cfd, ocfd, rtol=0, atol=FLOAT_TOL)
     assert np.array_equal(mit.view(np.uint64), omit.view(np.uint64)), "MIT not bit-identical"
     assert np.array_equal(cfd.view(np.uint64), ocfd.view(np.uint64)), "CFD not bit-identical"
-    st = ix.stats()
-    assert st["candidates"] == ix.count_candidates(guides)
+    check_comparisons(ix, guides, prune)
 
 
-def test_config0_hit_lists_match_oracle(config0):
+@PRUNE
+def test_config0_hit_lists_match_oracle(config0, prune):
     ix, oracle, sigs, guides = config0
-    for thr in (0.0, 75.0):
-        hits = ix.dump_hits(guides, 4, thr, "and")
-        _, _, ohits = oracle.score(guides, 4, thr, "and", want_hits=True)
-        assert np.array_equal(hits, ohits), thr
-        if thr == 0.0:
-            assert ix.stats()["hits"] == len(ohits)
+    ix.set_option("prune", prune)
+    try:
+        for dist, thr in ((4, 0.0), (4, 75.0), (3, 0.0), (2, 0.0), (1, 0.0), (0, 0.0)):
+            hits = ix.dump_hits(guides, dist, thr, "and")
+            _, _, ohits = oracle.score(guides, dist, thr, "and", want_hits=True)
+            assert np.array_equal(hits, ohits), (dist, thr)
+            if thr == 0.0:
+                assert ix.stats()["hits"] == len(ohits)
+    finally:
+        ix.set_option("prune", -1)
 
 
 def test_config0_properties(config0):
@@ -300,7 +329,7 @@ def test_runtime_threshold_build_of_the_scan_kernel(config0):
     assert ix.get_option("scan_generic") == 0
     for dist in (0, 1, 2, 3, 4):
         mit, cfd = ix.score(guides[:256], dist, 0.0, "and")
-        assert ix.stats()["candidates"] == ix.stats()["planned_comparisons"] == ix.count_candidates(guides[:256])
+        check_comparisons(ix, guides[:256])
         omit, ocfd = oracle.score(guides[:256], dist, 0.0, "and")
         assert np.array_equal(mit.view(np.uint64), omit.view(np.uint64)), dist
         assert np.array_equal(cfd.view(np.uint64), ocfd.view(np.uint64)), dist
@@ -316,16 +345,17 @@ def test_scheduling_knobs_do_not_change_results(config0):
     wm, wc = ix.score(batch, 4, 75.0, "and")
     expected = ix.count_candidates(batch)
     try:
-        for sched, blocks in (("64", 1024), ("8", 1024), ("200", 77), ("512", 4096)):
-            ix.set_option("item_guides", sched).set_option("scan_blocks", blocks)
+        for sched, blocks, prune in (("64", 1024, 0), ("8", 1024, 0), ("200", 77, 0), ("512", 4096, 0),
+                                     ("64", 1024, 1), ("8", 77, 1), ("200", 4096, 1)):
+            ix.set_option("item_guides", sched).set_option("scan_blocks", blocks).set_option("prune", prune)
             got = ix.dump_hits(batch, 4, 0.0, "and")
-            assert np.array_equal(got, want), (sched, blocks)
+            assert np.array_equal(got, want), (sched, blocks, prune)
             gm, gc = ix.score(batch, 4, 75.0, "and")
-            assert np.array_equal(gm, wm) and np.array_equal(gc, wc), (sched, blocks)
-            st = ix.stats()
-            assert st["candidates"] == expected == st["planned_comparisons"], (sched, blocks)
+            assert np.array_equal(gm, wm) and np.array_equal(gc, wc), (sched, blocks, prune)
+            st = check_comparisons(ix, batch, prune)
+            assert st["reference_comparisons"] == expected and st["pruned"] == 2 * prune, (sched, blocks, prune)
     finally:
-        ix.set_option("item_guides", 512).set_option("scan_blocks", 1024)
+        ix.set_option("item_guides", 512).set_option("scan_blocks", 1024).set_option("prune", -1)
     _, _, ohits = oracle.score(batch, 4, 0.0, "and", want_hits=True)
     assert np.array_equal(want, ohits)
     with pytest.raises(ca.IsslError):
@@ -379,10 +409,20 @@ def test_large_batch_paths(config0, monkeypatch):
     ix, oracle, sigs, guides = config0
     big = np.tile(guides, 300)  # 300k guides, every bucket ~1200 guides deep
     mit, cfd = ix.score(big, 4, 75.0, "and")
-    assert ix.stats()["candidates"] == 300 * ix.count_candidates(guides)
+    assert ix.stats()["reference_comparisons"] == 300 * ix.count_candidates(guides)
     base = ix.score(guides, 4, 75.0, "and")
     assert np.array_equal(mit, np.tile(base[0], 300)) and np.array_equal(cfd, np.tile(base[1], 300))
-    huge = np.tile(guides, 4300)  # 4.3M guides > 2^22: two pieces
+    ix.set_option("prune", 1)  # the same 300k guides through the successor-byte groups: 19.5 M guide slots
+    mit, cfd = ix.score(big, 4, 75.0, "and")
+    assert ix.stats()["pruned"] == 2
+    assert np.array_equal(mit, np.tile(base[0], 300)) and np.array_equal(cfd, np.tile(base[1], 300))
+    ix.set_option("prune", -1)
+    huge = np.tile(guides, 4300)  # 4.3M guides: pieces of 2^20 guides while the pruned scan may be chosen, else of 2^22
+    mit, cfd = ix.score(huge, 4, 75.0, "and")
+    assert np.array_equal(mit, np.tile(base[0], 4300)) and np.array_equal(cfd, np.tile(base[1], 4300))
+    assert ix.stats()["n_batches"] == 5 and ix.stats()["n_guides"] == len(huge)
+    assert ix.stats()["reference_comparisons"] == 4300 * ix.count_candidates(guides)
+    ix.set_option("prune", 0)
     mit, cfd = ix.score(huge, 4, 75.0, "and")
     assert np.array_equal(mit, np.tile(base[0], 4300)) and np.array_equal(cfd, np.tile(base[1], 4300))
     assert ix.stats()["n_batches"] == 2 and ix.stats()["n_guides"] == len(huge)
@@ -652,7 +692,7 @@ def test_config1_full_size_properties_and_oracle_sample(config1, tmp_path):
     ix, sigs, occ, guides = config1
     mit, cfd = ix.score(guides, 4, 75.0, "and")
     st = ix.stats()
-    assert st["candidates"] == ix.count_candidates(guides)              # every bucket of every guide was scanned
+    check_comparisons(ix, guides)
     assert st["scan_launches"] == 1
     assert np.all((mit > 0) & (mit <= 100) & (cfd > 0) & (cfd <= 100))
     # permutation and split invariance
@@ -767,6 +807,8 @@ def test_random_small_indexes_differential():
     rng = np.random.default_rng(int(os.environ.get("ISSL_FUZZ_SEED", 424242)))
     methods = ["and", "or", "avg", "mit", "cfd"]
     layouts = [{"inline_sigs": 1, "host_cold": 0}, {"inline_sigs": 0, "host_cold": 0}, {"inline_sigs": -1, "host_cold": 1}]
+    scans = [{"sorted_layout": 1, "prune": 1}, {"sorted_layout": 1, "prune": -1}, {"sorted_layout": 1, "prune": 0},
+             {"sorted_layout": 0, "prune": -1}]
     with tempfile.TemporaryDirectory() as tmp:
         for trial in range(trials):
             n_centres = int(rng.integers(1, 40))
@@ -785,11 +827,14 @@ def test_random_small_indexes_differential():
             ix = ca.IsslIndex.build_from_sites(sig, occ)
             path = os.path.join(tmp, f"t{trial}.issl")
             ix.write(path)
-            layout = layouts[int(rng.integers(0, 3))]
+            layout = dict(layouts[int(rng.integers(0, 3))])
+            if not layout["host_cold"]:   # (the sorted layout needs the cold sections in HBM)
+                layout.update(scans[int(rng.integers(0, 4)) if trial % 2 else 0])
             for key, value in layout.items():
                 ix.set_option(key, value)
             ix.upload(0)
             assert ix.get_option("cold_on_host") == layout["host_cold"]
+            assert ix.get_option("is_sorted") == layout.get("sorted_layout", 0)
             oracle = ou.OracleIndex(path)
             guides = np.concatenate([centres, centres ^ np.uint64(2 << 16), rng.integers(0, 1 << 40, size=5, dtype=np.uint64)])
             for _ in range(4):

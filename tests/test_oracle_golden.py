@@ -87,3 +87,23 @@ def test_first_matching_slice_rule_equals_seen_bitmap():
         assert zero[sl] and not any(zero[:sl])
     # and every (guide, site) pair appears once
     assert len({(int(h[0]), int(h[3])) for h in hits}) == len(hits)
+
+
+def test_successor_slice_pigeonhole_behind_the_pruned_scan():
+    """What the pruned scan of the HIP path rests on (csrc/issl_kernels.hip, k_fine_count): split the <= 4 mismatches of a
+    hit over the five slices in every possible way -- some slice matches exactly AND its cyclic successor has at most
+    one mismatch (none at all when there are <= 2 mismatches).  The reference scans whole buckets
+    (isslScoreOfftargets.cpp:344) and so finds the site in every exactly matching slice; the pruned scan needs one."""
+    import itertools
+    for counts in itertools.product(range(5), repeat=5):
+        total = sum(counts)
+        if total > 4:
+            continue
+        ok1 = any(counts[i] == 0 and counts[(i + 1) % 5] <= 1 for i in range(5))
+        assert ok1, counts
+        if total <= 2:
+            assert any(counts[i] == 0 and counts[(i + 1) % 5] == 0 for i in range(5)), counts
+    # and the bound is tight: with 5 mismatches no such slice need exist; with 3 an exact successor need not
+    assert not any(c == 0 for c in (1, 1, 1, 1, 1))
+    counts = (0, 1, 0, 1, 1)  # 3 mismatches: every exact slice is followed by a slice with one mismatch
+    assert not any(counts[i] == 0 and counts[(i + 1) % 5] == 0 for i in range(5))

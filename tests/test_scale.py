@@ -16,7 +16,7 @@ import pytest
 
 import crackling_amd as ca
 import oracle_util as ou
-from synth import random_sites_fast, random_guides, random_guides_fast, text_order_key
+from synth import random_sites_fast, random_guides, random_guides_fast, text_order_key, check_comparisons
 
 
 def test_fast_generator_is_sorted_and_distinct():
@@ -64,7 +64,7 @@ def test_scale_point_matches_oracle_on_a_sample(tmp_path):
         if rep and (best is None or st["ms_scan"] < best[1]["ms_scan"]):
             best = (wall, st)
     wall, st = best
-    assert st["candidates"] == ix.count_candidates(guides)
+    assert st["reference_comparisons"] == ix.count_candidates(guides)
     hdr = ix.header
     path = tmp / f"scale_{os.getpid()}.issl"
     try:
@@ -183,19 +183,29 @@ def test_device_built_scale_point(scale, tmp_path):
     sites farther away contribute nothing, and the scoring order (slice, position in bucket) of the survivors is
     unchanged.  The scan's own comparison counter must equal the bucket-table arithmetic: every bucket was scanned."""
     ix, guides = scale.ix, scale.guides
-    best = None
-    for rep in range(3):
-        t = time.time(); mit, cfd = ix.score(guides, 4, 75.0, "and"); wall = time.time() - t
-        st = ix.stats()
-        print(f"rep{rep} wall {wall * 1e3:.1f} ms scan {st['ms_scan']:.2f} ms", flush=True)
-        if rep and (best is None or st["ms_scan"] < best[1]["ms_scan"]):
-            best = (wall, st)
-    wall, st = best
-    assert st["candidates"] == ix.count_candidates(guides) == st["planned_comparisons"]
     omit, ocfd = scale.oracle_on_neighbourhoods(tmp_path, 75.0)
-    assert np.array_equal(mit[scale.pick].view(np.uint64), omit.view(np.uint64))
-    assert np.array_equal(cfd[scale.pick].view(np.uint64), ocfd.view(np.uint64))
     assert (omit < 100).any()  # the sample does meet off-targets
+    runs = {}
+    for prune in (0, -1):  # every bucket of every guide scanned (the reference's loop), then the planner's choice
+        ix.set_option("prune", prune)
+        best = None
+        for rep in range(3):
+            t = time.time(); mit, cfd = ix.score(guides, 4, 75.0, "and"); wall = time.time() - t
+            st = ix.stats()
+            print(f"prune={prune} rep{rep} wall {wall * 1e3:.1f} ms scan {st['ms_scan']:.2f} ms pruned={st['pruned']}", flush=True)
+            if rep and (best is None or st["ms_total"] < best[1]["ms_total"]):
+                best = (wall, st)
+        check_comparisons(ix, guides, prune)
+        assert np.array_equal(mit[scale.pick].view(np.uint64), omit.view(np.uint64)), prune
+        assert np.array_equal(cfd[scale.pick].view(np.uint64), ocfd.view(np.uint64)), prune
+        if prune == 0:
+            full_mit, full_cfd = mit, cfd
+        else:  # ALL guides of the batch: the pruned scan finds what the scan of the whole buckets finds
+            assert np.array_equal(mit.view(np.uint64), full_mit.view(np.uint64))
+            assert np.array_equal(cfd.view(np.uint64), full_cfd.view(np.uint64))
+        runs[prune] = best
+    wall, st = runs[-1]
+    full_st = runs[0][1]
     summary = {
         "what": f"tests/test_scale.py::test_device_built_scale_point: {scale.n_guides} guides vs a {scale.n_lines}-line synthetic "
                 f"index built on one MI355X (issl_index_build_on_device), 'and' thr 75 max_dist 4; {scale.n_check} guides checked "
@@ -203,11 +213,15 @@ def test_device_built_scale_point(scale, tmp_path):
         "distinct_sites": int(len(scale.sigs)), "image_GB": ix.device_bytes() / 1e9, "synth_s": scale.t_synth,
         "device_build_s": scale.t_build, "wall_ms": wall * 1e3, "scan_ms": st["ms_scan"], "verify_ms": st["ms_verify"],
         "group_ms": st["ms_group"], "replay_ms": st["ms_replay"], "pipeline_ms": st["ms_total"],
-        "comparisons": st["candidates"], "hits": st["hits"], "scan_launches": st["scan_launches"],
+        "pruned": st["pruned"], "comparisons": st["candidates"], "reference_comparisons": st["reference_comparisons"],
+        "hits": st["hits"], "scan_launches": st["scan_launches"],
         "scan_Tcmp_per_s": st["candidates"] / st["ms_scan"] / 1e9,
         "algorithmic_TBps": 8.0 * st["candidates"] / st["ms_scan"] / 1e9,
         "guides_per_s_kernels": scale.n_guides / st["ms_total"] * 1e3, "brute_force_check_s": scale.t_brute,
-        "cold_on_host": ix.get_option("cold_on_host"),
+        "cold_on_host": ix.get_option("cold_on_host"), "is_sorted": ix.get_option("is_sorted"),
+        "full_scan": {"scan_ms": full_st["ms_scan"], "pipeline_ms": full_st["ms_total"], "comparisons": full_st["candidates"],
+                      "scan_Tcmp_per_s": full_st["candidates"] / full_st["ms_scan"] / 1e9,
+                      "guides_per_s_kernels": scale.n_guides / full_st["ms_total"] * 1e3},
     }
     print(json.dumps(summary), flush=True)
     if os.environ.get("ISSL_SCALE_JSON"):
@@ -239,8 +253,7 @@ def test_methods_thresholds_distances_at_scale(scale, tmp_path, method, thr, max
     omit, ocfd, ohits = scale.oracle_on_neighbourhoods(tmp_path, thr, want_hits=True, method=method, max_dist=max_dist)
     assert np.array_equal(mit.view(np.uint64), omit.view(np.uint64)), (method, thr, max_dist)
     assert np.array_equal(cfd.view(np.uint64), ocfd.view(np.uint64)), (method, thr, max_dist)
-    st = scale.ix.stats()
-    assert st["candidates"] == scale.ix.count_candidates(sample) == st["planned_comparisons"]
+    check_comparisons(scale.ix, sample)
     hits = scale.ix.dump_hits(sample, max_dist, thr, method)
     assert len(hits) == len(ohits)
     assert np.array_equal(hits[:, [0, 1, 4, 5]], ohits[:, [0, 1, 4, 5]])
