@@ -50,7 +50,8 @@ __global__ __launch_bounds__(256) void k_sort_keys(const uint64_t *__restrict__ 
 
 __global__ __launch_bounds__(256) void k_fill_maps(const uint64_t *__restrict__ keys, const uint64_t *__restrict__ bucket_start,
                                                    const uint64_t *__restrict__ entries, uint64_t n_sites, uint64_t total,
-                                                   uint32_t *__restrict__ sid, uint32_t *__restrict__ pos_of,
+                                                   const uint64_t *__restrict__ sites, StreamRec *__restrict__ srec,
+                                                   uint32_t *__restrict__ pos_of,
                                                    uint32_t *__restrict__ flag)
 {
     for (uint64_t t = static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x; t < total; t += static_cast<uint64_t>(gridDim.x) * 256) {
@@ -62,7 +63,10 @@ __global__ __launch_bounds__(256) void k_fill_maps(const uint64_t *__restrict__ 
         if (e < bucket_start[bucket] || e >= bucket_start[bucket + 1]) { atomicOr(flag, 2u); continue; }
         const uint32_t p = static_cast<uint32_t>(e - bucket_start[bucket]);
         const uint32_t id = static_cast<uint32_t>(entries[e] & 0xFFFFFFFFull);
-        sid[t] = id; // t = bucket_start[bucket] + stream position inside the bucket: the buckets keep their places
+        if (id >= n_sites) continue; // flagged by k_sort_keys: the upload fails with a format error
+        StreamRec r; // t = bucket_start[bucket] + stream position inside the bucket: the buckets keep their places
+        r.sig = sites[id]; r.id = id; r.pos = p;
+        srec[t] = r;
         pos_of[static_cast<uint64_t>(bucket >> 8) * n_sites + id] = p;
     }
 }
@@ -85,7 +89,8 @@ __global__ __launch_bounds__(256) void k_sub_start(const uint64_t *__restrict__ 
 } // namespace
 
 int launch_sort_layout(const uint64_t *d_sites, const uint64_t *d_entries, const uint64_t *d_bucket_start, uint64_t n_sites,
-                       uint32_t n_slices, uint32_t n_buckets, uint32_t *d_sub_start, uint32_t *d_sid, uint32_t *d_pos_of, uint32_t *d_flag)
+                       uint32_t n_slices, uint32_t n_buckets, uint32_t *d_sub_start, StreamRec *d_srec, uint32_t *d_pos_of,
+                       uint32_t *d_flag)
 {
     const uint64_t total = n_sites * n_slices;
     if (n_slices > 8 || total >= (1ull << 32)) {
@@ -118,7 +123,7 @@ int launch_sort_layout(const uint64_t *d_sites, const uint64_t *d_entries, const
                                n_blocks, KeyItself{});
             std::swap(src, dst);
         }
-        hipLaunchKernelGGL(k_fill_maps, dim3(grid), dim3(256), 0, nullptr, src, d_bucket_start, d_entries, n_sites, total, d_sid,
+        hipLaunchKernelGGL(k_fill_maps, dim3(grid), dim3(256), 0, nullptr, src, d_bucket_start, d_entries, n_sites, total, d_sites, d_srec,
                            d_pos_of, d_flag);
         hipLaunchKernelGGL(k_sub_start, dim3((n_buckets * 257u + 255u) / 256u), dim3(256), 0, nullptr, src, d_bucket_start,
                            n_buckets, d_sub_start);

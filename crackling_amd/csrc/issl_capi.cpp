@@ -62,7 +62,7 @@ void layout_image(ImageHeader &h, const Geometry &g, uint64_t n_scores_unique, u
     if (cold_on_host) { h.off_occ8 = off; off = align256(off + g.n_sites * g.n_slices); }
     if (sorted && !cold_on_host) {
         h.off_sub_start = off; off = align256(off + 4 * h.n_buckets * 257);
-        h.off_sid = off;       off = align256(off + 4 * g.n_sites * g.n_slices);
+        h.off_srec = off;      off = align256(off + sizeof(StreamRec) * g.n_sites * g.n_slices);
         h.off_pos_of = off;    off = align256(off + 4 * g.n_sites * g.n_slices);
     }
     h.total_bytes = off;
@@ -83,7 +83,7 @@ ImageView make_view(const ImageHeader &h, void *base, void *cold)
     v.esig = h.off_esig ? reinterpret_cast<const uint64_t *>(p + h.off_esig) : nullptr;
     v.occ8 = h.off_occ8 ? reinterpret_cast<const uint8_t *>(p + h.off_occ8) : nullptr;
     v.sub_start = h.off_sub_start ? reinterpret_cast<const uint32_t *>(p + h.off_sub_start) : nullptr;
-    v.sid = h.off_sid ? reinterpret_cast<const uint32_t *>(p + h.off_sid) : nullptr;
+    v.srec = h.off_srec ? reinterpret_cast<const StreamRec *>(p + h.off_srec) : nullptr;
     v.pos_of = h.off_pos_of ? reinterpret_cast<const uint32_t *>(p + h.off_pos_of) : nullptr;
     v.scan = reinterpret_cast<const uint32_t *>(p + h.off_scan);
     v.n_sites = h.n_sites;
@@ -299,7 +299,7 @@ static int ensure_workspace(issl_index *ix, size_t n)
         w.cap_guides = cap;
         w.cap_gslots = slots;
         w.cap_items = items;
-        if (ix->hdr.off_sid) { // pruned scan: every guide sits in up to 13 successor-byte groups of each of its 5 buckets
+        if (ix->hdr.off_srec) { // pruned scan: every guide sits in up to 13 successor-byte groups of each of its 5 buckets
             const size_t m = std::min<size_t>(cap, kPruneMaxGuides);
             const size_t places = m * ix->hdr.n_slices * kFineWays;
             const size_t groups = std::min<size_t>(nb * 256, places);
@@ -439,14 +439,14 @@ static int finish_upload(issl_index *ix, const DeviceBuildInput *dbi = nullptr)
             HIP_TRY(hipMemcpy(base + ix->hdr.off_entries, h.entries, 8 * g.n_sites * g.n_slices, hipMemcpyHostToDevice));
             upload_note(ix, "entries", t0);
         }
-        if (ix->hdr.off_sid) { // order every bucket by the successor slice's byte; the stream is packed in that order
+        if (ix->hdr.off_srec) { // order every bucket by the successor slice's byte; the stream is packed in that order
             t0 = wall_ms();
             int src = launch_sort_layout(reinterpret_cast<const uint64_t *>(base + ix->hdr.off_sites),
                                          reinterpret_cast<const uint64_t *>(base + ix->hdr.off_entries),
                                          reinterpret_cast<const uint64_t *>(base + ix->hdr.off_bucket_start), g.n_sites,
                                          static_cast<uint32_t>(g.n_slices), static_cast<uint32_t>(nb),
                                          reinterpret_cast<uint32_t *>(base + ix->hdr.off_sub_start),
-                                         reinterpret_cast<uint32_t *>(base + ix->hdr.off_sid),
+                                         reinterpret_cast<StreamRec *>(base + ix->hdr.off_srec),
                                          reinterpret_cast<uint32_t *>(base + ix->hdr.off_pos_of), flag);
             if (src) return src;
             upload_note(ix, "sorted layout (successor-byte order of every bucket + position maps)", t0);
@@ -512,7 +512,7 @@ static bool want_inline_sigs(const Tuning &tn, const Geometry &g)
     return g.n_sites <= 600000000ull;
 }
 
-// The sorted layout costs 8 B per list entry (40 B per site) and lets the scan skip 243 of every 256 successor-byte groups
+// The sorted layout costs 20 B per list entry (100 B per site) and lets the scan skip 243 of every 256 successor-byte groups
 // (sorted_layout option / ISSL_SORTED_LAYOUT=0/1 overrides).
 static bool want_sorted(const Tuning &tn, const Geometry &g, bool list_order_only = false)
 {
@@ -905,7 +905,7 @@ int issl_index_get_option(const issl_index *idx, const char *key, long long *val
     else if (k == "host_cold") *value = t.host_cold;
     else if (k == "sorted_layout") *value = t.sorted_layout;
     else if (k == "prune") *value = t.prune;
-    else if (k == "is_sorted") *value = idx->d_image ? (idx->hdr.off_sid ? 1 : 0) : -1;                   // read-only
+    else if (k == "is_sorted") *value = idx->d_image ? (idx->hdr.off_srec ? 1 : 0) : -1;                   // read-only
     else if (k == "cold_on_host") *value = idx->d_image ? static_cast<long long>(idx->hdr.cold_on_host) : -1; // read-only: layout in use
     else if (k == "dense_mit") *value = idx->d_image ? (idx->hdr.off_mit_dense ? 1 : 0) : -1;              // read-only
     else if (k == "has_inline_sigs") *value = idx->d_image ? (idx->hdr.off_esig ? 1 : 0) : -1;            // read-only

@@ -41,7 +41,7 @@ namespace issl {
 // from `occ8`, one saturating byte per list entry kept in HBM with the hot part (5 B per site).  Host memory is read
 // only for occurrence counts >= 255 and for the site ids of issl_dump_hits.
 constexpr uint64_t kImageMagic = 0x314C535349444D41ull; // "AMDISSL1"
-constexpr uint32_t kImageVersion = 5;
+constexpr uint32_t kImageVersion = 6;
 constexpr uint32_t kTileCands = 2048; // candidates per scan tile: one wave, 64 lanes x 32 registers
 constexpr uint32_t kHeaderBytes = 4096;
 
@@ -65,12 +65,19 @@ struct ImageHeader {
     // "Sorted" layout (pruned scan, see below): inside every bucket the scan stream holds the candidates ordered by the
     // byte of the SUCCESSOR slice ((slice + 1) mod n_slices), ties in list order.  0 = absent (stream in list order).
     uint64_t off_sub_start; // u32[nb * 257]: first stream position (inside the bucket) of every successor-byte value
-    uint64_t off_sid;       // u32[N*S]: stream position (bucket_start[b] + q) -> site id of the candidate there
+    uint64_t off_srec;      // StreamRec[N*S]: stream position (bucket_start[b] + q) -> the candidate there (16 B)
     uint64_t off_pos_of;    // u32[N*S]: (slice s, site id) at s * N + id -> position of that site in its bucket of slice s
 };
 static_assert(sizeof(ImageHeader) <= kHeaderBytes, "header must fit its block");
 
 // Kernel-side view (raw pointers into the image).
+// Sorted layout: what k_verify needs to know about the candidate at a stream position, in one 16-byte load.
+struct alignas(16) StreamRec {
+    uint64_t sig;  // packed signature of the site
+    uint32_t id;   // site id (low half of the list entry)
+    uint32_t pos;  // position of the entry in the bucket's list = the reference's iteration order (:344)
+};
+
 struct ImageView {
     const uint64_t *bucket_start;
     const uint32_t *tile_first;
@@ -82,7 +89,7 @@ struct ImageView {
     const uint64_t *esig; // signature of the site behind every list entry, in list order, or null
     const uint8_t *occ8;  // min(occurrences, 255) of every list entry, or null (only with host-resident cold sections)
     const uint32_t *sub_start; // sorted layout: [nb][257] stream offsets of the successor-byte groups, or null
-    const uint32_t *sid;       // sorted layout: stream position -> site id, or null (stream in list order)
+    const StreamRec *srec;     // sorted layout: stream position -> candidate, or null (stream in list order)
     const uint32_t *pos_of;    // sorted layout: (slice, site id) -> list position in that slice's bucket, or null
     const uint32_t *scan;
     uint64_t n_sites;
@@ -135,7 +142,7 @@ int launch_build_entries(const uint64_t *d_sites, const uint32_t *d_occ, uint64_
 // uploads the list-order layout, which like the reference does not care).
 constexpr int kSortNeedsListOrder = -1000;
 int launch_sort_layout(const uint64_t *d_sites, const uint64_t *d_entries, const uint64_t *d_bucket_start, uint64_t n_sites,
-                       uint32_t n_slices, uint32_t n_buckets, uint32_t *d_sub_start, uint32_t *d_sid, uint32_t *d_pos_of,
+                       uint32_t n_slices, uint32_t n_buckets, uint32_t *d_sub_start, StreamRec *d_srec, uint32_t *d_pos_of,
                        uint32_t *d_flag);
 
 // ---- scoring workspace -------------------------------------------------------------------------

@@ -108,10 +108,10 @@ __global__ __launch_bounds__(256) void k_pack_scan_stream(ImageView v, uint32_t 
         for (uint32_t k0 = wave * 64u; k0 < kTileCands; k0 += 256u) {
             const uint64_t pos = tile_pos + k0 + lane;
             uint32_t w = 0;
-            if (pos < len && v.sid) {
-                // sorted layout: the stream holds the site v.sid names (ids checked when the maps were built); esig keeps
-                // the list order and is filled by k_fill_esig
-                w = scan_word(v.sites[v.sid[start + pos]], slice);
+            if (pos < len && v.srec) {
+                // sorted layout: the stream holds the candidates v.srec lists (built and checked by launch_sort_layout);
+                // esig keeps the list order and is filled by k_fill_esig
+                w = scan_word(v.srec[start + pos].sig, slice);
             } else if (pos < len) {
                 const uint64_t e = v.entries[start + pos];
                 const uint64_t id = e & 0xFFFFFFFFull;
@@ -165,7 +165,7 @@ void launch_pack_scan_stream(const ImageView &v, uint32_t *scan_out, uint64_t *e
                              uint32_t *error_flag, void *stream)
 {
     launch_pack_scan_range(v, scan_out, esig_out, occ8_out, error_flag, 0u, v.n_tiles, stream);
-    if (v.sid && esig_out) {
+    if (v.srec && esig_out) {
         const uint64_t total = v.n_sites * v.n_slices;
         const uint32_t grid = static_cast<uint32_t>(std::min<uint64_t>((total + 255) / 256, 1u << 20));
         if (grid) hipLaunchKernelGGL(k_fill_esig, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), v, esig_out, total, error_flag);
@@ -651,7 +651,7 @@ __global__ __launch_bounds__(256) void k_fine_ranges(const PlanInfo *__restrict_
 
 uint32_t prune_mode_for(const ImageView &v, const Tuning &tn, uint32_t n_guides, int max_dist)
 {
-    if (!v.sid || tn.prune == 0 || max_dist < 0 || max_dist > 4 || n_guides > kPruneMaxGuides || v.n_slices != 5 || v.slice_width != 8)
+    if (!v.srec || tn.prune == 0 || max_dist < 0 || max_dist > 4 || n_guides > kPruneMaxGuides || v.n_slices != 5 || v.slice_width != 8)
         return 0;
     return max_dist <= 2 ? 1u : 2u;
 }
@@ -1011,8 +1011,10 @@ __global__ __launch_bounds__(kChunkRecs) void k_verify(ImageView v, Workspace ws
             const uint64_t pos = static_cast<uint64_t>(tile - v.tile_first[bucket]) * kTileCands + offset; // in the stream
             if (pos >= lo_pos && pos < hi_pos) {
                 const uint64_t gsig = guides[guide];
-                // sorted layout: esig is in list order, the candidate's signature is rebuilt from the planes the scan read
-                const uint64_t ot = v.sid    ? candidate_signature(v, bucket, tile, offset)
+                // sorted layout: esig is in list order; signature, site id and list position come in one stream-order record
+                StreamRec sr{};
+                if (v.srec) sr = v.srec[start + pos];
+                const uint64_t ot = v.srec   ? sr.sig
                                     : v.esig ? v.esig[start + pos]
                                     : v.occ8 ? candidate_signature(v, bucket, tile, offset) // cold sections in host memory
                                              : v.sites[v.entries[start + pos] & 0xFFFFFFFFull];
@@ -1026,7 +1028,7 @@ __global__ __launch_bounds__(kChunkRecs) void k_verify(ImageView v, Workspace ws
                             if (((x >> (v.slice_width * j)) & low) == 0) earlier = true;
                         if (!earlier) {
                             // sorted layout: the key carries the position in the bucket's LIST (the reference's order)
-                            const uint64_t p = v.sid ? v.pos_of[static_cast<uint64_t>(slice) * v.n_sites + v.sid[start + pos]] : pos;
+                            const uint64_t p = v.srec ? sr.pos : pos;
                             key = (static_cast<uint64_t>(guide) << 35) | (static_cast<uint64_t>(slice) << 32) | p;
                         }
                     } else {
@@ -1043,7 +1045,7 @@ __global__ __launch_bounds__(kChunkRecs) void k_verify(ImageView v, Workspace ws
                             if (static_cast<uint32_t>(__builtin_popcountll((mm >> (v.slice_width * nx)) & low)) <= tol) reporter = j;
                         }
                         if (reporter == slice) {
-                            const uint64_t p = v.pos_of[static_cast<uint64_t>(first) * v.n_sites + v.sid[start + pos]];
+                            const uint64_t p = first == slice ? sr.pos : v.pos_of[static_cast<uint64_t>(first) * v.n_sites + sr.id];
                             key = (static_cast<uint64_t>(guide) << 35) | (static_cast<uint64_t>(first) << 32) | p;
                         }
                     }

@@ -16,6 +16,8 @@ ap.add_argument("--variants", default="", help="option settings to compare, sepa
                 "see issl_index_set_option), e.g. scan_blocks=1024/scan_blocks=2048,item_guides=256")
 ap.add_argument("--fast-synth", action="store_true", help="random_sites_fast + index built on the device (large indexes)")
 ap.add_argument("--dist", default="uniform", choices=["uniform", "markov"])
+ap.add_argument("--subsets", default="", help="comma list of batch sizes: score the first k guides for every k (default: all)")
+ap.add_argument("--max-dist", type=int, default=4)
 ap.add_argument("--json", default=None, help="write the best repetition (by scan time) of the last variant here")
 ap.add_argument("--write-issl", default=None)
 ap.add_argument("--write-guides", default=None)
@@ -40,15 +42,16 @@ best = None
 for variant in a.variants.split("/"):
   for kv in filter(None, variant.split(",")):
     ix.set_option(*kv.split("="))
-  print(f"-- {variant or 'defaults'}", flush=True)
-  for r in range(a.reps):
-    t = time.time(); mit, cfd = ix.score(guides, 4, a.thr, "and"); dt = time.time() - t
+  for k in [int(x) for x in a.subsets.split(",") if x] or [len(guides)]:
+   print(f"-- {variant or 'defaults'} | {k} guides", flush=True)
+   for r in range(a.reps):
+    t = time.time(); mit, cfd = ix.score(guides[:k], a.max_dist, a.thr, "and"); dt = time.time() - t
     st = ix.stats()
     algo = 8.0 * st["candidates"]
-    print(f"rep{r}: wall {dt*1e3:.2f} ms | bin {st['ms_bin']:.3f} scan {st['ms_scan']:.3f} verify {st['ms_verify']:.3f} group {st['ms_group']:.3f} "
+    print(f"rep{r}: pruned={st['pruned']} wall {dt*1e3:.2f} ms | bin {st['ms_bin']:.3f} scan {st['ms_scan']:.3f} verify {st['ms_verify']:.3f} group {st['ms_group']:.3f} "
           f"replay {st['ms_replay']:.3f} ms | cand {st['candidates']:.3e} hits {st['hits']} tiles {st['scan_tiles']} | "
           f"scan: {st['candidates']/st['ms_scan']/1e9:.2f} Tcmp/s, algorithmic {algo/st['ms_scan']/1e9:.1f} TB/s | "
-          f"{a.guides/st['ms_total']*1e3:.0f} guides/s (kernels)", flush=True)
+          f"{k/st['ms_total']*1e3:.0f} guides/s (kernels)", flush=True)
     if r > 0 and (best is None or st["ms_scan"] < best["scan_ms"]):
         best = {"what": f"tools/quick_perf.py --sites {a.sites} --guides {a.guides} --thr {a.thr} on one MI355X (best of {a.reps - 1} warm repetitions)",
                 "distinct_sites": int(len(sigs)), "image_GB": ix.device_bytes() / 1e9, "host_build_s": t_build, "upload_s": t_upload,
