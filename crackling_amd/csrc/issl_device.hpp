@@ -169,7 +169,8 @@ struct ScanItem {
     uint32_t tile0;  // sum of n_tiles of all earlier items (tiles are numbered in item order)
     uint32_t last_cands; // real candidates in the item's last tile (1..kTileCands): its other tiles are full
     uint32_t tile_abs;   // the item's first tile in the scan stream
-    uint32_t pad;
+    uint32_t window;     // candidates of the item: from offset (window & 0xFFFF) of its first tile up to (not including)
+                         // offset (window >> 16) of its last tile; the rest are padding or a neighbouring group's
 };
 
 // Start of a cost range of the scan: (item, tile inside the item, guide offset); item == n_items marks the end.

@@ -357,7 +357,7 @@ __global__ __launch_bounds__(256) void k_plan(ImageView v, uint32_t *__restrict_
                 it.tile0 = static_cast<uint32_t>(tile_at);
                 it.last_cands = static_cast<uint32_t>(blen - static_cast<uint64_t>(nt - 1u) * kTileCands);
                 it.tile_abs = v.tile_first[b];
-                it.pad = 0;
+                it.window = it.last_cands << 16;
                 items[item_at++] = it;
                 cost_at += static_cast<uint64_t>(nt) * (len + kTileFixedCost);
                 tile_at += nt;
@@ -372,7 +372,7 @@ __global__ __launch_bounds__(256) void k_plan(ImageView v, uint32_t *__restrict_
         if (!overflow) {
             ScanItem end;
             end.bucket = 0; end.g0 = 0; end.g1 = 0; end.n_tiles = 0; end.cost0 = tot_cost;
-            end.tile0 = static_cast<uint32_t>(tot_tiles); end.last_cands = 0; end.tile_abs = 0; end.pad = 0;
+            end.tile0 = static_cast<uint32_t>(tot_tiles); end.last_cands = 0; end.tile_abs = 0; end.window = 0;
             items[tot_items] = end;
         }
         plan->n_items = overflow ? 0u : static_cast<uint32_t>(tot_items);
@@ -551,7 +551,7 @@ __global__ __launch_bounds__(256) void k_fine_plan(FineSum *__restrict__ fsum, u
         if (fits && plan->error == 0 && (always || est_fine < est_full)) {
             ScanItem end;
             end.bucket = 0; end.g0 = 0; end.g1 = 0; end.n_tiles = 0; end.cost0 = t_cost;
-            end.tile0 = static_cast<uint32_t>(t_units); end.last_cands = 0; end.tile_abs = 0; end.pad = 0;
+            end.tile0 = static_cast<uint32_t>(t_units); end.last_cands = 0; end.tile_abs = 0; end.window = 0;
             fitems[t_items] = end;
             plan->n_items = static_cast<uint32_t>(t_items);
             plan->total_cost = t_cost;
@@ -614,7 +614,7 @@ __global__ __launch_bounds__(256) void k_fine_scatter(ImageView v, const uint64_
             it.tile0 = unit_at;
             it.last_cands = after < kTileCands ? static_cast<uint32_t>(after) : kTileCands;
             it.tile_abs = v.tile_first[b] + t_first;
-            it.pad = 0;
+            it.window = (s0 % kTileCands) | (((s1 - 1u) % kTileCands + 1u) << 16);
             fitems[item_at++] = it;
             cost_at += static_cast<uint64_t>(nt) * (len + kTileFixedCost);
             unit_at += nt;
@@ -751,8 +751,10 @@ __device__ __forceinline__ void half_add(uint32_t a, uint32_t b, uint32_t &sum, 
 // Position p mismatches iff low or high bit differs: (c[p] ^ G0p) | (c[16+p] ^ G1p) with the guide's bits
 // broadcast to all-zero / all-one scalars (isslScoreOfftargets.cpp:376-380 in transposed form); the 16 mismatch
 // planes are then counted with a carry-save adder tree.
+// `keep`: the lane's candidates that belong to the item (the others are padding or a neighbouring group's); folded into
+// the last operation of the count, which has an operand to spare for every compiled threshold but 1.
 template <int THR>
-__device__ __forceinline__ uint32_t near_plane(const uint32_t (&c)[kPlanes], uint32_t gw, uint32_t thr)
+__device__ __forceinline__ uint32_t near_plane(const uint32_t (&c)[kPlanes], uint32_t gw, uint32_t thr, uint32_t keep)
 {
     uint32_t m[16];
 #pragma unroll
@@ -785,14 +787,14 @@ __device__ __forceinline__ uint32_t near_plane(const uint32_t (&c)[kPlanes], uin
     // S4 >= 2 = p | (o & k4[3]), and  S4 >= 2 or (S4 >= 1 and w)  =  p | majority(o, k4[3], w).
     if (THR >= 0 && THR <= 4) {
         const uint32_t o = __builtin_amdgcn_bitop3_b32(k4[0], k4[1], k4[2], 0xFE); // a | b | c
-        // (the last operation of each case is ~(a | b) written as one bitop3: table 0x03, third operand unused)
-        if (THR == 0) return __builtin_amdgcn_bitop3_b32(o, __builtin_amdgcn_bitop3_b32(k4[3], n1, n0, 0xFE), o, 0x03);
-        if (THR == 1) return __builtin_amdgcn_bitop3_b32(o, k4[3], n1, 0x01);     // ~(a | b | c)
-        if (THR == 2) return __builtin_amdgcn_bitop3_b32(o, __builtin_amdgcn_bitop3_b32(k4[3], n1, n0, 0xF8), o, 0x03); // a | (b & c)
-        if (THR == 3) return __builtin_amdgcn_bitop3_b32(o, k4[3], o, 0x03);
+        // (the last operation of each case is ~(a | b) & keep as one bitop3: table 0x02)
+        if (THR == 0) return __builtin_amdgcn_bitop3_b32(o, __builtin_amdgcn_bitop3_b32(k4[3], n1, n0, 0xFE), keep, 0x02);
+        if (THR == 1) return __builtin_amdgcn_bitop3_b32(o, k4[3], n1, 0x01) & keep;     // ~(a | b | c)
+        if (THR == 2) return __builtin_amdgcn_bitop3_b32(o, __builtin_amdgcn_bitop3_b32(k4[3], n1, n0, 0xF8), keep, 0x02); // a | (b & c)
+        if (THR == 3) return __builtin_amdgcn_bitop3_b32(o, k4[3], keep, 0x02);
         const uint32_t p = __builtin_amdgcn_bitop3_b32(k4[0], k4[1], k4[2], 0xE8);            // majority
         const uint32_t z = __builtin_amdgcn_bitop3_b32(o, k4[3], n1 | n0, 0xE8);
-        return __builtin_amdgcn_bitop3_b32(p, z, p, 0x03);
+        return __builtin_amdgcn_bitop3_b32(p, z, keep, 0x02);
     }
     uint32_t a4;
     full_add(k4[0], k4[1], k4[2], a4, k8a);
@@ -809,7 +811,7 @@ __device__ __forceinline__ uint32_t near_plane(const uint32_t (&c)[kPlanes], uin
             eq &= ~n[b];
         }
     }
-    return ~gt;
+    return keep & ~gt;
 }
 
 // Cold block of the scan: the wave knows that SOME lane has a candidate within thr of the guide in slot
@@ -925,19 +927,25 @@ __global__ __launch_bounds__(1024, 8) void k_scan(const uint32_t *__restrict__ s
             const uint4 t4 = src[q * 64 + lane];
             c[4 * q + 0] = t4.x; c[4 * q + 1] = t4.y; c[4 * q + 2] = t4.z; c[4 * q + 3] = t4.w;
         }
+        // the lane's candidates that are the item's: offsets [lo, hi) of the tile
+        const int lo = (k == 0u) ? static_cast<int>(cur.window & 0xFFFFu) : 0;
+        const int hi = (k + 1u == cur.n_tiles) ? static_cast<int>(cur.window >> 16) : static_cast<int>(kTileCands);
+        const int below = lo - static_cast<int>(lane * 32u), upto = hi - static_cast<int>(lane * 32u);
+        const uint32_t keep = (below <= 0 ? ~0u : below >= 32 ? 0u : ~0u << below) &
+                              (upto >= 32 ? ~0u : upto <= 0 ? 0u : ~0u >> (32 - upto));
         if (stamps) { // diagnostics: how long the planes take to arrive once they are requested
             const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             plane_wait += __builtin_amdgcn_s_memrealtime() - t1;
         }
-        // Guide slots are padded to groups of 8 with a word (all T) that is far from the zero padding of the tiles;
-        // a padding slot that does come near a real candidate is dropped by k_verify.
+        // Guide slots are padded to groups of 8 with a word (all T); the padding slots behind the last guide are skipped
+        // below, one that does come near a real candidate would be dropped by k_verify.
         for (uint32_t g = g_begin; g < g_end; g += kGuideGroup) {
             const GuideGroup gg = *reinterpret_cast<const GuideGroup *>(gword_stream + g);
 #pragma unroll
             for (uint32_t uu = 0; uu < kGuideGroup; ++uu) {
                 if (g + uu >= g_end) break; // padding slots of the bucket's last group (scalar test, not taken: free)
-                const uint32_t ok = near_plane<THR>(c, gg.w[uu], thr);
+                const uint32_t ok = near_plane<THR>(c, gg.w[uu], thr, keep);
                 if (__ballot(ok != 0u) != 0ull) { // ~4 % of the (guide, tile) pairs on random data
                     note_candidates(ok, g + uu, tile, lane, w, raw, max_chunks, counters);
                     own_chunk = true;
