@@ -62,10 +62,13 @@ __global__ __launch_bounds__(256) void k_fill_maps(const uint64_t *__restrict__ 
         // signatures, isslScoreOfftargets.cpp:376) breaks the premise that the sort leaves every bucket in place.
         if (e < bucket_start[bucket] || e >= bucket_start[bucket + 1]) { atomicOr(flag, 2u); continue; }
         const uint32_t p = static_cast<uint32_t>(e - bucket_start[bucket]);
-        const uint32_t id = static_cast<uint32_t>(entries[e] & 0xFFFFFFFFull);
+        const uint64_t entry = entries[e];
+        const uint32_t id = static_cast<uint32_t>(entry & 0xFFFFFFFFull);
         if (id >= n_sites) continue; // flagged by k_sort_keys: the upload fails with a format error
+        const uint64_t occ = entry >> 32;
         StreamRec r; // t = bucket_start[bucket] + stream position inside the bucket: the buckets keep their places
-        r.sig = sites[id]; r.id = id; r.pos = p;
+        r.sig = (sites[id] & ((1ull << 40) - 1ull)) | ((occ < kOccSaturated ? occ : kOccSaturated) << 40);
+        r.id = id; r.pos = p;
         srec[t] = r;
         pos_of[static_cast<uint64_t>(bucket >> 8) * n_sites + id] = p;
     }

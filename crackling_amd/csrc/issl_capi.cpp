@@ -222,7 +222,8 @@ static int select_device(int device)
 static void free_workspace(Workspace &w)
 {
     void *ptrs[] = {w.ng, w.gfill, w.gstart, w.gword, w.gidx, w.gbucket, w.items, w.plan, w.range_start, w.counters, w.scan_count, w.sticky, w.stamps, w.gcur_big, w.terms, w.sorted, w.gcount,
-                    w.goff, w.blocksum, w.d_guides, w.d_mit, w.d_cfd, w.d_kept, w.d_hitrec};
+                    w.goff, w.blocksum, w.d_guides, w.d_mit, w.d_cfd, w.d_kept, w.d_hitrec, w.pay, w.rank, w.fword, w.fidx, w.fbucket,
+                    w.fitems, w.fcount, w.fsum};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (w.raw) (void)hipFree(w.raw);
@@ -245,6 +246,8 @@ static int ensure_hit_capacity(Workspace &w, size_t want)
     int rc;
     if ((rc = dev_alloc(w.sorted, want))) return rc;
     if ((rc = dev_alloc(w.terms, 2 * want))) return rc;
+    if ((rc = dev_alloc(w.pay, 2 * want))) return rc;
+    if ((rc = dev_alloc(w.rank, want))) return rc;
     w.cap_hits = want;
     return ISSL_OK;
 }
@@ -618,7 +621,7 @@ static int enqueue_batch(issl_index *ix, hipStream_t stream, const uint64_t *d_g
     launch_scan(ix->view, ws, tn, d_guides, n32, max_dist, prune_mode, stream);
     HIP_TRY(hipEventRecord(ix->ring[2 * slot + 1], stream));
     if (staged) HIP_TRY(hipEventRecord(lane.ev[2], stream));
-    launch_verify(ix->view, ws, d_guides, max_dist, prune_mode, stream);
+    launch_verify(ix->view, ws, d_guides, p, stream);
     if (staged) HIP_TRY(hipEventRecord(lane.ev[3], stream));
     launch_group_hits(ws, n32, stream);
     if (staged) HIP_TRY(hipEventRecord(lane.ev[4], stream));

@@ -72,8 +72,9 @@ static_assert(sizeof(ImageHeader) <= kHeaderBytes, "header must fit its block");
 
 // Kernel-side view (raw pointers into the image).
 // Sorted layout: what k_verify needs to know about the candidate at a stream position, in one 16-byte load.
+constexpr uint32_t kOccSaturated = 0xFFFFFFu; // StreamRec: occurrence counts from here on are read from the list entry
 struct alignas(16) StreamRec {
-    uint64_t sig;  // packed signature of the site
+    uint64_t sig;  // packed signature of the site (bits 0..39) | min(occurrences, kOccSaturated) << 40
     uint32_t id;   // site id (low half of the list entry)
     uint32_t pos;  // position of the entry in the bucket's list = the reference's iteration order (:344)
 };
@@ -239,7 +240,9 @@ struct Workspace {
     uint32_t *gcount = nullptr;  // [G+1] hits per guide
     uint32_t *goff = nullptr;    // [G+1] exclusive prefix
     uint32_t *gcur_big = nullptr; // [G] guides handed to k_replay_big
-    double *terms = nullptr;     // [2 * hit_cap] MIT/CFD terms of the hits of those guides
+    double *terms = nullptr;     // [2 * hit_cap] MIT/CFD terms of the hits, grouped by guide like `sorted`
+    double *pay = nullptr;       // [2 * hit_cap] the same terms as k_verify computed them, by raw-record slot
+    uint32_t *rank = nullptr;    // [hit_cap] place of a surviving raw record inside its guide's segment, by raw-record slot
     uint32_t *blocksum = nullptr;
     uint64_t *d_guides = nullptr; // staging for the host API
     double *d_mit = nullptr, *d_cfd = nullptr;
@@ -271,8 +274,7 @@ void launch_bin_guides(const ImageView &v, const Workspace &ws, const Tuning &tn
                        uint32_t prune_mode, void *stream);
 void launch_scan(const ImageView &v, const Workspace &ws, const Tuning &tn, const uint64_t *d_guides, uint32_t n,
                  int max_dist, uint32_t prune_mode, void *stream);
-void launch_verify(const ImageView &v, const Workspace &ws, const uint64_t *d_guides, int max_dist, uint32_t prune_mode,
-                   void *stream);
+void launch_verify(const ImageView &v, const Workspace &ws, const uint64_t *d_guides, const ScoreParams &p, void *stream);
 void launch_group_hits(const Workspace &ws, uint32_t n, void *stream);
 void launch_replay(const ImageView &v, const Workspace &ws, const uint64_t *d_guides, uint32_t n,
                    const ScoreParams &p, double *d_mit, double *d_cfd, uint32_t *d_kept, issl_hit *d_hitrec,

@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void k_pack_scan_stream(ImageView v, uint32_t 
             if (pos < len && v.srec) {
                 // sorted layout: the stream holds the candidates v.srec lists (built and checked by launch_sort_layout);
                 // esig keeps the list order and is filled by k_fill_esig
-                w = scan_word(v.srec[start + pos].sig, slice);
+                w = scan_word(v.srec[start + pos].sig & ((1ull << 40) - 1ull), slice);
             } else if (pos < len) {
                 const uint64_t e = v.entries[start + pos];
                 const uint64_t id = e & 0xFFFFFFFFull;
@@ -479,9 +479,10 @@ __global__ __launch_bounds__(256) void k_fine_count(ImageView v, const uint64_t 
     cnt[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t g0 = gstart[b], n = gfill[b];
-    for (uint32_t i = threadIdx.x; i < n; i += 256) {
+    for (uint32_t at = threadIdx.x; at < n * ways; at += 256) { // one (guide, way) pair per thread and step
+        const uint32_t i = at / ways, way = at - i * ways;
         const uint32_t gj = static_cast<uint32_t>(guides[gidx[g0 + i]] >> succ_shift) & 0xFFu;
-        for (uint32_t way = 0; way < ways; ++way) atomicAdd(&cnt[fine_way(gj, way)], 1u);
+        atomicAdd(&cnt[fine_way(gj, way)], 1u);
     }
     __syncthreads();
     const uint32_t w = threadIdx.x, c = cnt[w];
@@ -624,17 +625,16 @@ __global__ __launch_bounds__(256) void k_fine_scatter(ImageView v, const uint64_
     }
     __syncthreads();
     const uint32_t g0 = gstart[b], n = gfill[b];
-    for (uint32_t i = threadIdx.x; i < n; i += 256) {
+    for (uint32_t at = threadIdx.x; at < n * ways; at += 256) { // one (guide, way) pair per thread and step
+        const uint32_t i = at / ways, way = at - i * ways;
         const uint32_t guide = gidx[g0 + i], word = gword[g0 + i];
         const uint32_t gj = static_cast<uint32_t>(guides[guide] >> succ_shift) & 0xFFu;
-        for (uint32_t way = 0; way < ways; ++way) {
-            const uint32_t ww = fine_way(gj, way);
-            if (ss[ww + 1] == ss[ww]) continue; // no candidates there: the group has no slots
-            const uint32_t slot = slot_of[ww] + atomicAdd(&cursor[ww], 1u);
-            fword[slot] = word;
-            fidx[slot] = guide;
-            fbucket[slot] = (b << 8) | ww;
-        }
+        const uint32_t ww = fine_way(gj, way);
+        if (ss[ww + 1] == ss[ww]) continue; // no candidates there: the group has no slots
+        const uint32_t slot = slot_of[ww] + atomicAdd(&cursor[ww], 1u);
+        fword[slot] = word;
+        fidx[slot] = guide;
+        fbucket[slot] = (b << 8) | ww;
     }
 }
 
@@ -971,6 +971,57 @@ __global__ __launch_bounds__(1024, 8) void k_scan(const uint32_t *__restrict__ s
     }
 }
 
+// precalculatedScores[mask] with operator[] semantics: a missing mask contributes 0.0 (:394).
+// Reference-built tables hold masks with flags on even bits below bit 40 only; for those the image carries a
+// dense 2^20-entry table indexed by the 20 flags (one load instead of a 13-step search).
+__device__ inline double mit_lookup(const ImageView &v, uint64_t mask)
+{
+    if (v.mit_dense) {
+        if (mask >> 40) return 0.0;
+        const uint32_t idx = gather_even16(static_cast<uint32_t>(mask)) |
+                             (gather_even16(static_cast<uint32_t>(mask >> 32)) << 16);
+        return v.mit_dense[idx];
+    }
+    uint32_t lo = 0, hi = v.n_scores;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        const uint64_t m = v.score_mask[mid];
+        if (m == mask) return v.score_val[mid];
+        if (m < mask) lo = mid + 1; else hi = mid;
+    }
+    return 0.0;
+}
+
+// MIT and CFD terms of one scored off-target (isslScoreOfftargets.cpp:392-460) from the two signatures and the
+// occurrence count.  The CFD product multiplies the penalties of the mismatching positions in position order, as the
+// reference does; matching positions multiply by 1.0 (exact), which keeps the 20 table reads independent of each other.
+__device__ inline void score_terms(const ImageView &v, uint64_t gsig, uint64_t ot, uint32_t occ, bool calc_mit, bool calc_cfd,
+                                   double &mit_term, double &cfd_term, int &dist_out)
+{
+    mit_term = 0.0;
+    cfd_term = 0.0;
+    const uint64_t mm = mismatch_mask(gsig, ot);
+    const int dist = __builtin_popcountll(mm);
+    dist_out = dist;
+    if (calc_mit && dist > 0) mit_term = mit_lookup(v, mm) * static_cast<double>(occ); // :394
+    if (calc_cfd) {                                                                    // :399-460
+        double cfd;
+        if (dist == 0) {
+            cfd = 1.0;
+        } else {
+            cfd = issl_cfd_pam[10];
+#pragma unroll
+            for (uint32_t q = 0; q < 20; ++q) {
+                const uint32_t gb = static_cast<uint32_t>(gsig >> (2 * q)) & 3u;
+                const uint32_t ob = static_cast<uint32_t>(ot >> (2 * q)) & 3u;
+                const double pen = issl_cfd_pos[(q << 4) | (gb << 2) | (ob ^ 3u)];
+                cfd *= (gb != ob) ? pen : 1.0;
+            }
+        }
+        cfd_term = cfd * static_cast<double>(occ);
+    }
+}
+
 // Workgroups of the two passes over the raw chunks (one chunk per workgroup and step): enough of them that the
 // ~16 k first chunks of the scan waves are all in flight at once -- the passes are chains of dependent loads.
 constexpr uint32_t kTailGrid = 16384;
@@ -979,9 +1030,14 @@ constexpr uint32_t kTailGrid = 16384;
 // A record that survives is overwritten by its final key guide<<35 | slice<<32 | position-in-bucket,
 // every other slot by kDeadKey; the per-guide hit counts are accumulated for the grouping pass.
 __global__ __launch_bounds__(kChunkRecs) void k_verify(ImageView v, Workspace ws, const uint64_t *__restrict__ guides,
-                                                       int max_dist)
+                                                       ScoreParams p)
 {
     short_kernel_priority();
+    const int max_dist = p.max_dist;
+    const bool calc_mit = p.method == ISSL_METHOD_MIT || p.method == ISSL_METHOD_AND || p.method == ISSL_METHOD_OR ||
+                          p.method == ISSL_METHOD_AVG;
+    const bool calc_cfd = p.method == ISSL_METHOD_CFD || p.method == ISSL_METHOD_AND || p.method == ISSL_METHOD_OR ||
+                          p.method == ISSL_METHOD_AVG;
     const uint32_t prune_mode = ws.plan->fine; // what the scan of this batch worked through
     uint32_t n_chunks = ws.counters->raw_chunks;
     if (blockIdx.x == 0 && threadIdx.x == 0) { // what the host needs to know after any number of batches
@@ -1000,6 +1056,8 @@ __global__ __launch_bounds__(kChunkRecs) void k_verify(ImageView v, Workspace ws
         const bool in_use = t < used && t < kChunkRecs; // every lane stays: the counting below is done by the wave
         const uint64_t rec = in_use ? recs[t] : 0ull;
         uint64_t key = kDeadKey;
+        double mit_term = 0.0, cfd_term = 0.0; // of a record that survives: computed here, one thread per hit, so that the
+                                               // replay (one wave per guide, a chain of dependent steps) only adds them up
         const uint32_t offset = static_cast<uint32_t>(rec) & (kTileCands - 1u);
         const uint32_t tile = static_cast<uint32_t>(rec >> 11) & 0x3FFFFFFu;
         const uint32_t gslot = static_cast<uint32_t>(rec >> 37);
@@ -1022,7 +1080,7 @@ __global__ __launch_bounds__(kChunkRecs) void k_verify(ImageView v, Workspace ws
                 // sorted layout: esig is in list order; signature, site id and list position come in one stream-order record
                 StreamRec sr{};
                 if (v.srec) sr = v.srec[start + pos];
-                const uint64_t ot = v.srec   ? sr.sig
+                const uint64_t ot = v.srec   ? sr.sig & ((1ull << 40) - 1ull)
                                     : v.esig ? v.esig[start + pos]
                                     : v.occ8 ? candidate_signature(v, bucket, tile, offset) // cold sections in host memory
                                              : v.sites[v.entries[start + pos] & 0xFFFFFFFFull];
@@ -1036,8 +1094,8 @@ __global__ __launch_bounds__(kChunkRecs) void k_verify(ImageView v, Workspace ws
                             if (((x >> (v.slice_width * j)) & low) == 0) earlier = true;
                         if (!earlier) {
                             // sorted layout: the key carries the position in the bucket's LIST (the reference's order)
-                            const uint64_t p = v.srec ? sr.pos : pos;
-                            key = (static_cast<uint64_t>(guide) << 35) | (static_cast<uint64_t>(slice) << 32) | p;
+                            const uint64_t lp = v.srec ? sr.pos : pos;
+                            key = (static_cast<uint64_t>(guide) << 35) | (static_cast<uint64_t>(slice) << 32) | lp;
                         }
                     } else {
                         // Pruned scan: the guide meets this site once in every exactly matching slice whose successor
@@ -1053,15 +1111,29 @@ __global__ __launch_bounds__(kChunkRecs) void k_verify(ImageView v, Workspace ws
                             if (static_cast<uint32_t>(__builtin_popcountll((mm >> (v.slice_width * nx)) & low)) <= tol) reporter = j;
                         }
                         if (reporter == slice) {
-                            const uint64_t p = first == slice ? sr.pos : v.pos_of[static_cast<uint64_t>(first) * v.n_sites + sr.id];
-                            key = (static_cast<uint64_t>(guide) << 35) | (static_cast<uint64_t>(first) << 32) | p;
+                            const uint64_t lp = first == slice ? sr.pos : v.pos_of[static_cast<uint64_t>(first) * v.n_sites + sr.id];
+                            key = (static_cast<uint64_t>(guide) << 35) | (static_cast<uint64_t>(first) << 32) | lp;
                         }
+                    }
+                    if (key != kDeadKey) { // the hit will be scored: its terms (:392-460)
+                        uint32_t occ;
+                        if (v.srec) {
+                            occ = static_cast<uint32_t>(sr.sig >> 40);
+                            if (occ == kOccSaturated) occ = static_cast<uint32_t>(v.entries[start + sr.pos] >> 32);
+                        } else if (v.occ8) {
+                            occ = v.occ8[start + pos];
+                            if (occ == 255u) occ = static_cast<uint32_t>(v.entries[start + pos] >> 32); // (host memory)
+                        } else {
+                            occ = static_cast<uint32_t>(v.entries[start + pos] >> 32);
+                        }
+                        int dist;
+                        score_terms(v, gsig, ot, occ, calc_mit, calc_cfd, mit_term, cfd_term, dist);
                     }
                 }
             }
         }
         // Count the hit for its guide.  The count doubles as the hit's place in the guide's segment, so that the grouping
-        // pass scatters without a second atomic (the ranks borrow the not-yet-used `terms` buffer).  A dense guide's hits
+        // pass scatters without a second atomic (ws.rank, by raw-record slot).  A dense guide's hits
         // come in runs (one scan wave, consecutive tiles): lanes that share the guide of the first live lane take ONE
         // atomic together while such runs are at least 4 lanes long; everybody else adds for itself.
         const bool live = key != kDeadKey;
@@ -1083,7 +1155,11 @@ __global__ __launch_bounds__(kChunkRecs) void k_verify(ImageView v, Workspace ws
             todo &= ~same;
         }
         if ((todo >> lane) & 1ull) rank = atomicAdd(&ws.gcount[guide], 1u);
-        if (live) reinterpret_cast<uint32_t *>(ws.terms)[static_cast<uint64_t>(chunk) * kChunkRecs + t] = rank;
+        if (live) {
+            const uint64_t slot = static_cast<uint64_t>(chunk) * kChunkRecs + t;
+            ws.rank[slot] = rank;
+            reinterpret_cast<double2 *>(ws.pay)[slot] = make_double2(mit_term, cfd_term);
+        }
         if (!in_use) continue;
         recs[t] = key;
     }
@@ -1119,13 +1195,10 @@ void launch_scan(const ImageView &v, const Workspace &ws, const Tuning &tn, cons
     else launch_scan_thr<4>(v, ws, tn, thr, prune_mode, stream);
 }
 
-void launch_verify(const ImageView &v, const Workspace &ws, const uint64_t *d_guides, int max_dist, uint32_t prune_mode,
-                   void *stream)
+void launch_verify(const ImageView &v, const Workspace &ws, const uint64_t *d_guides, const ScoreParams &p, void *stream)
 {
-    if (max_dist < 0) return;
-    (void)prune_mode; // the kernel reads the mode the planner chose from ws.plan
-    hipLaunchKernelGGL(k_verify, dim3(kTailGrid), dim3(kChunkRecs), 0, static_cast<hipStream_t>(stream), v, ws, d_guides,
-                       max_dist);
+    if (p.max_dist < 0) return;
+    hipLaunchKernelGGL(k_verify, dim3(kTailGrid), dim3(kChunkRecs), 0, static_cast<hipStream_t>(stream), v, ws, d_guides, p);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1134,6 +1207,7 @@ void launch_verify(const ImageView &v, const Workspace &ws, const uint64_t *d_gu
 
 constexpr uint32_t kScanChunk = 2048; // elements per block in the device-wide prefix sum
 constexpr uint32_t kReplayLds = 512;  // guides with more hits than this go to k_replay_big (a whole workgroup each)
+static_assert(kReplayLds <= 512, "k_replay sorts (key, 9-bit index) pairs");
 constexpr uint32_t kBigLds = 7680;    // hits per slice k_replay_big sorts in LDS (2 x 30 KiB); longer slices are sorted in HBM
 
 __global__ __launch_bounds__(256) void k_prefix_block_sums(const uint32_t *__restrict__ in, uint32_t n,
@@ -1231,7 +1305,8 @@ __global__ __launch_bounds__(kChunkRecs) void k_group_scatter(const uint64_t *__
                                                               const Counters *__restrict__ counters, uint32_t cap_chunks,
                                                               const uint32_t *__restrict__ goff,
                                                               const uint32_t *__restrict__ rank,
-                                                              uint64_t *__restrict__ sorted)
+                                                              const double2 *__restrict__ pay,
+                                                              uint64_t *__restrict__ sorted, double2 *__restrict__ terms)
 {
     short_kernel_priority();
     uint32_t n_chunks = counters->raw_chunks;
@@ -1244,7 +1319,10 @@ __global__ __launch_bounds__(kChunkRecs) void k_group_scatter(const uint64_t *__
         const uint64_t key = recs[t];
         if (key == kDeadKey) continue;
         const uint32_t guide = static_cast<uint32_t>(key >> 35);
-        sorted[goff[guide] + rank[static_cast<uint64_t>(chunk) * kChunkRecs + t]] = key; // rank: k_verify's
+        const uint64_t slot = static_cast<uint64_t>(chunk) * kChunkRecs + t;
+        const uint32_t to = goff[guide] + rank[slot]; // rank: k_verify's
+        sorted[to] = key;
+        terms[to] = pay[slot];
     }
 }
 
@@ -1263,8 +1341,8 @@ void launch_group_hits(const Workspace &ws, uint32_t n, void *stream_)
                            ws.gcur_big, ws.counters);
     }
     hipLaunchKernelGGL(k_group_scatter, dim3(kTailGrid), dim3(kChunkRecs), 0, stream, ws.raw, ws.counters,
-                       static_cast<uint32_t>(ws.cap_chunks), ws.goff, reinterpret_cast<const uint32_t *>(ws.terms),
-                       ws.sorted);
+                       static_cast<uint32_t>(ws.cap_chunks), ws.goff, ws.rank, reinterpret_cast<const double2 *>(ws.pay),
+                       ws.sorted, reinterpret_cast<double2 *>(ws.terms));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1311,21 +1389,45 @@ __device__ inline double bcast_f64(double x, int lane)
 __device__ __forceinline__ bool accumulate_chunk(double mit_term, double cfd_term, uint32_t cnt, const ScoreParams &p,
                                                  uint32_t lane, double &tot_mit, double &tot_cfd, uint32_t &kept)
 {
+    auto passes = [&](double m, double c) {
+        if (p.method == ISSL_METHOD_AND) return m > p.maximum_sum && c > p.maximum_sum;
+        if (p.method == ISSL_METHOD_OR) return m > p.maximum_sum || c > p.maximum_sum;
+        if (p.method == ISSL_METHOD_AVG) return ((m + c) / 2.0) > p.maximum_sum;
+        if (p.method == ISSL_METHOD_MIT) return m > p.maximum_sum;
+        if (p.method == ISSL_METHOD_CFD) return c > p.maximum_sum;
+        return false;
+    };
+    // First the totals behind the chunk alone (the same additions in the same order).  Terms are products of
+    // non-negative table values and counts, so the totals only grow and every exit test is monotone in them: when the
+    // totals behind the chunk do not pass, no hit inside it did, and the per-hit bookkeeping below is not needed.  (A
+    // table with a negative entry, or a NaN, takes the careful pass.)
+    {
+        double tm = tot_mit, tc = tot_cfd;
+        for (uint32_t l0 = 0; l0 < cnt; l0 += 8) {
+#pragma unroll
+            for (uint32_t l = 0; l < 8; ++l) { // x + 0.0 == x: the empty lanes of the last group change nothing
+                tm += bcast_f64(mit_term, static_cast<int>(l0 + l));
+                tc += bcast_f64(cfd_term, static_cast<int>(l0 + l));
+            }
+        }
+        const bool grows = __ballot(lane < cnt && !(mit_term >= 0.0 && cfd_term >= 0.0)) == 0ull;
+        if (grows && !passes(tm, tc)) {
+            kept += cnt;
+            tot_mit = tm;
+            tot_cfd = tc;
+            return false;
+        }
+    }
     double tm = tot_mit, tc = tot_cfd, mine_m = 0.0, mine_c = 0.0;
     for (uint32_t l0 = 0; l0 < cnt; l0 += 8) {
 #pragma unroll
-        for (uint32_t l = 0; l < 8; ++l) { // x + 0.0 == x: the empty lanes of the last group change nothing
+        for (uint32_t l = 0; l < 8; ++l) {
             tm += bcast_f64(mit_term, static_cast<int>(l0 + l));
             tc += bcast_f64(cfd_term, static_cast<int>(l0 + l));
             if (lane == l0 + l) { mine_m = tm; mine_c = tc; }
         }
     }
-    bool exit_here = false;
-    if (p.method == ISSL_METHOD_AND) exit_here = mine_m > p.maximum_sum && mine_c > p.maximum_sum;
-    else if (p.method == ISSL_METHOD_OR) exit_here = mine_m > p.maximum_sum || mine_c > p.maximum_sum;
-    else if (p.method == ISSL_METHOD_AVG) exit_here = ((mine_m + mine_c) / 2.0) > p.maximum_sum;
-    else if (p.method == ISSL_METHOD_MIT) exit_here = mine_m > p.maximum_sum;
-    else if (p.method == ISSL_METHOD_CFD) exit_here = mine_c > p.maximum_sum;
+    const bool exit_here = passes(mine_m, mine_c);
     const uint64_t exits = __ballot(exit_here && lane < cnt);
     if (exits != 0ull) {
         const int first = __builtin_ctzll(exits);
@@ -1338,27 +1440,6 @@ __device__ __forceinline__ bool accumulate_chunk(double mit_term, double cfd_ter
     tot_mit = tm;
     tot_cfd = tc;
     return false;
-}
-
-// precalculatedScores[mask] with operator[] semantics: a missing mask contributes 0.0 (:394).
-// Reference-built tables hold masks with flags on even bits below bit 40 only; for those the image carries a
-// dense 2^20-entry table indexed by the 20 flags (one load instead of a 13-step search).
-__device__ inline double mit_lookup(const ImageView &v, uint64_t mask)
-{
-    if (v.mit_dense) {
-        if (mask >> 40) return 0.0;
-        const uint32_t idx = gather_even16(static_cast<uint32_t>(mask)) |
-                             (gather_even16(static_cast<uint32_t>(mask >> 32)) << 16);
-        return v.mit_dense[idx];
-    }
-    uint32_t lo = 0, hi = v.n_scores;
-    while (lo < hi) {
-        const uint32_t mid = (lo + hi) >> 1;
-        const uint64_t m = v.score_mask[mid];
-        if (m == mask) return v.score_val[mid];
-        if (m < mask) lo = mid + 1; else hi = mid;
-    }
-    return 0.0;
 }
 
 // MIT and CFD terms of one scored off-target (isslScoreOfftargets.cpp:392-460) and its record.
@@ -1396,23 +1477,8 @@ __device__ inline HitTerms hit_terms(const ImageView &v, uint64_t gsig, uint32_t
         occ = static_cast<uint32_t>(e >> 32);
         ot = v.esig ? v.esig[at] : v.sites[id]; // independent of `e` when the in-list copy exists
     }
-    const uint64_t mm = mismatch_mask(gsig, ot);
-    const int dist = __builtin_popcountll(mm);
-    if (calc_mit && dist > 0) t.mit = mit_lookup(v, mm) * static_cast<double>(occ); // :394
-    if (calc_cfd) {                                                                // :399-460
-        double cfd;
-        if (dist == 0) {
-            cfd = 1.0;
-        } else {
-            cfd = issl_cfd_pam[10];
-            for (uint32_t q = 0; q < 20; ++q) {
-                const uint32_t gb = static_cast<uint32_t>(gsig >> (2 * q)) & 3u;
-                const uint32_t ob = static_cast<uint32_t>(ot >> (2 * q)) & 3u;
-                if (gb != ob) cfd *= issl_cfd_pos[(q << 4) | (gb << 2) | (ob ^ 3u)];
-            }
-        }
-        t.cfd = cfd * static_cast<double>(occ);
-    }
+    int dist;
+    score_terms(v, gsig, ot, occ, calc_mit, calc_cfd, t.mit, t.cfd, dist);
     t.rec.guide = g; t.rec.slice = slice; t.rec.pos = pos; t.rec.id = id;
     t.rec.dist = static_cast<uint32_t>(dist); t.rec.occ = occ;
     return t;
@@ -1446,15 +1512,20 @@ __global__ __launch_bounds__(64) void k_replay(ImageView v, Workspace ws, const 
             stop = accumulate_chunk(mit_term, cfd_term, cnt, p, lane, tot_mit, tot_cfd, kept);
         };
 
+        // The terms of every hit were computed by k_verify and sit next to the keys (ws.terms, same index as ws.sorted);
+        // what is left is putting them in key order and adding them up.  issl_dump_hits also wants the expanded
+        // records: those are looked up here (hit_terms), the totals still come from the stored terms.
+        const double2 *__restrict__ terms2 = reinterpret_cast<const double2 *>(ws.terms);
         if (h <= 64) {
-            // Common case: no sort.  Lane l takes key l, computes its terms, finds the rank of its key among the
-            // h keys by counting, and drops the terms at that rank; lane r then owns the r-th hit in key order.
+            // Common case: no sort.  Lane l takes key l and its terms, finds the rank of its key among the h keys by
+            // counting, and drops the terms at that rank; lane r then owns the r-th hit in key order.
             uint64_t key = ~0ull;
-            HitTerms t;
-            t.mit = 0.0; t.cfd = 0.0;
+            double2 mine = make_double2(0.0, 0.0);
+            issl_hit rec{};
             if (lane < h) {
                 key = ws.sorted[h0 + lane];
-                t = hit_terms(v, gsig, g, key, calc_mit, calc_cfd, out_hits != nullptr);
+                mine = terms2[h0 + lane];
+                if (out_hits) rec = hit_terms(v, gsig, g, key, calc_mit, calc_cfd, true).rec;
             }
             uint32_t rank = 0;
             for (uint32_t j = 0; j < h; ++j) {
@@ -1464,29 +1535,31 @@ __global__ __launch_bounds__(64) void k_replay(ImageView v, Workspace ws, const 
                 rank += (other < key) ? 1u : 0u;
             }
             if (lane < h) {
-                ord_mit[rank] = t.mit;
-                ord_cfd[rank] = t.cfd;
-                if (out_hits) out_hits[h0 + rank] = t.rec;
+                ord_mit[rank] = mine.x;
+                ord_cfd[rank] = mine.y;
+                if (out_hits) out_hits[h0 + rank] = rec;
             }
             __syncthreads();
             const double mit_term = lane < h ? ord_mit[lane] : 0.0;
             const double cfd_term = lane < h ? ord_cfd[lane] : 0.0;
             accumulate(mit_term, cfd_term, h);
         } else {
+            // (slice, position) of every key with the key's index behind it, sorted in LDS; the terms follow by index
             uint64_t *data = keys;
-            for (uint32_t i = lane; i < h; i += 64) keys[i] = ws.sorted[h0 + i];
+            for (uint32_t i = lane; i < h; i += 64) keys[i] = ((ws.sorted[h0 + i] & ((1ull << 35) - 1ull)) << 9) | i; // h <= 512
             __syncthreads();
             wave_sort(data, h);
             __syncthreads();
             for (uint32_t base = 0; base < h && !stop; base += 64) {
                 const uint32_t idx = base + lane;
-                HitTerms t;
-                t.mit = 0.0; t.cfd = 0.0;
+                double2 mine = make_double2(0.0, 0.0);
                 if (idx < h) {
-                    t = hit_terms(v, gsig, g, data[idx], calc_mit, calc_cfd, out_hits != nullptr);
-                    if (out_hits) out_hits[h0 + idx] = t.rec;
+                    const uint64_t sv = data[idx];
+                    mine = terms2[h0 + static_cast<uint32_t>(sv & 511ull)];
+                    if (out_hits)
+                        out_hits[h0 + idx] = hit_terms(v, gsig, g, (static_cast<uint64_t>(g) << 35) | (sv >> 9), calc_mit, calc_cfd, true).rec;
                 }
-                accumulate(t.mit, t.cfd, (h - base < 64u) ? h - base : 64u);
+                accumulate(mine.x, mine.y, (h - base < 64u) ? h - base : 64u);
             }
         }
         if (lane == 0) {
