@@ -307,7 +307,9 @@ static int ensure_workspace(issl_index *ix, size_t n)
             const size_t places = m * ix->hdr.n_slices * kFineWays;
             const size_t groups = std::min<size_t>(nb * 256, places);
             const size_t fslots = places + kGuideGroup * groups;
-            const size_t fitems = groups + places / 8 + 2;
+            // one item per tile of a group (and per 512 guides of it): sized for ~4 tiles per group; a batch that needs
+            // more scans whole buckets and reports it (sticky[3]), finish_batches() then enlarges the list
+            const size_t fitems = std::max<size_t>(6 * (groups + places / 64) + 2, w.cap_fitems);
             if ((rc = dev_alloc(w.fword, fslots))) return rc;
             if ((rc = dev_alloc(w.fidx, fslots))) return rc;
             if ((rc = dev_alloc(w.fbucket, fslots))) return rc;
@@ -658,6 +660,14 @@ static int finish_batches(issl_index *ix, hipStream_t stream)
         HIP_TRY(hipMemset(lane.ws.sticky, 0, 16));
         set_error("internal error: scan item list overflow");
         return ISSL_E_DEVICE;
+    }
+    if (sticky[3] > lane.ws.cap_fitems && lane.ws.fitems) { // a pruned plan did not fit its item list: room for the next batch
+        const size_t want = static_cast<size_t>(sticky[3]) + sticky[3] / 4 + 2;
+        uint32_t zero = 0;
+        HIP_TRY(hipMemcpy(lane.ws.sticky + 3, &zero, 4, hipMemcpyHostToDevice));
+        int rc = dev_alloc(lane.ws.fitems, want + 1);
+        if (rc) return rc;
+        lane.ws.cap_fitems = want;
     }
     if (sticky[0]) {
         // max_chunks = largest number of chunks any batch asked for

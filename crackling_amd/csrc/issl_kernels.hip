@@ -494,8 +494,8 @@ __global__ __launch_bounds__(256) void k_fine_count(ImageView v, const uint64_t 
         const uint32_t nt = (s1 - 1u) / kTileCands - s0 / kTileCands + 1u;
         const uint32_t kk = (c + item_guides - 1u) / item_guides;
         slots = (c + kGuideGroup - 1u) / kGuideGroup * kGuideGroup;
-        items = kk;
         units = static_cast<uint64_t>(nt) * kk;
+        items = units; // one item per tile and chunk of guides: the scan finds the item of a unit without a search
         cost = static_cast<uint64_t>(nt) * (static_cast<uint64_t>(c) + static_cast<uint64_t>(kk) * kTileFixedCost);
         cand = static_cast<uint64_t>(s1 - s0) * c;
     }
@@ -516,7 +516,8 @@ __global__ __launch_bounds__(256) void k_fine_count(ImageView v, const uint64_t 
 // One block: exclusive prefix of the per-bucket totals (in place) and the plan of the pruned scan.
 __global__ __launch_bounds__(256) void k_fine_plan(FineSum *__restrict__ fsum, uint32_t nb, ScanItem *__restrict__ fitems,
                                                    uint32_t cap_items, uint32_t cap_slots, PlanInfo *__restrict__ plan,
-                                                   uint32_t scan_blocks, uint32_t prune_mode, uint32_t always)
+                                                   uint32_t scan_blocks, uint32_t prune_mode, uint32_t always,
+                                                   uint32_t *__restrict__ sticky)
 {
     short_kernel_priority();
     __shared__ uint64_t lds[256];
@@ -548,7 +549,9 @@ __global__ __launch_bounds__(256) void k_fine_plan(FineSum *__restrict__ fsum, u
         const uint64_t fine_pairs = t_cost - kTileFixedCost * t_units;
         const uint64_t est_full = full_pairs > kFetchPairs * full_fetch ? full_pairs : kFetchPairs * full_fetch;
         const uint64_t est_fine = fine_pairs > kFetchPairs * t_units ? fine_pairs : kFetchPairs * t_units;
-        const bool fits = t_items <= cap_items && t_slots <= cap_slots; // (the capacities cover every guide in 13 groups)
+        const bool fits = t_items <= cap_items && t_slots <= cap_slots; // (the slots cover every guide in 13 groups)
+        if (t_items > cap_items) // the host enlarges the item list for the next batches; this one scans whole buckets
+            atomicMax(&sticky[3], static_cast<uint32_t>(t_items < 0xFFFFFFFFull ? t_items : 0xFFFFFFFFull));
         if (fits && plan->error == 0 && (always || est_fine < est_full)) {
             ScanItem end;
             end.bucket = 0; end.g0 = 0; end.g1 = 0; end.n_tiles = 0; end.cost0 = t_cost;
@@ -589,36 +592,37 @@ __global__ __launch_bounds__(256) void k_fine_scatter(ImageView v, const uint64_
         nt = (s1 - 1u) / kTileCands - s0 / kTileCands + 1u;
         kk = (c + item_guides - 1u) / item_guides;
         slots = (c + kGuideGroup - 1u) / kGuideGroup * kGuideGroup;
-        items = kk;
         units = static_cast<uint64_t>(nt) * kk;
+        items = units;
         cost = static_cast<uint64_t>(nt) * (static_cast<uint64_t>(c) + static_cast<uint64_t>(kk) * kTileFixedCost);
     }
     const FineSum base = fbase[b];
     uint64_t cost_at = base.cost + block_exclusive_scan(cost, lds, nullptr);
     const uint32_t slot_at = base.slots + static_cast<uint32_t>(block_exclusive_scan(slots, lds, nullptr));
     uint32_t item_at = base.items + static_cast<uint32_t>(block_exclusive_scan(items, lds, nullptr));
-    uint32_t unit_at = base.units + static_cast<uint32_t>(block_exclusive_scan(units, lds, nullptr));
+    (void)units;
     slot_of[w] = slot_at;
     cursor[w] = 0;
     if (c) {
         const uint64_t blen = v.bucket_start[b + 1] - v.bucket_start[b];
         const uint32_t t_first = s0 / kTileCands, t_last = (s1 - 1u) / kTileCands;
-        const uint64_t after = blen - static_cast<uint64_t>(t_last) * kTileCands; // candidates from the last tile's start on
         for (uint32_t done = 0; done < c; done += item_guides) {
             const uint32_t len = (c - done < item_guides) ? c - done : item_guides;
-            ScanItem it;
-            it.bucket = (b << 8) | w;
-            it.g0 = slot_at + done; // item_guides is a multiple of 8
-            it.g1 = it.g0 + len;
-            it.n_tiles = nt;
-            it.cost0 = cost_at;
-            it.tile0 = unit_at;
-            it.last_cands = after < kTileCands ? static_cast<uint32_t>(after) : kTileCands;
-            it.tile_abs = v.tile_first[b] + t_first;
-            it.window = (s0 % kTileCands) | (((s1 - 1u) % kTileCands + 1u) << 16);
-            fitems[item_at++] = it;
-            cost_at += static_cast<uint64_t>(nt) * (len + kTileFixedCost);
-            unit_at += nt;
+            for (uint32_t t = t_first; t <= t_last; ++t) { // single-tile items: item index == unit number
+                const uint64_t after = blen - static_cast<uint64_t>(t) * kTileCands; // candidates of the bucket from this tile on
+                ScanItem it;
+                it.bucket = (b << 8) | w;
+                it.g0 = slot_at + done; // item_guides is a multiple of 8
+                it.g1 = it.g0 + len;
+                it.n_tiles = 1;
+                it.cost0 = cost_at;
+                it.tile0 = item_at;
+                it.last_cands = after < kTileCands ? static_cast<uint32_t>(after) : kTileCands;
+                it.tile_abs = v.tile_first[b] + t;
+                it.window = (t == t_first ? s0 % kTileCands : 0u) | ((t == t_last ? (s1 - 1u) % kTileCands + 1u : kTileCands) << 16);
+                fitems[item_at++] = it;
+                cost_at += len + kTileFixedCost;
+            }
         }
         // padding slots behind the group's guides
         for (uint32_t k2 = c; k2 < static_cast<uint32_t>(slots); ++k2) { fidx[slot_at + k2] = kNoGuide; fword[slot_at + k2] = kPadGuideWord; }
@@ -681,7 +685,7 @@ void launch_bin_guides(const ImageView &v, const Workspace &ws, const Tuning &tn
                            ws.fsum, tn.item_guides, ways);
         hipLaunchKernelGGL(k_fine_plan, dim3(1), dim3(256), 0, stream, ws.fsum, nb, ws.fitems,
                            static_cast<uint32_t>(ws.cap_fitems), static_cast<uint32_t>(ws.cap_fslots), ws.plan, tn.scan_blocks,
-                           prune_mode, tn.prune == 1 ? 1u : 0u);
+                           prune_mode, tn.prune == 1 ? 1u : 0u, ws.sticky);
         hipLaunchKernelGGL(k_fine_scatter, dim3(nb), dim3(256), 0, stream, v, d_guides, ws.gstart, ws.gfill, ws.gword, ws.gidx,
                            ws.fcount, ws.fsum, ws.plan, ws.fword, ws.fidx, ws.fbucket, ws.fitems, tn.item_guides, ways);
         hipLaunchKernelGGL(k_fine_ranges, dim3(range_blocks), dim3(256), 0, stream, ws.plan, ws.fitems, ws.range_start);
@@ -852,36 +856,23 @@ __device__ __forceinline__ void note_candidates(uint32_t ok, uint32_t gslot, uin
 // The streams the hot loop reads (scan planes, tile table, items, guide words, plan) are separate
 // `const __restrict__` kernel arguments: they are never written by this kernel, which lets the compiler fetch the
 // wave-uniform ones through the scalar cache.
-template <int THR>
-__global__ __launch_bounds__(1024, 8) void k_scan(const uint32_t *__restrict__ scan_stream,
-                                                  const ScanItem *__restrict__ items_full,
-                                                  const ScanItem *__restrict__ items_fine,
-                                                  const PlanInfo *__restrict__ plan,
-                                                  const RangeStart *__restrict__ range_start,
-                                                  const uint32_t *__restrict__ gword_full,
-                                                  const uint32_t *__restrict__ gword_fine, uint64_t *raw,
-                                                  uint32_t max_chunks, Counters *counters, uint32_t thr,
-                                                  unsigned long long *stamps, uint64_t *__restrict__ scan_count)
+// The work of one scan workgroup.  FINE: the plan of the pruned scan (single-tile items numbered like the units).  A
+// function template instantiated once per plan inside k_scan, so that each copy reads its item list and guide words
+// through the kernel's own `__restrict__` arguments (a pointer chosen at run time loses the scalar loads).
+template <int THR, bool FINE>
+__device__ __forceinline__ void scan_range(const uint32_t *__restrict__ scan_stream, const ScanItem *__restrict__ items,
+                                           const PlanInfo *__restrict__ plan, const RangeStart *__restrict__ range_start,
+                                           const uint32_t *__restrict__ gword_stream, uint64_t *raw, uint32_t max_chunks,
+                                           Counters *counters, uint32_t thr, unsigned long long *stamps,
+                                           uint64_t *__restrict__ scan_count, uint32_t *next_unit_p, uint32_t *waves_done_p,
+                                           unsigned long long *wg_compared_p, unsigned long long t_start)
 {
-    __shared__ uint32_t next_unit;
-    __shared__ uint32_t waves_done;
-    __shared__ unsigned long long wg_compared;
-    // stamps (diagnostics, normally null): per wave {start, end} in 100 MHz ticks, {XCC_ID, HW_ID} and the number of
-    // tiles it took; nothing else reads them
-    const unsigned long long t_start = stamps ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    uint32_t &next_unit = *next_unit_p;
+    uint32_t &waves_done = *waves_done_p;
+    unsigned long long &wg_compared = *wg_compared_p;
+    constexpr bool fine = FINE;
     uint32_t units_done = 0;
     unsigned long long plane_wait = 0ull; // stamps only: 100 MHz ticks this wave spent waiting for tile planes to arrive
-    if (threadIdx.x == 0) { next_unit = 0; waves_done = 0; wg_compared = 0ull; }
-    __syncthreads();
-    const uint32_t n_ranges = plan->n_ranges;
-    if (blockIdx.x >= n_ranges) {
-        if (threadIdx.x == 0) scan_count[blockIdx.x] = 0ull;
-        return;
-    }
-    // the plan of this batch: bucket-level items, or the successor-byte groups of the pruned scan (k_fine_plan)
-    const bool fine = plan->fine != 0u;
-    const ScanItem *__restrict__ items = fine ? items_fine : items_full;
-    const uint32_t *__restrict__ gword_stream = fine ? gword_fine : gword_full;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave_id = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
     // Raw records: the wave's first chunk is the one with its own number (no atomic); k_guide_hist cleared its header.
@@ -910,7 +901,8 @@ __global__ __launch_bounds__(1024, 8) void k_scan(const uint32_t *__restrict__ s
         if (u >= n_units) break;
         ++units_done;
         const uint32_t gt = tile_begin + u;            // tile number in item order
-        while (gt >= cur.tile0 + cur.n_tiles) cur = items[++it]; // tickets only grow: the cursor moves forward
+        if (fine) { it = gt; cur = items[gt]; }        // single-tile items: numbered like the units, no search
+        else while (gt >= cur.tile0 + cur.n_tiles) cur = items[++it]; // tickets only grow: the cursor moves forward
         const uint32_t k = gt - cur.tile0;
         const uint32_t g_begin = cur.g0 + (u == 0 ? first.goff : 0u);
         const uint32_t g_end = (gt == tile_last) ? cur.g0 + last.goff : cur.g1;
@@ -969,6 +961,38 @@ __global__ __launch_bounds__(1024, 8) void k_scan(const uint32_t *__restrict__ s
                                   __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); // XCC_ID, HW_ID
         stamps[4 * wave_id + 3] = units_done | (plane_wait << 32);
     }
+}
+
+template <int THR>
+__global__ __launch_bounds__(1024, 8) void k_scan(const uint32_t *__restrict__ scan_stream,
+                                                  const ScanItem *__restrict__ items_full,
+                                                  const ScanItem *__restrict__ items_fine,
+                                                  const PlanInfo *__restrict__ plan,
+                                                  const RangeStart *__restrict__ range_start,
+                                                  const uint32_t *__restrict__ gword_full,
+                                                  const uint32_t *__restrict__ gword_fine, uint64_t *raw,
+                                                  uint32_t max_chunks, Counters *counters, uint32_t thr,
+                                                  unsigned long long *stamps, uint64_t *__restrict__ scan_count)
+{
+    __shared__ uint32_t next_unit;
+    __shared__ uint32_t waves_done;
+    __shared__ unsigned long long wg_compared;
+    // stamps (diagnostics, normally null): per wave {start, end} in 100 MHz ticks, {XCC_ID, HW_ID} and the number of
+    // tiles it took; nothing else reads them
+    const unsigned long long t_start = stamps ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    if (threadIdx.x == 0) { next_unit = 0; waves_done = 0; wg_compared = 0ull; }
+    __syncthreads();
+    if (blockIdx.x >= plan->n_ranges) {
+        if (threadIdx.x == 0) scan_count[blockIdx.x] = 0ull;
+        return;
+    }
+    // the plan of this batch: bucket-level items, or the successor-byte groups of the pruned scan (k_fine_plan)
+    if (plan->fine != 0u)
+        scan_range<THR, true>(scan_stream, items_fine, plan, range_start, gword_fine, raw, max_chunks, counters, thr, stamps,
+                              scan_count, &next_unit, &waves_done, &wg_compared, t_start);
+    else
+        scan_range<THR, false>(scan_stream, items_full, plan, range_start, gword_full, raw, max_chunks, counters, thr, stamps,
+                               scan_count, &next_unit, &waves_done, &wg_compared, t_start);
 }
 
 // precalculatedScores[mask] with operator[] semantics: a missing mask contributes 0.0 (:394).
