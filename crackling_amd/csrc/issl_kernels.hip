@@ -1018,7 +1018,7 @@ __device__ inline double mit_lookup(const ImageView &v, uint64_t mask)
 
 // MIT and CFD terms of one scored off-target (isslScoreOfftargets.cpp:392-460) from the two signatures and the
 // occurrence count.  The CFD product multiplies the penalties of the mismatching positions in position order, as the
-// reference does; matching positions multiply by 1.0 (exact), which keeps the 20 table reads independent of each other.
+// reference's loop over all 20 positions does (:399-460); the walk over the set flags visits the same positions.
 __device__ inline void score_terms(const ImageView &v, uint64_t gsig, uint64_t ot, uint32_t occ, bool calc_mit, bool calc_cfd,
                                    double &mit_term, double &cfd_term, int &dist_out)
 {
@@ -1034,12 +1034,11 @@ __device__ inline void score_terms(const ImageView &v, uint64_t gsig, uint64_t o
             cfd = 1.0;
         } else {
             cfd = issl_cfd_pam[10];
-#pragma unroll
-            for (uint32_t q = 0; q < 20; ++q) {
+            for (uint64_t left = mm; left != 0ull; left &= left - 1ull) { // the mismatching positions, ascending (<= max_dist)
+                const uint32_t q = static_cast<uint32_t>(__builtin_ctzll(left)) >> 1;
                 const uint32_t gb = static_cast<uint32_t>(gsig >> (2 * q)) & 3u;
                 const uint32_t ob = static_cast<uint32_t>(ot >> (2 * q)) & 3u;
-                const double pen = issl_cfd_pos[(q << 4) | (gb << 2) | (ob ^ 3u)];
-                cfd *= (gb != ob) ? pen : 1.0;
+                cfd *= issl_cfd_pos[(q << 4) | (gb << 2) | (ob ^ 3u)];
             }
         }
         cfd_term = cfd * static_cast<double>(occ);
