@@ -211,7 +211,8 @@ struct FineSum {
 };
 
 constexpr uint32_t kFineWays = 13;      // successor bytes within one mismatch of a guide's: itself + 4 positions x 3 bases
-constexpr uint32_t kFetchPairs = 24;    // time of fetching one 8 KiB tile from HBM, in (guide, tile) comparisons of the chip
+constexpr uint32_t kFetchPairs = 10;    // time of fetching one 8 KiB tile, in (guide, tile) comparisons of the chip: measured 7
+                                        // (50 M sites, neighbouring groups share tiles in L2) to 12 (300 M sites)
 constexpr uint32_t kPruneMaxGuides = 1u << 20; // guides per pruned launch: 65 slots per guide + padding must fit the 27-bit slot field
 
 struct Workspace {

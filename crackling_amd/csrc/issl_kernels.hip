@@ -548,7 +548,8 @@ __global__ __launch_bounds__(256) void k_fine_plan(FineSum *__restrict__ fsum, u
         const uint64_t full_fetch = plan->tiles, full_pairs = plan->total_cost - kTileFixedCost * full_fetch;
         const uint64_t fine_pairs = t_cost - kTileFixedCost * t_units;
         const uint64_t est_full = full_pairs > kFetchPairs * full_fetch ? full_pairs : kFetchPairs * full_fetch;
-        const uint64_t est_fine = fine_pairs > kFetchPairs * t_units ? fine_pairs : kFetchPairs * t_units;
+        // (+ one comparison per guide slot of the pruned plan: placing a guide in its 13 groups is not free either)
+        const uint64_t est_fine = (fine_pairs > kFetchPairs * t_units ? fine_pairs : kFetchPairs * t_units) + t_slots;
         const bool fits = t_items <= cap_items && t_slots <= cap_slots; // (the slots cover every guide in 13 groups)
         if (t_items > cap_items) // the host enlarges the item list for the next batches; this one scans whole buckets
             atomicMax(&sticky[3], static_cast<uint32_t>(t_items < 0xFFFFFFFFull ? t_items : 0xFFFFFFFFull));
@@ -1179,7 +1180,7 @@ __global__ __launch_bounds__(kChunkRecs) void k_verify(ImageView v, Workspace ws
         }
         if ((todo >> lane) & 1ull) rank = atomicAdd(&ws.gcount[guide], 1u);
         if (live) {
-            const uint64_t slot = static_cast<uint64_t>(chunk) * kChunkRecs + t;
+            const uint64_t slot = static_cast<uint64_t>(chunk) * (kChunkRecs - 1u) + (t - 1u); // < cap_chunks * 127 <= cap_hits
             ws.rank[slot] = rank;
             reinterpret_cast<double2 *>(ws.pay)[slot] = make_double2(mit_term, cfd_term);
         }
@@ -1342,7 +1343,7 @@ __global__ __launch_bounds__(kChunkRecs) void k_group_scatter(const uint64_t *__
         const uint64_t key = recs[t];
         if (key == kDeadKey) continue;
         const uint32_t guide = static_cast<uint32_t>(key >> 35);
-        const uint64_t slot = static_cast<uint64_t>(chunk) * kChunkRecs + t;
+        const uint64_t slot = static_cast<uint64_t>(chunk) * (kChunkRecs - 1u) + (t - 1u);
         const uint32_t to = goff[guide] + rank[slot]; // rank: k_verify's
         sorted[to] = key;
         terms[to] = pay[slot];
