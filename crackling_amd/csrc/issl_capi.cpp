@@ -222,7 +222,7 @@ static int select_device(int device)
 static void free_workspace(Workspace &w)
 {
     void *ptrs[] = {w.ng, w.gfill, w.gstart, w.gword, w.gidx, w.gbucket, w.items, w.plan, w.range_start, w.counters, w.scan_count, w.sticky, w.stamps, w.gcur_big, w.terms, w.sorted, w.gcount,
-                    w.goff, w.blocksum, w.d_guides, w.d_mit, w.d_cfd, w.d_kept, w.d_hitrec, w.pay, w.rank, w.fword, w.fidx, w.fbucket,
+                    w.goff, w.blocksum, w.d_guides, w.d_mit, w.d_cfd, w.d_kept, w.d_hitrec, w.pay, w.rank, w.fword, w.fmeta,
                     w.fitems, w.fcount, w.fsum};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -311,8 +311,7 @@ static int ensure_workspace(issl_index *ix, size_t n)
             // more scans whole buckets and reports it (sticky[3]), finish_batches() then enlarges the list
             const size_t fitems = std::max<size_t>(6 * (groups + places / 64) + 2, w.cap_fitems);
             if ((rc = dev_alloc(w.fword, fslots))) return rc;
-            if ((rc = dev_alloc(w.fidx, fslots))) return rc;
-            if ((rc = dev_alloc(w.fbucket, fslots))) return rc;
+            if ((rc = dev_alloc(w.fmeta, fslots))) return rc;
             if ((rc = dev_alloc(w.fitems, fitems + 1))) return rc;
             if ((rc = dev_alloc(w.fcount, nb * 256))) return rc;
             if ((rc = dev_alloc(w.fsum, nb))) return rc;

@@ -223,8 +223,9 @@ struct Workspace {
     uint32_t *gidx = nullptr;    // guide index, kNoGuide in padding
     uint32_t *gbucket = nullptr; // bucket of the slot (valid where gidx is a guide)
     ScanItem *items = nullptr;   // [max_items+1]
-    // pruned scan: the same three arrays and the item list once more, grouped by (bucket, successor byte)
-    uint32_t *fword = nullptr, *fidx = nullptr, *fbucket = nullptr;
+    // pruned scan: the guide arrays and the item list once more, grouped by (bucket, successor byte)
+    uint32_t *fword = nullptr;   // scan words of the guides, grouped
+    uint2 *fmeta = nullptr;      // per slot {guide index (kNoGuide in padding), bucket << 8 | successor byte}
     ScanItem *fitems = nullptr;
     uint32_t *fcount = nullptr;  // [nb * 256] guides per (bucket, successor byte)
     FineSum *fsum = nullptr;     // [nb] per-bucket totals, then their exclusive prefix

@@ -574,7 +574,7 @@ __global__ __launch_bounds__(256) void k_fine_scatter(ImageView v, const uint64_
                                                       const uint32_t *__restrict__ gword, const uint32_t *__restrict__ gidx,
                                                       const uint32_t *__restrict__ fcount, const FineSum *__restrict__ fbase,
                                                       const PlanInfo *__restrict__ plan, uint32_t *__restrict__ fword,
-                                                      uint32_t *__restrict__ fidx, uint32_t *__restrict__ fbucket,
+                                                      uint2 *__restrict__ fmeta,
                                                       ScanItem *__restrict__ fitems, uint32_t item_guides, uint32_t ways)
 {
     short_kernel_priority();
@@ -626,7 +626,7 @@ __global__ __launch_bounds__(256) void k_fine_scatter(ImageView v, const uint64_
             }
         }
         // padding slots behind the group's guides
-        for (uint32_t k2 = c; k2 < static_cast<uint32_t>(slots); ++k2) { fidx[slot_at + k2] = kNoGuide; fword[slot_at + k2] = kPadGuideWord; }
+        for (uint32_t k2 = c; k2 < static_cast<uint32_t>(slots); ++k2) { fmeta[slot_at + k2] = make_uint2(kNoGuide, 0u); fword[slot_at + k2] = kPadGuideWord; }
     }
     __syncthreads();
     const uint32_t g0 = gstart[b], n = gfill[b];
@@ -638,8 +638,7 @@ __global__ __launch_bounds__(256) void k_fine_scatter(ImageView v, const uint64_
         if (ss[ww + 1] == ss[ww]) continue; // no candidates there: the group has no slots
         const uint32_t slot = slot_of[ww] + atomicAdd(&cursor[ww], 1u);
         fword[slot] = word;
-        fidx[slot] = guide;
-        fbucket[slot] = (b << 8) | ww;
+        fmeta[slot] = make_uint2(guide, (b << 8) | ww);
     }
 }
 
@@ -688,7 +687,7 @@ void launch_bin_guides(const ImageView &v, const Workspace &ws, const Tuning &tn
                            static_cast<uint32_t>(ws.cap_fitems), static_cast<uint32_t>(ws.cap_fslots), ws.plan, tn.scan_blocks,
                            prune_mode, tn.prune == 1 ? 1u : 0u, ws.sticky);
         hipLaunchKernelGGL(k_fine_scatter, dim3(nb), dim3(256), 0, stream, v, d_guides, ws.gstart, ws.gfill, ws.gword, ws.gidx,
-                           ws.fcount, ws.fsum, ws.plan, ws.fword, ws.fidx, ws.fbucket, ws.fitems, tn.item_guides, ways);
+                           ws.fcount, ws.fsum, ws.plan, ws.fword, ws.fmeta, ws.fitems, tn.item_guides, ways);
         hipLaunchKernelGGL(k_fine_ranges, dim3(range_blocks), dim3(256), 0, stream, ws.plan, ws.fitems, ws.range_start);
     }
 }
@@ -1053,7 +1052,7 @@ constexpr uint32_t kTailGrid = 16384;
 // Exact check of the raw records, IN PLACE: one thread per record, one chunk per 128-thread workgroup.
 // A record that survives is overwritten by its final key guide<<35 | slice<<32 | position-in-bucket,
 // every other slot by kDeadKey; the per-guide hit counts are accumulated for the grouping pass.
-__global__ __launch_bounds__(kChunkRecs) void k_verify(ImageView v, Workspace ws, const uint64_t *__restrict__ guides,
+__global__ __launch_bounds__(kChunkRecs, 8) void k_verify(ImageView v, Workspace ws, const uint64_t *__restrict__ guides,
                                                        ScoreParams p)
 {
     short_kernel_priority();
@@ -1071,8 +1070,6 @@ __global__ __launch_bounds__(kChunkRecs) void k_verify(ImageView v, Workspace ws
     }
     if (n_chunks > ws.cap_chunks) n_chunks = static_cast<uint32_t>(ws.cap_chunks);
     const uint64_t low = (1ull << v.slice_width) - 1ull;
-    const uint32_t *__restrict__ slot_guide = prune_mode ? ws.fidx : ws.gidx;
-    const uint32_t *__restrict__ slot_bucket = prune_mode ? ws.fbucket : ws.gbucket;
     for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
         uint64_t *recs = ws.raw + static_cast<uint64_t>(chunk) * kChunkRecs;
         const uint32_t used = static_cast<uint32_t>(recs[0]);
@@ -1085,10 +1082,13 @@ __global__ __launch_bounds__(kChunkRecs) void k_verify(ImageView v, Workspace ws
         const uint32_t offset = static_cast<uint32_t>(rec) & (kTileCands - 1u);
         const uint32_t tile = static_cast<uint32_t>(rec >> 11) & 0x3FFFFFFu;
         const uint32_t gslot = static_cast<uint32_t>(rec >> 37);
-        const uint32_t guide = in_use ? slot_guide[gslot] : kNoGuide;
+        // the guide slot knows its guide and its bucket (pruned scan: and its successor-byte group): no search for the tile's
+        uint32_t guide = kNoGuide, where = 0;
+        if (in_use) {
+            if (prune_mode) { const uint2 m = ws.fmeta[gslot]; guide = m.x; where = m.y; }
+            else { guide = ws.gidx[gslot]; where = ws.gbucket[gslot]; }
+        }
         if (guide != kNoGuide) {
-            // the guide slot knows its bucket (pruned scan: and its successor-byte group): no search for the tile's
-            const uint32_t where = slot_bucket[gslot];
             const uint32_t bucket = prune_mode ? where >> 8 : where;
             const uint32_t slice = bucket >> v.slice_width;
             const uint64_t start = v.bucket_start[bucket];
