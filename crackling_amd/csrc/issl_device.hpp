@@ -207,11 +207,12 @@ struct Counters {
 // Per bucket, pruned scan: what its successor-byte groups add to the plan (k_fine_count -> k_fine_plan -> k_fine_scatter).
 struct FineSum {
     uint64_t cost, cand;  // cost units and planned comparisons of the bucket's items
-    uint32_t slots, items, units, pad;
+    uint32_t slots, items, units;
+    uint32_t places;      // guides placed in the bucket's groups (every guide counts once per group it visits)
 };
 
 constexpr uint32_t kFineWays = 13;      // successor bytes within one mismatch of a guide's: itself + 4 positions x 3 bases
-constexpr uint32_t kFetchPairs = 10;    // time of fetching one 8 KiB tile, in (guide, tile) comparisons of the chip: measured 7
+constexpr uint32_t kFetchPairs = 8;     // time of fetching one 8 KiB tile, in (guide, tile) comparisons of the chip: measured 7
                                         // (50 M sites, neighbouring groups share tiles in L2) to 12 (300 M sites)
 constexpr uint32_t kPruneMaxGuides = 1u << 20; // guides per pruned launch: 65 slots per guide + padding must fit the 27-bit slot field
 

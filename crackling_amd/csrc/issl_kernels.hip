@@ -499,16 +499,17 @@ __global__ __launch_bounds__(256) void k_fine_count(ImageView v, const uint64_t 
         cost = static_cast<uint64_t>(nt) * (static_cast<uint64_t>(c) + static_cast<uint64_t>(kk) * kTileFixedCost);
         cand = static_cast<uint64_t>(s1 - s0) * c;
     }
-    uint64_t t_cost, t_cand, t_slots, t_items, t_units;
+    uint64_t t_cost, t_cand, t_slots, t_items, t_units, t_places;
     (void)block_exclusive_scan(cost, lds, &t_cost);
     (void)block_exclusive_scan(cand, lds, &t_cand);
     (void)block_exclusive_scan(slots, lds, &t_slots);
     (void)block_exclusive_scan(items, lds, &t_items);
     (void)block_exclusive_scan(units, lds, &t_units);
+    (void)block_exclusive_scan((c && s1 > s0) ? c : 0u, lds, &t_places);
     if (threadIdx.x == 0) {
         FineSum f;
         f.cost = t_cost; f.cand = t_cand; f.slots = static_cast<uint32_t>(t_slots); f.items = static_cast<uint32_t>(t_items);
-        f.units = static_cast<uint32_t>(t_units); f.pad = 0;
+        f.units = static_cast<uint32_t>(t_units); f.places = static_cast<uint32_t>(t_places);
         fsum[b] = f;
     }
 }
@@ -523,11 +524,13 @@ __global__ __launch_bounds__(256) void k_fine_plan(FineSum *__restrict__ fsum, u
     __shared__ uint64_t lds[256];
     const uint32_t per = (nb + 255u) / 256u;
     const uint32_t b0 = threadIdx.x * per, b1 = (b0 + per < nb) ? b0 + per : nb;
-    uint64_t cost = 0, cand = 0, slots = 0, items = 0, units = 0;
+    uint64_t cost = 0, cand = 0, slots = 0, items = 0, units = 0, places = 0;
     for (uint32_t b = b0; b < b1; ++b) {
         cost += fsum[b].cost; cand += fsum[b].cand; slots += fsum[b].slots; items += fsum[b].items; units += fsum[b].units;
+        places += fsum[b].places;
     }
-    uint64_t t_cost, t_cand, t_slots, t_items, t_units;
+    uint64_t t_cost, t_cand, t_slots, t_items, t_units, t_places;
+    (void)block_exclusive_scan(places, lds, &t_places);
     uint64_t cost_at = block_exclusive_scan(cost, lds, &t_cost);
     (void)block_exclusive_scan(cand, lds, &t_cand);
     uint64_t slot_at = block_exclusive_scan(slots, lds, &t_slots);
@@ -537,7 +540,7 @@ __global__ __launch_bounds__(256) void k_fine_plan(FineSum *__restrict__ fsum, u
         const FineSum f = fsum[b];
         FineSum at;
         at.cost = cost_at; at.cand = 0; at.slots = static_cast<uint32_t>(slot_at); at.items = static_cast<uint32_t>(item_at);
-        at.units = static_cast<uint32_t>(unit_at); at.pad = 0;
+        at.units = static_cast<uint32_t>(unit_at); at.places = 0;
         fsum[b] = at;
         cost_at += f.cost; slot_at += f.slots; item_at += f.items; unit_at += f.units;
     }
@@ -548,8 +551,8 @@ __global__ __launch_bounds__(256) void k_fine_plan(FineSum *__restrict__ fsum, u
         const uint64_t full_fetch = plan->tiles, full_pairs = plan->total_cost - kTileFixedCost * full_fetch;
         const uint64_t fine_pairs = t_cost - kTileFixedCost * t_units;
         const uint64_t est_full = full_pairs > kFetchPairs * full_fetch ? full_pairs : kFetchPairs * full_fetch;
-        // (+ one comparison per guide slot of the pruned plan: placing a guide in its 13 groups is not free either)
-        const uint64_t est_fine = (fine_pairs > kFetchPairs * t_units ? fine_pairs : kFetchPairs * t_units) + t_slots;
+        // (+ one comparison per place of a guide in a group: binning every guide 65 times is not free either)
+        const uint64_t est_fine = (fine_pairs > kFetchPairs * t_units ? fine_pairs : kFetchPairs * t_units) + t_places;
         const bool fits = t_items <= cap_items && t_slots <= cap_slots; // (the slots cover every guide in 13 groups)
         if (t_items > cap_items) // the host enlarges the item list for the next batches; this one scans whole buckets
             atomicMax(&sticky[3], static_cast<uint32_t>(t_items < 0xFFFFFFFFull ? t_items : 0xFFFFFFFFull));
