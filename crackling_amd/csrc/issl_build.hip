@@ -27,35 +27,35 @@ struct SliceEntry {
 };
 
 // ---- sorted layout: every bucket's candidates ordered by the byte of the successor slice -------------------------
-// key = (slice << 16 | own byte << 8 | successor byte) << 40 | index of the list entry.  The lists are already grouped
-// by (slice, own byte); three stable 8-bit passes (successor byte, own byte, slice) leave them grouped and order every
-// bucket by successor byte, ties in list order.
+// One slice at a time (16 B per site of temporary memory): key = (slice << 16 | own byte << 8 | successor byte) << 40 |
+// index of the list entry.  A slice's lists are already grouped by own byte; two stable 8-bit passes (successor byte,
+// own byte) leave them grouped and order every bucket by successor byte, ties in list order.
 constexpr uint32_t kKeyShift = 40;
 
 __global__ __launch_bounds__(256) void k_sort_keys(const uint64_t *__restrict__ sites, const uint64_t *__restrict__ entries,
-                                                   uint64_t n_sites, uint32_t n_slices, uint64_t *__restrict__ keys,
-                                                   uint32_t *__restrict__ flag)
+                                                   uint64_t n_sites, uint32_t n_slices, uint32_t slice,
+                                                   uint64_t *__restrict__ keys, uint32_t *__restrict__ flag)
 {
-    const uint64_t total = n_sites * n_slices;
-    for (uint64_t e = static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x; e < total; e += static_cast<uint64_t>(gridDim.x) * 256) {
-        const uint32_t slice = static_cast<uint32_t>(e / n_sites); // every slice lists every site once
+    const uint64_t e0 = static_cast<uint64_t>(slice) * n_sites; // every slice lists every site once
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x; i < n_sites; i += static_cast<uint64_t>(gridDim.x) * 256) {
+        const uint64_t e = e0 + i;
         const uint64_t id = entries[e] & 0xFFFFFFFFull;
         if (id >= n_sites) atomicOr(flag, 1u); // reported as a format error, like the pack kernel does
         const uint64_t sig = id < n_sites ? sites[id] : 0ull;
         const uint32_t own = static_cast<uint32_t>(sig >> (8u * slice)) & 0xFFu;
         const uint32_t succ = static_cast<uint32_t>(sig >> (8u * ((slice + 1u) % n_slices))) & 0xFFu;
-        keys[e] = (static_cast<uint64_t>((slice << 16) | (own << 8) | succ) << kKeyShift) | e;
+        keys[i] = (static_cast<uint64_t>((slice << 16) | (own << 8) | succ) << kKeyShift) | e;
     }
 }
 
 __global__ __launch_bounds__(256) void k_fill_maps(const uint64_t *__restrict__ keys, const uint64_t *__restrict__ bucket_start,
-                                                   const uint64_t *__restrict__ entries, uint64_t n_sites, uint64_t total,
+                                                   const uint64_t *__restrict__ entries, uint64_t n_sites, uint32_t slice,
                                                    const uint64_t *__restrict__ sites, StreamRec *__restrict__ srec,
-                                                   uint32_t *__restrict__ pos_of,
-                                                   uint32_t *__restrict__ flag)
+                                                   uint32_t *__restrict__ pos_of, uint32_t *__restrict__ flag)
 {
-    for (uint64_t t = static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x; t < total; t += static_cast<uint64_t>(gridDim.x) * 256) {
-        const uint64_t key = keys[t];
+    const uint64_t t0 = static_cast<uint64_t>(slice) * n_sites;
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x; i < n_sites; i += static_cast<uint64_t>(gridDim.x) * 256) {
+        const uint64_t key = keys[i];
         const uint64_t e = key & ((1ull << kKeyShift) - 1ull);
         const uint32_t bucket = static_cast<uint32_t>(key >> (kKeyShift + 8)); // slice << 8 | own byte
         // An entry listed in a bucket its signature does not belong to (the reference does not care: it compares whole
@@ -66,27 +66,30 @@ __global__ __launch_bounds__(256) void k_fill_maps(const uint64_t *__restrict__ 
         const uint32_t id = static_cast<uint32_t>(entry & 0xFFFFFFFFull);
         if (id >= n_sites) continue; // flagged by k_sort_keys: the upload fails with a format error
         const uint64_t occ = entry >> 32;
-        StreamRec r; // t = bucket_start[bucket] + stream position inside the bucket: the buckets keep their places
+        StreamRec r; // t0 + i = bucket_start[bucket] + stream position inside the bucket: the buckets keep their places
         r.sig = (sites[id] & ((1ull << 40) - 1ull)) | ((occ < kOccSaturated ? occ : kOccSaturated) << 40);
         r.id = id; r.pos = p;
-        srec[t] = r;
-        pos_of[static_cast<uint64_t>(bucket >> 8) * n_sites + id] = p;
+        srec[t0 + i] = r;
+        pos_of[t0 + id] = p;
     }
 }
 
 __global__ __launch_bounds__(256) void k_sub_start(const uint64_t *__restrict__ keys, const uint64_t *__restrict__ bucket_start,
-                                                   uint32_t n_buckets, uint32_t *__restrict__ sub_start)
+                                                   uint64_t n_sites, uint32_t slice, uint32_t buckets_per_slice,
+                                                   uint32_t *__restrict__ sub_start)
 {
     const uint32_t idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= n_buckets * 257u) return;
-    const uint32_t bucket = idx / 257u, w = idx % 257u;
-    uint64_t lo = bucket_start[bucket], hi = bucket_start[bucket + 1];
+    if (idx >= buckets_per_slice * 257u) return;
+    const uint32_t bucket = slice * buckets_per_slice + idx / 257u, w = idx % 257u;
+    const uint64_t t0 = static_cast<uint64_t>(slice) * n_sites; // keys[] holds this slice only
+    uint64_t lo = bucket_start[bucket] - t0, hi = bucket_start[bucket + 1] - t0;
+    if (bucket_start[bucket] < t0 || hi > n_sites || lo > hi) { lo = 0; hi = 0; } // (inconsistent sizes: flagged by k_fill_maps)
     const uint64_t first = lo;
     while (lo < hi) { // first stream position of the bucket whose successor byte is >= w
         const uint64_t mid = (lo + hi) >> 1;
         if (((keys[mid] >> kKeyShift) & 0xFFull) < w) lo = mid + 1; else hi = mid;
     }
-    sub_start[idx] = static_cast<uint32_t>(lo - first);
+    sub_start[static_cast<uint64_t>(bucket) * 257u + w] = static_cast<uint32_t>(lo - first);
 }
 
 } // namespace
@@ -95,14 +98,13 @@ int launch_sort_layout(const uint64_t *d_sites, const uint64_t *d_entries, const
                        uint32_t n_slices, uint32_t n_buckets, uint32_t *d_sub_start, StreamRec *d_srec, uint32_t *d_pos_of,
                        uint32_t *d_flag)
 {
-    const uint64_t total = n_sites * n_slices;
-    if (n_slices > 8 || total >= (1ull << 32)) {
-        set_error("the sorted layout handles up to 2^32 - 1 list entries");
+    if (n_slices == 0 || n_slices > 8 || n_buckets % n_slices != 0 || n_sites >= (1ull << 32)) {
+        set_error("the sorted layout handles up to 8 slices of up to 2^32 - 1 sites");
         return ISSL_E_UNSUPPORTED;
     }
     uint64_t *keys = nullptr, *tmp = nullptr;
     uint32_t *d_hist = nullptr;
-    const uint32_t n_blocks = static_cast<uint32_t>((total + 256ull * kSortItems - 1) / (256ull * kSortItems));
+    const uint32_t n_blocks = static_cast<uint32_t>((n_sites + 256ull * kSortItems - 1) / (256ull * kSortItems));
     auto fail = [&](hipError_t e, const char *what) {
         set_error(std::string("HIP error: ") + hipGetErrorString(e) + " (" + what + ")");
         if (keys) (void)hipFree(keys);
@@ -111,27 +113,27 @@ int launch_sort_layout(const uint64_t *d_sites, const uint64_t *d_entries, const
         return ISSL_E_DEVICE;
     };
     hipError_t e;
-    if ((e = hipMalloc(reinterpret_cast<void **>(&keys), 8 * std::max<uint64_t>(total, 1))) != hipSuccess) return fail(e, "sort keys");
-    if ((e = hipMalloc(reinterpret_cast<void **>(&tmp), 8 * std::max<uint64_t>(total, 1))) != hipSuccess) return fail(e, "sort keys");
+    if ((e = hipMalloc(reinterpret_cast<void **>(&keys), 8 * std::max<uint64_t>(n_sites, 1))) != hipSuccess) return fail(e, "sort keys");
+    if ((e = hipMalloc(reinterpret_cast<void **>(&tmp), 8 * std::max<uint64_t>(n_sites, 1))) != hipSuccess) return fail(e, "sort keys");
     if ((e = hipMalloc(reinterpret_cast<void **>(&d_hist), 4ull * 256 * std::max(n_blocks, 1u))) != hipSuccess) return fail(e, "sort histograms");
-    const uint32_t grid = static_cast<uint32_t>(std::min<uint64_t>((total + 255) / 256, 1u << 20));
-    if (total) {
-        hipLaunchKernelGGL(k_sort_keys, dim3(grid), dim3(256), 0, nullptr, d_sites, d_entries, n_sites, n_slices, keys, d_flag);
+    const uint32_t grid = static_cast<uint32_t>(std::min<uint64_t>((n_sites + 255) / 256, 1u << 20));
+    const uint32_t per_slice = n_buckets / n_slices;
+    if (n_sites == 0) (void)hipMemset(d_sub_start, 0, 4ull * n_buckets * 257);
+    for (uint32_t slice = 0; slice < n_slices && n_sites; ++slice) {
+        hipLaunchKernelGGL(k_sort_keys, dim3(grid), dim3(256), 0, nullptr, d_sites, d_entries, n_sites, n_slices, slice, keys, d_flag);
         uint64_t *src = keys, *dst = tmp;
-        for (uint32_t pass = 0; pass < 3; ++pass) {
+        for (uint32_t pass = 0; pass < 2; ++pass) { // successor byte, then own byte
             const uint32_t shift = kKeyShift + 8 * pass;
-            hipLaunchKernelGGL(k_radix_hist, dim3(n_blocks), dim3(256), 0, nullptr, src, total, shift, d_hist, n_blocks);
+            hipLaunchKernelGGL(k_radix_hist, dim3(n_blocks), dim3(256), 0, nullptr, src, n_sites, shift, d_hist, n_blocks);
             hipLaunchKernelGGL(k_radix_scan, dim3(1), dim3(1024), 0, nullptr, d_hist, 256ull * n_blocks);
-            hipLaunchKernelGGL(k_radix_scatter<KeyItself>, dim3(n_blocks), dim3(256), 0, nullptr, src, dst, total, shift, d_hist,
+            hipLaunchKernelGGL(k_radix_scatter<KeyItself>, dim3(n_blocks), dim3(256), 0, nullptr, src, dst, n_sites, shift, d_hist,
                                n_blocks, KeyItself{});
             std::swap(src, dst);
         }
-        hipLaunchKernelGGL(k_fill_maps, dim3(grid), dim3(256), 0, nullptr, src, d_bucket_start, d_entries, n_sites, total, d_sites, d_srec,
-                           d_pos_of, d_flag);
-        hipLaunchKernelGGL(k_sub_start, dim3((n_buckets * 257u + 255u) / 256u), dim3(256), 0, nullptr, src, d_bucket_start,
-                           n_buckets, d_sub_start);
-    } else {
-        (void)hipMemset(d_sub_start, 0, 4ull * n_buckets * 257);
+        hipLaunchKernelGGL(k_fill_maps, dim3(grid), dim3(256), 0, nullptr, src, d_bucket_start, d_entries, n_sites, slice, d_sites,
+                           d_srec, d_pos_of, d_flag);
+        hipLaunchKernelGGL(k_sub_start, dim3((per_slice * 257u + 255u) / 256u), dim3(256), 0, nullptr, src, d_bucket_start,
+                           n_sites, slice, per_slice, d_sub_start);
     }
     e = hipDeviceSynchronize();
     if (e != hipSuccess) return fail(e, "sorted layout");

@@ -307,9 +307,11 @@ static int ensure_workspace(issl_index *ix, size_t n)
             const size_t places = m * ix->hdr.n_slices * kFineWays;
             const size_t groups = std::min<size_t>(nb * 256, places);
             const size_t fslots = places + kGuideGroup * groups;
-            // one item per tile of a group (and per 512 guides of it): sized for ~4 tiles per group; a batch that needs
-            // more scans whole buckets and reports it (sticky[3]), finish_batches() then enlarges the list
-            const size_t fitems = std::max<size_t>(6 * (groups + places / 64) + 2, w.cap_fitems);
+            // one item per tile of a group (and per 512 guides of it): sized from the mean group length (uniform data has
+            // sites / 65536 candidates per group, +1.2 tiles for the ends); a batch that needs more scans whole buckets
+            // and reports it (sticky[3]), finish_batches() then enlarges the list for the next one
+            const size_t tiles_per_group = static_cast<size_t>(ix->hdr.n_sites / (65536ull * kTileCands)) + 4;
+            const size_t fitems = std::max<size_t>(tiles_per_group * (groups + places / 64) + 2, w.cap_fitems);
             if ((rc = dev_alloc(w.fword, fslots))) return rc;
             if ((rc = dev_alloc(w.fmeta, fslots))) return rc;
             if ((rc = dev_alloc(w.fitems, fitems + 1))) return rc;
@@ -522,7 +524,8 @@ static bool want_sorted(const Tuning &tn, const Geometry &g, bool list_order_onl
 {
     if (list_order_only) return false;
     if (tn.sorted_layout >= 0) return tn.sorted_layout == 1;
-    return g.n_sites <= 600000000ull;
+    (void)g;
+    return true; // whenever it fits the free HBM (upload_common tries the layouts in turn)
 }
 
 static uint64_t count_tiles(const HostIndex &h)
@@ -975,8 +978,8 @@ static int upload_common(issl_index *idx, int device, void *buf, size_t bytes, c
     for (const LayoutChoice &c : choices) {
         layout_image(idx->hdr, idx->geo, m.size(), n_tiles, dense, c.inline_sigs, c.cold, c.sorted);
         // temporary device memory: while a host-cold image is packed, signatures + one slice list; for the sorted layout
-        // two arrays of 8 B per list entry
-        const uint64_t temp = c.cold ? 16 * idx->geo.n_sites : c.sorted ? 16 * idx->geo.n_sites * idx->geo.n_slices + (64ull << 20) : 0;
+        // two key arrays of 8 B per site (one slice at a time)
+        const uint64_t temp = c.cold ? 16 * idx->geo.n_sites : c.sorted ? 16 * idx->geo.n_sites + (64ull << 20) : 0;
         if (buf) {
             if (bytes < idx->hdr.total_bytes || (reinterpret_cast<uintptr_t>(buf) & 255u)) {
                 why = "device buffer too small or not 256-byte aligned";

@@ -138,7 +138,7 @@ int launch_build_entries(const uint64_t *d_sites, const uint32_t *d_occ, uint64_
 
 // Sorted layout (issl_build.hip): orders every bucket's list by the successor slice's byte (three stable radix passes
 // over keys built from the signatures) and writes the three maps of the image; d_sites / d_entries / d_bucket_start are
-// the image's own sections.  Needs 16 B per list entry of temporary device memory.  Synchronous.  d_flag: a zeroed device
+// the image's own sections.  Works one slice at a time and needs 16 B per site of temporary device memory.  Synchronous.  d_flag: a zeroed device
 // word.  Returns kSortNeedsListOrder when some entry sits in a bucket its signature does not select (the caller then
 // uploads the list-order layout, which like the reference does not care).
 constexpr int kSortNeedsListOrder = -1000;

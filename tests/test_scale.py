@@ -128,8 +128,9 @@ class ScalePoint:
         want_lines = int(os.environ.get("ISSL_SCALE_SITES", 300_000_000))
         want_guides = int(os.environ.get("ISSL_SCALE_GUIDES", 100_000))
         # host: 12 B/site generated (twice while the chunks are concatenated) + brute-force temporaries, + 48 B/site pinned
-        # when the cold sections are forced into host memory; HBM: 108 B/site with the in-list signatures (<= 600 M
-        # sites), 68 without, 20 with host-resident cold sections (+ 16 B/site of temporaries while it is packed)
+        # when the cold sections are forced into host memory; HBM, smallest layout the library falls back to: 108 B/site
+        # with the in-list signatures (<= 600 M sites), 68 without, 20 with host-resident cold sections (+ 16 B/site of
+        # temporaries while it is packed); the sorted layout of the pruned scan adds 100 B/site where that fits
         host_cold = os.environ.get("ISSL_FORCE_HOST_COLD") == "1"
         per_site_hbm = 36 if host_cold else (110 if want_lines <= 600_000_000 else 70)
         # (host peak: 24 B/site while the generated chunks are concatenated; later 12 B/site + 48 B/site pinned + ~25 GB
