@@ -171,8 +171,9 @@ int issl_index_copy_image_to(const issl_index *idx, void *dev_dst, size_t bytes)
  * 4.29 G sites = 292 GB of image).  Only the scan stream (20 B/site) is read by the scan; the site table and the slice
  * lists (isslScoreOfftargets.cpp:200-204,235-240; 48 B/site) are touched for the ~2e-5 of the comparisons that come
  * within max_dist.  issl_index_upload / issl_index_build_on_device therefore fall back, in this order, to an image
- * without the optional in-list signatures and to an image whose cold sections stay in pinned, mapped HOST memory and
- * are read across PCIe by the verify and replay kernels (option host_cold / ISSL_FORCE_HOST_COLD=1 forces that layout;
+ * without the sorted layout's maps, without the optional in-list signatures, and to an image whose cold sections stay
+ * in pinned, mapped HOST memory (option host_cold / ISSL_FORCE_HOST_COLD=1 forces that layout; the kernels rebuild
+ * signatures from the scan stream and read host memory only for occurrence counts >= 255 and for issl_dump_hits;
  * results are identical).  issl_index_cold() returns that host buffer (NULL / 0 when everything is in HBM); another
  * device of the same process adopts a copy of the hot image plus the SAME host buffer with
  * issl_index_attach_image_cold (issl_node does this).  Images with host-resident cold sections cannot be attached in
@@ -186,11 +187,17 @@ int issl_index_attach_image_cold(int device, void *dev_buf, size_t bytes, void *
  *   scan_blocks (ISSL_SCAN_BLOCKS) workgroups of the scan launch      item_guides (ISSL_ITEM_GUIDES) guides per scan item
  *   scan_generic (ISSL_SCAN_GENERIC) 0|1 runtime-threshold scan       stage_timing (ISSL_STAGE_TIMING) 0|1 events at every stage
  *   raw_chunks (ISSL_RAW_CHUNKS) initial raw-record buffer
- *   inline_sigs (ISSL_INLINE_SIGS) -1|0|1, host_cold (ISSL_FORCE_HOST_COLD) -1|0|1: image layout, read at upload
+ *   inline_sigs (ISSL_INLINE_SIGS) -1|0|1, host_cold (ISSL_FORCE_HOST_COLD) -1|0|1, sorted_layout (ISSL_SORTED_LAYOUT)
+ *     -1|0|1: image layout, read at upload.  The sorted layout stores every bucket ordered by the byte of the next slice
+ *     (+100 B per site of position maps) and is what the pruned scan needs; -1 = whenever it fits the free HBM
+ *   prune (ISSL_PRUNE) -1|0|1: scan only the successor-byte groups of a bucket that can hold a site within max_dist (13
+ *     of 256 for max_dist <= 4, 1 of 256 for <= 2; same hits and scores as the reference's scan of the whole bucket,
+ *     isslScoreOfftargets.cpp:344): -1 = a planning kernel decides per batch from the two plans' estimated times,
+ *     0 = never, 1 = whenever the image is sorted and max_dist <= 4
  *   scan_stamps (ISSL_SCAN_STAMPS) file for per-wave clocks (diagnostics) */
 int issl_index_set_option(issl_index *idx, const char *key, const char *value);
-/* Current value of an integer knob; also the read-only keys cold_on_host, has_inline_sigs and dense_mit (layout of
- * the uploaded image: 0/1, -1 before an upload). */
+/* Current value of an integer knob; also the read-only keys cold_on_host, has_inline_sigs, is_sorted and dense_mit
+ * (layout of the uploaded image: 0/1, -1 before an upload). */
 int issl_index_get_option(const issl_index *idx, const char *key, long long *value);
 
 /* ---- guides (A2, isslScoreOfftargets.cpp:63-71,82-89,275-305) ---------------------------- */
