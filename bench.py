@@ -240,7 +240,9 @@ def main():
         while not index.finish(stream):
             fn()
 
+    lanes = index.get_option("lanes")
     settle(step)
+    settle(step)  # (both lanes' scratch buffers)
     if a.spinup_ms > 0:  # part of the set-up, reported as config.spinup_ms
         t_spin = time.perf_counter()
         while (time.perf_counter() - t_spin) * 1e3 < a.spinup_ms:
@@ -272,11 +274,13 @@ def main():
     scan_ms = st["ms_scan"]
     # Stage breakdown (bin / verify / group / replay) from a short UNTIMED pass: the timed region records only the event
     # pair around the scan, because every further event record costs ~4 us of stream time.
-    index.set_option("stage_timing", 1)
+    # One lane for it: in the timed region consecutive batches alternate between two workspaces / streams, so that the
+    # short kernels of one batch run beside the scan of the next; a kernel's time is then not its own.
+    index.set_option("stage_timing", 1).set_option("lanes", 1)
     for _ in range(3):
         step()
     index.finish(stream)
-    index.set_option("stage_timing", 0)
+    index.set_option("stage_timing", 0).set_option("lanes", lanes)
     stages = index.stats()
     per_rank = None
     if use_dist:
@@ -298,6 +302,7 @@ def main():
         g = d_guides[:n_weak].contiguous()
         m = torch.empty(n_weak, dtype=torch.float64, device=dev)
         c = torch.empty_like(m)
+        settle(lambda: step(g, m, c))
         settle(lambda: step(g, m, c))
         weak_steps = 10
         barrier()
@@ -323,6 +328,7 @@ def main():
                 m = torch.empty(n_small, dtype=torch.float64, device=dev)
                 c = torch.empty_like(m)
                 settle(lambda: step(g, m, c))
+                settle(lambda: step(g, m, c))
                 for _ in range(5):
                     step(g, m, c)
                 index.finish(stream)
@@ -342,10 +348,36 @@ def main():
                     "hbm_physical_frac": phys / s2["ms_scan"] / 1e6 / HBM_PEAK_GBS,
                     "algorithmic_GBps": 8.0 * s2["candidates"] / s2["ms_scan"] / 1e6,
                 }
+            # two lanes: consecutive batches on two workspaces / streams (option lanes=2), the short kernels of one batch
+            # beside the scan of the next
+            index.set_option("lanes", 2)
+            try:
+                settle(step)
+                settle(step)
+                for _ in range(4):
+                    step()
+                index.finish(stream)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                reps = a.steps
+                for _ in range(reps):
+                    step()
+                index.finish(stream)
+                dt = time.perf_counter() - t1
+                s2 = index.stats()
+                extras["two_lanes"] = {
+                    "guides_per_step": n_mine, "steps": reps, "ms_per_step": dt * 1e3 / reps, "guides_per_s": n_mine * reps / dt,
+                    "scan_ms": s2["ms_scan"], "scan_ms_events": s2["ms_scan_events"],
+                    "note": "option lanes=2 (not the default): throughput of back-to-back batches rises, every kernel shares "
+                            "the chip with the other lane's and takes longer (scan_ms is the launch's own span)",
+                }
+            finally:
+                index.set_option("lanes", lanes)
             # the same batch with the pruned scan switched off: every bucket of every guide compared in full, which is
             # what the reference's loop (:344) does and what round 1 and the first half of round 2 measured
             index.set_option("prune", 0)
             try:
+                settle(step)
                 settle(step)
                 for _ in range(2):
                     step()
@@ -368,6 +400,7 @@ def main():
                 }
             finally:
                 index.set_option("prune", -1)
+                settle(step)
                 settle(step)
             # the caller-visible host entry point: guides from host memory, scores back to host memory, one sync per call
             t1 = time.perf_counter()
@@ -437,6 +470,10 @@ def main():
                 "traffic_source": traffic_src,
                 "traffic_computed": tile_bytes + 8.0 * st["raw_records"],
                 "avg_launch_ms": scan_ms,
+                "avg_launch_ms_events": st["ms_scan_events"],
+                "avg_launch_ms_alone": stages["ms_scan"],
+                "frac_alone": useful_valu_cycles / (N_SIMD * PEAK_CLOCK_HZ * stages["ms_scan"] * 1e-3),
+                "lanes": lanes,
                 "pruned": st["pruned"],
                 "comparisons_per_launch": cmp_per_launch,
                 "planned_comparisons": st["planned_comparisons"],
@@ -450,7 +487,9 @@ def main():
                 "hbm_physical_GBps": tile_bytes / t_scan / 1e9,
                 "hbm_physical_frac": tile_bytes / t_scan / 1e9 / HBM_PEAK_GBS,
                 "hbm_regime": extras.get("hbm_regime_64_guides"),
-                "note": "pruned != 0: every bucket is stored ordered by the byte of the next slice and a guide is compared only "
+                "note": "avg_launch_ms is the launch's own span (first workgroup in to last workgroup out, stamped by the kernel "
+                        "on the 100 MHz constant clock), avg_launch_ms_events the HIP event pair around the launch on its "
+                        "stream; they differ only when a second lane shares the chip (extras.two_lanes).  pruned != 0: every bucket is stored ordered by the byte of the next slice and a guide is compared only "
                         "with the 13 of 256 groups of its five buckets that can hold a site within 4 mismatches (pigeonhole over "
                         "the cyclic successor slice; same hits, bit-identical scores), so the kernel makes "
                         "comparisons_per_launch, not reference_comparisons_per_launch.  frac = (comparisons made / 2048 x 62 "
@@ -460,7 +499,7 @@ def main():
                         "comparison OF THE REFERENCE, no credit for reuse or pruning) and is not a fraction of anything "
                         "physical; extras.whole_bucket_scan is the same kernel working through whole buckets (frac ~0.76)",
             },
-            "kernel_ms": {"bin": stages["ms_bin"], "scan": scan_ms, "verify": stages["ms_verify"], "group": stages["ms_group"],
+            "kernel_ms": {"bin": stages["ms_bin"], "scan": stages["ms_scan"], "verify": stages["ms_verify"], "group": stages["ms_group"],
                           "replay": stages["ms_replay"], "pipeline": stages["ms_total"]},
             "hits_per_step": st["hits"],
             "setup_s": timings,

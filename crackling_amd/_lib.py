@@ -57,6 +57,7 @@ class Stats(C.Structure):
         ("ms_bin", C.c_double), ("ms_scan", C.c_double), ("ms_verify", C.c_double), ("ms_group", C.c_double),
         ("ms_replay", C.c_double), ("ms_total", C.c_double), ("scan_launches", C.c_uint64), ("raw_records", C.c_uint64), ("n_batches", C.c_uint64),
         ("planned_comparisons", C.c_uint64), ("reference_comparisons", C.c_uint64), ("pruned", C.c_uint64),
+        ("ms_scan_events", C.c_double),
     ]
 
 

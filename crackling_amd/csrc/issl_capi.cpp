@@ -110,11 +110,12 @@ Tuning Tuning::from_env()
     t.host_cold = -1;
     t.sorted_layout = -1;
     t.prune = -1;
+    t.lanes = 1;
     static const char *const keys[][2] = {
         {"ISSL_SCAN_BLOCKS", "scan_blocks"}, {"ISSL_ITEM_GUIDES", "item_guides"},
         {"ISSL_SCAN_GENERIC", "scan_generic"}, {"ISSL_STAGE_TIMING", "stage_timing"}, {"ISSL_RAW_CHUNKS", "raw_chunks"},
         {"ISSL_INLINE_SIGS", "inline_sigs"}, {"ISSL_FORCE_HOST_COLD", "host_cold"}, {"ISSL_SCAN_STAMPS", "scan_stamps"},
-        {"ISSL_SORTED_LAYOUT", "sorted_layout"}, {"ISSL_PRUNE", "prune"},
+        {"ISSL_SORTED_LAYOUT", "sorted_layout"}, {"ISSL_PRUNE", "prune"}, {"ISSL_LANES", "lanes"},
     };
     for (const auto &k : keys)
         if (const char *e = std::getenv(k[0])) (void)t.set(k[1], e); // values out of range leave the default
@@ -137,6 +138,7 @@ bool Tuning::set(const char *key, const char *value)
     else if (k == "host_cold") { if (!is_int || n < -1 || n > 1) return false; host_cold = static_cast<int>(n); }
     else if (k == "sorted_layout") { if (!is_int || n < -1 || n > 1) return false; sorted_layout = static_cast<int>(n); }
     else if (k == "prune") { if (!is_int || n < -1 || n > 1) return false; prune = static_cast<int>(n); }
+    else if (k == "lanes") { if (!is_int || n < 1 || n > 2) return false; lanes = static_cast<int>(n); }
     else if (k == "scan_stamps") stamps_path = value;
     else return false;
     return true;
@@ -177,7 +179,10 @@ struct issl_index {
     bool owns_cold = false;
     ImageHeader hdr{};
     ImageView view{};
-    Lane lane;
+    Lane lane;                // workspace + stream of the synchronous entry points and of every other asynchronous batch
+    Lane lane2;               // ... and of the batches in between (lanes option = 2)
+    uint32_t n_async = 0;     // asynchronous batches enqueued so far: picks the lane
+    Lane *last_lane = nullptr; // lane of the most recent batch (whose counters issl_last_stats reports)
     hipEvent_t ring[2 * kRing] = {}; // scan begin/end of the batches enqueued since the last finish
     bool have_events = false;
     issl_stats stats{};
@@ -221,7 +226,7 @@ static int select_device(int device)
 
 static void free_workspace(Workspace &w)
 {
-    void *ptrs[] = {w.ng, w.gfill, w.gstart, w.gword, w.gidx, w.gbucket, w.items, w.plan, w.range_start, w.counters, w.scan_count, w.sticky, w.stamps, w.gcur_big, w.terms, w.sorted, w.gcount,
+    void *ptrs[] = {w.ng, w.gfill, w.gstart, w.gword, w.gidx, w.gbucket, w.items, w.plan, w.range_start, w.counters, w.scan_count, w.scan_span, w.sticky, w.stamps, w.gcur_big, w.terms, w.sorted, w.gcount,
                     w.goff, w.blocksum, w.d_guides, w.d_mit, w.d_cfd, w.d_kept, w.d_hitrec, w.pay, w.rank, w.fword, w.fmeta,
                     w.fitems, w.fcount, w.fsum};
     for (void *p : ptrs)
@@ -263,9 +268,8 @@ static int ensure_raw_capacity(Workspace &w, size_t chunks)
 
 static uint32_t scan_waves(const Tuning &tn) { return tn.scan_blocks * 16u; }
 
-static int ensure_workspace(issl_index *ix, size_t n)
+static int ensure_workspace(issl_index *ix, size_t n, Lane &lane)
 {
-    Lane &lane = ix->lane;
     Workspace &w = lane.ws;
     const Tuning &tn = ix->tuning;
     const size_t nb = ix->hdr.n_buckets;
@@ -280,6 +284,8 @@ static int ensure_workspace(issl_index *ix, size_t n)
         if ((rc = dev_alloc(w.plan, 1))) return rc;
         if ((rc = dev_alloc(w.range_start, kMaxRanges + 2))) return rc;
         if ((rc = dev_alloc(w.scan_count, kScanMaxBlocks))) return rc;
+        if ((rc = dev_alloc(w.scan_span, 2 * kSpanRing))) return rc;
+        HIP_TRY(hipMemset(w.scan_span, 0, 16 * kSpanRing));
         HIP_TRY(hipMemset(w.scan_count, 0, 8 * kScanMaxBlocks));
         w.n_buckets = static_cast<uint32_t>(nb);
     }
@@ -538,17 +544,20 @@ static uint64_t count_tiles(const HostIndex &h)
 static void release_device(issl_index *ix)
 {
     if (ix->device >= 0) (void)hipSetDevice(ix->device);
-    Lane &lane = ix->lane;
-    if (lane.ready) {
-        (void)hipStreamSynchronize(lane.stream);
-        for (auto &e : lane.ev) (void)hipEventDestroy(e);
-        (void)hipEventDestroy(lane.done);
-        (void)hipStreamDestroy(lane.stream);
-        lane.ready = false;
+    for (Lane *lp : {&ix->lane, &ix->lane2}) {
+        Lane &lane = *lp;
+        if (lane.ready) {
+            (void)hipStreamSynchronize(lane.stream);
+            for (auto &e : lane.ev) (void)hipEventDestroy(e);
+            (void)hipEventDestroy(lane.done);
+            (void)hipStreamDestroy(lane.stream);
+            lane.ready = false;
+        }
+        free_workspace(lane.ws);
+        lane.last_n = 0;
+        lane.pending = 0;
     }
-    free_workspace(lane.ws);
-    lane.last_n = 0;
-    lane.pending = 0;
+    ix->last_lane = nullptr;
     if (ix->have_events) {
         for (auto &e : ix->ring) (void)hipEventDestroy(e);
         ix->have_events = false;
@@ -583,7 +592,7 @@ static int new_index_from_host(std::unique_ptr<HostIndex> h, issl_index **out)
 // `staged`: record an event at every stage boundary (bin / scan / verify / group / replay times in issl_stats).  An event
 // record costs ~4 us of stream time on MI355X -- 5 % of a 10 k-guide batch for the six of them -- so the asynchronous
 // back-to-back path records only the pair around the scan and the end of the batch unless the stage_timing knob is set.
-static int enqueue_batch(issl_index *ix, hipStream_t stream, const uint64_t *d_guides, size_t n, int max_dist,
+static int enqueue_batch(issl_index *ix, Lane &lane, hipStream_t stream, const uint64_t *d_guides, size_t n, int max_dist,
                          double threshold, int method, double *d_mit, double *d_cfd, bool dump, bool staged)
 {
     if (!ix->d_image) {
@@ -596,9 +605,8 @@ static int enqueue_batch(issl_index *ix, hipStream_t stream, const uint64_t *d_g
     }
     HIP_TRY(hipSetDevice(ix->device));
     if (n == 0) return ISSL_OK;
-    int rc = ensure_workspace(ix, n);
+    int rc = ensure_workspace(ix, n, lane);
     if (rc) return rc;
-    Lane &lane = ix->lane;
     Workspace &ws = lane.ws;
     const Tuning &tn = ix->tuning;
     // `sorted` always has room for every raw slot, so the whole pipeline runs without a host round trip;
@@ -618,6 +626,7 @@ static int enqueue_batch(issl_index *ix, hipStream_t stream, const uint64_t *d_g
     const uint32_t slot = ix->n_pending % kRing;
     lane.staged = staged;
     if (staged) HIP_TRY(hipEventRecord(lane.ev[0], stream));
+    ws.span_slot = lane.pending % kSpanRing;
     const uint32_t prune_mode = prune_mode_for(ix->view, tn, n32, max_dist);
     launch_bin_guides(ix->view, ws, tn, d_guides, n32, prune_mode, stream);
     if (staged) HIP_TRY(hipEventRecord(lane.ev[1], stream));
@@ -638,6 +647,7 @@ static int enqueue_batch(issl_index *ix, hipStream_t stream, const uint64_t *d_g
     lane.last_n = n32;
     lane.last_max_dist = max_dist;
     lane.last_prune = prune_mode;
+    ix->last_lane = &lane;
     return ISSL_OK;
 }
 
@@ -649,33 +659,51 @@ static int finish_batches(issl_index *ix, hipStream_t stream)
     if (!ix->d_image || ix->n_pending == 0) return ISSL_OK;
     HIP_TRY(hipSetDevice(ix->device));
     HIP_TRY(hipStreamSynchronize(stream));
-    Lane &lane = ix->lane;
-    if (lane.ready && lane.pending) HIP_TRY(hipStreamSynchronize(lane.stream));
+    for (Lane *lp : {&ix->lane, &ix->lane2})
+        if (lp->ready && lp->pending) HIP_TRY(hipStreamSynchronize(lp->stream));
     HIP_TRY(hipGetLastError());
     const uint32_t batches = ix->n_pending;
     ix->n_pending = 0;
-    lane.pending = 0;
-    uint32_t sticky[4] = {0, 0, 0, 0};
-    HIP_TRY(hipMemcpy(sticky, lane.ws.sticky, sizeof sticky, hipMemcpyDeviceToHost));
-    const uint32_t max_chunks = sticky[1];
-    if (sticky[2] & 2u) {
-        HIP_TRY(hipMemset(lane.ws.sticky, 0, 16));
-        set_error("internal error: scan item list overflow");
-        return ISSL_E_DEVICE;
+    bool retry = false;
+    uint32_t max_chunks = 0; // of the lane whose counters are reported
+    Lane &lane = ix->last_lane ? *ix->last_lane : ix->lane;
+    double span_sum = 0.0;   // scan launches by the kernel's own clock stamps (ticks of 10 ns)
+    uint32_t span_count = 0;
+    for (Lane *lp : {&ix->lane, &ix->lane2}) {
+        if (!lp->pending) continue;
+        {
+            const uint32_t have = lp->pending < kSpanRing ? lp->pending : kSpanRing;
+            unsigned long long spans[2 * kSpanRing];
+            HIP_TRY(hipMemcpy(spans, lp->ws.scan_span, 16 * have, hipMemcpyDeviceToHost));
+            for (uint32_t i = 0; i < have; ++i)
+                if (spans[2 * i + 1] > spans[2 * i]) { span_sum += static_cast<double>(spans[2 * i + 1] - spans[2 * i]); ++span_count; }
+        }
+        lp->pending = 0;
+        uint32_t sticky[4] = {0, 0, 0, 0};
+        HIP_TRY(hipMemcpy(sticky, lp->ws.sticky, sizeof sticky, hipMemcpyDeviceToHost));
+        if (lp == &lane) max_chunks = sticky[1];
+        if (sticky[2] & 2u) {
+            HIP_TRY(hipMemset(lp->ws.sticky, 0, 16));
+            set_error("internal error: scan item list overflow");
+            return ISSL_E_DEVICE;
+        }
+        if (sticky[3] > lp->ws.cap_fitems && lp->ws.fitems) { // a pruned plan did not fit its item list: room for the next batch
+            const size_t want = static_cast<size_t>(sticky[3]) + sticky[3] / 4 + 2;
+            uint32_t zero = 0;
+            HIP_TRY(hipMemcpy(lp->ws.sticky + 3, &zero, 4, hipMemcpyHostToDevice));
+            int rc = dev_alloc(lp->ws.fitems, want + 1);
+            if (rc) return rc;
+            lp->ws.cap_fitems = want;
+        }
+        if (sticky[0]) {
+            // sticky[1] = largest number of chunks any batch asked for
+            HIP_TRY(hipMemset(lp->ws.sticky, 0, 16));
+            int rc = ensure_raw_capacity(lp->ws, static_cast<size_t>(sticky[1]) + sticky[1] / 8 + 1024);
+            if (rc) return rc;
+            retry = true;
+        }
     }
-    if (sticky[3] > lane.ws.cap_fitems && lane.ws.fitems) { // a pruned plan did not fit its item list: room for the next batch
-        const size_t want = static_cast<size_t>(sticky[3]) + sticky[3] / 4 + 2;
-        uint32_t zero = 0;
-        HIP_TRY(hipMemcpy(lane.ws.sticky + 3, &zero, 4, hipMemcpyHostToDevice));
-        int rc = dev_alloc(lane.ws.fitems, want + 1);
-        if (rc) return rc;
-        lane.ws.cap_fitems = want;
-    }
-    if (sticky[0]) {
-        // max_chunks = largest number of chunks any batch asked for
-        HIP_TRY(hipMemset(lane.ws.sticky, 0, 16));
-        int rc = ensure_raw_capacity(lane.ws, static_cast<size_t>(max_chunks) + max_chunks / 8 + 1024);
-        if (rc) return rc;
+    if (retry) {
         set_error("raw record buffer was too small for a batch; it has been enlarged, score the batch again");
         return ISSL_E_RETRY;
     }
@@ -701,7 +729,8 @@ static int finish_batches(issl_index *ix, hipStream_t stream)
     ix->stats = issl_stats{};
     ix->stats.n_guides = lane.last_n;
     ix->stats.ms_bin = ms[0];
-    ix->stats.ms_scan = have ? scan_sum / have : ms[1]; // mean over the batches since the last finish
+    ix->stats.ms_scan_events = have ? scan_sum / have : ms[1]; // mean over the batches since the last finish
+    ix->stats.ms_scan = span_count ? span_sum / span_count * 1e-5 : 0.0;
     ix->stats.ms_verify = ms[2];
     ix->stats.ms_group = ms[3];
     ix->stats.ms_replay = ms[4];
@@ -735,7 +764,7 @@ static int score_core(issl_index *ix, const uint64_t *d_guides, size_t n, int ma
     ix->stats.n_guides = n;
     if (n == 0) return ISSL_OK;
     for (int attempt = 0;; ++attempt) {
-        rc = enqueue_batch(ix, stream, d_guides, n, max_dist, threshold, method, d_mit, d_cfd, dump, true);
+        rc = enqueue_batch(ix, ix->lane, stream, d_guides, n, max_dist, threshold, method, d_mit, d_cfd, dump, true);
         if (rc) return rc;
         rc = finish_batches(ix, stream);
         if (rc == ISSL_OK) {
@@ -897,10 +926,11 @@ int issl_index_set_option(issl_index *idx, const char *key, const char *value)
     if (idx->d_image && t.scan_blocks != idx->tuning.scan_blocks) {
         // every scan wave owns the raw chunk with its own number: keep at least that many
         HIP_TRY(hipSetDevice(idx->device));
-        if (idx->lane.ws.cap_chunks && idx->lane.ws.cap_chunks < size_t(scan_waves(t)) * 2) {
-            int rc = ensure_raw_capacity(idx->lane.ws, size_t(scan_waves(t)) * 4);
-            if (rc) return rc;
-        }
+        for (Lane *lp : {&idx->lane, &idx->lane2})
+            if (lp->ws.cap_chunks && lp->ws.cap_chunks < size_t(scan_waves(t)) * 2) {
+                int rc = ensure_raw_capacity(lp->ws, size_t(scan_waves(t)) * 4);
+                if (rc) return rc;
+            }
     }
     idx->tuning = t;
     return ISSL_OK;
@@ -920,6 +950,7 @@ int issl_index_get_option(const issl_index *idx, const char *key, long long *val
     else if (k == "host_cold") *value = t.host_cold;
     else if (k == "sorted_layout") *value = t.sorted_layout;
     else if (k == "prune") *value = t.prune;
+    else if (k == "lanes") *value = t.lanes;
     else if (k == "is_sorted") *value = idx->d_image ? (idx->hdr.off_srec ? 1 : 0) : -1;                   // read-only
     else if (k == "cold_on_host") *value = idx->d_image ? static_cast<long long>(idx->hdr.cold_on_host) : -1; // read-only: layout in use
     else if (k == "dense_mit") *value = idx->d_image ? (idx->hdr.off_mit_dense ? 1 : 0) : -1;              // read-only
@@ -1237,14 +1268,17 @@ int issl_score_device_async(issl_index *idx, const uint64_t *d_guides, size_t n,
         return ISSL_E_ARG;
     }
     HIP_TRY(hipSetDevice(idx->device));
-    int rc = ensure_workspace(idx, n); // creates the internal stream on first use
+    // lanes option = 2: consecutive batches use different workspaces and streams, so that the short, latency-bound
+    // kernels behind one batch's scan run in the wave slots the next batch's scan leaves free: +9-11 % guides/s at 100 k
+    // guides x 300 M sites; every kernel then shares the chip and takes longer, which is why it is not the default
+    Lane &lane = (idx->tuning.lanes == 2 && (idx->n_async++ & 1u)) ? idx->lane2 : idx->lane;
+    int rc = ensure_workspace(idx, n, lane); // creates the internal stream on first use
     if (rc) return rc;
-    Lane &lane = idx->lane;
     if (stream) { // inputs are produced on the caller's stream: the batch starts after what is enqueued there now
         HIP_TRY(hipEventRecord(lane.ev[0], static_cast<hipStream_t>(stream)));
         HIP_TRY(hipStreamWaitEvent(lane.stream, lane.ev[0], 0));
     }
-    return enqueue_batch(idx, lane.stream, d_guides, n, max_dist, threshold, method, d_mit, d_cfd, false,
+    return enqueue_batch(idx, lane, lane.stream, d_guides, n, max_dist, threshold, method, d_mit, d_cfd, false,
                          idx->tuning.stage_timing);
 }
 
@@ -1252,8 +1286,8 @@ int issl_score_wait(issl_index *idx, void *stream)
 {
     if (!idx) { set_error("null argument"); return ISSL_E_ARG; }
     if (idx->device >= 0) HIP_TRY(hipSetDevice(idx->device));
-    if (idx->lane.ready && idx->lane.pending)
-        HIP_TRY(hipStreamWaitEvent(static_cast<hipStream_t>(stream), idx->lane.done, 0));
+    for (Lane *lp : {&idx->lane, &idx->lane2})
+        if (lp->ready && lp->pending) HIP_TRY(hipStreamWaitEvent(static_cast<hipStream_t>(stream), lp->done, 0));
     return ISSL_OK;
 }
 
@@ -1301,7 +1335,7 @@ int issl_score(issl_index *idx, const uint64_t *guides, size_t n, int max_dist, 
         Workspace &ws = idx->lane.ws;
         int rc = finish_batches(idx, nullptr); // asynchronous batches may still use the staging buffers
         if (rc) return rc;
-        rc = ensure_workspace(idx, cnt);
+        rc = ensure_workspace(idx, cnt, idx->lane);
         if (rc) return rc;
         if (presize) {
             const double slots = std::min(static_cast<double>(cand) * records_per_comparison, budget_slots);
@@ -1318,6 +1352,7 @@ int issl_score(issl_index *idx, const uint64_t *guides, size_t n, int max_dist, 
         total.planned_comparisons += s.planned_comparisons; total.reference_comparisons += s.reference_comparisons;
         total.pruned = std::max(total.pruned, s.pruned);
         total.scan_tiles += s.scan_tiles; total.ms_bin += s.ms_bin; total.ms_scan += s.ms_scan;
+        total.ms_scan_events += s.ms_scan_events;
         total.ms_verify += s.ms_verify; total.ms_group += s.ms_group; total.ms_replay += s.ms_replay;
         total.ms_total += s.ms_total; total.scan_launches += s.scan_launches;
         total.raw_records = std::max(total.raw_records, s.raw_records); total.n_batches += s.n_batches;
@@ -1339,7 +1374,7 @@ int issl_dump_hits(issl_index *idx, const uint64_t *guides, size_t n, int max_di
     int rc = finish_batches(idx, nullptr);
     if (rc) return rc;
     Workspace &ws = idx->lane.ws;
-    rc = ensure_workspace(idx, n);
+    rc = ensure_workspace(idx, n, idx->lane);
     if (rc) return rc;
     HIP_TRY(hipMemcpy(ws.d_guides, guides, 8 * n, hipMemcpyHostToDevice));
     rc = score_core(idx, ws.d_guides, n, max_dist, threshold, method, ws.d_mit, ws.d_cfd, nullptr, true);

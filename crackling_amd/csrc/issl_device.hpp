@@ -123,6 +123,9 @@ struct Tuning {
     int prune;              // ISSL_PRUNE         scan only the successor-byte groups that can hold a hit (needs the sorted
                             //                    layout and max_dist <= 4): -1 when the plan estimates it to be faster,
                             //                    0 never, 1 whenever possible
+    int lanes;              // ISSL_LANES         1|2 (default 1): workspaces + streams that asynchronous batches alternate
+                            //                    between (2: the short kernels of one batch fill the wave slots the scan of
+                            //                    the next leaves)
     int host_cold;          // ISSL_FORCE_HOST_COLD  -1 automatic (image larger than the free HBM), 0 never, 1 always
     std::string stamps_path; // ISSL_SCAN_STAMPS  dump per-wave clocks of the scan here (diagnostics)
     static Tuning from_env();
@@ -156,6 +159,7 @@ constexpr uint32_t kScanGridBlocks = 256u * 4u; // scan launch: 256 CUs x 2 resi
 constexpr uint32_t kScanMaxBlocks = 8192u;       // upper bound of the ISSL_SCAN_BLOCKS knob
 constexpr uint32_t kScanWaves = kScanMaxBlocks * 16u;
 constexpr uint32_t kMaxRanges = kScanMaxBlocks;  // one equal-cost range per workgroup
+constexpr uint32_t kSpanRing = 64;              // batches per lane whose scan spans are kept until the next finish
 constexpr uint32_t kChunkRecs = 128;            // raw-record chunk: 1 KiB, slot 0 is the fill count
 constexpr uint64_t kDeadKey = ~0ull;            // raw slot that did not survive the exact check
 
@@ -236,6 +240,10 @@ struct Workspace {
     uint64_t *raw = nullptr;     // [(cap_chunks+1) * kChunkRecs] raw records of the scan, chunked
     size_t cap_chunks = 0;
     Counters *counters = nullptr;
+    unsigned long long *scan_span = nullptr; // [2 * kSpanRing] first start / last end of the scan workgroups of the lane's
+                                    // recent batches, in ticks of the 100 MHz constant clock (s_memrealtime): the
+                                    // kernel's own duration also when another stream shares the chip
+    uint32_t span_slot = 0;         // slot of the batch being enqueued
     uint64_t *scan_count = nullptr; // [kScanMaxBlocks] comparisons every scan workgroup actually made (real candidates x real guides)
     unsigned long long *stamps = nullptr; // [4 * kScanWaves] scan wave clocks, then replay phase clocks (ISSL_SCAN_STAMPS diagnostics)
     uint32_t *sticky = nullptr;  // [4] survives the per-batch resets: [0] raw overflow seen, [1] max chunks asked, [2] plan errors, [3] items a pruned plan wanted beyond cap_fitems

@@ -232,6 +232,8 @@ __global__ __launch_bounds__(256) void k_guide_hist(Workspace ws, const uint64_t
         Counters c{};
         c.raw_chunks = n_scan_waves;
         *ws.counters = c;
+        ws.scan_span[2u * ws.span_slot] = ~0ull;
+        ws.scan_span[2u * ws.span_slot + 1u] = 0ull;
     }
     __syncthreads();
     if (blockIdx.x * 256 < n)
@@ -868,7 +870,8 @@ __device__ __forceinline__ void scan_range(const uint32_t *__restrict__ scan_str
                                            const uint32_t *__restrict__ gword_stream, uint64_t *raw, uint32_t max_chunks,
                                            Counters *counters, uint32_t thr, unsigned long long *stamps,
                                            uint64_t *__restrict__ scan_count, uint32_t *next_unit_p, uint32_t *waves_done_p,
-                                           unsigned long long *wg_compared_p, unsigned long long t_start)
+                                           unsigned long long *wg_compared_p, unsigned long long t_start,
+                                           unsigned long long *span)
 {
     uint32_t &next_unit = *next_unit_p;
     uint32_t &waves_done = *waves_done_p;
@@ -955,7 +958,10 @@ __device__ __forceinline__ void scan_range(const uint32_t *__restrict__ scan_str
     // comparisons of the workgroup: summed in LDS, stored (not added: no reset needed) by its last wave
     if (lane == 0) {
         atomicAdd(&wg_compared, compared);
-        if (atomicAdd(&waves_done, 1u) == (blockDim.x >> 6) - 1u) scan_count[blockIdx.x] = atomicAdd(&wg_compared, 0ull);
+        if (atomicAdd(&waves_done, 1u) == (blockDim.x >> 6) - 1u) {
+            scan_count[blockIdx.x] = atomicAdd(&wg_compared, 0ull);
+            atomicMax(span + 1, static_cast<unsigned long long>(__builtin_amdgcn_s_memrealtime()));
+        }
     }
     if (stamps && lane == 0) {
         stamps[4 * wave_id] = t_start;
@@ -975,27 +981,29 @@ __global__ __launch_bounds__(1024, 8) void k_scan(const uint32_t *__restrict__ s
                                                   const uint32_t *__restrict__ gword_full,
                                                   const uint32_t *__restrict__ gword_fine, uint64_t *raw,
                                                   uint32_t max_chunks, Counters *counters, uint32_t thr,
-                                                  unsigned long long *stamps, uint64_t *__restrict__ scan_count)
+                                                  unsigned long long *stamps, uint64_t *__restrict__ scan_count,
+                                                  unsigned long long *span)
 {
     __shared__ uint32_t next_unit;
     __shared__ uint32_t waves_done;
     __shared__ unsigned long long wg_compared;
     // stamps (diagnostics, normally null): per wave {start, end} in 100 MHz ticks, {XCC_ID, HW_ID} and the number of
     // tiles it took; nothing else reads them
-    const unsigned long long t_start = stamps ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
     if (threadIdx.x == 0) { next_unit = 0; waves_done = 0; wg_compared = 0ull; }
     __syncthreads();
     if (blockIdx.x >= plan->n_ranges) {
         if (threadIdx.x == 0) scan_count[blockIdx.x] = 0ull;
         return;
     }
+    if (threadIdx.x == 0) atomicMin(span, t_start); // the launch's own span: first workgroup in, last one out
     // the plan of this batch: bucket-level items, or the successor-byte groups of the pruned scan (k_fine_plan)
     if (plan->fine != 0u)
         scan_range<THR, true>(scan_stream, items_fine, plan, range_start, gword_fine, raw, max_chunks, counters, thr, stamps,
-                              scan_count, &next_unit, &waves_done, &wg_compared, t_start);
+                              scan_count, &next_unit, &waves_done, &wg_compared, t_start, span);
     else
         scan_range<THR, false>(scan_stream, items_full, plan, range_start, gword_full, raw, max_chunks, counters, thr, stamps,
-                               scan_count, &next_unit, &waves_done, &wg_compared, t_start);
+                               scan_count, &next_unit, &waves_done, &wg_compared, t_start, span);
 }
 
 // precalculatedScores[mask] with operator[] semantics: a missing mask contributes 0.0 (:394).
@@ -1199,7 +1207,8 @@ static void launch_scan_thr(const ImageView &v, const Workspace &ws, const Tunin
     // pruned scan: the items and guide words grouped by (bucket, successor byte); the plan says which list counts
     hipLaunchKernelGGL(k_scan<THR>, dim3(tn.scan_blocks), dim3(1024), 0, stream, v.scan, ws.items,
                        prune_mode ? ws.fitems : ws.items, ws.plan, ws.range_start, ws.gword, prune_mode ? ws.fword : ws.gword,
-                       ws.raw, static_cast<uint32_t>(ws.cap_chunks), ws.counters, thr, ws.stamps, ws.scan_count);
+                       ws.raw, static_cast<uint32_t>(ws.cap_chunks), ws.counters, thr, ws.stamps, ws.scan_count,
+                       ws.scan_span + 2u * ws.span_slot);
 }
 
 void launch_scan(const ImageView &v, const Workspace &ws, const Tuning &tn, const uint64_t *d_guides, uint32_t n,

@@ -69,8 +69,9 @@ typedef struct {
     uint32_t occ;   /* occurrences = high 32 bits of the entry, :348 */
 } issl_hit;
 
-/* Timings and counters of the last issl_score* call on an index (milliseconds, GPU events).  ms_scan is always
- * measured (mean over the batches since the last finish); the other stage times and ms_total are filled by the
+/* Timings and counters of the last issl_score* call on an index (milliseconds).  ms_scan is always measured (mean over
+ * the batches since the last finish) by the scan kernel itself: first workgroup in to last workgroup out on the 100 MHz
+ * constant clock (s_memrealtime), i.e. the launch's own duration; the other stage times (GPU events) and ms_total are filled by the
  * synchronous entry points, and by issl_score_device_async only when the stage_timing option is set (every event
  * record costs ~4 us of stream time, which back-to-back batches should not pay). */
 typedef struct {
@@ -97,6 +98,9 @@ typedef struct {
                                        loop :344 without early exit (host equivalent: issl_count_candidates) */
     uint64_t pruned;              /* 0: full scan; 1 / 2: pruned scan over the successor-byte groups equal to / within
                                      one mismatch of the guide's own (max_dist <= 2 / <= 4, sorted image) */
+    double ms_scan_events;        /* the scan launches by the HIP event pair recorded around them on their stream; equals
+                                     ms_scan for batches on one lane, includes the wait for wave slots when a second
+                                     lane shares the device (lanes option) */
 } issl_stats;
 
 const char *issl_last_error(void);

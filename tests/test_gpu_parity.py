@@ -444,10 +444,42 @@ def test_one_site_index(tmp_path):
     ix.close()
 
 
-def test_async_batches(config0):
-    """issl_score_device_async / issl_score_wait / issl_score_finish: several batches in flight on the internal stream."""
+@pytest.mark.parametrize("lanes", [1, 2])
+def test_async_batches(config0, lanes):
+    """issl_score_device_async / issl_score_wait / issl_score_finish: several batches in flight on the internal stream --
+    or, with the lanes option = 2, alternating between two workspaces and streams (the batches then overlap)."""
     import torch
     ix, oracle, sigs, guides = config0
+    ix.set_option("lanes", lanes)
+    try:
+        _async_batches(ix, oracle, guides, torch)
+        if lanes == 2:   # many batches in flight on both lanes, one of them larger than anything before (workspace growth)
+            rng = np.random.default_rng(9)
+            big = np.concatenate([guides, guides ^ (rng.integers(0, 4, size=len(guides), dtype=np.uint64) << np.uint64(10))])
+            batches = [big, guides[:77], guides[100:900], guides[:1], big[::-1].copy(), guides[5:505]] * 3
+            outs = []
+            for g in batches:
+                d_g = torch.from_numpy(g.view(np.int64)).cuda()
+                d_m = torch.empty(len(g), dtype=torch.float64, device="cuda:0"); d_c = torch.empty_like(d_m)
+                outs.append((g, d_g, d_m, d_c))
+            while True:
+                for g, d_g, d_m, d_c in outs:
+                    ix.score_device_async(d_g, d_m, d_c, 4, 75.0, "and")
+                if ix.finish():
+                    break
+            assert ix.stats()["n_batches"] == len(batches)
+            want = {}
+            for g, d_g, d_m, d_c in outs:
+                key = g.tobytes()
+                if key not in want:
+                    want[key] = oracle.score(g, 4, 75.0, "and")
+                assert np.array_equal(d_m.cpu().numpy().view(np.uint64), want[key][0].view(np.uint64))
+                assert np.array_equal(d_c.cpu().numpy().view(np.uint64), want[key][1].view(np.uint64))
+    finally:
+        ix.set_option("lanes", 1)
+
+
+def _async_batches(ix, oracle, guides, torch):
     stream = torch.cuda.current_stream().cuda_stream
     parts = [guides[:300], guides[300:301], guides[301:]]
     outs = []
