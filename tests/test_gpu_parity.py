@@ -907,3 +907,48 @@ def test_image_without_inline_signatures(golden, monkeypatch):
     assert ix.device_bytes() == n_with
     assert np.array_equal(ix.dump_hits(guides, 4, 0.0, "and"), hits)
     ix.close()
+
+
+def test_runtime_threshold_kernel_with_the_pruned_scan(config0):
+    """The runtime-threshold build of the scan kernel (scan_generic) working through the successor-byte groups."""
+    ix, oracle, sigs, guides = config0
+    ix.set_option("scan_generic", 1).set_option("prune", 1)
+    try:
+        for dist in (0, 1, 2, 3, 4):
+            hits = ix.dump_hits(guides[:300], dist, 0.0, "and")
+            assert ix.stats()["pruned"] == (1 if dist <= 2 else 2)
+            _, _, ohits = oracle.score(guides[:300], dist, 0.0, "and", want_hits=True)
+            assert np.array_equal(hits, ohits), dist
+    finally:
+        ix.set_option("scan_generic", 0).set_option("prune", -1)
+
+
+def test_index_with_entries_in_foreign_buckets_keeps_the_list_order(golden_uniform):
+    """No builder writes a slice list that holds a site whose signature does not select it, but the format allows it and
+    the reference would still score such an entry (it compares whole signatures, isslScoreOfftargets.cpp:376).  The
+    sorted layout cannot be built for such a file (ordering by signature would move entries between buckets): the
+    upload notices and falls back to the list-order image; scoring works as it does with the sorted layout switched off."""
+    data = bytearray(golden_uniform.issl.read_bytes())
+    hdr = np.frombuffer(bytes(data[:48]), dtype=np.uint64)
+    n, n_slices, n_scores = int(hdr[0]), int(hdr[4]), int(hdr[5])
+    sizes_at = 48 + 16 * n_scores + 8 * n
+    sizes = np.frombuffer(bytes(data[sizes_at:sizes_at + 8 * n_slices * 256]), dtype=np.uint64)
+    starts = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    entries_at = sizes_at + 8 * n_slices * 256
+    full = [b for b in range(256) if sizes[b] > 0]          # two non-empty buckets of slice 0: swap their first entries
+    a, b = entries_at + 8 * int(starts[full[0]]), entries_at + 8 * int(starts[full[-1]])
+    data[a:a + 8], data[b:b + 8] = data[b:b + 8], data[a:a + 8]
+    guides = ca.encode_guides(golden_uniform.guides)
+    ix = ca.IsslIndex.from_bytes(bytes(data)).upload(0)
+    assert ix.get_option("is_sorted") == 0
+    got = ix.score(guides, 4, 75.0, "and")
+    ix.close()
+    plain = ca.IsslIndex.from_bytes(bytes(data))
+    plain.set_option("sorted_layout", 0)
+    plain.upload(0)
+    want = plain.score(guides, 4, 75.0, "and")
+    plain.close()
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    intact = ca.IsslIndex.open(golden_uniform.issl).upload(0)
+    assert intact.get_option("is_sorted") == 1
+    intact.close()
