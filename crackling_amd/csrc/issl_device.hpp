@@ -172,10 +172,12 @@ struct ScanItem {
     uint32_t n_tiles;
     uint64_t cost0;  // sum of costs of all earlier items; tile cost = (g1-g0)+kTileFixedCost
     uint32_t tile0;  // sum of n_tiles of all earlier items (tiles are numbered in item order)
-    uint32_t last_cands; // real candidates in the item's last tile (1..kTileCands): its other tiles are full
-    uint32_t tile_abs;   // the item's first tile in the scan stream
-    uint32_t window;     // candidates of the item: from offset (window & 0xFFFF) of its first tile up to (not including)
-                         // offset (window >> 16) of its last tile; the rest are padding or a neighbouring group's
+    uint32_t last_cands; // real candidates in the item's last unit (1..kTileCands): its other units are full
+    uint32_t group_abs;  // where the item's first unit starts in the scan stream, in groups of 32 candidates (tile * 64 +
+                         // group): a unit is 2048 consecutive candidates of the bucket from there on -- whole tiles for
+                         // bucket-level items, a window that may straddle two tiles for the pruned scan's
+    uint32_t window;     // candidates of the item: from offset (window & 0xFFFF) of its first unit up to (not including)
+                         // offset (window >> 16) of its last unit; the rest are padding or a neighbouring group's
 };
 
 // Start of a cost range of the scan: (item, tile inside the item, guide offset); item == n_items marks the end.

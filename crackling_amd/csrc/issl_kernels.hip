@@ -358,7 +358,7 @@ __global__ __launch_bounds__(256) void k_plan(ImageView v, uint32_t *__restrict_
                 it.cost0 = cost_at;
                 it.tile0 = static_cast<uint32_t>(tile_at);
                 it.last_cands = static_cast<uint32_t>(blen - static_cast<uint64_t>(nt - 1u) * kTileCands);
-                it.tile_abs = v.tile_first[b];
+                it.group_abs = v.tile_first[b] * 64u;
                 it.window = it.last_cands << 16;
                 items[item_at++] = it;
                 cost_at += static_cast<uint64_t>(nt) * (len + kTileFixedCost);
@@ -374,7 +374,7 @@ __global__ __launch_bounds__(256) void k_plan(ImageView v, uint32_t *__restrict_
         if (!overflow) {
             ScanItem end;
             end.bucket = 0; end.g0 = 0; end.g1 = 0; end.n_tiles = 0; end.cost0 = tot_cost;
-            end.tile0 = static_cast<uint32_t>(tot_tiles); end.last_cands = 0; end.tile_abs = 0; end.window = 0;
+            end.tile0 = static_cast<uint32_t>(tot_tiles); end.last_cands = 0; end.group_abs = 0; end.window = 0;
             items[tot_items] = end;
         }
         plan->n_items = overflow ? 0u : static_cast<uint32_t>(tot_items);
@@ -493,11 +493,11 @@ __global__ __launch_bounds__(256) void k_fine_count(ImageView v, const uint64_t 
     fcount[static_cast<uint64_t>(b) * 256u + w] = (s1 > s0) ? c : 0u; // a group without candidates takes no guides
     uint64_t cost = 0, cand = 0, slots = 0, items = 0, units = 0;
     if (c && s1 > s0) {
-        const uint32_t nt = (s1 - 1u) / kTileCands - s0 / kTileCands + 1u;
+        const uint32_t nt = (s1 - (s0 & ~31u) + kTileCands - 1u) / kTileCands; // windows of 2048 from the group's first lane group on
         const uint32_t kk = (c + item_guides - 1u) / item_guides;
         slots = (c + kGuideGroup - 1u) / kGuideGroup * kGuideGroup;
         units = static_cast<uint64_t>(nt) * kk;
-        items = units; // one item per tile and chunk of guides: the scan finds the item of a unit without a search
+        items = units; // one item per window and chunk of guides: the scan finds the item of a unit without a search
         cost = static_cast<uint64_t>(nt) * (static_cast<uint64_t>(c) + static_cast<uint64_t>(kk) * kTileFixedCost);
         cand = static_cast<uint64_t>(s1 - s0) * c;
     }
@@ -561,7 +561,7 @@ __global__ __launch_bounds__(256) void k_fine_plan(FineSum *__restrict__ fsum, u
         if (fits && plan->error == 0 && (always || est_fine < est_full)) {
             ScanItem end;
             end.bucket = 0; end.g0 = 0; end.g1 = 0; end.n_tiles = 0; end.cost0 = t_cost;
-            end.tile0 = static_cast<uint32_t>(t_units); end.last_cands = 0; end.tile_abs = 0; end.window = 0;
+            end.tile0 = static_cast<uint32_t>(t_units); end.last_cands = 0; end.group_abs = 0; end.window = 0;
             fitems[t_items] = end;
             plan->n_items = static_cast<uint32_t>(t_items);
             plan->total_cost = t_cost;
@@ -595,7 +595,7 @@ __global__ __launch_bounds__(256) void k_fine_scatter(ImageView v, const uint64_
     uint64_t cost = 0, slots = 0, items = 0, units = 0;
     uint32_t nt = 0, kk = 0;
     if (c) { // (fcount is zero where the group has no candidates)
-        nt = (s1 - 1u) / kTileCands - s0 / kTileCands + 1u;
+        nt = (s1 - (s0 & ~31u) + kTileCands - 1u) / kTileCands;
         kk = (c + item_guides - 1u) / item_guides;
         slots = (c + kGuideGroup - 1u) / kGuideGroup * kGuideGroup;
         units = static_cast<uint64_t>(nt) * kk;
@@ -611,11 +611,12 @@ __global__ __launch_bounds__(256) void k_fine_scatter(ImageView v, const uint64_
     cursor[w] = 0;
     if (c) {
         const uint64_t blen = v.bucket_start[b + 1] - v.bucket_start[b];
-        const uint32_t t_first = s0 / kTileCands, t_last = (s1 - 1u) / kTileCands;
+        const uint32_t s0a = s0 & ~31u; // a window starts on a lane group (32 candidates), not on a tile
         for (uint32_t done = 0; done < c; done += item_guides) {
             const uint32_t len = (c - done < item_guides) ? c - done : item_guides;
-            for (uint32_t t = t_first; t <= t_last; ++t) { // single-tile items: item index == unit number
-                const uint64_t after = blen - static_cast<uint64_t>(t) * kTileCands; // candidates of the bucket from this tile on
+            for (uint32_t t = 0; t < nt; ++t) { // single-window items: item index == unit number
+                const uint32_t wstart = s0a + t * kTileCands;                 // position in the bucket
+                const uint64_t after = blen - wstart;                         // candidates of the bucket from there on
                 ScanItem it;
                 it.bucket = (b << 8) | w;
                 it.g0 = slot_at + done; // item_guides is a multiple of 8
@@ -624,8 +625,8 @@ __global__ __launch_bounds__(256) void k_fine_scatter(ImageView v, const uint64_
                 it.cost0 = cost_at;
                 it.tile0 = item_at;
                 it.last_cands = after < kTileCands ? static_cast<uint32_t>(after) : kTileCands;
-                it.tile_abs = v.tile_first[b] + t;
-                it.window = (t == t_first ? s0 % kTileCands : 0u) | ((t == t_last ? (s1 - 1u) % kTileCands + 1u : kTileCands) << 16);
+                it.group_abs = v.tile_first[b] * 64u + (wstart >> 5);
+                it.window = (t == 0 ? s0 - s0a : 0u) | ((s1 - wstart < kTileCands ? s1 - wstart : kTileCands) << 16);
                 fitems[item_at++] = it;
                 cost_at += len + kTileFixedCost;
             }
@@ -824,8 +825,9 @@ __device__ __forceinline__ uint32_t near_plane(const uint32_t (&c)[kPlanes], uin
 }
 
 // Cold block of the scan: the wave knows that SOME lane has a candidate within thr of the guide in slot
-// gslot.  `ok` = this lane's plane of such candidates; candidate bit j of lane l sits at tile offset 32 l + j.
-__device__ __forceinline__ void note_candidates(uint32_t ok, uint32_t gslot, uint32_t tile, uint32_t lane,
+// gslot.  `ok` = this lane's plane of such candidates; candidate bit j of the lane sits at offset 32 grp + j of `tile`
+// (the lane's own: a window of the pruned scan straddles two tiles).
+__device__ __forceinline__ void note_candidates(uint32_t ok, uint32_t gslot, uint32_t tile, uint32_t grp, uint32_t lane,
                                                 RawWriter &w, uint64_t *raw, uint32_t max_chunks, Counters *counters)
 {
     while (true) {
@@ -842,7 +844,7 @@ __device__ __forceinline__ void note_candidates(uint32_t ok, uint32_t gslot, uin
             ok &= ok - 1u;
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(who >> 32),
                                                             __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(who), 0u));
-            w.chunk[w.fill + rank] = raw_record(gslot, tile, lane * 32u + j);
+            w.chunk[w.fill + rank] = raw_record(gslot, tile, grp * 32u + j);
         }
         w.fill += n;
     }
@@ -871,7 +873,7 @@ __device__ __forceinline__ void scan_range(const uint32_t *__restrict__ scan_str
                                            Counters *counters, uint32_t thr, unsigned long long *stamps,
                                            uint64_t *__restrict__ scan_count, uint32_t *next_unit_p, uint32_t *waves_done_p,
                                            unsigned long long *wg_compared_p, unsigned long long t_start,
-                                           unsigned long long *span)
+                                           unsigned long long *span, uint32_t n_tiles)
 {
     uint32_t &next_unit = *next_unit_p;
     uint32_t &waves_done = *waves_done_p;
@@ -914,15 +916,26 @@ __device__ __forceinline__ void scan_range(const uint32_t *__restrict__ scan_str
         const uint32_t g_end = (gt == tile_last) ? cur.g0 + last.goff : cur.g1;
 
         // ---- one tile: 2048 candidates, tile k of the item, guide slots [g_begin, g_end) -----------
-        const uint32_t tile = cur.tile_abs + k;
-        // comparisons made here: the tile's real candidates (only a bucket's last tile is padded) x the real guides
+        // The unit: 2048 consecutive candidates of the bucket from lane group cur.group_abs + 64 k on; lane l takes the
+        // 32 of group (first + l).  Bucket-level items start on a tile; a window of the pruned scan may start on any lane
+        // group and then straddles two tiles -- the same eight 16-byte loads per lane, from two places.  (A window at the
+        // very end of the stream would reach past it: those lanes read the last tile instead, and `keep` hides them.)
+        const uint32_t glane = cur.group_abs + (k << 6) + lane;
+        uint32_t tile = glane >> 6, grp = glane & 63u;
+        if (fine) {
+            if (tile >= n_tiles) tile = n_tiles - 1u;
+        } else {
+            tile = __builtin_amdgcn_readfirstlane(tile); // (whole tiles: uniform)
+            grp = lane;
+        }
+        // comparisons made here: the unit's real candidates (only a bucket's last one is short) x the real guides
         compared += static_cast<unsigned long long>((k + 1u == cur.n_tiles) ? cur.last_cands : kTileCands) * (g_end - g_begin);
         const uint4 *__restrict__ src =
-            reinterpret_cast<const uint4 *>(scan_stream + static_cast<uint64_t>(tile) * kTileCands);
+            reinterpret_cast<const uint4 *>(scan_stream + static_cast<uint64_t>(tile) * kTileCands) + grp;
         uint32_t c[kPlanes];
 #pragma unroll
         for (int q = 0; q < kPlanes / 4; ++q) {
-            const uint4 t4 = src[q * 64 + lane];
+            const uint4 t4 = src[q * 64];
             c[4 * q + 0] = t4.x; c[4 * q + 1] = t4.y; c[4 * q + 2] = t4.z; c[4 * q + 3] = t4.w;
         }
         // the lane's candidates that are the item's: offsets [lo, hi) of the tile
@@ -945,7 +958,7 @@ __device__ __forceinline__ void scan_range(const uint32_t *__restrict__ scan_str
                 if (g + uu >= g_end) break; // padding slots of the bucket's last group (scalar test, not taken: free)
                 const uint32_t ok = near_plane<THR>(c, gg.w[uu], thr, keep);
                 if (__ballot(ok != 0u) != 0ull) { // ~4 % of the (guide, tile) pairs on random data
-                    note_candidates(ok, g + uu, tile, lane, w, raw, max_chunks, counters);
+                    note_candidates(ok, g + uu, tile, grp, lane, w, raw, max_chunks, counters);
                     own_chunk = true;
                 }
             }
@@ -982,7 +995,7 @@ __global__ __launch_bounds__(1024, 8) void k_scan(const uint32_t *__restrict__ s
                                                   const uint32_t *__restrict__ gword_fine, uint64_t *raw,
                                                   uint32_t max_chunks, Counters *counters, uint32_t thr,
                                                   unsigned long long *stamps, uint64_t *__restrict__ scan_count,
-                                                  unsigned long long *span)
+                                                  unsigned long long *span, uint32_t n_tiles)
 {
     __shared__ uint32_t next_unit;
     __shared__ uint32_t waves_done;
@@ -1000,10 +1013,10 @@ __global__ __launch_bounds__(1024, 8) void k_scan(const uint32_t *__restrict__ s
     // the plan of this batch: bucket-level items, or the successor-byte groups of the pruned scan (k_fine_plan)
     if (plan->fine != 0u)
         scan_range<THR, true>(scan_stream, items_fine, plan, range_start, gword_fine, raw, max_chunks, counters, thr, stamps,
-                              scan_count, &next_unit, &waves_done, &wg_compared, t_start, span);
+                              scan_count, &next_unit, &waves_done, &wg_compared, t_start, span, n_tiles);
     else
         scan_range<THR, false>(scan_stream, items_full, plan, range_start, gword_full, raw, max_chunks, counters, thr, stamps,
-                               scan_count, &next_unit, &waves_done, &wg_compared, t_start, span);
+                               scan_count, &next_unit, &waves_done, &wg_compared, t_start, span, n_tiles);
 }
 
 // precalculatedScores[mask] with operator[] semantics: a missing mask contributes 0.0 (:394).
@@ -1208,7 +1221,7 @@ static void launch_scan_thr(const ImageView &v, const Workspace &ws, const Tunin
     hipLaunchKernelGGL(k_scan<THR>, dim3(tn.scan_blocks), dim3(1024), 0, stream, v.scan, ws.items,
                        prune_mode ? ws.fitems : ws.items, ws.plan, ws.range_start, ws.gword, prune_mode ? ws.fword : ws.gword,
                        ws.raw, static_cast<uint32_t>(ws.cap_chunks), ws.counters, thr, ws.stamps, ws.scan_count,
-                       ws.scan_span + 2u * ws.span_slot);
+                       ws.scan_span + 2u * ws.span_slot, v.n_tiles);
 }
 
 void launch_scan(const ImageView &v, const Workspace &ws, const Tuning &tn, const uint64_t *d_guides, uint32_t n,
