@@ -198,6 +198,9 @@ int issl_index_attach_image_cold(int device, void *dev_buf, size_t bytes, void *
  *     of 256 for max_dist <= 4, 1 of 256 for <= 2; same hits and scores as the reference's scan of the whole bucket,
  *     isslScoreOfftargets.cpp:344): -1 = a planning kernel decides per batch from the two plans' estimated times,
  *     0 = never, 1 = whenever the image is sorted and max_dist <= 4
+ *   lanes (ISSL_LANES) 1|2: workspaces and streams that the batches of issl_score_device_async alternate between
+ *     (default 1).  With 2, the short kernels behind one batch's scan run beside the next batch's scan (+7-11 % guides/s
+ *     for back-to-back batches); outputs of two consecutive batches must then be different buffers
  *   scan_stamps (ISSL_SCAN_STAMPS) file for per-wave clocks (diagnostics) */
 int issl_index_set_option(issl_index *idx, const char *key, const char *value);
 /* Current value of an integer knob; also the read-only keys cold_on_host, has_inline_sigs, is_sorted and dense_mit
