@@ -952,3 +952,58 @@ def test_index_with_entries_in_foreign_buckets_keeps_the_list_order(golden_unifo
     intact = ca.IsslIndex.open(golden_uniform.issl).upload(0)
     assert intact.get_option("is_sorted") == 1
     intact.close()
+
+
+def test_pruned_scan_on_groups_of_many_windows(tmp_path):
+    """Successor-byte groups that are several scan windows long, start in the middle of a tile and share tiles with their
+    neighbours -- at a size the oracle scores in full: 70 k sites, most of them with the same first slice and one of three
+    neighbouring values of the second one.  Hit lists and scores for max_dist 0..4, pruned and whole-bucket scan."""
+    rng = np.random.default_rng(77)
+    a, b = 0x5A, 0xC3
+    centres = rng.integers(0, 1 << 24, size=200, dtype=np.uint64)
+
+    def rest(n):   # the other 12 positions: a centre with up to three substitutions, so that guides have many neighbours
+        r = centres[rng.integers(0, len(centres), size=n)]
+        for _ in range(3):
+            r = r ^ (rng.integers(0, 4, size=n, dtype=np.uint64) << (np.uint64(2) * rng.integers(0, 12, size=n).astype(np.uint64)))
+        return r << np.uint64(16)
+
+    sites = np.concatenate([
+        rest(30_000) | np.uint64(a) | (np.uint64(b) << np.uint64(8)),
+        rest(15_000) | np.uint64(a) | (np.uint64(b ^ 1) << np.uint64(8)),      # neighbouring group, one mismatch away
+        rest(7_000) | np.uint64(a) | (np.uint64(b ^ 0x10) << np.uint64(8)),    # another single-mismatch group
+        rest(5_000) | np.uint64(a) | (np.uint64(b ^ 0x11) << np.uint64(8)),    # two mismatches in the successor byte
+        rng.integers(0, 1 << 40, size=13_000, dtype=np.uint64)])
+    sig = np.unique(sites)
+    sig = sig[np.argsort(text_order_key(sig), kind="stable")]
+    occ = rng.integers(1, 4, size=len(sig)).astype(np.uint32)
+    ix = ca.IsslIndex.build_from_sites(sig, occ)
+    path = tmp_path / "windows.issl"
+    ix.write(path)
+    ix.upload(0)
+    assert ix.get_option("is_sorted") == 1
+    oracle = ou.OracleIndex(path)
+    picks = sig[rng.integers(0, len(sig), size=400)]
+    guides = picks.copy()
+    for k in range(len(guides)):  # 0..4 substitutions anywhere
+        for pos in rng.choice(20, size=int(rng.integers(0, 5)), replace=False):
+            guides[k] ^= np.uint64(int(rng.integers(1, 4)) << (2 * int(pos)))
+    try:
+        for prune in (1, 0):
+            ix.set_option("prune", prune)
+            for dist, thr, method in ((4, 0.0, "and"), (4, 75.0, "and"), (3, 0.0, "or"), (2, 0.0, "mit"), (1, 50.0, "cfd"), (0, 0.0, "avg")):
+                hits = ix.dump_hits(guides, dist, thr, method)
+                st = ix.stats()
+                assert st["pruned"] == (0 if prune == 0 else (1 if dist <= 2 else 2))
+                omit, ocfd, ohits = oracle.score(guides, dist, thr, method, want_hits=True)
+                assert np.array_equal(hits, ohits), (prune, dist, thr, method)
+                if (dist, thr) == (4, 0.0):
+                    assert len(ohits) > 20_000   # (the guides do have neighbours in the big groups)
+                mit, cfd = ix.score(guides, dist, thr, method)
+                assert np.array_equal(mit.view(np.uint64), omit.view(np.uint64)), (prune, dist, thr, method)
+                assert np.array_equal(cfd.view(np.uint64), ocfd.view(np.uint64)), (prune, dist, thr, method)
+            if prune == 1:
+                assert st["scan_tiles"] > 5 * 13   # the big groups are several windows long
+    finally:
+        oracle.close()
+        ix.close()
