@@ -104,10 +104,10 @@ void release(Resident &r)
     r = Resident{};
 }
 
-// A process that scores ONE page and exits pays for the sorted image layout (0.9 ns per site at upload) and earns
-// ~0.5 fs per site and guide from the pruned scan it enables: worth it from ~1.5 M guides up, whatever the index
+// A process that scores ONE page and exits pays for the sorted image layout (0.36 ns per site at upload) and earns
+// ~0.5 fs per site and guide from the pruned scan it enables: worth it from ~0.7 M guides up, whatever the index
 // size.  The resident server keeps its indexes and always builds it.
-constexpr long long kSortedLayoutPaysFromGuides = 1500000;
+constexpr long long kSortedLayoutPaysFromGuides = 750000;
 
 // Open + upload.  Several devices only when ISSL_DEVICES asks for them.  one_shot_guides: guides of the only page this
 // process will score, or -1 (resident server).

@@ -115,7 +115,7 @@ int launch_sort_layout(const uint64_t *d_sites, const uint64_t *d_entries, const
     hipError_t e;
     if ((e = hipMalloc(reinterpret_cast<void **>(&keys), 8 * std::max<uint64_t>(n_sites, 1))) != hipSuccess) return fail(e, "sort keys");
     if ((e = hipMalloc(reinterpret_cast<void **>(&tmp), 8 * std::max<uint64_t>(n_sites, 1))) != hipSuccess) return fail(e, "sort keys");
-    if ((e = hipMalloc(reinterpret_cast<void **>(&d_hist), 4ull * 256 * std::max(n_blocks, 1u))) != hipSuccess) return fail(e, "sort histograms");
+    if ((e = hipMalloc(reinterpret_cast<void **>(&d_hist), 4ull * radix_hist_words(std::max(n_blocks, 1u)))) != hipSuccess) return fail(e, "sort histograms");
     const uint32_t grid = static_cast<uint32_t>(std::min<uint64_t>((n_sites + 255) / 256, 1u << 20));
     const uint32_t per_slice = n_buckets / n_slices;
     if (n_sites == 0) (void)hipMemset(d_sub_start, 0, 4ull * n_buckets * 257);
@@ -125,7 +125,7 @@ int launch_sort_layout(const uint64_t *d_sites, const uint64_t *d_entries, const
         for (uint32_t pass = 0; pass < 2; ++pass) { // successor byte, then own byte
             const uint32_t shift = kKeyShift + 8 * pass;
             hipLaunchKernelGGL(k_radix_hist, dim3(n_blocks), dim3(256), 0, nullptr, src, n_sites, shift, d_hist, n_blocks);
-            hipLaunchKernelGGL(k_radix_scan, dim3(1), dim3(1024), 0, nullptr, d_hist, 256ull * n_blocks);
+            launch_radix_scan(d_hist, n_blocks, nullptr);
             hipLaunchKernelGGL(k_radix_scatter<KeyItself>, dim3(n_blocks), dim3(256), 0, nullptr, src, dst, n_sites, shift, d_hist,
                                n_blocks, KeyItself{});
             std::swap(src, dst);
@@ -162,7 +162,7 @@ int launch_build_entries(const uint64_t *d_sites, const uint32_t *d_occ, uint64_
     }
     const uint32_t n_blocks = static_cast<uint32_t>((n_sites + 256ull * kSortItems - 1) / (256ull * kSortItems));
     uint32_t *d_hist = nullptr;
-    hipError_t e = hipMalloc(reinterpret_cast<void **>(&d_hist), 4ull * 256 * n_blocks);
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&d_hist), 4ull * radix_hist_words(n_blocks));
     if (e != hipSuccess) {
         set_error(std::string("HIP error: ") + hipGetErrorString(e) + " (histograms of the device-side builder)");
         return ISSL_E_DEVICE;
@@ -170,7 +170,7 @@ int launch_build_entries(const uint64_t *d_sites, const uint32_t *d_occ, uint64_
     for (uint32_t s = slice_begin; s < slice_end; ++s) {
         const uint32_t shift = slice_width * s;
         hipLaunchKernelGGL(k_radix_hist, dim3(n_blocks), dim3(256), 0, nullptr, d_sites, n_sites, shift, d_hist, n_blocks);
-        hipLaunchKernelGGL(k_radix_scan, dim3(1), dim3(1024), 0, nullptr, d_hist, 256ull * n_blocks);
+        launch_radix_scan(d_hist, n_blocks, nullptr);
         hipLaunchKernelGGL(k_radix_scatter<SliceEntry>, dim3(n_blocks), dim3(256), 0, nullptr, d_sites,
                            d_entries + static_cast<uint64_t>(s - slice_begin) * n_sites, n_sites, shift, d_hist, n_blocks,
                            SliceEntry{d_occ});

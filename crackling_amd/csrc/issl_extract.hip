@@ -147,11 +147,11 @@ int radix_sort(uint64_t *d_keys, uint64_t *d_tmp, uint64_t n, uint32_t bits)
     if (n < 2) return ISSL_OK;
     const uint32_t n_blocks = static_cast<uint32_t>((n + 256ull * kSortItems - 1) / (256ull * kSortItems));
     uint32_t *d_hist = nullptr;
-    EX_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_hist), 4ull * 256 * n_blocks));
+    EX_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_hist), 4ull * radix_hist_words(n_blocks)));
     uint64_t *src = d_keys, *dst = d_tmp;
     for (uint32_t shift = 0; shift < bits; shift += 8) {
         hipLaunchKernelGGL(k_radix_hist, dim3(n_blocks), dim3(256), 0, nullptr, src, n, shift, d_hist, n_blocks);
-        hipLaunchKernelGGL(k_radix_scan, dim3(1), dim3(1024), 0, nullptr, d_hist, 256ull * n_blocks);
+        launch_radix_scan(d_hist, n_blocks, nullptr);
         hipLaunchKernelGGL(k_radix_scatter<KeyItself>, dim3(n_blocks), dim3(256), 0, nullptr, src, dst, n, shift, d_hist,
                            n_blocks, KeyItself{});
         std::swap(src, dst);
