@@ -24,7 +24,8 @@ groups of its buckets that can hold a hit, ~1/13.5 of the reference's comparison
 denominator (the clock the chip holds under this load is lower, see profiles/); `hbm_frac` = measured HBM bytes of the
 launch / time / 8 TB/s.  The SURVEY 8(d) algorithmic-bytes figure (8 B per comparison of the REFERENCE, no credit for
 reuse or pruning) is kept as `algorithmic_over_hbm_peak`; `extras.whole_bucket_scan` runs the same batch with pruning
-off; `hbm_regime` is the 64-guides-per-step point.
+off; `hbm_regime` is north_star's own point, 10 000 guides per step, where the pruned scan is bound by HBM (two guides
+per group: `hbm_pmc_frac` = PMC-measured bytes of a launch / its time / 8 TB/s).
 `cpu_baseline` times the CPU oracle (oracle/issl_oracle.c, the restatement of the reference's OpenMP scorer) on a
 bounded sample of the same workload -- baseline only, rank 0, N=1.
 """
@@ -51,6 +52,18 @@ TILE_BYTES = 8192           # one scan tile: 2048 candidates x 4 B
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
+
+
+def traffic_point(sites, guides, dist, pruned):
+    """HBM bytes per k_scan launch of this workload from a PMC profile (profiles/scan_traffic.json), or None."""
+    prof = ROOT / "profiles" / "scan_traffic.json"
+    try:
+        for rec in json.loads(prof.read_text()).get("points", []):
+            if (rec.get("sites"), rec.get("guides"), rec.get("distribution"), rec.get("pruned")) == (sites, guides, dist, pruned):
+                return rec.get("hbm_bytes_per_launch")
+    except Exception:  # noqa: BLE001
+        pass
+    return None
 
 
 def host_description():
@@ -340,7 +353,10 @@ def main():
                 dt = time.perf_counter() - t1
                 s2 = index.stats()
                 phys = s2["scan_tiles"] * TILE_BYTES
+                pmc = traffic_point(a.sites, n_small, a.dist, s2["pruned"])
                 extras[label] = {
+                    "hbm_pmc_bytes_per_launch": pmc, "hbm_pmc_frac": (pmc / s2["ms_scan"] / 1e6 / HBM_PEAK_GBS) if pmc else None,
+                    "pruned": s2["pruned"],
                     "guides_per_step": n_small, "steps": reps, "ms_per_step": dt * 1e3 / reps, "guides_per_s": n_small * reps / dt,
                     "scan_ms": s2["ms_scan"], "comparisons_per_launch": s2["candidates"],
                     "scan_Tcmp_per_s": s2["candidates"] / s2["ms_scan"] / 1e9,
@@ -429,7 +445,7 @@ def main():
         if prof.exists():
             try:
                 for rec in json.loads(prof.read_text()).get("points", []):
-                    if (rec.get("sites"), rec.get("guides"), rec.get("distribution")) == (a.sites, n_mine, a.dist):
+                    if (rec.get("sites"), rec.get("guides"), rec.get("distribution"), rec.get("pruned")) == (a.sites, n_mine, a.dist, st["pruned"]):
                         traffic = rec.get("hbm_bytes_per_launch")
                         traffic_src = rec.get("source")
             except Exception:
@@ -486,7 +502,7 @@ def main():
                 "algorithmic_over_hbm_peak": algo_bytes / t_scan / 1e9 / HBM_PEAK_GBS,
                 "hbm_physical_GBps": tile_bytes / t_scan / 1e9,
                 "hbm_physical_frac": tile_bytes / t_scan / 1e9 / HBM_PEAK_GBS,
-                "hbm_regime": extras.get("hbm_regime_64_guides"),
+                "hbm_regime": extras.get("north_star_10k_guides"),
                 "note": "avg_launch_ms is the launch's own span (first workgroup in to last workgroup out, stamped by the kernel "
                         "on the 100 MHz constant clock), avg_launch_ms_events the HIP event pair around the launch on its "
                         "stream; they differ only when a second lane shares the chip (extras.two_lanes).  pruned != 0: every bucket is stored ordered by the byte of the next slice and a guide is compared only "
@@ -497,7 +513,8 @@ def main():
                         "itself; a tile now serves ~20 guides instead of ~400, so tile fetches (hbm_frac, hbm_physical_*) and "
                         "the per-tile set-up share the time with the VALU work.  algorithmic_* is SURVEY 8(d)'s figure (8 B per "
                         "comparison OF THE REFERENCE, no credit for reuse or pruning) and is not a fraction of anything "
-                        "physical; extras.whole_bucket_scan is the same kernel working through whole buckets (frac ~0.76)",
+                        "physical; extras.whole_bucket_scan is the same kernel working through whole buckets (frac ~0.75); hbm_regime is the "
+                        "same kernel at north_star's 10 000 guides per step, where it is HBM-bound (hbm_pmc_frac)",
             },
             "kernel_ms": {"bin": stages["ms_bin"], "scan": stages["ms_scan"], "verify": stages["ms_verify"], "group": stages["ms_group"],
                           "replay": stages["ms_replay"], "pipeline": stages["ms_total"]},

@@ -48,10 +48,15 @@ for name, row in stats.items():
     print(f'{name[:60]:60s} calls={row["Calls"]:>5s} avg_ns={float(row["AverageNs"]):12.0f} pct={row["Percentage"]}')
 if len(sys.argv) >= 6 and "scan_hbm_bytes_per_launch" in summary:
     sites, guides, dist = int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
+    pruned = None  # which plan the profiled launches followed: from the bench line of the kernel-trace pass
+    for line in open(src / "kt.log", errors="replace"):
+        if line.startswith("{"):
+            pruned = json.loads(line).get("roofline", {}).get("pruned")
     path = pathlib.Path(__file__).resolve().parent.parent / "profiles" / "scan_traffic.json"
     rec = json.loads(path.read_text()) if path.exists() else {}
-    points = [p for p in rec.get("points", []) if (p.get("sites"), p.get("guides"), p.get("distribution")) != (sites, guides, dist)]
-    points.append({"sites": sites, "guides": guides, "distribution": dist,
+    points = [p for p in rec.get("points", [])
+              if (p.get("sites"), p.get("guides"), p.get("distribution"), p.get("pruned")) != (sites, guides, dist, pruned)]
+    points.append({"sites": sites, "guides": guides, "distribution": dist, "pruned": pruned,
                    "hbm_bytes_per_launch": summary["scan_hbm_bytes_per_launch"]["total_bytes"],
                    "fetch_corrected_bytes": summary["scan_hbm_bytes_per_launch"]["fetch_corrected_bytes"],
                    "write_bytes": summary["scan_hbm_bytes_per_launch"]["write_bytes"],
