@@ -113,9 +113,17 @@ int launch_sort_layout(const uint64_t *d_sites, const uint64_t *d_entries, const
         return ISSL_E_DEVICE;
     };
     hipError_t e;
-    if ((e = hipMalloc(reinterpret_cast<void **>(&keys), 8 * std::max<uint64_t>(n_sites, 1))) != hipSuccess) return fail(e, "sort keys");
-    if ((e = hipMalloc(reinterpret_cast<void **>(&tmp), 8 * std::max<uint64_t>(n_sites, 1))) != hipSuccess) return fail(e, "sort keys");
-    if ((e = hipMalloc(reinterpret_cast<void **>(&d_hist), 4ull * radix_hist_words(std::max(n_blocks, 1u)))) != hipSuccess) return fail(e, "sort histograms");
+    // (no room for the temporaries after all: the caller uploads the list-order image instead of failing)
+    auto no_room = [&]() {
+        (void)hipGetLastError();
+        if (keys) (void)hipFree(keys);
+        if (tmp) (void)hipFree(tmp);
+        if (d_hist) (void)hipFree(d_hist);
+        return kSortNeedsListOrder;
+    };
+    if (hipMalloc(reinterpret_cast<void **>(&keys), 8 * std::max<uint64_t>(n_sites, 1)) != hipSuccess) { keys = nullptr; return no_room(); }
+    if (hipMalloc(reinterpret_cast<void **>(&tmp), 8 * std::max<uint64_t>(n_sites, 1)) != hipSuccess) { tmp = nullptr; return no_room(); }
+    if (hipMalloc(reinterpret_cast<void **>(&d_hist), 4ull * radix_hist_words(std::max(n_blocks, 1u))) != hipSuccess) { d_hist = nullptr; return no_room(); }
     const uint32_t grid = static_cast<uint32_t>(std::min<uint64_t>((n_sites + 255) / 256, 1u << 20));
     const uint32_t per_slice = n_buckets / n_slices;
     if (n_sites == 0) (void)hipMemset(d_sub_start, 0, 4ull * n_buckets * 257);
