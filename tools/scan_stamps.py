@@ -8,6 +8,9 @@ import sys
 import numpy as np
 
 a = np.fromfile(sys.argv[1], dtype=np.uint64).reshape(-1, 4)
+# the scan waves come first (16 per workgroup, 1024 workgroups unless scan_blocks says otherwise: second argument); the
+# dump also holds the phase clocks of the many-hit replay behind them
+a = a[:int(sys.argv[2]) if len(sys.argv) > 2 else 16384]
 wave = np.arange(len(a))
 live = a[:, 1] > 0
 a, wave = a[live], wave[live]
