@@ -227,11 +227,8 @@ int issl_node_score(issl_node *nd, const uint64_t *guides, size_t n, int max_dis
     // The reference cuts its guide loop statically (OpenMP, isslScoreOfftargets.cpp:316); Crackling emits guides in
     // genome order, so contiguous eighths would give the GPU with the repeat-dense region the longest shard.  The
     // batch is a queue of chunks instead: every device thread takes the next one when it is done with its last
-    // (scores land at the chunk's place in the caller's arrays, so input order is kept).  About three chunks per
-    // device: a chunk has ~1 ms of fixed cost on a 300 M-site index and the pruned scan serves more guides per fetched
-    // window the larger the batch is (8 M guides/s at 10 k guides per batch, 28 M at 100 k), while the queue evens out
-    // chunks that differ by a factor of three.
-    const size_t chunk = std::min<size_t>(262144, std::max<size_t>(16384, (n + world * 3 - 1) / (world * 3)));
+    // (scores land at the chunk's place in the caller's arrays, so input order is kept).
+    const size_t chunk = std::min<size_t>(262144, std::max<size_t>(16384, (n + world * 8 - 1) / (world * 8)));
     std::atomic<size_t> next{0};
     std::atomic<bool> failed{false};
     auto work = [&](size_t r) {
