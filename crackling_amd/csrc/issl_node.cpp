@@ -95,23 +95,29 @@ static int broadcast_image(issl_node *nd, size_t bytes, int *used_rccl)
         ncclResult_t r = g_rccl.CommInitAll(comms.data(), n, nd->devices.data());
         if (r == ncclSuccess) {
             bool ok = true;
+            int n_streams = 0;
             for (int i = 0; i < n && ok; ++i) {
                 ok = hipSetDevice(nd->devices[i]) == hipSuccess && hipStreamCreate(&streams[i]) == hipSuccess;
+                if (ok) n_streams = i + 1;
             }
-            if (ok) {
+            // in pieces of 1 GiB (a 300 M-site image is 61 GB): no collective takes a count beyond 2^31
+            const size_t piece = size_t(1) << 30;
+            for (size_t at = 0; at < bytes && ok; at += piece) {
+                const size_t len = bytes - at < piece ? bytes - at : piece;
                 g_rccl.GroupStart();
                 for (int i = 0; i < n; ++i) {
                     (void)hipSetDevice(nd->devices[i]);
-                    r = g_rccl.Broadcast(nd->images[0], nd->images[i], bytes, ncclUint8, 0, comms[i], streams[i]);
+                    r = g_rccl.Broadcast(static_cast<const uint8_t *>(nd->images[0]) + at, static_cast<uint8_t *>(nd->images[i]) + at, len,
+                                         ncclUint8, 0, comms[i], streams[i]);
                     if (r != ncclSuccess) ok = false;
                 }
                 r = g_rccl.GroupEnd();
                 if (r != ncclSuccess) ok = false;
-                for (int i = 0; i < n; ++i) {
-                    (void)hipSetDevice(nd->devices[i]);
-                    if (hipStreamSynchronize(streams[i]) != hipSuccess) ok = false;
-                    (void)hipStreamDestroy(streams[i]);
-                }
+            }
+            for (int i = 0; i < n_streams; ++i) { // (also after a failure: nothing stays in flight, no stream leaks)
+                (void)hipSetDevice(nd->devices[i]);
+                if (hipStreamSynchronize(streams[i]) != hipSuccess) ok = false;
+                (void)hipStreamDestroy(streams[i]);
             }
             for (int i = 0; i < n; ++i) g_rccl.CommDestroy(comms[i]);
             if (ok) {

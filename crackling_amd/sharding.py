@@ -42,13 +42,15 @@ def shard_size(n, world, rank, chunk=DEFAULT_CHUNK):
     return mine * chunk + (rest if full % world == rank else 0)
 
 
-def broadcast_image(dist, torch, index, device, src=0, index_cls=None):
+def broadcast_image(dist, torch, index, device, src=0, index_cls=None, piece_bytes=1 << 30):
     """Rank `src` holds an IsslIndex (host arrays, or an image already on `device`); every rank ends up with an
     IsslIndex attached to its own copy of the image.  Returns (index, seconds spent in the broadcast proper).
 
     The image travels as ONE uint8 tensor: rank `src` builds it straight into the tensor (host arrays) or copies its
-    device-built image there; the others receive and attach (issl_index_attach_image).  `index_cls` (default
-    IsslIndex) provides attach_tensor(); the CPU tests pass a host-memory stand-in with the same methods."""
+    device-built image there; the others receive and attach (issl_index_attach_image).  The broadcast itself goes in
+    pieces of `piece_bytes` (1 GiB: a 300 M-site image is 61 GB, and no collective has to take a count beyond 2^31).
+    `index_cls` (default IsslIndex) provides attach_tensor(); the CPU tests pass a host-memory stand-in with the same
+    methods."""
     import time
     if index_cls is None:
         from .scorer import IsslIndex as index_cls
@@ -71,7 +73,8 @@ def broadcast_image(dist, torch, index, device, src=0, index_cls=None):
             attach = False
     _sync(torch, device)
     t0 = time.perf_counter()
-    dist.broadcast(image, src)
+    for at in range(0, n, piece_bytes):
+        dist.broadcast(image[at:at + piece_bytes], src)
     _sync(torch, device)
     seconds = time.perf_counter() - t0
     return (index_cls.attach_tensor(image) if attach else index), seconds

@@ -71,7 +71,9 @@ def _worker(rank, world, port, issl, guides_path, out_path, device_built, chunk)
     guides = np.load(guides_path)
     # only rank 0 has the index; everybody else receives the image (same calls as bench.py)
     index = HostImageIndex(open(issl, "rb").read(), device_built=device_built) if rank == 0 else None
-    index, seconds = sharding.broadcast_image(dist, torch, index, torch.device("cpu"), index_cls=HostImageIndex)
+    # (pieces of 1000 bytes: the golden image goes in several hundred broadcasts, like a 61 GB one in 1 GiB pieces)
+    index, seconds = sharding.broadcast_image(dist, torch, index, torch.device("cpu"), index_cls=HostImageIndex,
+                                              piece_bytes=1000 if chunk == 16 else 1 << 30)
     assert seconds >= 0 and index.oracle is not None and not index.closed
     # one batch through score_sharded ...
     mit, cfd = sharding.score_sharded(dist, torch, index.score, guides, chunk=chunk)
