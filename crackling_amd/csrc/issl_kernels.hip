@@ -720,8 +720,12 @@ __device__ __forceinline__ uint64_t raw_record(uint32_t gslot, uint32_t tile, ui
 }
 
 struct RawWriter {
-    uint64_t *chunk; // current chunk of this wave (wave-uniform)
-    uint32_t fill;   // used slots of the current chunk, header included
+    uint64_t *chunk;   // current chunk of this wave (wave-uniform)
+    uint32_t fill;     // used slots of the current chunk, header included
+    uint32_t left;     // further chunks of the wave's current reservation (they follow the current one)
+    uint32_t reserve;  // chunks the next reservation takes: 1, 2, 4 ... 16 -- a wave in a hit-dense bucket fills a chunk
+                       // every few guides, and every reservation is a returning atomic that the wave waits for with all
+                       // its record stores; a wave with few hits never reserves a chunk it does not use
 };
 
 __device__ __forceinline__ void raw_retire(const RawWriter &w, uint32_t lane)
@@ -732,15 +736,25 @@ __device__ __forceinline__ void raw_retire(const RawWriter &w, uint32_t lane)
 __device__ __forceinline__ void raw_acquire(RawWriter &w, uint64_t *raw, uint32_t max_chunks, Counters *counters,
                                             uint32_t lane)
 {
+    w.fill = 1;
+    if (w.left != 0u) { // the next chunk of the reservation: its header was cleared with all the others (k_guide_hist)
+        w.chunk += kChunkRecs;
+        w.left -= 1u;
+        return;
+    }
+    const uint32_t take = w.reserve;
     uint32_t idx = 0;
-    if (lane == 0) idx = atomicAdd(&counters->raw_chunks, 1u);
+    if (lane == 0) idx = atomicAdd(&counters->raw_chunks, take);
     idx = __builtin_amdgcn_readfirstlane(idx);
-    if (idx >= max_chunks) { // buffer exhausted: write into the spare chunk, the host grows the buffer and re-runs
+    if (idx + take > max_chunks) { // buffer exhausted: write into the spare chunk, the host grows the buffer and re-runs
         idx = max_chunks;
         if (lane == 0) counters->raw_overflow = 1u;
+        w.chunk = raw + static_cast<uint64_t>(idx) * kChunkRecs;
+        return; // (left stays 0: every further chunk comes here again)
     }
     w.chunk = raw + static_cast<uint64_t>(idx) * kChunkRecs;
-    w.fill = 1;
+    w.left = take - 1u;
+    if (take < 16u) w.reserve = take * 2u;
 }
 
 // ---- bit-sliced distance test -------------------------------------------------------------------
@@ -888,6 +902,8 @@ __device__ __forceinline__ void scan_range(const uint32_t *__restrict__ scan_str
     const bool no_own_chunk = wave_id >= max_chunks; // buffer smaller than the wave count: spare chunk + overflow flag
     w.chunk = raw + static_cast<uint64_t>(no_own_chunk ? max_chunks : wave_id) * kChunkRecs;
     w.fill = 1;
+    w.left = 0;
+    w.reserve = 1;
     bool own_chunk = false;
     unsigned long long compared = 0ull; // (real candidate, real guide) pairs this wave has compared; wave-uniform
 
