@@ -330,7 +330,7 @@ static int ensure_workspace(issl_index *ix, size_t n, Lane &lane)
     if (w.cap_chunks == 0) {
         // every scan wave may hold one partly filled chunk; beyond that ~1 record per 50k comparisons.
         // raw_chunks knob: start with a small raw buffer (tests of the grow-and-rerun path)
-        const size_t want = tn.raw_chunks ? tn.raw_chunks : std::max<size_t>(size_t(scan_waves(tn)) * 4, n);
+        const size_t want = tn.raw_chunks ? tn.raw_chunks : std::max<size_t>(size_t(scan_waves(tn)) * 6, n);
         if ((rc = ensure_raw_capacity(w, want))) return rc;
     }
     if (!ix->have_events) {
@@ -1339,7 +1339,8 @@ int issl_score(issl_index *idx, const uint64_t *guides, size_t n, int max_dist, 
         if (rc) return rc;
         if (presize) {
             const double slots = std::min(static_cast<double>(cand) * records_per_comparison, budget_slots);
-            rc = ensure_raw_capacity(ws, static_cast<size_t>(slots / (kChunkRecs - 1)) + size_t(scan_waves(idx->tuning)) * 2);
+            // (+ every scan wave's own first chunk and the unused tail of its last reservation of up to 16)
+            rc = ensure_raw_capacity(ws, static_cast<size_t>(slots / (kChunkRecs - 1)) + size_t(scan_waves(idx->tuning)) * 10);
             if (rc) return rc;
         }
         HIP_TRY(hipMemcpy(ws.d_guides, guides + at, 8 * cnt, hipMemcpyHostToDevice));
