@@ -26,51 +26,67 @@ struct SliceEntry {
     __device__ uint64_t operator()(uint64_t, uint64_t i) const { return (static_cast<uint64_t>(occ[i]) << 32) | i; }
 };
 
-// ---- sorted layout: every bucket's candidates ordered by the byte of the successor slice -------------------------
+// ---- sorted layouts: every bucket's candidates ordered by the byte of the successor slice ------------------------
 // One slice at a time (16 B per site of temporary memory): key = (slice << 16 | own byte << 8 | successor byte) << 40 |
 // index of the list entry.  A slice's lists are already grouped by own byte; two stable 8-bit passes (successor byte,
 // own byte) leave them grouped and order every bucket by successor byte, ties in list order.
 constexpr uint32_t kKeyShift = 40;
 
-__global__ __launch_bounds__(256) void k_sort_keys(const uint64_t *__restrict__ sites, const uint64_t *__restrict__ entries,
-                                                   uint64_t n_sites, uint32_t n_slices, uint32_t slice,
-                                                   uint64_t *__restrict__ keys, uint32_t *__restrict__ flag)
+__global__ __launch_bounds__(256) void k_sort_keys(const uint64_t *__restrict__ sites, const uint64_t *__restrict__ list,
+                                                   const uint64_t *__restrict__ bucket_start, uint64_t n_sites,
+                                                   uint32_t n_slices, uint32_t slice, uint64_t *__restrict__ keys,
+                                                   uint32_t *__restrict__ flag)
 {
     const uint64_t e0 = static_cast<uint64_t>(slice) * n_sites; // every slice lists every site once
     for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x; i < n_sites; i += static_cast<uint64_t>(gridDim.x) * 256) {
         const uint64_t e = e0 + i;
-        const uint64_t id = entries[e] & 0xFFFFFFFFull;
+        const uint64_t id = list[i] & 0xFFFFFFFFull;
         if (id >= n_sites) atomicOr(flag, 1u); // reported as a format error, like the pack kernel does
         const uint64_t sig = id < n_sites ? sites[id] : 0ull;
         const uint32_t own = static_cast<uint32_t>(sig >> (8u * slice)) & 0xFFu;
         const uint32_t succ = static_cast<uint32_t>(sig >> (8u * ((slice + 1u) % n_slices))) & 0xFFu;
         keys[i] = (static_cast<uint64_t>((slice << 16) | (own << 8) | succ) << kKeyShift) | e;
+        // The scoring order of the sorted layouts is (slice, site id): every list must be ascending by id, as the builder
+        // writes it (isslCreateIndex.cpp:218-234).  (An entry in the wrong bucket is k_fill_maps' to flag.)
+        if (i > 0 && e > bucket_start[(slice << 8) | own]) {
+            const uint64_t before = list[i - 1] & 0xFFFFFFFFull;
+            if (before == id) atomicOr(flag, 4u);     // the same site twice: not an index
+            else if (before > id) atomicOr(flag, 2u); // valid, but only in list order
+        }
     }
 }
 
 __global__ __launch_bounds__(256) void k_fill_maps(const uint64_t *__restrict__ keys, const uint64_t *__restrict__ bucket_start,
-                                                   const uint64_t *__restrict__ entries, uint64_t n_sites, uint32_t slice,
+                                                   const uint64_t *__restrict__ list, uint64_t n_sites, uint32_t slice,
                                                    const uint64_t *__restrict__ sites, StreamRec *__restrict__ srec,
-                                                   uint32_t *__restrict__ pos_of, uint32_t *__restrict__ flag)
+                                                   uint32_t *__restrict__ sid, uint32_t *__restrict__ site_occ,
+                                                   uint32_t *__restrict__ flag)
 {
     const uint64_t t0 = static_cast<uint64_t>(slice) * n_sites;
     for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x; i < n_sites; i += static_cast<uint64_t>(gridDim.x) * 256) {
         const uint64_t key = keys[i];
         const uint64_t e = key & ((1ull << kKeyShift) - 1ull);
         const uint32_t bucket = static_cast<uint32_t>(key >> (kKeyShift + 8)); // slice << 8 | own byte
-        // An entry listed in a bucket its signature does not belong to (the reference does not care: it compares whole
-        // signatures, isslScoreOfftargets.cpp:376) breaks the premise that the sort leaves every bucket in place.
-        if (e < bucket_start[bucket] || e >= bucket_start[bucket + 1]) { atomicOr(flag, 2u); continue; }
+        // An entry listed in a bucket its signature does not belong to: not an index (see k_pack_scan_stream).
+        if (e < bucket_start[bucket] || e >= bucket_start[bucket + 1]) { atomicOr(flag, 4u); continue; }
         const uint32_t p = static_cast<uint32_t>(e - bucket_start[bucket]);
-        const uint64_t entry = entries[e];
+        const uint64_t entry = list[e - t0];
         const uint32_t id = static_cast<uint32_t>(entry & 0xFFFFFFFFull);
         if (id >= n_sites) continue; // flagged by k_sort_keys: the upload fails with a format error
         const uint64_t occ = entry >> 32;
-        StreamRec r; // t0 + i = bucket_start[bucket] + stream position inside the bucket: the buckets keep their places
-        r.sig = (sites[id] & ((1ull << 40) - 1ull)) | ((occ < kOccSaturated ? occ : kOccSaturated) << 40);
-        r.id = id; r.pos = p;
-        srec[t0 + i] = r;
-        pos_of[t0 + id] = p;
+        // one count per site: the reference takes the count of the entry it meets first (:348); an index whose lists
+        // disagree about a site keeps its list-order layout
+        if (slice == 0) site_occ[id] = static_cast<uint32_t>(occ);
+        else if (site_occ[id] != static_cast<uint32_t>(occ)) atomicOr(flag, 2u);
+        // t0 + i = bucket_start[bucket] + stream position inside the bucket: the buckets keep their places
+        if (srec) {
+            StreamRec r;
+            r.sig = (sites[id] & ((1ull << 40) - 1ull)) | ((occ < kOccSaturated ? occ : kOccSaturated) << 40);
+            r.id = id; r.pos = p;
+            srec[t0 + i] = r;
+        } else {
+            sid[t0 + i] = id;
+        }
     }
 }
 
@@ -94,64 +110,82 @@ __global__ __launch_bounds__(256) void k_sub_start(const uint64_t *__restrict__ 
 
 } // namespace
 
-int launch_sort_layout(const uint64_t *d_sites, const uint64_t *d_entries, const uint64_t *d_bucket_start, uint64_t n_sites,
-                       uint32_t n_slices, uint32_t n_buckets, uint32_t *d_sub_start, StreamRec *d_srec, uint32_t *d_pos_of,
-                       uint32_t *d_flag)
+int SortTemp::alloc(uint64_t n_sites)
 {
-    if (n_slices == 0 || n_slices > 8 || n_buckets % n_slices != 0 || n_sites >= (1ull << 32)) {
-        set_error("the sorted layout handles up to 8 slices of up to 2^32 - 1 sites");
+    release();
+    const uint32_t n_blocks = static_cast<uint32_t>((n_sites + 256ull * kSortItems - 1) / (256ull * kSortItems));
+    if (hipMalloc(reinterpret_cast<void **>(&keys), 8 * std::max<uint64_t>(n_sites, 1)) != hipSuccess) keys = nullptr;
+    if (keys && hipMalloc(reinterpret_cast<void **>(&tmp), 8 * std::max<uint64_t>(n_sites, 1)) != hipSuccess) tmp = nullptr;
+    if (tmp && hipMalloc(reinterpret_cast<void **>(&hist), 4ull * radix_hist_words(std::max(n_blocks, 1u))) != hipSuccess) hist = nullptr;
+    if (!hist) {
+        (void)hipGetLastError();
+        release();
+        return kSortNoRoom;
+    }
+    return ISSL_OK;
+}
+
+void SortTemp::release()
+{
+    if (keys) (void)hipFree(keys);
+    if (tmp) (void)hipFree(tmp);
+    if (hist) (void)hipFree(hist);
+    keys = tmp = nullptr;
+    hist = nullptr;
+}
+
+int launch_sort_slice(SortTemp &t, const uint64_t *d_sites, const uint64_t *d_list, const uint64_t *d_bucket_start,
+                      uint64_t n_sites, uint32_t n_slices, uint32_t n_buckets, uint32_t slice, uint32_t *d_sub_start,
+                      StreamRec *d_srec, uint32_t *d_sid, uint32_t *d_site_occ, uint32_t *d_flag)
+{
+    if (n_slices == 0 || n_slices > 8 || n_buckets != n_slices * 256u || n_sites >= (1ull << 32) || slice >= n_slices) {
+        set_error("the sorted layout handles up to 8 slices of 8 bits and up to 2^32 - 1 sites");
         return ISSL_E_UNSUPPORTED;
     }
-    uint64_t *keys = nullptr, *tmp = nullptr;
-    uint32_t *d_hist = nullptr;
-    const uint32_t n_blocks = static_cast<uint32_t>((n_sites + 256ull * kSortItems - 1) / (256ull * kSortItems));
-    auto fail = [&](hipError_t e, const char *what) {
-        set_error(std::string("HIP error: ") + hipGetErrorString(e) + " (" + what + ")");
-        if (keys) (void)hipFree(keys);
-        if (tmp) (void)hipFree(tmp);
-        if (d_hist) (void)hipFree(d_hist);
-        return ISSL_E_DEVICE;
-    };
-    hipError_t e;
-    // (no room for the temporaries after all: the caller uploads the list-order image instead of failing)
-    auto no_room = [&]() {
-        (void)hipGetLastError();
-        if (keys) (void)hipFree(keys);
-        if (tmp) (void)hipFree(tmp);
-        if (d_hist) (void)hipFree(d_hist);
-        return kSortNeedsListOrder;
-    };
-    if (hipMalloc(reinterpret_cast<void **>(&keys), 8 * std::max<uint64_t>(n_sites, 1)) != hipSuccess) { keys = nullptr; return no_room(); }
-    if (hipMalloc(reinterpret_cast<void **>(&tmp), 8 * std::max<uint64_t>(n_sites, 1)) != hipSuccess) { tmp = nullptr; return no_room(); }
-    if (hipMalloc(reinterpret_cast<void **>(&d_hist), 4ull * radix_hist_words(std::max(n_blocks, 1u))) != hipSuccess) { d_hist = nullptr; return no_room(); }
-    const uint32_t grid = static_cast<uint32_t>(std::min<uint64_t>((n_sites + 255) / 256, 1u << 20));
     const uint32_t per_slice = n_buckets / n_slices;
-    if (n_sites == 0) (void)hipMemset(d_sub_start, 0, 4ull * n_buckets * 257);
-    for (uint32_t slice = 0; slice < n_slices && n_sites; ++slice) {
-        hipLaunchKernelGGL(k_sort_keys, dim3(grid), dim3(256), 0, nullptr, d_sites, d_entries, n_sites, n_slices, slice, keys, d_flag);
-        uint64_t *src = keys, *dst = tmp;
-        for (uint32_t pass = 0; pass < 2; ++pass) { // successor byte, then own byte
-            const uint32_t shift = kKeyShift + 8 * pass;
-            hipLaunchKernelGGL(k_radix_hist, dim3(n_blocks), dim3(256), 0, nullptr, src, n_sites, shift, d_hist, n_blocks);
-            launch_radix_scan(d_hist, n_blocks, nullptr);
-            hipLaunchKernelGGL(k_radix_scatter<KeyItself>, dim3(n_blocks), dim3(256), 0, nullptr, src, dst, n_sites, shift, d_hist,
-                               n_blocks, KeyItself{});
-            std::swap(src, dst);
-        }
-        hipLaunchKernelGGL(k_fill_maps, dim3(grid), dim3(256), 0, nullptr, src, d_bucket_start, d_entries, n_sites, slice, d_sites,
-                           d_srec, d_pos_of, d_flag);
-        hipLaunchKernelGGL(k_sub_start, dim3((per_slice * 257u + 255u) / 256u), dim3(256), 0, nullptr, src, d_bucket_start,
-                           n_sites, slice, per_slice, d_sub_start);
+    if (n_sites == 0) {
+        (void)hipMemsetAsync(d_sub_start + static_cast<uint64_t>(slice) * per_slice * 257u, 0, 4ull * per_slice * 257u, nullptr);
+        return ISSL_OK;
     }
-    e = hipDeviceSynchronize();
-    if (e != hipSuccess) return fail(e, "sorted layout");
-    (void)hipFree(keys);
-    (void)hipFree(tmp);
-    (void)hipFree(d_hist);
+    const uint32_t n_blocks = static_cast<uint32_t>((n_sites + 256ull * kSortItems - 1) / (256ull * kSortItems));
+    const uint32_t grid = static_cast<uint32_t>(std::min<uint64_t>((n_sites + 255) / 256, 1u << 20));
+    hipLaunchKernelGGL(k_sort_keys, dim3(grid), dim3(256), 0, nullptr, d_sites, d_list, d_bucket_start, n_sites, n_slices, slice,
+                       t.keys, d_flag);
+    uint64_t *src = t.keys, *dst = t.tmp;
+    for (uint32_t pass = 0; pass < 2; ++pass) { // successor byte, then own byte
+        const uint32_t shift = kKeyShift + 8 * pass;
+        hipLaunchKernelGGL(k_radix_hist, dim3(n_blocks), dim3(256), 0, nullptr, src, n_sites, shift, t.hist, n_blocks);
+        launch_radix_scan(t.hist, n_blocks, nullptr);
+        hipLaunchKernelGGL(k_radix_scatter<KeyItself>, dim3(n_blocks), dim3(256), 0, nullptr, src, dst, n_sites, shift, t.hist,
+                           n_blocks, KeyItself{});
+        std::swap(src, dst);
+    }
+    hipLaunchKernelGGL(k_fill_maps, dim3(grid), dim3(256), 0, nullptr, src, d_bucket_start, d_list, n_sites, slice, d_sites,
+                       d_srec, d_sid, d_site_occ, d_flag);
+    hipLaunchKernelGGL(k_sub_start, dim3((per_slice * 257u + 255u) / 256u), dim3(256), 0, nullptr, src, d_bucket_start,
+                       n_sites, slice, per_slice, d_sub_start);
+    if (hipGetLastError() != hipSuccess) {
+        set_error("HIP error launching the sorted-layout kernels");
+        return ISSL_E_DEVICE;
+    }
+    return ISSL_OK;
+}
+
+int finish_sort(uint32_t *d_flag)
+{
+    hipError_t e = hipDeviceSynchronize();
     uint32_t flags = 0;
-    if ((e = hipMemcpy(&flags, d_flag, 4, hipMemcpyDeviceToHost)) != hipSuccess) return fail(e, "sorted layout");
+    if (e == hipSuccess) e = hipMemcpy(&flags, d_flag, 4, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) {
+        set_error(std::string("HIP error: ") + hipGetErrorString(e) + " (sorted layout)");
+        return ISSL_E_DEVICE;
+    }
     if (flags & 1u) {
         set_error("Error reading index: a slice entry refers to an off-target id beyond the site table");
+        return ISSL_E_FORMAT;
+    }
+    if (flags & 4u) {
+        set_error("Error reading index: a slice list holds an off-target in a bucket its signature does not select, or twice");
         return ISSL_E_FORMAT;
     }
     if (flags & 2u) { // cleared for the pack kernel, which shares the flag word

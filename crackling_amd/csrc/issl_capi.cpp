@@ -24,7 +24,7 @@ namespace issl {
 static uint64_t align256(uint64_t x) { return (x + 255ull) & ~255ull; }
 
 void layout_image(ImageHeader &h, const Geometry &g, uint64_t n_scores_unique, uint64_t n_tiles, bool dense_mit,
-                  bool inline_sigs, bool cold_on_host, bool sorted)
+                  const LayoutSpec &spec)
 {
     std::memset(&h, 0, sizeof h);
     h.magic = kImageMagic;
@@ -41,29 +41,26 @@ void layout_image(ImageHeader &h, const Geometry &g, uint64_t n_scores_unique, u
     h.n_tiles = n_tiles;
     h.tile_cands = kTileCands;
     const uint64_t sites_b = align256(8 * g.n_sites), lists_b = align256(8 * g.n_sites * g.n_slices);
-    uint64_t off = kHeaderBytes;
+    const bool esig = spec.inline_sigs && spec.cold == 0 && spec.sorted == 0; // in-list signatures: list-order layouts in HBM
+    uint64_t off = kHeaderBytes, cold_off = 0;
     h.off_bucket_start = off; off = align256(off + 8 * (h.n_buckets + 1));
     h.off_tile_first = off;   off = align256(off + 4 * (h.n_buckets + 1));
     h.off_score_mask = off;   off = align256(off + 8 * n_scores_unique);
     h.off_score_val = off;    off = align256(off + 8 * n_scores_unique);
     if (dense_mit) { h.off_mit_dense = off; off = align256(off + 8ull * (1u << 20)); }
-    if (cold_on_host) { // the cold sections form a buffer of their own (pinned host memory); no in-list signatures there
-        h.cold_on_host = 1;
-        h.off_sites = 0;
-        h.off_entries = sites_b;
-        h.cold_bytes = sites_b + lists_b;
-    } else {
-        h.off_sites = off;    off += sites_b;
-        h.off_entries = off;  off += lists_b;
-        h.cold_bytes = sites_b + lists_b + (inline_sigs ? lists_b : 0);
-    }
+    h.cold_on_host = spec.cold;
+    // the cold sections form a buffer of their own (pinned host memory): site table first, then the slice lists
+    if (spec.cold & 2u) { h.off_sites = cold_off; cold_off += sites_b; } else { h.off_sites = off; off += sites_b; }
+    if (spec.cold & 1u) { h.off_entries = cold_off; cold_off += lists_b; } else { h.off_entries = off; off += lists_b; }
+    h.cold_bytes = spec.cold ? cold_off : sites_b + lists_b + (esig ? lists_b : 0);
     h.off_scan = off;         off = align256(off + 4ull * kTileCands * n_tiles);
-    if (inline_sigs && !cold_on_host) { h.off_esig = off; off += lists_b; }
-    if (cold_on_host) { h.off_occ8 = off; off = align256(off + g.n_sites * g.n_slices); }
-    if (sorted && !cold_on_host) {
+    if (esig) { h.off_esig = off; off += lists_b; }
+    if (spec.cold == 3u) { h.off_occ8 = off; off = align256(off + g.n_sites * g.n_slices); }
+    if (spec.sorted) {
         h.off_sub_start = off; off = align256(off + 4 * h.n_buckets * 257);
-        h.off_srec = off;      off = align256(off + sizeof(StreamRec) * g.n_sites * g.n_slices);
-        h.off_pos_of = off;    off = align256(off + 4 * g.n_sites * g.n_slices);
+        if (spec.sorted == 1) { h.off_srec = off; off = align256(off + sizeof(StreamRec) * g.n_sites * g.n_slices); }
+        else                  { h.off_sid = off;  off = align256(off + 4 * g.n_sites * g.n_slices); }
+        h.off_site_occ = off; off = align256(off + 4 * g.n_sites);
     }
     h.total_bytes = off;
 }
@@ -71,20 +68,21 @@ void layout_image(ImageHeader &h, const Geometry &g, uint64_t n_scores_unique, u
 ImageView make_view(const ImageHeader &h, void *base, void *cold)
 {
     uint8_t *p = static_cast<uint8_t *>(base);
-    uint8_t *c = h.cold_on_host ? static_cast<uint8_t *>(cold) : p;
+    uint8_t *c = static_cast<uint8_t *>(cold);
     ImageView v;
     v.bucket_start = reinterpret_cast<const uint64_t *>(p + h.off_bucket_start);
     v.tile_first = reinterpret_cast<const uint32_t *>(p + h.off_tile_first);
     v.score_mask = reinterpret_cast<const uint64_t *>(p + h.off_score_mask);
     v.score_val = reinterpret_cast<const double *>(p + h.off_score_val);
     v.mit_dense = h.off_mit_dense ? reinterpret_cast<const double *>(p + h.off_mit_dense) : nullptr;
-    v.sites = reinterpret_cast<const uint64_t *>(c + h.off_sites);
-    v.entries = reinterpret_cast<const uint64_t *>(c + h.off_entries);
+    v.sites = reinterpret_cast<const uint64_t *>(((h.cold_on_host & 2u) ? c : p) + h.off_sites);
+    v.entries = reinterpret_cast<const uint64_t *>(((h.cold_on_host & 1u) ? c : p) + h.off_entries);
     v.esig = h.off_esig ? reinterpret_cast<const uint64_t *>(p + h.off_esig) : nullptr;
     v.occ8 = h.off_occ8 ? reinterpret_cast<const uint8_t *>(p + h.off_occ8) : nullptr;
     v.sub_start = h.off_sub_start ? reinterpret_cast<const uint32_t *>(p + h.off_sub_start) : nullptr;
     v.srec = h.off_srec ? reinterpret_cast<const StreamRec *>(p + h.off_srec) : nullptr;
-    v.pos_of = h.off_pos_of ? reinterpret_cast<const uint32_t *>(p + h.off_pos_of) : nullptr;
+    v.sid = h.off_sid ? reinterpret_cast<const uint32_t *>(p + h.off_sid) : nullptr;
+    v.site_occ = h.off_site_occ ? reinterpret_cast<const uint32_t *>(p + h.off_site_occ) : nullptr;
     v.scan = reinterpret_cast<const uint32_t *>(p + h.off_scan);
     v.n_sites = h.n_sites;
     v.n_buckets = static_cast<uint32_t>(h.n_buckets);
@@ -109,6 +107,7 @@ Tuning Tuning::from_env()
     t.inline_sigs = -1;
     t.host_cold = -1;
     t.sorted_layout = -1;
+    t.compact = -1;
     t.prune = -1;
     t.lanes = 1;
     static const char *const keys[][2] = {
@@ -116,6 +115,7 @@ Tuning Tuning::from_env()
         {"ISSL_SCAN_GENERIC", "scan_generic"}, {"ISSL_STAGE_TIMING", "stage_timing"}, {"ISSL_RAW_CHUNKS", "raw_chunks"},
         {"ISSL_INLINE_SIGS", "inline_sigs"}, {"ISSL_FORCE_HOST_COLD", "host_cold"}, {"ISSL_SCAN_STAMPS", "scan_stamps"},
         {"ISSL_SORTED_LAYOUT", "sorted_layout"}, {"ISSL_PRUNE", "prune"}, {"ISSL_LANES", "lanes"},
+        {"ISSL_COMPACT", "compact"},
     };
     for (const auto &k : keys)
         if (const char *e = std::getenv(k[0])) (void)t.set(k[1], e); // values out of range leave the default
@@ -137,6 +137,7 @@ bool Tuning::set(const char *key, const char *value)
     else if (k == "inline_sigs") { if (!is_int || n < -1 || n > 1) return false; inline_sigs = static_cast<int>(n); }
     else if (k == "host_cold") { if (!is_int || n < -1 || n > 1) return false; host_cold = static_cast<int>(n); }
     else if (k == "sorted_layout") { if (!is_int || n < -1 || n > 1) return false; sorted_layout = static_cast<int>(n); }
+    else if (k == "compact") { if (!is_int || n < -1 || n > 1) return false; compact = static_cast<int>(n); }
     else if (k == "prune") { if (!is_int || n < -1 || n > 1) return false; prune = static_cast<int>(n); }
     else if (k == "lanes") { if (!is_int || n < 1 || n > 2) return false; lanes = static_cast<int>(n); }
     else if (k == "scan_stamps") stamps_path = value;
@@ -308,7 +309,7 @@ static int ensure_workspace(issl_index *ix, size_t n, Lane &lane)
         w.cap_guides = cap;
         w.cap_gslots = slots;
         w.cap_items = items;
-        if (ix->hdr.off_srec) { // pruned scan: every guide sits in up to 13 successor-byte groups of each of its 5 buckets
+        if (ix->hdr.off_sub_start) { // pruned scan: every guide sits in up to 13 successor-byte groups of each of its 5 buckets
             const size_t m = std::min<size_t>(cap, kPruneMaxGuides);
             const size_t places = m * ix->hdr.n_slices * kFineWays;
             const size_t groups = std::min<size_t>(nb * 256, places);
@@ -429,13 +430,80 @@ static int finish_upload(issl_index *ix, const DeviceBuildInput *dbi = nullptr)
     uint32_t *flag = static_cast<uint32_t *>(flag_mem.p);
     HIP_TRY(hipMemset(flag, 0, 4));
     uint32_t *scan_out = reinterpret_cast<uint32_t *>(base + ix->hdr.off_scan);
-    if (dbi) {
+    if (dbi && !ix->hdr.off_sub_start) { // (the sorted layouts keep the counts in the image)
         HIP_TRY(hipMalloc(&occ_mem.p, 4 * g.n_sites));
         HIP_TRY(hipMemcpy(occ_mem.p, dbi->occ, 4 * g.n_sites, hipMemcpyHostToDevice));
     }
     const uint32_t *d_occ = static_cast<const uint32_t *>(occ_mem.p);
+    DevTemp seen_mem; // list-order layouts: one bit per (slice, site) -- every slice must list every site once
+    uint32_t *seen = nullptr;
+    if (!ix->hdr.off_sub_start) {
+        const uint64_t words = (g.n_sites * g.n_slices + 31) / 32 + 1;
+        HIP_TRY(hipMalloc(&seen_mem.p, 4 * words));
+        HIP_TRY(hipMemset(seen_mem.p, 0, 4 * words));
+        seen = static_cast<uint32_t *>(seen_mem.p);
+    }
     double t0 = wall_ms();
-    if (!ix->hdr.cold_on_host) {
+    if (ix->hdr.off_sub_start) {
+        // Sorted layouts.  Site table and counts into the image, then one slice at a time: the slice's list (in the
+        // image, or -- lists in pinned host memory -- in a temporary 8 B/site device copy), the successor-byte order
+        // of its buckets, its part of the stream maps.
+        const uint64_t n = g.n_sites;
+        uint64_t *d_sites = reinterpret_cast<uint64_t *>(base + ix->hdr.off_sites);
+        uint32_t *d_site_occ = reinterpret_cast<uint32_t *>(base + ix->hdr.off_site_occ);
+        HIP_TRY(hipMemcpy(d_sites, dbi ? dbi->sigs : h.sites, 8 * n, hipMemcpyHostToDevice));
+        if (dbi) HIP_TRY(hipMemcpy(d_site_occ, dbi->occ, 4 * n, hipMemcpyHostToDevice)); // (k_fill_maps writes the same again)
+        upload_note(ix, "sites", t0);
+        t0 = wall_ms();
+        SortTemp st;
+        int src = st.alloc(n);
+        if (src) return src;
+        const bool lists_cold = (ix->hdr.cold_on_host & 1u) != 0;
+        DevTemp list_mem;
+        uint64_t *d_entries = lists_cold ? nullptr : reinterpret_cast<uint64_t *>(base + ix->hdr.off_entries);
+        uint64_t *c_entries = lists_cold ? reinterpret_cast<uint64_t *>(static_cast<uint8_t *>(ix->h_cold) + ix->hdr.off_entries) : nullptr;
+        if (lists_cold) {
+            if (hipMalloc(&list_mem.p, std::max<uint64_t>(8 * n, 8)) != hipSuccess) { (void)hipGetLastError(); list_mem.p = nullptr; return kSortNoRoom; }
+        } else if (dbi) { // isslCreateIndex.cpp:218-234 on the device
+            int brc = launch_build_entries(d_sites, d_site_occ, n, 0, static_cast<uint32_t>(g.n_slices),
+                                           static_cast<uint32_t>(g.slice_width), d_entries);
+            if (brc) return brc;
+            upload_note(ix, "slice lists built on the device", t0);
+        } else {
+            HIP_TRY(hipMemcpy(d_entries, h.entries, 8 * n * g.n_slices, hipMemcpyHostToDevice));
+            upload_note(ix, "entries", t0);
+        }
+        t0 = wall_ms();
+        for (uint64_t sl = 0; sl < g.n_slices; ++sl) {
+            const uint64_t *d_list = lists_cold ? static_cast<uint64_t *>(list_mem.p) : d_entries + sl * n;
+            if (lists_cold) {
+                uint64_t *t_list = static_cast<uint64_t *>(list_mem.p);
+                if (dbi) {
+                    int brc = launch_build_entries(d_sites, d_site_occ, n, static_cast<uint32_t>(sl), static_cast<uint32_t>(sl + 1),
+                                                   static_cast<uint32_t>(g.slice_width), t_list);
+                    if (brc) return brc;
+                    HIP_TRY(hipMemcpy(c_entries + sl * n, t_list, 8 * n, hipMemcpyDeviceToHost));
+                } else {
+                    std::memcpy(c_entries + sl * n, h.entries + sl * n, 8 * n);
+                    HIP_TRY(hipMemcpy(t_list, c_entries + sl * n, 8 * n, hipMemcpyHostToDevice));
+                }
+            }
+            src = launch_sort_slice(st, d_sites, d_list, reinterpret_cast<const uint64_t *>(base + ix->hdr.off_bucket_start), n,
+                                    static_cast<uint32_t>(g.n_slices), static_cast<uint32_t>(nb),
+                                    static_cast<uint32_t>(sl), reinterpret_cast<uint32_t *>(base + ix->hdr.off_sub_start),
+                                    ix->hdr.off_srec ? reinterpret_cast<StreamRec *>(base + ix->hdr.off_srec) : nullptr,
+                                    ix->hdr.off_sid ? reinterpret_cast<uint32_t *>(base + ix->hdr.off_sid) : nullptr, d_site_occ, flag);
+            if (src) return src;
+            if (lists_cold) HIP_TRY(hipDeviceSynchronize()); // the temporary list is overwritten by the next slice
+        }
+        src = finish_sort(flag);
+        if (src) return src;
+        st.release();
+        upload_note(ix, "sorted layout (successor-byte order of every bucket + stream maps)", t0);
+        t0 = wall_ms();
+        launch_pack_scan_stream(ix->view, scan_out, nullptr, nullptr, flag, nullptr, nullptr);
+        HIP_TRY(hipGetLastError());
+    } else if (!ix->hdr.cold_on_host) {
         // Plain copies from the (file-mapped) host arrays: measured 48 GB/s on a 14 GB index, where a 12-thread
         // pipeline through pinned staging buffers reached 24 GB/s.
         HIP_TRY(hipMemcpy(base + ix->hdr.off_sites, dbi ? dbi->sigs : h.sites, 8 * g.n_sites, hipMemcpyHostToDevice));
@@ -451,26 +519,14 @@ static int finish_upload(issl_index *ix, const DeviceBuildInput *dbi = nullptr)
             HIP_TRY(hipMemcpy(base + ix->hdr.off_entries, h.entries, 8 * g.n_sites * g.n_slices, hipMemcpyHostToDevice));
             upload_note(ix, "entries", t0);
         }
-        if (ix->hdr.off_srec) { // order every bucket by the successor slice's byte; the stream is packed in that order
-            t0 = wall_ms();
-            int src = launch_sort_layout(reinterpret_cast<const uint64_t *>(base + ix->hdr.off_sites),
-                                         reinterpret_cast<const uint64_t *>(base + ix->hdr.off_entries),
-                                         reinterpret_cast<const uint64_t *>(base + ix->hdr.off_bucket_start), g.n_sites,
-                                         static_cast<uint32_t>(g.n_slices), static_cast<uint32_t>(nb),
-                                         reinterpret_cast<uint32_t *>(base + ix->hdr.off_sub_start),
-                                         reinterpret_cast<StreamRec *>(base + ix->hdr.off_srec),
-                                         reinterpret_cast<uint32_t *>(base + ix->hdr.off_pos_of), flag);
-            if (src) return src;
-            upload_note(ix, "sorted layout (successor-byte order of every bucket + position maps)", t0);
-        }
         t0 = wall_ms();
         // scan stream: built on the device from sites + entries
         launch_pack_scan_stream(ix->view, scan_out,
                                 ix->hdr.off_esig ? reinterpret_cast<uint64_t *>(base + ix->hdr.off_esig) : nullptr, nullptr, flag,
-                                nullptr);
+                                seen, nullptr);
         HIP_TRY(hipGetLastError());
     } else {
-        // Cold sections in pinned host memory: the scan stream is packed one slice at a time from temporary device
+        // List-order layout with sites and lists in pinned host memory: the scan stream is packed one slice at a time from temporary device
         // copies of the signatures (8 B/site) and of that slice's list (8 B/site); random reads of the site table
         // across PCIe would take minutes.  With a device-side build the lists are made here and copied out.
         uint8_t *cold = static_cast<uint8_t *>(ix->h_cold);
@@ -498,7 +554,7 @@ static int finish_upload(issl_index *ix, const DeviceBuildInput *dbi = nullptr)
             ImageView pv = ix->view;
             pv.sites = t_sites;
             pv.entries = t_list - sl * n; // bucket_start of the slice's first bucket is sl * n: every site sits in one bucket per slice
-            launch_pack_scan_range(pv, scan_out, nullptr, reinterpret_cast<uint8_t *>(base + ix->hdr.off_occ8), flag,
+            launch_pack_scan_range(pv, scan_out, nullptr, reinterpret_cast<uint8_t *>(base + ix->hdr.off_occ8), flag, seen,
                                    tfirst[sl << g.slice_width], tfirst[(sl + 1) << g.slice_width], nullptr);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipDeviceSynchronize());
@@ -509,8 +565,12 @@ static int finish_upload(issl_index *ix, const DeviceBuildInput *dbi = nullptr)
     uint32_t err = 0;
     HIP_TRY(hipMemcpy(&err, flag, 4, hipMemcpyDeviceToHost));
     upload_note(ix, "scan stream", t0);
-    if (err) {
+    if (err & 1u) {
         set_error("Error reading index: a slice entry refers to an off-target id beyond the site table");
+        return ISSL_E_FORMAT;
+    }
+    if (err) {
+        set_error("Error reading index: a slice list holds an off-target in a bucket its signature does not select, or twice");
         return ISSL_E_FORMAT;
     }
     return ISSL_OK;
@@ -524,14 +584,38 @@ static bool want_inline_sigs(const Tuning &tn, const Geometry &g)
     return g.n_sites <= 600000000ull;
 }
 
-// The sorted layout costs 20 B per list entry (100 B per site) and lets the scan skip 243 of every 256 successor-byte groups
-// (sorted_layout option / ISSL_SORTED_LAYOUT=0/1 overrides).
-static bool want_sorted(const Tuning &tn, const Geometry &g, bool list_order_only = false)
+// The layouts an upload tries, in turn, until one fits the free HBM.  Bytes per site next to the 20 B of the scan
+// stream: sorted 132 (16-byte stream records, site table, counts, slice lists), compact sorted 72 or -- slice lists in
+// pinned host memory -- 32; list order 88 / 48 (with / without the in-list signatures) or, all cold sections in host
+// memory, 5.  The sorted ones let the scan skip 243 of every 256 successor-byte groups; they need lists that ascend by
+// site id (list_order_only: this index's do not).  Explicit options are honoured or the upload fails.
+static std::vector<LayoutSpec> layout_choices(const Tuning &tn, const Geometry &g, bool list_order_only)
 {
-    if (list_order_only) return false;
-    if (tn.sorted_layout >= 0) return tn.sorted_layout == 1;
-    (void)g;
-    return true; // whenever it fits the free HBM (upload_common tries the layouts in turn)
+    std::vector<LayoutSpec> c;
+    auto spec = [](bool esig, uint32_t cold, uint32_t sorted) { LayoutSpec s; s.inline_sigs = esig; s.cold = cold; s.sorted = sorted; return s; };
+    const bool may_sort = !list_order_only && tn.sorted_layout != 0 && tn.inline_sigs != 1;
+    const bool must_sort = tn.sorted_layout == 1 || tn.compact == 1;
+    if (may_sort || must_sort) {
+        if (tn.host_cold == 1) {
+            if (tn.compact == 1 || tn.sorted_layout == 1) c.push_back(spec(false, 1, 2));
+        } else {
+            if (tn.compact != 1) c.push_back(spec(false, 0, 1));
+            if (tn.compact != 0) {
+                c.push_back(spec(false, 0, 2));
+                if (tn.host_cold == -1) c.push_back(spec(false, 1, 2));
+            }
+        }
+    }
+    if (!must_sort) {
+        if (tn.host_cold == 1) {
+            c.push_back(spec(false, 3, 0));
+        } else {
+            if (want_inline_sigs(tn, g)) c.push_back(spec(true, 0, 0));
+            if (tn.inline_sigs != 1) c.push_back(spec(false, 0, 0));
+            if (tn.host_cold == -1 && tn.inline_sigs != 1) c.push_back(spec(false, 3, 0));
+        }
+    }
+    return c;
 }
 
 static uint64_t count_tiles(const HostIndex &h)
@@ -844,8 +928,8 @@ int issl_index_write(const issl_index *idx, const char *path)
     const uint8_t *base = static_cast<const uint8_t *>(idx->d_image);
     const uint8_t *cold = static_cast<const uint8_t *>(idx->h_cold);
     std::vector<uint8_t> stage;
-    auto stream_out = [&](uint64_t off, uint64_t bytes) {
-        if (idx->hdr.cold_on_host) { // the section already sits in host memory
+    auto stream_out = [&](uint64_t off, uint64_t bytes, bool in_host) {
+        if (in_host) { // the section already sits in host memory
             ok = ok && std::fwrite(cold + off, 1, bytes, fp) == bytes;
             return;
         }
@@ -856,9 +940,9 @@ int issl_index_write(const issl_index *idx, const char *path)
                  std::fwrite(stage.data(), 1, len, fp) == len;
         }
     };
-    stream_out(idx->hdr.off_sites, 8 * idx->geo.n_sites);
+    stream_out(idx->hdr.off_sites, 8 * idx->geo.n_sites, (idx->hdr.cold_on_host & 2u) != 0);
     ok = ok && std::fwrite(idx->host->sizes, 8, idx->geo.n_buckets(), fp) == idx->geo.n_buckets();
-    stream_out(idx->hdr.off_entries, 8 * idx->geo.n_sites * idx->geo.n_slices);
+    stream_out(idx->hdr.off_entries, 8 * idx->geo.n_sites * idx->geo.n_slices, (idx->hdr.cold_on_host & 1u) != 0);
     ok = (std::fclose(fp) == 0) && ok;
     if (!ok) {
         set_error(std::string("could not write '") + path + "' from the device image");
@@ -907,9 +991,9 @@ int issl_index_device_bytes(const issl_index *idx, size_t *out)
     idx->host->unique_scores(m, v);
     ImageHeader h;
     // the layout an upload tries first (issl_index_upload falls back to smaller ones when the HBM is short)
-    const bool cold = idx->tuning.host_cold == 1;
-    layout_image(h, idx->geo, m.size(), count_tiles(*idx->host), masks_are_dense(m),
-                 !cold && want_inline_sigs(idx->tuning, idx->geo), cold, !cold && want_sorted(idx->tuning, idx->geo, idx->list_order_only));
+    const std::vector<LayoutSpec> choices = layout_choices(idx->tuning, idx->geo, idx->list_order_only);
+    if (choices.empty()) { set_error("the layout options of this index contradict each other"); return ISSL_E_ARG; }
+    layout_image(h, idx->geo, m.size(), count_tiles(*idx->host), masks_are_dense(m), choices.front());
     *out = h.total_bytes;
     return ISSL_OK;
 }
@@ -949,20 +1033,18 @@ int issl_index_get_option(const issl_index *idx, const char *key, long long *val
     else if (k == "inline_sigs") *value = t.inline_sigs;
     else if (k == "host_cold") *value = t.host_cold;
     else if (k == "sorted_layout") *value = t.sorted_layout;
+    else if (k == "compact") *value = t.compact;
     else if (k == "prune") *value = t.prune;
     else if (k == "lanes") *value = t.lanes;
-    else if (k == "is_sorted") *value = idx->d_image ? (idx->hdr.off_srec ? 1 : 0) : -1;                   // read-only
-    else if (k == "cold_on_host") *value = idx->d_image ? static_cast<long long>(idx->hdr.cold_on_host) : -1; // read-only: layout in use
+    else if (k == "is_sorted") *value = idx->d_image ? ((idx->hdr.off_srec || idx->hdr.off_sid) ? 1 : 0) : -1; // read-only
+    else if (k == "is_compact") *value = idx->d_image ? (idx->hdr.off_sid ? 1 : 0) : -1;                   // read-only
+    else if (k == "cold_on_host") *value = idx->d_image ? (idx->hdr.cold_on_host ? 1 : 0) : -1;            // read-only: layout in use
+    else if (k == "cold_sections") *value = idx->d_image ? static_cast<long long>(idx->hdr.cold_on_host) : -1; // read-only: 0, 1 (lists), 3 (lists + sites)
     else if (k == "dense_mit") *value = idx->d_image ? (idx->hdr.off_mit_dense ? 1 : 0) : -1;              // read-only
     else if (k == "has_inline_sigs") *value = idx->d_image ? (idx->hdr.off_esig ? 1 : 0) : -1;            // read-only
     else { set_error(std::string("unknown option: ") + key); return ISSL_E_ARG; }
     return ISSL_OK;
 }
-
-// Layouts an upload tries in turn: with the in-list signatures, without them, with the cold sections in host memory.
-struct LayoutChoice {
-    bool inline_sigs, cold, sorted;
-};
 
 static int upload_common(issl_index *idx, int device, void *buf, size_t bytes, const DeviceBuildInput *dbi = nullptr)
 {
@@ -988,29 +1070,17 @@ static int upload_common(issl_index *idx, int device, void *buf, size_t bytes, c
     std::vector<double> v;
     idx->host->unique_scores(m, v);
     const Tuning &tn = idx->tuning;
-    std::vector<LayoutChoice> choices;
-    if (tn.host_cold == 1) {
-        choices.push_back({false, true, false});
-    } else {
-        const bool sorted = want_sorted(tn, idx->geo, idx->list_order_only); // explicit inline_sigs=1 / sorted_layout=1 are honoured or fail
-        if (want_inline_sigs(tn, idx->geo)) choices.push_back({true, false, sorted});
-        if (tn.inline_sigs != 1) choices.push_back({false, false, sorted});
-        if (sorted && tn.sorted_layout != 1) {
-            if (want_inline_sigs(tn, idx->geo)) choices.push_back({true, false, false});
-            if (tn.inline_sigs != 1) choices.push_back({false, false, false});
-        }
-        if (tn.host_cold == -1 && tn.inline_sigs != 1 && tn.sorted_layout != 1) choices.push_back({false, true, false});
-    }
+    const std::vector<LayoutSpec> choices = layout_choices(tn, idx->geo, idx->list_order_only);
     idx->device = device;
     const uint64_t n_tiles = count_tiles(*idx->host);
     const bool dense = masks_are_dense(m);
-    std::string why;
-    bool placed = false;
-    for (const LayoutChoice &c : choices) {
-        layout_image(idx->hdr, idx->geo, m.size(), n_tiles, dense, c.inline_sigs, c.cold, c.sorted);
-        // temporary device memory: while a host-cold image is packed, signatures + one slice list; for the sorted layout
-        // two key arrays of 8 B per site (one slice at a time)
-        const uint64_t temp = c.cold ? 16 * idx->geo.n_sites : c.sorted ? 16 * idx->geo.n_sites + (64ull << 20) : 0;
+    std::string why = "the layout options of this index contradict each other";
+    for (const LayoutSpec &c : choices) {
+        layout_image(idx->hdr, idx->geo, m.size(), n_tiles, dense, c);
+        // temporary device memory: while a list-order host-cold image is packed, signatures + one slice list; for the
+        // sorted layouts two key arrays of 8 B per site (one slice at a time) and, lists in host memory, one slice list
+        const uint64_t ns = idx->geo.n_sites;
+        const uint64_t temp = c.sorted ? 16 * ns + (c.cold ? 8 * ns : 0) + (64ull << 20) : c.cold ? 16 * ns : 0;
         if (buf) {
             if (bytes < idx->hdr.total_bytes || (reinterpret_cast<uintptr_t>(buf) & 255u)) {
                 why = "device buffer too small or not 256-byte aligned";
@@ -1050,25 +1120,32 @@ static int upload_common(issl_index *idx, int device, void *buf, size_t bytes, c
             idx->owns_cold = true;
             HIP_TRY(hipHostGetDevicePointer(&idx->d_cold, idx->h_cold, 0));
         }
-        placed = true;
-        break;
+        upload_note(idx, c.cold ? "layout + allocation (cold sections in pinned host memory)" : "layout + allocation", t0);
+        rc = finish_upload(idx, dbi);
+        if (rc == ISSL_OK) return ISSL_OK;
+        release_device(idx);
+        if (rc == kSortNoRoom) { // the temporaries of the sort did not fit after all: the next, smaller layout
+            why = "no device memory for the temporaries of the sorted layout";
+            t0 = wall_ms();
+            continue;
+        }
+        if (rc == kSortNeedsListOrder) {
+            if (tn.sorted_layout == 1 || tn.compact == 1) {
+                set_error("this index cannot take the sorted layout that was asked for: a list is not ascending by site id, "
+                          "holds a site in a bucket its signature does not select, or carries different counts for one site");
+                return ISSL_E_UNSUPPORTED;
+            }
+            idx->list_order_only = true; // once more, with the stream in list order
+            return upload_common(idx, device, buf, bytes, dbi);
+        }
+        return rc;
     }
-    if (!placed) {
-        set_error("cannot place the index image: " + why);
-        return buf ? ISSL_E_ARG : ISSL_E_DEVICE;
-    }
-    upload_note(idx, idx->hdr.cold_on_host ? "layout + allocation (cold sections in pinned host memory)" : "layout + allocation", t0);
-    rc = finish_upload(idx, dbi);
-    if (rc) release_device(idx);
-    if (rc == kSortNeedsListOrder) { // once more, with the stream in list order
-        idx->list_order_only = true;
-        return upload_common(idx, device, buf, bytes, dbi);
-    }
-    return rc;
+    set_error("cannot place the index image: " + why);
+    return buf ? ISSL_E_ARG : ISSL_E_DEVICE;
 }
 
-int issl_index_build_on_device(const uint64_t *sigs, const uint32_t *occ, size_t n_sites, size_t n_lines,
-                               size_t seq_len, size_t slice_width, int device, issl_index **out)
+int issl_index_build_on_device_opt(const uint64_t *sigs, const uint32_t *occ, size_t n_sites, size_t n_lines,
+                                   size_t seq_len, size_t slice_width, int device, const char *options, issl_index **out)
 {
     if (!sigs || !occ || !out) { set_error("null argument"); return ISSL_E_ARG; }
     std::unique_ptr<HostIndex> h(new (std::nothrow) HostIndex());
@@ -1078,6 +1155,17 @@ int issl_index_build_on_device(const uint64_t *sigs, const uint32_t *occ, size_t
     issl_index *ix = nullptr;
     rc = new_index_from_host(std::move(h), &ix);
     if (rc) return rc;
+    for (std::string rest = options ? options : ""; !rest.empty();) { // "key=value,key=value"
+        const size_t comma = rest.find(',');
+        const std::string item = rest.substr(0, comma);
+        rest = comma == std::string::npos ? std::string() : rest.substr(comma + 1);
+        const size_t eq = item.find('=');
+        if (eq == std::string::npos || !ix->tuning.set(item.substr(0, eq).c_str(), item.substr(eq + 1).c_str())) {
+            set_error("unknown option or value out of range: " + item);
+            issl_index_close(ix);
+            return ISSL_E_ARG;
+        }
+    }
     const DeviceBuildInput dbi{sigs, occ};
     rc = upload_common(ix, device, nullptr, 0, &dbi);
     if (rc) {
@@ -1086,6 +1174,12 @@ int issl_index_build_on_device(const uint64_t *sigs, const uint32_t *occ, size_t
     }
     *out = ix;
     return ISSL_OK;
+}
+
+int issl_index_build_on_device(const uint64_t *sigs, const uint32_t *occ, size_t n_sites, size_t n_lines,
+                               size_t seq_len, size_t slice_width, int device, issl_index **out)
+{
+    return issl_index_build_on_device_opt(sigs, occ, n_sites, n_lines, seq_len, slice_width, device, nullptr, out);
 }
 
 int issl_index_upload(issl_index *idx, int device) { return upload_common(idx, device, nullptr, 0); }

@@ -41,7 +41,7 @@ namespace issl {
 // from `occ8`, one saturating byte per list entry kept in HBM with the hot part (5 B per site).  Host memory is read
 // only for occurrence counts >= 255 and for the site ids of issl_dump_hits.
 constexpr uint64_t kImageMagic = 0x314C535349444D41ull; // "AMDISSL1"
-constexpr uint32_t kImageVersion = 6;
+constexpr uint32_t kImageVersion = 7;
 constexpr uint32_t kTileCands = 2048; // candidates per scan tile: one wave, 64 lanes x 32 registers
 constexpr uint32_t kHeaderBytes = 4096;
 
@@ -59,14 +59,21 @@ struct ImageHeader {
         off_scan;
     uint64_t off_mit_dense; // 0: absent (table holds masks outside the 20 even bits)
     uint64_t off_esig;      // 0: absent (large indexes: +8 B per list entry do not pay for themselves in HBM)
-    uint64_t cold_on_host;  // 1: off_sites / off_entries are offsets into the pinned host buffer of cold_bytes bytes
-    uint64_t cold_bytes;    // bytes of sites + entries (+ esig) wherever they live
-    uint64_t off_occ8;      // u8[N*S]: min(occurrences, 255) per list entry; present (in HBM) only when cold_on_host
-    // "Sorted" layout (pruned scan, see below): inside every bucket the scan stream holds the candidates ordered by the
+    uint64_t cold_on_host;  // bit 0: off_entries, bit 1: off_sites are offsets into the pinned host buffer of cold_bytes
+                            // bytes (3: the list-order host-cold layout; 1: a compact sorted image whose slice lists
+                            // did not fit the HBM; 0: everything in HBM)
+    uint64_t cold_bytes;    // bytes of the sections that live in that buffer
+    uint64_t off_occ8;      // u8[N*S]: min(occurrences, 255) per list entry; present (in HBM) only when cold_on_host == 3
+    // "Sorted" layouts (pruned scan, see below): inside every bucket the scan stream holds the candidates ordered by the
     // byte of the SUCCESSOR slice ((slice + 1) mod n_slices), ties in list order.  0 = absent (stream in list order).
+    // They need every list ascending by site id (what isslCreateIndex.cpp:218-234 writes: ids are appended in
+    // ascending order) and one occurrence count per site: a hit's place in the reference's scoring order is then
+    // (first matching slice, site id) and nothing has to remember list positions.
     uint64_t off_sub_start; // u32[nb * 257]: first stream position (inside the bucket) of every successor-byte value
-    uint64_t off_srec;      // StreamRec[N*S]: stream position (bucket_start[b] + q) -> the candidate there (16 B)
-    uint64_t off_pos_of;    // u32[N*S]: (slice s, site id) at s * N + id -> position of that site in its bucket of slice s
+    uint64_t off_srec;      // StreamRec[N*S]: stream position (bucket_start[b] + q) -> the candidate there (16 B); or
+    uint64_t off_sid;       // u32[N*S]: ... -> its site id alone (the COMPACT sorted layout: 4 B instead of 16 B per
+                            // list entry; signature and count come from `sites` / `site_occ` by id)
+    uint64_t off_site_occ;  // u32[N]: occurrence count of every site (sorted layouts)
 };
 static_assert(sizeof(ImageHeader) <= kHeaderBytes, "header must fit its block");
 
@@ -90,8 +97,9 @@ struct ImageView {
     const uint64_t *esig; // signature of the site behind every list entry, in list order, or null
     const uint8_t *occ8;  // min(occurrences, 255) of every list entry, or null (only with host-resident cold sections)
     const uint32_t *sub_start; // sorted layout: [nb][257] stream offsets of the successor-byte groups, or null
-    const StreamRec *srec;     // sorted layout: stream position -> candidate, or null (stream in list order)
-    const uint32_t *pos_of;    // sorted layout: (slice, site id) -> list position in that slice's bucket, or null
+    const StreamRec *srec;     // sorted layout: stream position -> candidate, or null
+    const uint32_t *sid;       // compact sorted layout: stream position -> site id, or null
+    const uint32_t *site_occ;  // sorted layouts: occurrence count by site id, or null
     const uint32_t *scan;
     uint64_t n_sites;
     uint32_t n_buckets;
@@ -103,9 +111,15 @@ struct ImageView {
 
 // Layout computation shared by upload and attach.  Fills every field of `h` from the geometry,
 // the number of unique scores and the bucket sizes (sizes may be null when n_tiles is given).
+// What an image keeps beside the scan stream.
+struct LayoutSpec {
+    bool inline_sigs = false; // `esig` (list-order layouts only)
+    uint32_t cold = 0;        // ImageHeader::cold_on_host: 0, 1 (slice lists in host memory) or 3 (site table too)
+    uint32_t sorted = 0;      // 0: stream in list order; 1: sorted, 16-byte stream records; 2: sorted, compact
+};
 void layout_image(ImageHeader &h, const Geometry &g, uint64_t n_scores_unique, uint64_t n_tiles, bool dense_mit,
-                  bool inline_sigs, bool cold_on_host, bool sorted);
-// `cold`: device-visible address of the pinned host buffer when h.cold_on_host, else ignored.
+                  const LayoutSpec &spec);
+// `cold`: device-visible address of the pinned host buffer when h.cold_on_host != 0, else ignored.
 ImageView make_view(const ImageHeader &h, void *base, void *cold);
 
 // ---- tuning knobs ------------------------------------------------------------------------------
@@ -119,7 +133,11 @@ struct Tuning {
     bool upload_timing;     // ISSL_UPLOAD_TIMING one stderr line per upload stage
     size_t raw_chunks;      // ISSL_RAW_CHUNKS    initial raw-record buffer in chunks (0: sized from the launch)
     int inline_sigs;        // ISSL_INLINE_SIGS   -1 automatic, 0 never, 1 always
-    int sorted_layout;      // ISSL_SORTED_LAYOUT -1 automatic (up to 600 M sites, cold sections in HBM), 0 never, 1 always
+    int sorted_layout;      // ISSL_SORTED_LAYOUT -1 automatic (whenever the lists allow it and an image fits), 0 never, 1 always
+    int compact;            // ISSL_COMPACT       the sorted layout with 4 instead of 16 bytes per stream position: -1 when
+                            //                    the 16-byte one does not fit the free HBM, 0 never, 1 always (with host_cold=1:
+                            //                    the slice lists -- read by issl_dump_hits and issl_index_write only -- in
+                            //                    pinned host memory)
     int prune;              // ISSL_PRUNE         scan only the successor-byte groups that can hold a hit (needs the sorted
                             //                    layout and max_dist <= 4): -1 when the plan estimates it to be faster,
                             //                    0 never, 1 whenever possible
@@ -139,15 +157,30 @@ struct Tuning {
 int launch_build_entries(const uint64_t *d_sites, const uint32_t *d_occ, uint64_t n_sites, uint32_t slice_begin,
                          uint32_t slice_end, uint32_t slice_width, uint64_t *d_entries);
 
-// Sorted layout (issl_build.hip): orders every bucket's list by the successor slice's byte (three stable radix passes
-// over keys built from the signatures) and writes the three maps of the image; d_sites / d_entries / d_bucket_start are
-// the image's own sections.  Works one slice at a time and needs 16 B per site of temporary device memory.  Synchronous.  d_flag: a zeroed device
-// word.  Returns kSortNeedsListOrder when some entry sits in a bucket its signature does not select (the caller then
-// uploads the list-order layout, which like the reference does not care).
-constexpr int kSortNeedsListOrder = -1000;
-int launch_sort_layout(const uint64_t *d_sites, const uint64_t *d_entries, const uint64_t *d_bucket_start, uint64_t n_sites,
-                       uint32_t n_slices, uint32_t n_buckets, uint32_t *d_sub_start, StreamRec *d_srec, uint32_t *d_pos_of,
-                       uint32_t *d_flag);
+// Sorted layouts (issl_build.hip): order every bucket's list by the successor slice's byte (two stable radix passes per
+// slice over keys built from the signatures) and write the maps of the image.  One slice at a time, 16 B per site of
+// temporary device memory (SortTemp, allocated once per upload).
+constexpr int kSortNeedsListOrder = -1000; // the index cannot take a sorted layout: an entry sits in a bucket its signature
+                                           // does not select, a list is not ascending by site id, or a site carries
+                                           // different counts in different lists (no builder writes any of these; the
+                                           // reference does not care, isslScoreOfftargets.cpp:344-348,376) -- the caller
+                                           // uploads a list-order layout instead
+constexpr int kSortNoRoom = -1001;         // no device memory for the temporaries: the caller tries the next layout
+struct SortTemp {
+    uint64_t *keys = nullptr, *tmp = nullptr;
+    uint32_t *hist = nullptr;
+    int alloc(uint64_t n_sites); // ISSL_OK or kSortNoRoom
+    void release();
+    ~SortTemp() { release(); }
+};
+// Slice `slice`: d_list = its n_sites list entries (occ << 32 | id) in list order, anywhere on the device; writes the
+// slice's part of sub_start, of srec OR sid (the other one null) and -- slice 0 -- site_occ (later slices check their
+// counts against it).  Asynchronous on the null stream; d_flag: a device word zeroed before the first slice.
+int launch_sort_slice(SortTemp &t, const uint64_t *d_sites, const uint64_t *d_list, const uint64_t *d_bucket_start,
+                      uint64_t n_sites, uint32_t n_slices, uint32_t n_buckets, uint32_t slice, uint32_t *d_sub_start,
+                      StreamRec *d_srec, uint32_t *d_sid, uint32_t *d_site_occ, uint32_t *d_flag);
+// Synchronises and reads the flag word: ISSL_OK, ISSL_E_FORMAT (an id beyond the site table), kSortNeedsListOrder.
+int finish_sort(uint32_t *d_flag);
 
 // ---- scoring workspace -------------------------------------------------------------------------
 constexpr uint32_t kGuideGroup = 8;    // guide words fetched per scalar load
@@ -276,10 +309,13 @@ struct ScoreParams {
 };
 
 // Launchers (issl_kernels.hip).  All asynchronous on `stream`.
+// error_flag bits: 1 = an entry's id lies beyond the site table, 4 = a list holds a site in a bucket its signature does
+// not select, or twice (`seen`: a zeroed bitmap of n_slices * n_sites bits, list-order layouts; null for the sorted
+// ones, whose construction has checked both).
 void launch_pack_scan_stream(const ImageView &v, uint32_t *scan_out, uint64_t *esig_out, uint8_t *occ8_out,
-                             uint32_t *error_flag, void *stream);
+                             uint32_t *error_flag, uint32_t *seen, void *stream);
 void launch_pack_scan_range(const ImageView &v, uint32_t *scan_out, uint64_t *esig_out, uint8_t *occ8_out,
-                            uint32_t *error_flag, uint32_t tile_begin, uint32_t tile_end, void *stream);
+                            uint32_t *error_flag, uint32_t *seen, uint32_t tile_begin, uint32_t tile_end, void *stream);
 // prune_mode: 0 = full scan of the five buckets of every guide; 1 / 2 = pruned scan over the successor-byte groups equal
 // to / within one mismatch of the guide's own successor byte (enough for max_dist <= 2 / <= 4, see k_fine_count).
 uint32_t prune_mode_for(const ImageView &v, const Tuning &tn, uint32_t n_guides, int max_dist);

@@ -84,8 +84,8 @@ __host__ __device__ inline uint32_t plane_word(uint32_t r, uint32_t group)
 __global__ __launch_bounds__(256) void k_pack_scan_stream(ImageView v, uint32_t *__restrict__ scan_out,
                                                           uint64_t *__restrict__ esig_out,
                                                           uint8_t *__restrict__ occ8_out,
-                                                          uint32_t *__restrict__ error_flag, uint32_t tile_begin,
-                                                          uint32_t tile_end)
+                                                          uint32_t *__restrict__ error_flag, uint32_t *__restrict__ seen,
+                                                          uint32_t tile_begin, uint32_t tile_end)
 {
     for (uint32_t t = tile_begin + blockIdx.x; t < tile_end; t += gridDim.x) {
         // bucket of tile t: last b with tile_first[b] <= t (uniform binary search)
@@ -108,15 +108,23 @@ __global__ __launch_bounds__(256) void k_pack_scan_stream(ImageView v, uint32_t 
         for (uint32_t k0 = wave * 64u; k0 < kTileCands; k0 += 256u) {
             const uint64_t pos = tile_pos + k0 + lane;
             uint32_t w = 0;
-            if (pos < len && v.srec) {
-                // sorted layout: the stream holds the candidates v.srec lists (built and checked by launch_sort_layout);
-                // esig keeps the list order and is filled by k_fill_esig
-                w = scan_word(v.srec[start + pos].sig & ((1ull << 40) - 1ull), slice);
+            if (pos < len && (v.srec || v.sid)) {
+                // sorted layouts: the stream holds the candidates v.srec / v.sid list (built and checked by launch_sort_slice)
+                w = scan_word(v.srec ? v.srec[start + pos].sig & ((1ull << 40) - 1ull) : v.sites[v.sid[start + pos]], slice);
             } else if (pos < len) {
                 const uint64_t e = v.entries[start + pos];
                 const uint64_t id = e & 0xFFFFFFFFull;
                 if (id < v.n_sites) {
                     const uint64_t sig = v.sites[id];
+                    // Every slice must list every site once, in the bucket its signature selects: the scan compares the
+                    // 16 positions outside the slice and the first-matching-slice rule stands in for the reference's
+                    // seen-bitmap (:385-390) on exactly that premise.  `seen`: one bit per (slice, site).
+                    if (((sig >> (v.slice_width * slice)) & ((1ull << v.slice_width) - 1ull)) != (b & ((1u << v.slice_width) - 1u)))
+                        atomicOr(error_flag, 4u);
+                    if (seen) {
+                        const uint64_t bit = static_cast<uint64_t>(slice) * v.n_sites + id;
+                        if (atomicOr(&seen[bit >> 5], 1u << (bit & 31u)) & (1u << (bit & 31u))) atomicOr(error_flag, 4u);
+                    }
                     w = scan_word(sig, slice);
                     if (esig_out) esig_out[start + pos] = sig;
                     if (occ8_out) occ8_out[start + pos] = static_cast<uint8_t>((e >> 32) < 255ull ? (e >> 32) : 255ull);
@@ -138,38 +146,22 @@ __global__ __launch_bounds__(256) void k_pack_scan_stream(ImageView v, uint32_t 
     }
 }
 
-// Sorted layout: the in-list signatures, in list order (the pack kernel walks the stream order there).
-__global__ __launch_bounds__(256) void k_fill_esig(ImageView v, uint64_t *__restrict__ esig_out, uint64_t total,
-                                                   uint32_t *__restrict__ error_flag)
-{
-    for (uint64_t e = static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x; e < total; e += static_cast<uint64_t>(gridDim.x) * 256) {
-        const uint64_t id = v.entries[e] & 0xFFFFFFFFull;
-        if (id < v.n_sites) esig_out[e] = v.sites[id];
-        else atomicOr(error_flag, 1u);
-    }
-}
-
 // Tiles [tile_begin, tile_end) only: the upload of an image whose cold sections stay in host memory packs one slice
 // at a time from temporary device copies (v.entries then points at the slice's list minus the slice's offset).
 void launch_pack_scan_range(const ImageView &v, uint32_t *scan_out, uint64_t *esig_out, uint8_t *occ8_out,
-                            uint32_t *error_flag, uint32_t tile_begin, uint32_t tile_end, void *stream)
+                            uint32_t *error_flag, uint32_t *seen, uint32_t tile_begin, uint32_t tile_end, void *stream)
 {
     if (tile_end <= tile_begin) return;
     const uint32_t n = tile_end - tile_begin;
     const uint32_t grid = n < 65536u ? n : 65536u;
     hipLaunchKernelGGL(k_pack_scan_stream, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), v,
-                       scan_out, esig_out, occ8_out, error_flag, tile_begin, tile_end);
+                       scan_out, esig_out, occ8_out, error_flag, seen, tile_begin, tile_end);
 }
 
 void launch_pack_scan_stream(const ImageView &v, uint32_t *scan_out, uint64_t *esig_out, uint8_t *occ8_out,
-                             uint32_t *error_flag, void *stream)
+                             uint32_t *error_flag, uint32_t *seen, void *stream)
 {
-    launch_pack_scan_range(v, scan_out, esig_out, occ8_out, error_flag, 0u, v.n_tiles, stream);
-    if (v.srec && esig_out) {
-        const uint64_t total = v.n_sites * v.n_slices;
-        const uint32_t grid = static_cast<uint32_t>(std::min<uint64_t>((total + 255) / 256, 1u << 20));
-        if (grid) hipLaunchKernelGGL(k_fill_esig, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), v, esig_out, total, error_flag);
-    }
+    launch_pack_scan_range(v, scan_out, esig_out, occ8_out, error_flag, seen, 0u, v.n_tiles, stream);
 }
 
 // The packed signature of the candidate at offset `offset` of scan tile `tile` of bucket `bucket`, rebuilt from the
@@ -661,7 +653,7 @@ __global__ __launch_bounds__(256) void k_fine_ranges(const PlanInfo *__restrict_
 
 uint32_t prune_mode_for(const ImageView &v, const Tuning &tn, uint32_t n_guides, int max_dist)
 {
-    if (!v.srec || tn.prune == 0 || max_dist < 0 || max_dist > 4 || n_guides > kPruneMaxGuides || v.n_slices != 5 || v.slice_width != 8)
+    if ((!v.srec && !v.sid) || tn.prune == 0 || max_dist < 0 || max_dist > 4 || n_guides > kPruneMaxGuides || v.n_slices != 5 || v.slice_width != 8)
         return 0;
     return max_dist <= 2 ? 1u : 2u;
 }
@@ -1141,10 +1133,14 @@ __global__ __launch_bounds__(kChunkRecs, 8) void k_verify(ImageView v, Workspace
             const uint64_t pos = static_cast<uint64_t>(tile - v.tile_first[bucket]) * kTileCands + offset; // in the stream
             if (pos >= lo_pos && pos < hi_pos) {
                 const uint64_t gsig = guides[guide];
-                // sorted layout: esig is in list order; signature, site id and list position come in one stream-order record
+                // sorted layouts: signature, site id (and a 24-bit copy of the count) come in one stream-order record, or --
+                // compact -- the id alone, with the signature behind it in the site table
                 StreamRec sr{};
                 if (v.srec) sr = v.srec[start + pos];
+                else if (v.sid) sr.id = v.sid[start + pos];
+                const bool by_id = v.srec || v.sid; // the scoring order is (slice, site id): ImageHeader
                 const uint64_t ot = v.srec   ? sr.sig & ((1ull << 40) - 1ull)
+                                    : v.sid  ? v.sites[sr.id]
                                     : v.esig ? v.esig[start + pos]
                                     : v.occ8 ? candidate_signature(v, bucket, tile, offset) // cold sections in host memory
                                              : v.sites[v.entries[start + pos] & 0xFFFFFFFFull];
@@ -1157,14 +1153,15 @@ __global__ __launch_bounds__(kChunkRecs, 8) void k_verify(ImageView v, Workspace
                         for (uint32_t j = 0; j < slice; ++j)
                             if (((x >> (v.slice_width * j)) & low) == 0) earlier = true;
                         if (!earlier) {
-                            // sorted layout: the key carries the position in the bucket's LIST (the reference's order)
-                            const uint64_t lp = v.srec ? sr.pos : pos;
+                            // list-order layouts: the key carries the position in the bucket's list, which is the stream
+                            // position; sorted layouts: the site id (lists ascend by id, so the order is the same)
+                            const uint64_t lp = by_id ? sr.id : pos;
                             key = (static_cast<uint64_t>(guide) << 35) | (static_cast<uint64_t>(slice) << 32) | lp;
                         }
                     } else {
                         // Pruned scan: the guide meets this site once in every exactly matching slice whose successor
                         // slice has at most `tol` mismatches (k_fine_count); the smallest such slice reports it, under
-                        // the slice the reference would meet it in first and its list position there.
+                        // the slice the reference would meet it in first.
                         const uint32_t tol = prune_mode == 1 ? 0u : 1u;
                         const uint64_t mm = mismatch_mask(gsig, ot);
                         uint32_t first = slice, reporter = slice;
@@ -1174,16 +1171,16 @@ __global__ __launch_bounds__(kChunkRecs, 8) void k_verify(ImageView v, Workspace
                             const uint32_t nx = (j + 1u) % v.n_slices;
                             if (static_cast<uint32_t>(__builtin_popcountll((mm >> (v.slice_width * nx)) & low)) <= tol) reporter = j;
                         }
-                        if (reporter == slice) {
-                            const uint64_t lp = first == slice ? sr.pos : v.pos_of[static_cast<uint64_t>(first) * v.n_sites + sr.id];
-                            key = (static_cast<uint64_t>(guide) << 35) | (static_cast<uint64_t>(first) << 32) | lp;
-                        }
+                        if (reporter == slice)
+                            key = (static_cast<uint64_t>(guide) << 35) | (static_cast<uint64_t>(first) << 32) | sr.id;
                     }
                     if (key != kDeadKey) { // the hit will be scored: its terms (:392-460)
                         uint32_t occ;
                         if (v.srec) {
                             occ = static_cast<uint32_t>(sr.sig >> 40);
-                            if (occ == kOccSaturated) occ = static_cast<uint32_t>(v.entries[start + sr.pos] >> 32);
+                            if (occ == kOccSaturated) occ = v.site_occ[sr.id];
+                        } else if (v.sid) {
+                            occ = v.site_occ[sr.id];
                         } else if (v.occ8) {
                             occ = v.occ8[start + pos];
                             if (occ == 255u) occ = static_cast<uint32_t>(v.entries[start + pos] >> 32); // (host memory)
@@ -1521,12 +1518,28 @@ __device__ inline HitTerms hit_terms(const ImageView &v, uint64_t gsig, uint32_t
     t.cfd = 0.0;
     const uint64_t low = (1ull << v.slice_width) - 1ull;
     const uint32_t slice = static_cast<uint32_t>(key >> 32) & 7u;
-    const uint32_t pos = static_cast<uint32_t>(key);
+    uint32_t pos = static_cast<uint32_t>(key);
     const uint32_t bucket = (slice << v.slice_width) + static_cast<uint32_t>((gsig >> (v.slice_width * slice)) & low);
     const uint64_t at = v.bucket_start[bucket] + pos;
     uint32_t id = 0, occ;
     uint64_t ot;
-    if (v.occ8) {
+    if (v.srec || v.sid) {
+        // sorted layouts: the key's low word is the site id; issl_dump_hits also wants the position in the bucket's list
+        // (:344): the lists ascend by id, so a binary search finds it (in host memory when the lists live there)
+        id = pos;
+        ot = v.sites[id];
+        occ = v.site_occ[id];
+        pos = 0;
+        if (want_id) {
+            const uint64_t *list = v.entries + v.bucket_start[bucket];
+            uint64_t lo = 0, hi = v.bucket_start[bucket + 1] - v.bucket_start[bucket];
+            while (lo < hi) {
+                const uint64_t mid = (lo + hi) >> 1;
+                if (static_cast<uint32_t>(list[mid]) < id) lo = mid + 1; else hi = mid;
+            }
+            pos = static_cast<uint32_t>(lo);
+        }
+    } else if (v.occ8) {
         // cold sections in host memory: signature from the scan planes, occurrences from the byte copy in HBM; the list
         // entry itself (PCIe) only for counts that do not fit a byte and for the site id of issl_dump_hits
         ot = candidate_signature(v, bucket, v.tile_first[bucket] + (pos >> 11), pos & (kTileCands - 1u));

@@ -100,15 +100,17 @@ class IsslIndex:
         return cls(h)
 
     @classmethod
-    def build_on_device(cls, sigs, occ, device=0, n_lines=None, seq_len=20, slice_width=8):
-        """Like build_from_sites + upload, but the slice lists are built on the GPU (no 48 B/site host arrays)."""
+    def build_on_device(cls, sigs, occ, device=0, n_lines=None, seq_len=20, slice_width=8, options=None):
+        """Like build_from_sites + upload, but the slice lists are built on the GPU (no 48 B/site host arrays).
+        options: layout options of the image, e.g. {"compact": 1, "host_cold": 1}."""
         sigs = np.ascontiguousarray(sigs, dtype=np.uint64)
         occ = np.ascontiguousarray(occ, dtype=np.uint32)
         if n_lines is None:
             n_lines = int(occ.sum(dtype=np.uint64))
         h = C.c_void_p()
-        check(lib.issl_index_build_on_device(sigs.ctypes.data, occ.ctypes.data, len(sigs), n_lines, seq_len,
-                                             slice_width, device, C.byref(h)))
+        opts = ",".join(f"{k}={v}" for k, v in (options or {}).items()).encode() or None
+        check(lib.issl_index_build_on_device_opt(sigs.ctypes.data, occ.ctypes.data, len(sigs), n_lines, seq_len,
+                                                 slice_width, device, opts, C.byref(h)))
         return cls(h)
 
     @classmethod

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define ISSL_ABI_VERSION 3
+#define ISSL_ABI_VERSION 4
 
 enum {
     ISSL_OK = 0,
@@ -137,6 +137,11 @@ int issl_index_build_from_sites(const uint64_t *sigs, const uint32_t *occ, size_
 int issl_index_build_on_device(const uint64_t *sigs, const uint32_t *occ, size_t n_sites,
                                size_t n_lines, size_t seq_len, size_t slice_width, int device,
                                issl_index **out);
+/* The same with layout options for the image it makes, as issl_index_set_option would set them on a handle before
+ * issl_index_upload: `options` = "key=value,key=value" (e.g. "compact=1,host_cold=1") or NULL.  (ABI 4) */
+int issl_index_build_on_device_opt(const uint64_t *sigs, const uint32_t *occ, size_t n_sites,
+                                   size_t n_lines, size_t seq_len, size_t slice_width, int device,
+                                   const char *options, issl_index **out);
 
 /* Write the .issl bytes (isslCreateIndex.cpp:256-289). */
 int issl_index_write(const issl_index *idx, const char *path);

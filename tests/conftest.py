@@ -12,6 +12,14 @@ sys.path.insert(0, str(ROOT / "tests"))
 GOLD = ROOT / "tests" / "golden"
 
 
+SCALE_NOTES = []  # tests/test_scale.py: the sizes its points actually ran at, printed behind the test summary
+
+
+def pytest_terminal_summary(terminalreporter):
+    for note in SCALE_NOTES:
+        terminalreporter.write_line("scale point ran: " + note)
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
@@ -78,3 +86,15 @@ def golden_oddtable():
     """The clustered index with a rewritten local-MIT table: duplicate masks (first pair wins), masks with odd bits,
     patterns missing from the table -- outputs of the compiled reference (oracle/make_golden_oddtable.py)."""
     return Golden("oddtable")
+
+
+# Golden sets that exercise branches no builder-made index reaches (oracle/make_golden_extra.py; all of them outputs
+# of the compiled reference): occurrence counts at the saturation points of the image's 8- and 24-bit copies, counts
+# that differ between the five lists of a site, a score table with negative, NaN and +inf values under guides with
+# thousands of hits.
+EXTRA_SETS = ["bigocc", "mixedocc", "signedtable"]
+
+
+@pytest.fixture(scope="session", params=EXTRA_SETS)
+def golden_extra(request):
+    return Golden(request.param)

@@ -838,9 +838,8 @@ def test_random_small_indexes_differential():
     trials = int(os.environ.get("ISSL_FUZZ_TRIALS", 12))
     rng = np.random.default_rng(int(os.environ.get("ISSL_FUZZ_SEED", 424242)))
     methods = ["and", "or", "avg", "mit", "cfd"]
-    layouts = [{"inline_sigs": 1, "host_cold": 0}, {"inline_sigs": 0, "host_cold": 0}, {"inline_sigs": -1, "host_cold": 1}]
-    scans = [{"sorted_layout": 1, "prune": 1}, {"sorted_layout": 1, "prune": -1}, {"sorted_layout": 1, "prune": 0},
-             {"sorted_layout": 0, "prune": -1}]
+    from test_layouts import LAYOUTS, SORTED
+    names = list(LAYOUTS)
     with tempfile.TemporaryDirectory() as tmp:
         for trial in range(trials):
             n_centres = int(rng.integers(1, 40))
@@ -859,14 +858,15 @@ def test_random_small_indexes_differential():
             ix = ca.IsslIndex.build_from_sites(sig, occ)
             path = os.path.join(tmp, f"t{trial}.issl")
             ix.write(path)
-            layout = dict(layouts[int(rng.integers(0, 3))])
-            if not layout["host_cold"]:   # (the sorted layout needs the cold sections in HBM)
-                layout.update(scans[int(rng.integers(0, 4)) if trial % 2 else 0])
+            name = names[int(rng.integers(0, len(names)))] if trial % 3 else SORTED[(trial // 3) % 3]
+            layout = dict(LAYOUTS[name])
+            if name in SORTED:
+                layout["prune"] = int(rng.integers(-1, 2)) if trial % 2 else 1
             for key, value in layout.items():
                 ix.set_option(key, value)
             ix.upload(0)
-            assert ix.get_option("cold_on_host") == layout["host_cold"]
-            assert ix.get_option("is_sorted") == layout.get("sorted_layout", 0)
+            assert ix.get_option("is_sorted") == (1 if name in SORTED else 0)
+            layout["name"] = name
             oracle = ou.OracleIndex(path)
             guides = np.concatenate([centres, centres ^ np.uint64(2 << 16), rng.integers(0, 1 << 40, size=5, dtype=np.uint64)])
             for _ in range(4):
@@ -883,32 +883,6 @@ def test_random_small_indexes_differential():
             ix.close()
 
 
-def test_image_without_inline_signatures(golden, monkeypatch):
-    """Indexes above 600 M sites leave the optional in-list signature section out of the image (verify and replay then
-    go entries -> sites); force that layout on the golden indexes: smaller image, same stdout, same hit lists."""
-    guides = ca.encode_guides(golden.guides)
-    with_sigs = ca.IsslIndex.open(golden.issl)
-    n_with = with_sigs.device_bytes()
-    with_sigs.close()
-    monkeypatch.setenv("ISSL_INLINE_SIGS", "0")
-    ix = ca.IsslIndex.open(golden.issl)
-    assert ix.device_bytes() < n_with
-    ix.upload(0)
-    for key in ("and|75|4", "or|0|4", "cfd|75|2"):
-        if key not in golden.expected:
-            continue
-        method, thr, dist = key.split("|")
-        mit, cfd = ix.score(guides, int(dist), float(thr), method)
-        assert ca.format_scores(guides, mit, cfd, method) == golden.expected[key], key
-    hits = ix.dump_hits(guides, 4, 0.0, "and")
-    ix.close()
-    monkeypatch.setenv("ISSL_INLINE_SIGS", "1")
-    ix = ca.IsslIndex.open(golden.issl).upload(0)
-    assert ix.device_bytes() == n_with
-    assert np.array_equal(ix.dump_hits(guides, 4, 0.0, "and"), hits)
-    ix.close()
-
-
 def test_runtime_threshold_kernel_with_the_pruned_scan(config0):
     """The runtime-threshold build of the scan kernel (scan_generic) working through the successor-byte groups."""
     ix, oracle, sigs, guides = config0
@@ -921,37 +895,6 @@ def test_runtime_threshold_kernel_with_the_pruned_scan(config0):
             assert np.array_equal(hits, ohits), dist
     finally:
         ix.set_option("scan_generic", 0).set_option("prune", -1)
-
-
-def test_index_with_entries_in_foreign_buckets_keeps_the_list_order(golden_uniform):
-    """No builder writes a slice list that holds a site whose signature does not select it, but the format allows it and
-    the reference would still score such an entry (it compares whole signatures, isslScoreOfftargets.cpp:376).  The
-    sorted layout cannot be built for such a file (ordering by signature would move entries between buckets): the
-    upload notices and falls back to the list-order image; scoring works as it does with the sorted layout switched off."""
-    data = bytearray(golden_uniform.issl.read_bytes())
-    hdr = np.frombuffer(bytes(data[:48]), dtype=np.uint64)
-    n, n_slices, n_scores = int(hdr[0]), int(hdr[4]), int(hdr[5])
-    sizes_at = 48 + 16 * n_scores + 8 * n
-    sizes = np.frombuffer(bytes(data[sizes_at:sizes_at + 8 * n_slices * 256]), dtype=np.uint64)
-    starts = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
-    entries_at = sizes_at + 8 * n_slices * 256
-    full = [b for b in range(256) if sizes[b] > 0]          # two non-empty buckets of slice 0: swap their first entries
-    a, b = entries_at + 8 * int(starts[full[0]]), entries_at + 8 * int(starts[full[-1]])
-    data[a:a + 8], data[b:b + 8] = data[b:b + 8], data[a:a + 8]
-    guides = ca.encode_guides(golden_uniform.guides)
-    ix = ca.IsslIndex.from_bytes(bytes(data)).upload(0)
-    assert ix.get_option("is_sorted") == 0
-    got = ix.score(guides, 4, 75.0, "and")
-    ix.close()
-    plain = ca.IsslIndex.from_bytes(bytes(data))
-    plain.set_option("sorted_layout", 0)
-    plain.upload(0)
-    want = plain.score(guides, 4, 75.0, "and")
-    plain.close()
-    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
-    intact = ca.IsslIndex.open(golden_uniform.issl).upload(0)
-    assert intact.get_option("is_sorted") == 1
-    intact.close()
 
 
 def test_pruned_scan_on_groups_of_many_windows(tmp_path):

@@ -1,0 +1,181 @@
+"""Every image layout against every golden set of the compiled reference (stdout text and hit lists), through the C ABI.
+
+Layouts:
+  sorted        stream ordered by the successor slice's byte, 16-byte stream records          (pruned scan)
+  compact       the same order, 4-byte site ids per stream position                           (pruned scan)
+  compact_cold  ... with the slice lists in pinned host memory (what a 3 G-site index gets)   (pruned scan)
+  list_esig     stream in list order, in-list signatures
+  list          stream in list order
+  host_cold     stream in list order, site table and lists in pinned host memory (occ8 + plane rebuild)
+The sorted layouts score in (slice, site id) order, the list-order ones in (slice, list position) order; on indexes whose
+lists ascend by id -- every builder's -- the two are the reference's order (isslScoreOfftargets.cpp:330-348)."""
+import numpy as np
+import pytest
+
+import crackling_amd as ca
+import oracle_util as ou
+from conftest import Golden
+
+pytestmark = pytest.mark.gpu
+
+LAYOUTS = {
+    "sorted": {"sorted_layout": 1, "compact": 0, "host_cold": 0},
+    "compact": {"compact": 1, "host_cold": 0},
+    "compact_cold": {"compact": 1, "host_cold": 1},
+    "list_esig": {"sorted_layout": 0, "inline_sigs": 1, "host_cold": 0},
+    "list": {"sorted_layout": 0, "inline_sigs": 0, "host_cold": 0},
+    "host_cold": {"sorted_layout": 0, "host_cold": 1},
+}
+SORTED = ("sorted", "compact", "compact_cold")
+SETS = ["uniform", "clustered", "edge", "oddtable", "bigocc", "signedtable"]
+
+
+def _open(path_or_bytes, layout):
+    ix = ca.IsslIndex.from_bytes(path_or_bytes) if isinstance(path_or_bytes, (bytes, bytearray)) else ca.IsslIndex.open(path_or_bytes)
+    for key, value in LAYOUTS[layout].items():
+        ix.set_option(key, value)
+    return ix
+
+
+def _check_layout(ix, layout):
+    assert ix.get_option("is_sorted") == (1 if layout in SORTED else 0)
+    assert ix.get_option("is_compact") == (1 if layout in ("compact", "compact_cold") else 0)
+    assert ix.get_option("cold_sections") == {"compact_cold": 1, "host_cold": 3}.get(layout, 0)
+    assert ix.get_option("has_inline_sigs") == (1 if layout == "list_esig" else 0)
+
+
+@pytest.mark.parametrize("layout", list(LAYOUTS))
+@pytest.mark.parametrize("name", SETS)
+def test_every_layout_reproduces_the_reference(name, layout):
+    g = Golden(name)
+    ix = _open(g.issl, layout).upload(0)
+    _check_layout(ix, layout)
+    sigs = ca.encode_guides([s.encode() for s in g.guides])
+    try:
+        for prune in ((0, 1) if layout in SORTED else (-1,)):
+            ix.set_option("prune", prune)
+            for key, want in g.expected.items():
+                method, thr, dist = key.split("|")
+                mit, cfd = ix.score(sigs, int(dist), float(thr), method)
+                assert ca.format_scores(sigs, mit, cfd, method) == want, (key, prune)
+                if prune == 1 and 0 <= int(dist) <= 4:
+                    assert ix.stats()["pruned"] == (1 if int(dist) <= 2 else 2)
+            for thr in g.hit_thresholds():
+                hits = ix.dump_hits(sigs, 4, float(thr), "and")
+                want = g.hits(thr)
+                assert hits.shape == want.shape, (thr, prune, hits.shape, want.shape)
+                assert np.array_equal(hits, want), (thr, prune)
+    finally:
+        ix.close()
+
+
+def test_layout_sizes(golden_uniform):
+    """HBM bytes per layout, in the order an upload tries them (issl_index_device_bytes needs no device)."""
+    size = {}
+    for layout in LAYOUTS:
+        ix = _open(golden_uniform.issl, layout)
+        size[layout] = ix.device_bytes()
+        ix.close()
+    auto = ca.IsslIndex.open(golden_uniform.issl)
+    assert auto.device_bytes() == size["sorted"]
+    auto.close()
+    n = 8200  # about the sites of the set: the sections differ by whole multiples of it
+    assert size["sorted"] > size["compact"] + 50 * n > size["compact_cold"] + 80 * n
+    assert size["list_esig"] > size["list"] + 30 * n > size["host_cold"] + 60 * n
+
+
+def test_counts_that_differ_between_a_sites_lists_keep_the_list_order():
+    """tests/golden/mixedocc: the five list entries of a site carry different occurrence counts; the reference takes the
+    count of the entry it meets first (:348).  The sorted layouts keep ONE count per site, so the upload must notice and
+    fall back to a list-order image; asking for a sorted layout explicitly fails."""
+    g = Golden("mixedocc")
+    sigs = ca.encode_guides([s.encode() for s in g.guides])
+    for layout in (None, "list_esig", "list", "host_cold"):
+        ix = ca.IsslIndex.open(g.issl) if layout is None else _open(g.issl, layout)
+        ix.upload(0)
+        assert ix.get_option("is_sorted") == 0
+        for key, want in g.expected.items():
+            method, thr, dist = key.split("|")
+            mit, cfd = ix.score(sigs, int(dist), float(thr), method)
+            assert ca.format_scores(sigs, mit, cfd, method) == want, (layout, key)
+        for thr in g.hit_thresholds():
+            assert np.array_equal(ix.dump_hits(sigs, 4, float(thr), "and"), g.hits(thr)), (layout, thr)
+        ix.close()
+    for layout in SORTED:
+        ix = _open(g.issl, layout)
+        with pytest.raises(ca.IsslError) as e:
+            ix.upload(0)
+        assert "sorted layout" in str(e.value)
+        ix.close()
+
+
+def _sections(data):
+    hdr = np.frombuffer(bytes(data[:48]), dtype=np.uint64)
+    n, n_slices, n_scores = int(hdr[0]), int(hdr[4]), int(hdr[5])
+    sizes_at = 48 + 16 * n_scores + 8 * n
+    sizes = np.frombuffer(bytes(data[sizes_at:sizes_at + 8 * n_slices * 256]), dtype=np.uint64)
+    starts = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    return n, n_slices, sizes, starts, sizes_at + 8 * n_slices * 256
+
+
+def test_lists_that_do_not_ascend_by_site_id_keep_the_list_order(golden_uniform, tmp_path):
+    """Every builder appends site ids in ascending order (isslCreateIndex.cpp:218-234), but the format does not ask for
+    it and the reference scores a bucket in whatever order its list has (:344).  An index whose lists were shuffled inside
+    their buckets is valid; the sorted layouts (scoring order = site id) cannot hold it: list-order image, results equal to
+    the oracle's on the same file."""
+    data = bytearray(golden_uniform.issl.read_bytes())
+    n, n_slices, sizes, starts, entries_at = _sections(data)
+    rng = np.random.default_rng(5)
+    ent = np.frombuffer(bytes(data[entries_at:entries_at + 8 * n * n_slices]), dtype=np.uint64).copy()
+    for b in range(n_slices * 256):
+        if sizes[b] > 1:
+            seg = ent[starts[b]:starts[b + 1]]
+            ent[starts[b]:starts[b + 1]] = seg[rng.permutation(len(seg))]
+    data[entries_at:entries_at + 8 * n * n_slices] = ent.tobytes()
+    path = tmp_path / "shuffled.issl"
+    path.write_bytes(bytes(data))
+    oracle = ou.OracleIndex(path)
+    guides = ca.encode_guides(golden_uniform.guides)
+    for layout in (None, "list", "host_cold"):
+        ix = ca.IsslIndex.open(path) if layout is None else _open(path, layout)
+        ix.upload(0)
+        assert ix.get_option("is_sorted") == 0
+        for thr in (0.0, 75.0):
+            omit, ocfd, ohits = oracle.score(guides, 4, thr, "and", want_hits=True)
+            mit, cfd = ix.score(guides, 4, thr, "and")
+            assert np.array_equal(mit.view(np.uint64), omit.view(np.uint64)) and np.array_equal(cfd.view(np.uint64), ocfd.view(np.uint64))
+            assert np.array_equal(ix.dump_hits(guides, 4, thr, "and"), ohits)
+        ix.close()
+    oracle.close()
+    ix = _open(path, "sorted")
+    with pytest.raises(ca.IsslError):
+        ix.upload(0)
+    ix.close()
+
+
+@pytest.mark.parametrize("layout", [None] + list(LAYOUTS))
+def test_a_site_in_a_foreign_bucket_or_listed_twice_is_a_format_error(golden_uniform, layout):
+    """A slice list that holds a site whose signature does not select it, or the same site twice: no builder writes
+    either.  The reference would still run (it compares whole signatures and keeps a seen-bitmap, :376,:385-390), but
+    the scan compares only the 16 positions outside the slice and the first-matching-slice rule stands in for the bitmap
+    on the premise that every slice lists every site once, in its own bucket -- so the upload refuses the file in EVERY
+    layout (ISSL_E_FORMAT) instead of scoring it differently from the reference in some."""
+    base = golden_uniform.issl.read_bytes()
+    n, n_slices, sizes, starts, entries_at = _sections(base)
+    full = [b for b in range(256) if sizes[b] > 1]
+    # (a) swap the first entries of two buckets of slice 0; (b) overwrite an entry with its neighbour (a duplicate)
+    swapped = bytearray(base)
+    a, b = entries_at + 8 * int(starts[full[0]]), entries_at + 8 * int(starts[full[-1]])
+    swapped[a:a + 8], swapped[b:b + 8] = swapped[b:b + 8], swapped[a:a + 8]
+    twice = bytearray(base)
+    at = entries_at + 8 * int(starts[256 + full[3]])
+    twice[at + 8:at + 16] = twice[at:at + 8]
+    for data in (swapped, twice):
+        ix = ca.IsslIndex.from_bytes(bytes(data)) if layout is None else _open(bytes(data), layout)
+        with pytest.raises(ca.IsslError) as e:
+            ix.upload(0)
+        assert "Error reading index" in str(e.value)
+        ix.close()
+    intact = ca.IsslIndex.open(golden_uniform.issl).upload(0)
+    assert intact.get_option("is_sorted") == 1
+    intact.close()

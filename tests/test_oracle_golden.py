@@ -51,6 +51,21 @@ def test_oracle_matches_reference_on_a_table_with_duplicate_odd_and_missing_mask
         assert np.array_equal(hits, g.hits(thr)), thr
 
 
+def test_oracle_matches_reference_on_large_counts_and_signed_tables(golden_extra):
+    """isslScoreOfftargets.cpp:348 (the count of the entry met first, a uint32), :394 / :460 (whatever the table holds
+    is added: negative, NaN, inf) -- reference outputs of oracle/make_golden_extra.py; one thread, like the golden run."""
+    g = golden_extra
+    ix = ou.OracleIndex(g.issl)
+    sigs = ou.encode(g.guides)
+    for key, want in g.expected.items():
+        method, thr, dist = key.split("|")
+        mit, cfd = ix.score(sigs, int(dist), float(thr), method, threads=1)
+        assert ou.format_tsv([l.split("\t")[0] for l in want.splitlines()], mit, cfd, method) == want, key
+    for thr in g.hit_thresholds():
+        _, _, hits = ix.score(sigs, 4, float(thr), "and", threads=1, want_hits=True)
+        assert np.array_equal(hits, g.hits(thr)), thr
+
+
 def test_oracle_thread_count_invariance(golden_uniform):
     ix = ou.OracleIndex(golden_uniform.issl)
     sigs = ou.encode(golden_uniform.guides)

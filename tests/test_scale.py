@@ -1,10 +1,12 @@
 """Scale points: BASELINE configs[2] (100 k guides x 300 M-line index, one GPU), configs[3]'s shape on one GPU (1 M
 guides over three replicas of that index) and hit lists at that size, checked against the CPU oracle.
 
-The device-built tests run at configs[2]'s full size whenever the GPU has >= 40 GB of free HBM and the host has the
-memory for the site table (else at 20 M lines x 20 k guides); the host-built test keeps 20 M lines (it writes the
-.issl for the oracle).  The bigger points of profiles/ are the same tests with ISSL_SCALE_SITES / ISSL_SCALE_GUIDES /
-ISSL_SCALE_JSON set (e.g. 3 000 000 000 sites = BASELINE configs[4]'s index on ONE MI355X).  The .issl for the
+The device-built tests run at configs[2]'s full size or not at all (they fail on an MI355X that cannot hold it and are
+skipped on a smaller GPU; the size is part of the test id and is printed behind the test summary); the host-built test
+keeps 20 M lines (it writes the .issl for the oracle).  The bigger points of profiles/ are the same tests with
+ISSL_SCALE_SITES / ISSL_SCALE_GUIDES / ISSL_SCALE_JSON set; test_layout_for_indexes_beyond_the_hbm_at_scale is
+BASELINE configs[4]'s layout at the largest size the box's host memory holds (ISSL_BEYOND_HBM_LINES=3000000000 is
+configs[4] itself on ONE MI355X).  The .issl for the
 oracle goes to ISSL_SCALE_TMP (default: pytest's tmp dir; use /dev/shm for files larger than the disk)."""
 import json
 import os
@@ -120,36 +122,39 @@ def _free_hbm_bytes():
 
 
 class ScalePoint:
-    """One device-built index shared by the tests below (built once per module: synthesis dominates the cost)."""
+    """One device-built index shared by the tests below (built once per module: synthesis dominates the cost).  The size
+    is the one asked for or the point does not run: it FAILS when the box is an MI355X-class GPU (>= 40 GB of free HBM)
+    that cannot hold it -- a green suite means the full size ran -- and is skipped, with the reason, on a smaller GPU."""
 
-    def __init__(self):
+    def __init__(self, n_lines, n_guides, options=None, n_check=None, what="configs[2]"):
         from concurrent.futures import ThreadPoolExecutor
+        import conftest
         self.threads = min(32, os.cpu_count() or 8)
-        want_lines = int(os.environ.get("ISSL_SCALE_SITES", 300_000_000))
-        want_guides = int(os.environ.get("ISSL_SCALE_GUIDES", 100_000))
-        # host: 12 B/site generated (twice while the chunks are concatenated) + brute-force temporaries, + 48 B/site pinned
-        # when the cold sections are forced into host memory; HBM, smallest layout the library falls back to: 108 B/site
-        # with the in-list signatures (<= 600 M sites), 68 without, 20 with host-resident cold sections (+ 16 B/site of
-        # temporaries while it is packed); the sorted layout of the pruned scan adds 100 B/site where that fits
-        host_cold = os.environ.get("ISSL_FORCE_HOST_COLD") == "1"
-        per_site_hbm = 36 if host_cold else (110 if want_lines <= 600_000_000 else 70)
-        # (host peak: 24 B/site while the generated chunks are concatenated; later 12 B/site + 48 B/site pinned + ~25 GB
-        # of brute-force temporaries)
-        host_need = max(want_lines * 40, want_lines * 60 + 32e9) if host_cold else want_lines * 40
-        fits = (host_need <= 0.75 * _memory_limit_bytes()
-                and _free_hbm_bytes() >= max(40e9, want_lines * per_site_hbm + 10e9))
-        if not fits and "ISSL_SCALE_SITES" in os.environ:
-            pytest.skip(f"{want_lines} lines need ~{host_need / 1e9:.0f} GB of host memory "
-                        f"(limit {_memory_limit_bytes() / 1e9:.0f}) and ~{want_lines * per_site_hbm / 1e9:.0f} GB of HBM (free {_free_hbm_bytes() / 1e9:.0f})")
-        self.n_lines, self.n_guides = (want_lines, want_guides) if fits else (20_000_000, 20_000)
+        options = dict(options or {})
+        lists_cold = options.get("host_cold") == 1
+        # HBM per site: sorted layout 152 B (+ 16 B of temporaries while it is built); compact with the lists in host
+        # memory 52 B (+ 24 B of temporaries).  Host: 12 B/site generated (twice while the chunks are concatenated) +
+        # brute-force temporaries, + 40 B/site pinned for host-resident lists
+        per_site_hbm = 76 if lists_cold else 168
+        host_need = n_lines * (24 + (40 if lists_cold else 0)) + 16e9
+        free_hbm, limit = _free_hbm_bytes(), _memory_limit_bytes()
+        if free_hbm < 40e9:
+            pytest.skip(f"{what}: {free_hbm / 1e9:.0f} GB of free HBM -- not the MI355X this point is sized for")
+        if host_need > 0.8 * limit or free_hbm < n_lines * per_site_hbm + 8e9:
+            pytest.fail(f"{what}: {n_lines} lines need ~{host_need / 1e9:.0f} GB of host memory (limit {limit / 1e9:.0f}) and "
+                        f"~{n_lines * per_site_hbm / 1e9:.0f} GB of HBM (free {free_hbm / 1e9:.0f}); the point does not shrink")
+        self.n_lines, self.n_guides = n_lines, n_guides
         t = time.time(); self.sigs, self.occ = random_sites_fast(self.n_lines, seed=11, threads=self.threads); self.t_synth = time.time() - t
         self.guides = random_guides_fast(self.sigs, self.n_guides, seed=12)
-        t = time.time(); self.ix = ca.IsslIndex.build_on_device(self.sigs, self.occ, device=0); self.t_build = time.time() - t
-        print(f"scale point: {self.n_lines} lines, {len(self.sigs)} distinct sites, synth {self.t_synth:.1f}s, built on the "
-              f"device in {self.t_build:.1f}s, image {self.ix.device_bytes() / 1e9:.1f} GB", flush=True)
+        t = time.time(); self.ix = ca.IsslIndex.build_on_device(self.sigs, self.occ, device=0, options=options); self.t_build = time.time() - t
+        note = (f"{what}: {self.n_lines} lines ({len(self.sigs)} distinct sites) x {self.n_guides} guides, image "
+                f"{self.ix.device_bytes() / 1e9:.1f} GB in HBM + {self.ix.cold()[1] / 1e9:.1f} GB pinned, sorted={self.ix.get_option('is_sorted')} "
+                f"compact={self.ix.get_option('is_compact')}")
+        conftest.SCALE_NOTES.append(note)
+        print(f"scale point {note}; synth {self.t_synth:.1f}s, built on the device in {self.t_build:.1f}s", flush=True)
         # the checker: for a sample of guides every site within 4 mismatches, by brute force over the site table; those
         # sites (+ bystanders), with their occurrences and in the same relative order, form a small index for the oracle
-        self.n_check = int(os.environ.get("ISSL_SCALE_CHECK", 64))
+        self.n_check = n_check or int(os.environ.get("ISSL_SCALE_CHECK", 64))
         self.pick = np.linspace(0, self.n_guides - 1, self.n_check).astype(np.int64)
         t = time.time()
         with ThreadPoolExecutor(max_workers=min(self.threads, 16)) as pool:
@@ -170,19 +175,20 @@ class ScalePoint:
         return out
 
 
-@pytest.fixture(scope="module")
-def scale():
-    sp = ScalePoint()
+SCALE_SIZE = (int(os.environ.get("ISSL_SCALE_SITES", 300_000_000)), int(os.environ.get("ISSL_SCALE_GUIDES", 100_000)))
+
+
+@pytest.fixture(scope="module", params=[SCALE_SIZE], ids=lambda p: f"{p[0]}lines-{p[1]}guides")
+def scale(request):
+    options = {"compact": 1, "host_cold": 1} if os.environ.get("ISSL_SCALE_LAYOUT") == "compact_cold" else None
+    sp = ScalePoint(request.param[0], request.param[1], options=options)
     yield sp
     sp.ix.close()
 
 
-@pytest.mark.gpu
-def test_device_built_scale_point(scale, tmp_path):
-    """BASELINE configs[2] on one MI355X: index built ON the GPU (issl_index_build_on_device: no 48 B/site host arrays),
-    100 k guides scored; a sample is bit-identical to the CPU oracle on the index of its brute-force neighbourhoods --
-    sites farther away contribute nothing, and the scoring order (slice, position in bucket) of the survivors is
-    unchanged.  The scan's own comparison counter must equal the bucket-table arithmetic: every bucket was scanned."""
+def _score_and_check(scale, tmp_path, what):
+    """Whole buckets (the reference's loop), then the planner's choice: a sample bit-identical to the oracle, ALL scores of
+    the batch identical between the two scans, comparison counters consistent; returns the summary."""
     ix, guides = scale.ix, scale.guides
     omit, ocfd = scale.oracle_on_neighbourhoods(tmp_path, 75.0)
     assert (omit < 100).any()  # the sample does meet off-targets
@@ -207,24 +213,46 @@ def test_device_built_scale_point(scale, tmp_path):
         runs[prune] = best
     wall, st = runs[-1]
     full_st = runs[0][1]
+    assert st["pruned"] == 2   # at these sizes the planner prunes
     summary = {
-        "what": f"tests/test_scale.py::test_device_built_scale_point: {scale.n_guides} guides vs a {scale.n_lines}-line synthetic "
+        "what": f"{what}: {scale.n_guides} guides vs a {scale.n_lines}-line synthetic "
                 f"index built on one MI355X (issl_index_build_on_device), 'and' thr 75 max_dist 4; {scale.n_check} guides checked "
-                f"bit-for-bit against the CPU oracle on the index of their brute-force neighbourhoods",
-        "distinct_sites": int(len(scale.sigs)), "image_GB": ix.device_bytes() / 1e9, "synth_s": scale.t_synth,
+                f"bit-for-bit against the CPU oracle on the index of their brute-force neighbourhoods; all {scale.n_guides} scores "
+                f"identical between the whole-bucket and the pruned scan",
+        "distinct_sites": int(len(scale.sigs)), "image_GB": ix.device_bytes() / 1e9, "pinned_host_GB": ix.cold()[1] / 1e9,
+        "synth_s": scale.t_synth,
         "device_build_s": scale.t_build, "wall_ms": wall * 1e3, "scan_ms": st["ms_scan"], "verify_ms": st["ms_verify"],
-        "group_ms": st["ms_group"], "replay_ms": st["ms_replay"], "pipeline_ms": st["ms_total"],
+        "bin_ms": st["ms_bin"], "group_ms": st["ms_group"], "replay_ms": st["ms_replay"], "pipeline_ms": st["ms_total"],
         "pruned": st["pruned"], "comparisons": st["candidates"], "reference_comparisons": st["reference_comparisons"],
         "hits": st["hits"], "scan_launches": st["scan_launches"],
         "scan_Tcmp_per_s": st["candidates"] / st["ms_scan"] / 1e9,
         "algorithmic_TBps": 8.0 * st["candidates"] / st["ms_scan"] / 1e9,
         "guides_per_s_kernels": scale.n_guides / st["ms_total"] * 1e3, "brute_force_check_s": scale.t_brute,
-        "cold_on_host": ix.get_option("cold_on_host"), "is_sorted": ix.get_option("is_sorted"),
+        "cold_sections": ix.get_option("cold_sections"), "is_sorted": ix.get_option("is_sorted"), "is_compact": ix.get_option("is_compact"),
         "full_scan": {"scan_ms": full_st["ms_scan"], "pipeline_ms": full_st["ms_total"], "comparisons": full_st["candidates"],
                       "scan_Tcmp_per_s": full_st["candidates"] / full_st["ms_scan"] / 1e9,
                       "guides_per_s_kernels": scale.n_guides / full_st["ms_total"] * 1e3},
     }
     print(json.dumps(summary), flush=True)
+    return summary
+
+
+def _hit_lists_match(scale, tmp_path):
+    for thr in (0.0, 75.0):
+        got = scale.ix.dump_hits(scale.guides[scale.pick], 4, thr, "and")
+        _, _, want = scale.oracle_on_neighbourhoods(tmp_path, thr, want_hits=True)
+        assert len(got) == len(want) and len(got) > scale.n_check // 2, (thr, len(got), len(want))
+        assert np.array_equal(got[:, [0, 1, 4, 5]], want[:, [0, 1, 4, 5]]), thr           # guide, slice, dist, occ
+        assert np.array_equal(scale.sigs[got[:, 3]], scale.sigs[scale.keep][want[:, 3]]), thr  # the same sites
+
+
+@pytest.mark.gpu
+def test_device_built_scale_point(scale, tmp_path):
+    """BASELINE configs[2] on one MI355X: index built ON the GPU (issl_index_build_on_device: no 48 B/site host arrays),
+    100 k guides scored; a sample is bit-identical to the CPU oracle on the index of its brute-force neighbourhoods --
+    sites farther away contribute nothing, and the scoring order (slice, position in bucket) of the survivors is
+    unchanged.  The scan's own comparison counter must equal the bucket-table arithmetic: every bucket was scanned."""
+    summary = _score_and_check(scale, tmp_path, "tests/test_scale.py::test_device_built_scale_point")
     if os.environ.get("ISSL_SCALE_JSON"):
         json.dump(summary, open(os.environ["ISSL_SCALE_JSON"], "w"), indent=1)
 
@@ -234,12 +262,7 @@ def test_hit_lists_at_scale(scale, tmp_path):
     """Bit-exact hit lists at configs[2]'s size: for the sampled guides, (slice, site, distance, occurrences) of every
     scored off-target in scoring order, without and with early exit, against the oracle on the neighbourhood index
     (site ids and bucket positions differ between the two indexes; the sites and their order do not)."""
-    for thr in (0.0, 75.0):
-        got = scale.ix.dump_hits(scale.guides[scale.pick], 4, thr, "and")
-        _, _, want = scale.oracle_on_neighbourhoods(tmp_path, thr, want_hits=True)
-        assert len(got) == len(want) and len(got) > scale.n_check // 2, (thr, len(got), len(want))
-        assert np.array_equal(got[:, [0, 1, 4, 5]], want[:, [0, 1, 4, 5]]), thr           # guide, slice, dist, occ
-        assert np.array_equal(scale.sigs[got[:, 3]], scale.sigs[scale.keep][want[:, 3]]), thr  # the same sites
+    _hit_lists_match(scale, tmp_path)
 
 
 @pytest.mark.gpu
@@ -319,3 +342,37 @@ def test_cold_sections_in_host_memory_at_scale(monkeypatch, tmp_path):
     got2 = again.score(guides[:5000], 4, 75.0, "and")
     assert np.array_equal(got2[0].view(np.uint64), want[0][:5000].view(np.uint64))
     again.close()
+
+
+def _beyond_hbm_lines():
+    """BASELINE configs[4]'s index does not fit the default layouts; its layout (compact sorted image, slice lists in
+    pinned host memory) is exercised here at the largest of these line counts whose host arrays fit this box's memory
+    limit (ISSL_BEYOND_HBM_LINES overrides; 3 000 000 000 = configs[4] itself: profiles/r03_scale_3g_*)."""
+    if "ISSL_BEYOND_HBM_LINES" in os.environ:
+        return int(os.environ["ISSL_BEYOND_HBM_LINES"])
+    for n in (1_000_000_000, 600_000_000, 300_000_000, 100_000_000):
+        if n * 64 + 16e9 <= 0.8 * _memory_limit_bytes():
+            return n
+    return 0
+
+
+@pytest.mark.gpu
+def test_layout_for_indexes_beyond_the_hbm_at_scale(tmp_path):
+    """configs[4]-shaped point: the layout an index larger than the HBM gets (compact sorted image: scan stream, site ids
+    per stream position, site table and counts in HBM = 52 B/site; slice lists in pinned host memory), forced, at the
+    largest size the box's host memory allows (the size is printed behind the test summary).  Pruned scan against the
+    scan of whole buckets on all guides, a sample and its hit lists against the oracle."""
+    n_lines = _beyond_hbm_lines()
+    if not n_lines:
+        pytest.skip(f"host memory limit {_memory_limit_bytes() / 1e9:.0f} GB: no room for the pinned slice lists of even 100 M lines")
+    sp = ScalePoint(n_lines, int(os.environ.get("ISSL_SCALE_GUIDES", 100_000)), options={"compact": 1, "host_cold": 1},
+                    n_check=int(os.environ.get("ISSL_SCALE_CHECK", 32)), what="configs[4]-shaped (compact image, lists in host memory)")
+    try:
+        assert sp.ix.get_option("is_compact") == 1 and sp.ix.get_option("cold_sections") == 1
+        assert sp.ix.cold()[1] >= 40 * len(sp.sigs) and sp.ix.device_bytes() < 60 * len(sp.sigs) + (64 << 20)
+        summary = _score_and_check(sp, tmp_path, "tests/test_scale.py::test_layout_for_indexes_beyond_the_hbm_at_scale")
+        _hit_lists_match(sp, tmp_path)
+        if os.environ.get("ISSL_BEYOND_HBM_JSON"):
+            json.dump(summary, open(os.environ["ISSL_BEYOND_HBM_JSON"], "w"), indent=1)
+    finally:
+        sp.ix.close()
