@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void k_sort_keys(const uint64_t *__restrict__ 
 }
 
 __global__ __launch_bounds__(256) void k_fill_maps(const uint64_t *__restrict__ keys, const uint64_t *__restrict__ bucket_start,
-                                                   const uint64_t *__restrict__ list, uint64_t n_sites, uint32_t slice,
+                                                   const uint32_t *__restrict__ tile_first, const uint64_t *__restrict__ list, uint64_t n_sites, uint32_t slice,
                                                    const uint64_t *__restrict__ sites, StreamRec *__restrict__ srec,
                                                    uint32_t *__restrict__ sid, uint32_t *__restrict__ site_occ,
                                                    uint32_t *__restrict__ flag)
@@ -78,14 +78,16 @@ __global__ __launch_bounds__(256) void k_fill_maps(const uint64_t *__restrict__ 
         // disagree about a site keeps its list-order layout
         if (slice == 0) site_occ[id] = static_cast<uint32_t>(occ);
         else if (site_occ[id] != static_cast<uint32_t>(occ)) atomicOr(flag, 2u);
-        // t0 + i = bucket_start[bucket] + stream position inside the bucket: the buckets keep their places
+        // t0 + i = bucket_start[bucket] + stream position inside the bucket (the buckets keep their places); the maps are
+        // indexed like the scan stream itself, where every bucket starts on a tile
+        const uint64_t at = static_cast<uint64_t>(tile_first[bucket]) * kTileCands + (t0 + i - bucket_start[bucket]);
         if (srec) {
             StreamRec r;
             r.sig = (sites[id] & ((1ull << 40) - 1ull)) | ((occ < kOccSaturated ? occ : kOccSaturated) << 40);
             r.id = id; r.pos = p;
-            srec[t0 + i] = r;
+            srec[at] = r;
         } else {
-            sid[t0 + i] = id;
+            sid[at] = id;
         }
     }
 }
@@ -135,7 +137,7 @@ void SortTemp::release()
 }
 
 int launch_sort_slice(SortTemp &t, const uint64_t *d_sites, const uint64_t *d_list, const uint64_t *d_bucket_start,
-                      uint64_t n_sites, uint32_t n_slices, uint32_t n_buckets, uint32_t slice, uint32_t *d_sub_start,
+                      const uint32_t *d_tile_first, uint64_t n_sites, uint32_t n_slices, uint32_t n_buckets, uint32_t slice, uint32_t *d_sub_start,
                       StreamRec *d_srec, uint32_t *d_sid, uint32_t *d_site_occ, uint32_t *d_flag)
 {
     if (n_slices == 0 || n_slices > 8 || n_buckets != n_slices * 256u || n_sites >= (1ull << 32) || slice >= n_slices) {
@@ -160,7 +162,7 @@ int launch_sort_slice(SortTemp &t, const uint64_t *d_sites, const uint64_t *d_li
                            n_blocks, KeyItself{});
         std::swap(src, dst);
     }
-    hipLaunchKernelGGL(k_fill_maps, dim3(grid), dim3(256), 0, nullptr, src, d_bucket_start, d_list, n_sites, slice, d_sites,
+    hipLaunchKernelGGL(k_fill_maps, dim3(grid), dim3(256), 0, nullptr, src, d_bucket_start, d_tile_first, d_list, n_sites, slice, d_sites,
                        d_srec, d_sid, d_site_occ, d_flag);
     hipLaunchKernelGGL(k_sub_start, dim3((per_slice * 257u + 255u) / 256u), dim3(256), 0, nullptr, src, d_bucket_start,
                        n_sites, slice, per_slice, d_sub_start);

@@ -58,8 +58,8 @@ void layout_image(ImageHeader &h, const Geometry &g, uint64_t n_scores_unique, u
     if (spec.cold == 3u) { h.off_occ8 = off; off = align256(off + g.n_sites * g.n_slices); }
     if (spec.sorted) {
         h.off_sub_start = off; off = align256(off + 4 * h.n_buckets * 257);
-        if (spec.sorted == 1) { h.off_srec = off; off = align256(off + sizeof(StreamRec) * g.n_sites * g.n_slices); }
-        else                  { h.off_sid = off;  off = align256(off + 4 * g.n_sites * g.n_slices); }
+        if (spec.sorted == 1) { h.off_srec = off; off = align256(off + sizeof(StreamRec) * kTileCands * n_tiles); }
+        else                  { h.off_sid = off;  off = align256(off + 4ull * kTileCands * n_tiles); }
         h.off_site_occ = off; off = align256(off + 4 * g.n_sites);
     }
     h.total_bytes = off;
@@ -109,13 +109,14 @@ Tuning Tuning::from_env()
     t.sorted_layout = -1;
     t.compact = -1;
     t.prune = -1;
+    t.tail_shapes = 1;
     t.lanes = 1;
     static const char *const keys[][2] = {
         {"ISSL_SCAN_BLOCKS", "scan_blocks"}, {"ISSL_ITEM_GUIDES", "item_guides"},
         {"ISSL_SCAN_GENERIC", "scan_generic"}, {"ISSL_STAGE_TIMING", "stage_timing"}, {"ISSL_RAW_CHUNKS", "raw_chunks"},
         {"ISSL_INLINE_SIGS", "inline_sigs"}, {"ISSL_FORCE_HOST_COLD", "host_cold"}, {"ISSL_SCAN_STAMPS", "scan_stamps"},
         {"ISSL_SORTED_LAYOUT", "sorted_layout"}, {"ISSL_PRUNE", "prune"}, {"ISSL_LANES", "lanes"},
-        {"ISSL_COMPACT", "compact"},
+        {"ISSL_COMPACT", "compact"}, {"ISSL_TAIL_SHAPES", "tail_shapes"},
     };
     for (const auto &k : keys)
         if (const char *e = std::getenv(k[0])) (void)t.set(k[1], e); // values out of range leave the default
@@ -140,6 +141,7 @@ bool Tuning::set(const char *key, const char *value)
     else if (k == "compact") { if (!is_int || n < -1 || n > 1) return false; compact = static_cast<int>(n); }
     else if (k == "prune") { if (!is_int || n < -1 || n > 1) return false; prune = static_cast<int>(n); }
     else if (k == "lanes") { if (!is_int || n < 1 || n > 2) return false; lanes = static_cast<int>(n); }
+    else if (k == "tail_shapes") { if (!is_int || n < 0 || n > 1) return false; tail_shapes = static_cast<int>(n); }
     else if (k == "scan_stamps") stamps_path = value;
     else return false;
     return true;
@@ -228,7 +230,7 @@ static int select_device(int device)
 static void free_workspace(Workspace &w)
 {
     void *ptrs[] = {w.ng, w.gfill, w.gstart, w.gword, w.gidx, w.gbucket, w.items, w.plan, w.range_start, w.counters, w.scan_count, w.scan_span, w.sticky, w.stamps, w.gcur_big, w.terms, w.sorted, w.gcount,
-                    w.goff, w.blocksum, w.d_guides, w.d_mit, w.d_cfd, w.d_kept, w.d_hitrec, w.pay, w.rank, w.fword, w.fmeta,
+                    w.goff, w.blocksum, w.d_guides, w.d_mit, w.d_cfd, w.d_kept, w.d_hitrec, w.hit_raw, w.hit_grp, w.fword, w.fmeta,
                     w.fitems, w.fcount, w.fsum};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -252,8 +254,8 @@ static int ensure_hit_capacity(Workspace &w, size_t want)
     int rc;
     if ((rc = dev_alloc(w.sorted, want))) return rc;
     if ((rc = dev_alloc(w.terms, 2 * want))) return rc;
-    if ((rc = dev_alloc(w.pay, 2 * want))) return rc;
-    if ((rc = dev_alloc(w.rank, want))) return rc;
+    if ((rc = dev_alloc(w.hit_raw, want))) return rc;
+    if ((rc = dev_alloc(w.hit_grp, want))) return rc;
     w.cap_hits = want;
     return ISSL_OK;
 }
@@ -319,7 +321,7 @@ static int ensure_workspace(issl_index *ix, size_t n, Lane &lane)
             // and reports it (sticky[3]), finish_batches() then enlarges the list for the next one
             const size_t tiles_per_group = static_cast<size_t>(ix->hdr.n_sites / (65536ull * kTileCands)) + 4;
             const size_t fitems = std::max<size_t>(tiles_per_group * (groups + places / 64) + 2, w.cap_fitems);
-            if ((rc = dev_alloc(w.fword, fslots))) return rc;
+            if ((rc = dev_alloc(w.fword, fslots + 64))) return rc; // (+ slack: short_unit_masks reads whole groups of 32 slots)
             if ((rc = dev_alloc(w.fmeta, fslots))) return rc;
             if ((rc = dev_alloc(w.fitems, fitems + 1))) return rc;
             if ((rc = dev_alloc(w.fcount, nb * 256))) return rc;
@@ -488,7 +490,8 @@ static int finish_upload(issl_index *ix, const DeviceBuildInput *dbi = nullptr)
                     HIP_TRY(hipMemcpy(t_list, c_entries + sl * n, 8 * n, hipMemcpyHostToDevice));
                 }
             }
-            src = launch_sort_slice(st, d_sites, d_list, reinterpret_cast<const uint64_t *>(base + ix->hdr.off_bucket_start), n,
+            src = launch_sort_slice(st, d_sites, d_list, reinterpret_cast<const uint64_t *>(base + ix->hdr.off_bucket_start),
+                                    reinterpret_cast<const uint32_t *>(base + ix->hdr.off_tile_first), n,
                                     static_cast<uint32_t>(g.n_slices), static_cast<uint32_t>(nb),
                                     static_cast<uint32_t>(sl), reinterpret_cast<uint32_t *>(base + ix->hdr.off_sub_start),
                                     ix->hdr.off_srec ? reinterpret_cast<StreamRec *>(base + ix->hdr.off_srec) : nullptr,
@@ -1036,6 +1039,7 @@ int issl_index_get_option(const issl_index *idx, const char *key, long long *val
     else if (k == "compact") *value = t.compact;
     else if (k == "prune") *value = t.prune;
     else if (k == "lanes") *value = t.lanes;
+    else if (k == "tail_shapes") *value = t.tail_shapes;
     else if (k == "is_sorted") *value = idx->d_image ? ((idx->hdr.off_srec || idx->hdr.off_sid) ? 1 : 0) : -1; // read-only
     else if (k == "is_compact") *value = idx->d_image ? (idx->hdr.off_sid ? 1 : 0) : -1;                   // read-only
     else if (k == "cold_on_host") *value = idx->d_image ? (idx->hdr.cold_on_host ? 1 : 0) : -1;            // read-only: layout in use

@@ -70,8 +70,9 @@ struct ImageHeader {
     // ascending order) and one occurrence count per site: a hit's place in the reference's scoring order is then
     // (first matching slice, site id) and nothing has to remember list positions.
     uint64_t off_sub_start; // u32[nb * 257]: first stream position (inside the bucket) of every successor-byte value
-    uint64_t off_srec;      // StreamRec[N*S]: stream position (bucket_start[b] + q) -> the candidate there (16 B); or
-    uint64_t off_sid;       // u32[N*S]: ... -> its site id alone (the COMPACT sorted layout: 4 B instead of 16 B per
+    uint64_t off_srec;      // StreamRec[n_tiles * 2048]: position in the (tile-padded) scan stream -> the candidate there
+                            // (16 B): a noted record names its entry by itself (tile, offset), no table in between; or
+    uint64_t off_sid;       // u32[n_tiles * 2048]: ... -> its site id alone (the COMPACT sorted layout: 4 B instead of 16 B per
                             // list entry; signature and count come from `sites` / `site_occ` by id)
     uint64_t off_site_occ;  // u32[N]: occurrence count of every site (sorted layouts)
 };
@@ -141,6 +142,8 @@ struct Tuning {
     int prune;              // ISSL_PRUNE         scan only the successor-byte groups that can hold a hit (needs the sorted
                             //                    layout and max_dist <= 4): -1 when the plan estimates it to be faster,
                             //                    0 never, 1 whenever possible
+    int tail_shapes;        // ISSL_TAIL_SHAPES   1 (default): the short last unit of a successor-byte group runs 2 / 4 guides
+                            //                    per pass on 16 / 8 candidates per lane; 0: every unit is a full one (A/B)
     int lanes;              // ISSL_LANES         1|2 (default 1): workspaces + streams that asynchronous batches alternate
                             //                    between (2: the short kernels of one batch fill the wave slots the scan of
                             //                    the next leaves)
@@ -177,7 +180,7 @@ struct SortTemp {
 // slice's part of sub_start, of srec OR sid (the other one null) and -- slice 0 -- site_occ (later slices check their
 // counts against it).  Asynchronous on the null stream; d_flag: a device word zeroed before the first slice.
 int launch_sort_slice(SortTemp &t, const uint64_t *d_sites, const uint64_t *d_list, const uint64_t *d_bucket_start,
-                      uint64_t n_sites, uint32_t n_slices, uint32_t n_buckets, uint32_t slice, uint32_t *d_sub_start,
+                      const uint32_t *d_tile_first, uint64_t n_sites, uint32_t n_slices, uint32_t n_buckets, uint32_t slice, uint32_t *d_sub_start,
                       StreamRec *d_srec, uint32_t *d_sid, uint32_t *d_site_occ, uint32_t *d_flag);
 // Synchronises and reads the flag word: ISSL_OK, ISSL_E_FORMAT (an id beyond the site table), kSortNeedsListOrder.
 int finish_sort(uint32_t *d_flag);
@@ -185,7 +188,10 @@ int finish_sort(uint32_t *d_flag);
 // ---- scoring workspace -------------------------------------------------------------------------
 constexpr uint32_t kGuideGroup = 8;    // guide words fetched per scalar load
 constexpr uint32_t kItemGuides = 512;  // guides per scan item (bounds one tile's work)
-constexpr uint32_t kTileFixedCost = 4; // cost of fetching a tile, in guide-comparisons of that tile
+constexpr uint32_t kGuideCost = 4;      // cost of one guide against one full unit of 2048 candidates (32 per lane); against a
+                                        // short unit of 16 / 8 candidates per lane it is 2 / 1: two / four guides then share
+                                        // every instruction (ScanItem::shape)
+constexpr uint32_t kTileFixedCost = 4 * kGuideCost; // cost of fetching a unit = four guide comparisons of a full one
 constexpr uint32_t kNoGuide = 0xFFFFFFFFu;
 constexpr uint32_t kPadGuideWord = 0xFFFFFFFFu; // scan word of padding guide slots: 16 x T, distance 16 from tile padding
 constexpr uint32_t kScanGridBlocks = 256u * 4u; // scan launch: 256 CUs x 2 resident workgroups of 16 waves, two rounds
@@ -211,13 +217,27 @@ struct ScanItem {
                          // bucket-level items, a window that may straddle two tiles for the pruned scan's
     uint32_t window;     // candidates of the item: from offset (window & 0xFFFF) of its first unit up to (not including)
                          // offset (window >> 16) of its last unit; the rest are padding or a neighbouring group's
+    uint32_t shape;      // candidates per lane of the item's units: 32 = a full unit of 2048 candidates, one guide per
+                         // pass; 16 / 8 = the SHORT last unit of a successor-byte group (<= 1024 / <= 512 candidates):
+                         // every register then holds the lane's 16 / 8 candidates two / four times over and a pass
+                         // compares two / four guides at once, with masks the wave makes in LDS (short_unit_masks)
+    uint32_t pad;
 };
+static_assert(sizeof(ScanItem) == 48, "scan items are fetched with scalar loads");
 
 // Start of a cost range of the scan: (item, tile inside the item, guide offset); item == n_items marks the end.
 struct RangeStart {
     uint32_t item;
     uint32_t tile;
     uint32_t goff; // guide offset inside the item (multiple of 8): a tile may be shared by two ranges
+    uint32_t pad;
+};
+
+// One scored off-target as k_verify leaves it: 32 bytes = one aligned half sector, written and moved in one piece.
+struct alignas(32) HitRec {
+    uint64_t key;      // guide << 35 | first matching slice << 32 | site id (sorted layouts) or list position
+    double mit, cfd;   // its terms (isslScoreOfftargets.cpp:392-460)
+    uint32_t rank;     // place among its guide's hits in arrival order (k_verify's returning atomic)
     uint32_t pad;
 };
 
@@ -233,6 +253,8 @@ struct PlanInfo {
                           // (full scan) or successor-byte groups (pruned scan) it visits
     uint64_t reference_candidates; // sum over guides of their five bucket lengths = what the reference compares
     uint64_t tiles;       // (tile, item) pairs the scan works through
+    uint32_t fine_slots;  // pruned plan: guide slots in use (a multiple of 8)
+    uint32_t pad;
 };
 
 // Updated by the scan with atomics.
@@ -282,13 +304,13 @@ struct Workspace {
     uint64_t *scan_count = nullptr; // [kScanMaxBlocks] comparisons every scan workgroup actually made (real candidates x real guides)
     unsigned long long *stamps = nullptr; // [4 * kScanWaves] scan wave clocks, then replay phase clocks (ISSL_SCAN_STAMPS diagnostics)
     uint32_t *sticky = nullptr;  // [4] survives the per-batch resets: [0] raw overflow seen, [1] max chunks asked, [2] plan errors, [3] items a pruned plan wanted beyond cap_fitems
-    uint64_t *sorted = nullptr;  // [hit_cap] keys guide<<35 | slice<<32 | pos, grouped by guide
+    uint64_t *sorted = nullptr;  // [hit_cap] many-hit replay: a guide's keys in scoring order
     uint32_t *gcount = nullptr;  // [G+1] hits per guide
     uint32_t *goff = nullptr;    // [G+1] exclusive prefix
     uint32_t *gcur_big = nullptr; // [G] guides handed to k_replay_big
-    double *terms = nullptr;     // [2 * hit_cap] MIT/CFD terms of the hits, grouped by guide like `sorted`
-    double *pay = nullptr;       // [2 * hit_cap] the same terms as k_verify computed them, by raw-record slot
-    uint32_t *rank = nullptr;    // [hit_cap] place of a surviving raw record inside its guide's segment, by raw-record slot
+    double *terms = nullptr;     // [2 * hit_cap] many-hit replay: MIT/CFD terms of a guide's hits in scoring order
+    HitRec *hit_raw = nullptr;   // [hit_cap] what k_verify found out about a surviving raw record, by raw-record slot
+    HitRec *hit_grp = nullptr;   // [hit_cap] the same records grouped by guide (k_group_scatter): what the replay reads
     uint32_t *blocksum = nullptr;
     uint64_t *d_guides = nullptr; // staging for the host API
     double *d_mit = nullptr, *d_cfd = nullptr;

@@ -110,7 +110,8 @@ __global__ __launch_bounds__(256) void k_pack_scan_stream(ImageView v, uint32_t 
             uint32_t w = 0;
             if (pos < len && (v.srec || v.sid)) {
                 // sorted layouts: the stream holds the candidates v.srec / v.sid list (built and checked by launch_sort_slice)
-                w = scan_word(v.srec ? v.srec[start + pos].sig & ((1ull << 40) - 1ull) : v.sites[v.sid[start + pos]], slice);
+                const uint64_t at = static_cast<uint64_t>(t) * kTileCands + k0 + lane; // the maps are indexed like the stream
+                w = scan_word(v.srec ? v.srec[at].sig & ((1ull << 40) - 1ull) : v.sites[v.sid[at]], slice);
             } else if (pos < len) {
                 const uint64_t e = v.entries[start + pos];
                 const uint64_t id = e & 0xFFFFFFFFull;
@@ -280,18 +281,19 @@ __device__ __forceinline__ RangeStart range_start_of(const ScanItem *__restrict_
             const uint32_t mid = (a + z) >> 1;
             if (items[mid].cost0 <= lo) a = mid; else z = mid;
         }
-        // A tile of an item costs kTileFixedCost (fetching it) + one unit per guide.  A boundary may fall between two
-        // groups of 8 guides INSIDE a tile: then two waves share that tile (both fetch it), which makes the ranges
-        // equal to within 8 guides instead of within one tile.
+        // A unit of an item costs kTileFixedCost (fetching it) + shape / 8 per guide (kGuideCost for a full unit).  A
+        // boundary may fall between two groups of 8 guides INSIDE a unit: then two waves share that unit (both fetch
+        // it), which makes the ranges equal to within 8 guides instead of within one unit.
         const ScanItem it = items[a];
         const uint32_t len = it.g1 - it.g0;
-        const uint64_t tile_cost = static_cast<uint64_t>(len) + kTileFixedCost;
+        const uint32_t per_guide = it.shape >> 3;
+        const uint64_t tile_cost = static_cast<uint64_t>(len) * per_guide + kTileFixedCost;
         const uint64_t rel = lo - it.cost0;
         uint64_t k = rel / tile_cost;
         const uint64_t rem = rel % tile_cost;
         uint32_t goff = 0;
-        if (rem > kTileFixedCost) { // (inside the fetch part the tile starts the range: positions stay monotone in r)
-            goff = (static_cast<uint32_t>(rem - kTileFixedCost) + kGuideGroup - 1u) & ~(kGuideGroup - 1u);
+        if (rem > kTileFixedCost) { // (inside the fetch part the unit starts the range: positions stay monotone in r)
+            goff = ((static_cast<uint32_t>(rem - kTileFixedCost) + per_guide - 1u) / per_guide + kGuideGroup - 1u) & ~(kGuideGroup - 1u);
             if (goff >= len) { goff = 0; ++k; }
         }
         if (k >= it.n_tiles) { out.item = a + 1; out.tile = 0; out.goff = 0; }
@@ -321,7 +323,7 @@ __global__ __launch_bounds__(256) void k_plan(ImageView v, uint32_t *__restrict_
         if (g && nt) {
             const uint32_t k = (g + item_guides - 1u) / item_guides;
             n_it += k;
-            cost += static_cast<uint64_t>(nt) * (static_cast<uint64_t>(g) + static_cast<uint64_t>(k) * kTileFixedCost);
+            cost += static_cast<uint64_t>(nt) * (static_cast<uint64_t>(g) * kGuideCost + static_cast<uint64_t>(k) * kTileFixedCost);
             cand += (v.bucket_start[b + 1] - v.bucket_start[b]) * g;
             wtiles += static_cast<uint64_t>(nt) * k;
         }
@@ -352,8 +354,9 @@ __global__ __launch_bounds__(256) void k_plan(ImageView v, uint32_t *__restrict_
                 it.last_cands = static_cast<uint32_t>(blen - static_cast<uint64_t>(nt - 1u) * kTileCands);
                 it.group_abs = v.tile_first[b] * 64u;
                 it.window = it.last_cands << 16;
+                it.shape = 32; it.pad = 0;
                 items[item_at++] = it;
-                cost_at += static_cast<uint64_t>(nt) * (len + kTileFixedCost);
+                cost_at += static_cast<uint64_t>(nt) * (len * kGuideCost + kTileFixedCost);
                 tile_at += nt;
             }
         }
@@ -367,6 +370,7 @@ __global__ __launch_bounds__(256) void k_plan(ImageView v, uint32_t *__restrict_
             ScanItem end;
             end.bucket = 0; end.g0 = 0; end.g1 = 0; end.n_tiles = 0; end.cost0 = tot_cost;
             end.tile0 = static_cast<uint32_t>(tot_tiles); end.last_cands = 0; end.group_abs = 0; end.window = 0;
+            end.shape = 32; end.pad = 0;
             items[tot_items] = end;
         }
         plan->n_items = overflow ? 0u : static_cast<uint32_t>(tot_items);
@@ -451,6 +455,32 @@ __global__ __launch_bounds__(256) void k_guide_scatter(const uint64_t *__restric
 // scans the whole bucket, isslScoreOfftargets.cpp:344, and finds the same sites.  k_verify re-attributes a hit to the
 // first exactly matching slice and its position there (pos_of), which is what the reference's order is made of.
 
+// Units of one successor-byte group: its candidates [s0, s1) of the bucket's stream are covered from the group's first
+// lane group (32 candidates) on by n_full full units of 2048 candidates and, for the `rest` behind them, one last unit of
+// the smallest shape that holds it: 8, 16 or 32 candidates per lane (512 / 1024 / 2048 per unit).  In a short unit every
+// plane register holds the lane's candidates 4 / 2 times over and one pass of the distance test serves 4 / 2 guides:
+// the same comparisons per instruction as a full unit, a quarter / half of the idle lanes.
+struct GroupUnits {
+    uint32_t s0a, n_full, rest, shape, units;
+};
+__device__ __forceinline__ GroupUnits group_units(uint32_t s0, uint32_t s1, uint32_t tail_shapes)
+{
+    GroupUnits u;
+    u.s0a = s0 & ~31u;
+    const uint32_t span = s1 - u.s0a;
+    u.n_full = span / kTileCands;
+    u.rest = span - u.n_full * kTileCands;
+    u.shape = (!tail_shapes || u.rest > 1024u) ? 32u : u.rest > 512u ? 16u : 8u;
+    u.units = u.n_full + (u.rest ? 1u : 0u);
+    return u;
+}
+// cost of the group's units against `len` guides (one chunk of at most item_guides of them)
+__device__ __forceinline__ uint64_t group_cost(const GroupUnits &u, uint32_t len)
+{
+    return static_cast<uint64_t>(u.n_full) * (static_cast<uint64_t>(len) * kGuideCost + kTileFixedCost) +
+           (u.rest ? static_cast<uint64_t>(len) * (u.shape >> 3) + kTileFixedCost : 0ull);
+}
+
 // The successor bytes a guide with successor byte `gj` visits: way 0 = gj itself, ways 1..12 = one position changed.
 __device__ __forceinline__ uint32_t fine_way(uint32_t gj, uint32_t way)
 {
@@ -463,7 +493,8 @@ __device__ __forceinline__ uint32_t fine_way(uint32_t gj, uint32_t way)
 __global__ __launch_bounds__(256) void k_fine_count(ImageView v, const uint64_t *__restrict__ guides,
                                                     const uint32_t *__restrict__ gstart, const uint32_t *__restrict__ gfill,
                                                     const uint32_t *__restrict__ gidx, uint32_t *__restrict__ fcount,
-                                                    FineSum *__restrict__ fsum, uint32_t item_guides, uint32_t ways)
+                                                    FineSum *__restrict__ fsum, uint32_t item_guides, uint32_t ways,
+                                                    uint32_t tail_shapes)
 {
     short_kernel_priority();
     __shared__ uint32_t cnt[256];
@@ -485,12 +516,12 @@ __global__ __launch_bounds__(256) void k_fine_count(ImageView v, const uint64_t 
     fcount[static_cast<uint64_t>(b) * 256u + w] = (s1 > s0) ? c : 0u; // a group without candidates takes no guides
     uint64_t cost = 0, cand = 0, slots = 0, items = 0, units = 0;
     if (c && s1 > s0) {
-        const uint32_t nt = (s1 - (s0 & ~31u) + kTileCands - 1u) / kTileCands; // windows of 2048 from the group's first lane group on
+        const GroupUnits gu = group_units(s0, s1, tail_shapes);
         const uint32_t kk = (c + item_guides - 1u) / item_guides;
         slots = (c + kGuideGroup - 1u) / kGuideGroup * kGuideGroup;
-        units = static_cast<uint64_t>(nt) * kk;
-        items = units; // one item per window and chunk of guides: the scan finds the item of a unit without a search
-        cost = static_cast<uint64_t>(nt) * (static_cast<uint64_t>(c) + static_cast<uint64_t>(kk) * kTileFixedCost);
+        units = static_cast<uint64_t>(gu.units) * kk;
+        items = units; // one item per unit and chunk of guides: the scan finds the item of a unit without a search
+        for (uint32_t done = 0; done < c; done += item_guides) cost += group_cost(gu, c - done < item_guides ? c - done : item_guides);
         cand = static_cast<uint64_t>(s1 - s0) * c;
     }
     uint64_t t_cost, t_cand, t_slots, t_items, t_units, t_places;
@@ -542,11 +573,13 @@ __global__ __launch_bounds__(256) void k_fine_plan(FineSum *__restrict__ fsum, u
         // Which plan is faster?  Comparing and fetching overlap: time ~ max((guide, tile) pairs, kFetchPairs x tile
         // fetches).  Few guides per successor-byte group make the pruned scan fetch-bound (every group reads its own
         // tiles, a bucket-level item reads a tile once for up to 512 guides); costs are pairs + kTileFixedCost x fetches.
+        // (all in cost units: kGuideCost per pair of a guide with a full unit)
+        const uint64_t fetch_cost = static_cast<uint64_t>(kFetchPairs) * kGuideCost;
         const uint64_t full_fetch = plan->tiles, full_pairs = plan->total_cost - kTileFixedCost * full_fetch;
         const uint64_t fine_pairs = t_cost - kTileFixedCost * t_units;
-        const uint64_t est_full = full_pairs > kFetchPairs * full_fetch ? full_pairs : kFetchPairs * full_fetch;
+        const uint64_t est_full = full_pairs > fetch_cost * full_fetch ? full_pairs : fetch_cost * full_fetch;
         // (+ one comparison per place of a guide in a group: binning every guide 65 times is not free either)
-        const uint64_t est_fine = (fine_pairs > kFetchPairs * t_units ? fine_pairs : kFetchPairs * t_units) + t_places;
+        const uint64_t est_fine = (fine_pairs > fetch_cost * t_units ? fine_pairs : fetch_cost * t_units) + t_places * kGuideCost;
         const bool fits = t_items <= cap_items && t_slots <= cap_slots; // (the slots cover every guide in 13 groups)
         if (t_items > cap_items) // the host enlarges the item list for the next batches; this one scans whole buckets
             atomicMax(&sticky[3], static_cast<uint32_t>(t_items < 0xFFFFFFFFull ? t_items : 0xFFFFFFFFull));
@@ -554,6 +587,7 @@ __global__ __launch_bounds__(256) void k_fine_plan(FineSum *__restrict__ fsum, u
             ScanItem end;
             end.bucket = 0; end.g0 = 0; end.g1 = 0; end.n_tiles = 0; end.cost0 = t_cost;
             end.tile0 = static_cast<uint32_t>(t_units); end.last_cands = 0; end.group_abs = 0; end.window = 0;
+            end.shape = 32; end.pad = 0;
             fitems[t_items] = end;
             plan->n_items = static_cast<uint32_t>(t_items);
             plan->total_cost = t_cost;
@@ -561,6 +595,7 @@ __global__ __launch_bounds__(256) void k_fine_plan(FineSum *__restrict__ fsum, u
             plan->tiles = t_units;
             plan->n_ranges = t_units == 0 ? 0u : scan_blocks;
             plan->fine = prune_mode;
+            plan->fine_slots = static_cast<uint32_t>(t_slots);
         }
     }
 }
@@ -572,7 +607,8 @@ __global__ __launch_bounds__(256) void k_fine_scatter(ImageView v, const uint64_
                                                       const uint32_t *__restrict__ fcount, const FineSum *__restrict__ fbase,
                                                       const PlanInfo *__restrict__ plan, uint32_t *__restrict__ fword,
                                                       uint2 *__restrict__ fmeta,
-                                                      ScanItem *__restrict__ fitems, uint32_t item_guides, uint32_t ways)
+                                                      ScanItem *__restrict__ fitems, uint32_t item_guides, uint32_t ways,
+                                                      uint32_t tail_shapes)
 {
     short_kernel_priority();
     if (!plan->fine) return; // the bucket-level plan stays
@@ -584,31 +620,31 @@ __global__ __launch_bounds__(256) void k_fine_scatter(ImageView v, const uint64_
     const uint32_t c = fcount[static_cast<uint64_t>(b) * 256u + w];
     const uint32_t *ss = v.sub_start + static_cast<uint64_t>(b) * 257u;
     const uint32_t s0 = ss[w], s1 = ss[w + 1];
-    uint64_t cost = 0, slots = 0, items = 0, units = 0;
-    uint32_t nt = 0, kk = 0;
+    uint64_t cost = 0, slots = 0, items = 0;
+    uint32_t kk = 0;
+    GroupUnits gu{};
     if (c) { // (fcount is zero where the group has no candidates)
-        nt = (s1 - (s0 & ~31u) + kTileCands - 1u) / kTileCands;
+        gu = group_units(s0, s1, tail_shapes);
         kk = (c + item_guides - 1u) / item_guides;
         slots = (c + kGuideGroup - 1u) / kGuideGroup * kGuideGroup;
-        units = static_cast<uint64_t>(nt) * kk;
-        items = units;
-        cost = static_cast<uint64_t>(nt) * (static_cast<uint64_t>(c) + static_cast<uint64_t>(kk) * kTileFixedCost);
+        items = static_cast<uint64_t>(gu.units) * kk;
+        for (uint32_t done = 0; done < c; done += item_guides) cost += group_cost(gu, c - done < item_guides ? c - done : item_guides);
     }
     const FineSum base = fbase[b];
     uint64_t cost_at = base.cost + block_exclusive_scan(cost, lds, nullptr);
     const uint32_t slot_at = base.slots + static_cast<uint32_t>(block_exclusive_scan(slots, lds, nullptr));
     uint32_t item_at = base.items + static_cast<uint32_t>(block_exclusive_scan(items, lds, nullptr));
-    (void)units;
     slot_of[w] = slot_at;
     cursor[w] = 0;
     if (c) {
         const uint64_t blen = v.bucket_start[b + 1] - v.bucket_start[b];
-        const uint32_t s0a = s0 & ~31u; // a window starts on a lane group (32 candidates), not on a tile
         for (uint32_t done = 0; done < c; done += item_guides) {
             const uint32_t len = (c - done < item_guides) ? c - done : item_guides;
-            for (uint32_t t = 0; t < nt; ++t) { // single-window items: item index == unit number
-                const uint32_t wstart = s0a + t * kTileCands;                 // position in the bucket
-                const uint64_t after = blen - wstart;                         // candidates of the bucket from there on
+            for (uint32_t t = 0; t < gu.units; ++t) { // single-unit items: item index == unit number
+                const bool full = t < gu.n_full;
+                const uint32_t shape = full ? 32u : gu.shape, cap = 64u * shape;  // candidates the unit covers
+                const uint32_t wstart = gu.s0a + t * kTileCands;               // position in the bucket (a lane group)
+                const uint64_t after = blen - wstart;                           // candidates of the bucket from there on
                 ScanItem it;
                 it.bucket = (b << 8) | w;
                 it.g0 = slot_at + done; // item_guides is a multiple of 8
@@ -616,11 +652,12 @@ __global__ __launch_bounds__(256) void k_fine_scatter(ImageView v, const uint64_
                 it.n_tiles = 1;
                 it.cost0 = cost_at;
                 it.tile0 = item_at;
-                it.last_cands = after < kTileCands ? static_cast<uint32_t>(after) : kTileCands;
+                it.last_cands = after < cap ? static_cast<uint32_t>(after) : cap;
                 it.group_abs = v.tile_first[b] * 64u + (wstart >> 5);
-                it.window = (t == 0 ? s0 - s0a : 0u) | ((s1 - wstart < kTileCands ? s1 - wstart : kTileCands) << 16);
+                it.window = (t == 0 ? s0 - gu.s0a : 0u) | ((s1 - wstart < cap ? s1 - wstart : cap) << 16);
+                it.shape = shape; it.pad = 0;
                 fitems[item_at++] = it;
-                cost_at += len + kTileFixedCost;
+                cost_at += static_cast<uint64_t>(len) * (shape >> 3) + kTileFixedCost;
             }
         }
         // padding slots behind the group's guides
@@ -680,12 +717,13 @@ void launch_bin_guides(const ImageView &v, const Workspace &ws, const Tuning &tn
     if (prune_mode) { // regroup by (bucket, successor byte); k_fine_plan decides which of the two plans the scan follows
         const uint32_t ways = prune_mode == 1 ? 1u : kFineWays;
         hipLaunchKernelGGL(k_fine_count, dim3(nb), dim3(256), 0, stream, v, d_guides, ws.gstart, ws.gfill, ws.gidx, ws.fcount,
-                           ws.fsum, tn.item_guides, ways);
+                           ws.fsum, tn.item_guides, ways, static_cast<uint32_t>(tn.tail_shapes));
         hipLaunchKernelGGL(k_fine_plan, dim3(1), dim3(256), 0, stream, ws.fsum, nb, ws.fitems,
                            static_cast<uint32_t>(ws.cap_fitems), static_cast<uint32_t>(ws.cap_fslots), ws.plan, tn.scan_blocks,
                            prune_mode, tn.prune == 1 ? 1u : 0u, ws.sticky);
         hipLaunchKernelGGL(k_fine_scatter, dim3(nb), dim3(256), 0, stream, v, d_guides, ws.gstart, ws.gfill, ws.gword, ws.gidx,
-                           ws.fcount, ws.fsum, ws.plan, ws.fword, ws.fmeta, ws.fitems, tn.item_guides, ways);
+                           ws.fcount, ws.fsum, ws.plan, ws.fword, ws.fmeta, ws.fitems, tn.item_guides, ways,
+                           static_cast<uint32_t>(tn.tail_shapes));
         hipLaunchKernelGGL(k_fine_ranges, dim3(range_blocks), dim3(256), 0, stream, ws.plan, ws.fitems, ws.range_start);
     }
 }
@@ -770,6 +808,9 @@ __device__ __forceinline__ void half_add(uint32_t a, uint32_t b, uint32_t &sum, 
 // `keep`: the lane's candidates that belong to the item (the others are padding or a neighbouring group's); folded into
 // the last operation of the count, which has an operand to spare for every compiled threshold but 1.
 template <int THR>
+__device__ __forceinline__ uint32_t count_near(const uint32_t (&m)[16], uint32_t thr, uint32_t keep);
+
+template <int THR>
 __device__ __forceinline__ uint32_t near_plane(const uint32_t (&c)[kPlanes], uint32_t gw, uint32_t thr, uint32_t keep)
 {
     uint32_t m[16];
@@ -779,6 +820,57 @@ __device__ __forceinline__ uint32_t near_plane(const uint32_t (&c)[kPlanes], uin
         const uint32_t g1 = 0u - ((gw >> (16 + p)) & 1u);
         m[p] = (c[p] ^ g0) | (c[16 + p] ^ g1);
     }
+    return count_near<THR>(m, thr, keep);
+}
+
+// The same test in a SHORT unit: every plane register holds the lane's 16 / 8 candidates two / four times over, and
+// mask word p (32 words in LDS, made by the wave itself: short_unit_masks) carries bit p of two / four guides' scan
+// words, each spread over its field: one pass, two / four guides.  The masks arrive as wave-uniform VGPRs (every lane
+// reads the same 16 bytes), four positions at a time so that they never occupy more than a handful of registers.
+template <int THR>
+__device__ __forceinline__ uint32_t near_plane_masks(const uint32_t (&c)[kPlanes], const uint4 *gm /*LDS, 8 x uint4*/,
+                                                     uint32_t thr, uint32_t keep)
+{
+    uint32_t m[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint4 lo = gm[q], hi = gm[4 + q];
+        asm volatile("" ::: "memory"); // (keeps the next loads behind these: at most two steps' masks are live)
+        m[4 * q + 0] = (c[4 * q + 0] ^ lo.x) | (c[16 + 4 * q + 0] ^ hi.x);
+        m[4 * q + 1] = (c[4 * q + 1] ^ lo.y) | (c[16 + 4 * q + 1] ^ hi.y);
+        m[4 * q + 2] = (c[4 * q + 2] ^ lo.z) | (c[16 + 4 * q + 2] ^ hi.z);
+        m[4 * q + 3] = (c[4 * q + 3] ^ lo.w) | (c[16 + 4 * q + 3] ^ hi.w);
+    }
+    return count_near<THR>(m, thr, keep);
+}
+
+// Masks of up to 8 passes of a short unit (guide slots g0 .. g0 + 8 * per - 1) into the wave's own 1 KiB of LDS: lane
+// (pass i, quarter q) makes the four words 4q .. 4q + 3 of pass i: bit p of each of the pass's `per` guide words, spread
+// over that guide's field of `shape` bits.
+__device__ __forceinline__ void short_unit_masks(const uint32_t *__restrict__ gword_stream, uint32_t g0, uint32_t shape,
+                                                 uint32_t lane, uint4 *lds_masks)
+{
+    const uint32_t per = 32u / shape, field = shape == 16u ? 0xFFFFu : 0xFFu;
+    const uint32_t i = lane >> 3, q = lane & 7u;
+    uint32_t gw[4];
+#pragma unroll
+    for (uint32_t j = 0; j < 4; ++j) gw[j] = j < per ? gword_stream[g0 + i * per + j] : 0u;
+    uint32_t m[4];
+#pragma unroll
+    for (uint32_t r = 0; r < 4; ++r) {
+        const uint32_t p = 4u * q + r;
+        uint32_t x = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j) x |= (0u - ((gw[j] >> p) & 1u)) & (field << ((j * shape) & 31u)) & (j < per ? ~0u : 0u);
+        m[r] = x;
+    }
+    lds_masks[i * 8u + q] = make_uint4(m[0], m[1], m[2], m[3]);
+}
+
+// The planes of candidates whose mismatch planes m[0..15] count up to at most THR.
+template <int THR>
+__device__ __forceinline__ uint32_t count_near(const uint32_t (&m)[16], uint32_t thr, uint32_t keep)
+{
     uint32_t s0, s1, s2, s3, s4, t, u, n0, n1, n2;
     uint32_t k2[8], k4[4], k8a, k8b;
     // weight 1: 16 planes
@@ -830,11 +922,13 @@ __device__ __forceinline__ uint32_t near_plane(const uint32_t (&c)[kPlanes], uin
     return keep & ~gt;
 }
 
-// Cold block of the scan: the wave knows that SOME lane has a candidate within thr of the guide in slot
-// gslot.  `ok` = this lane's plane of such candidates; candidate bit j of the lane sits at offset 32 grp + j of `tile`
-// (the lane's own: a window of the pruned scan straddles two tiles).
-__device__ __forceinline__ void note_candidates(uint32_t ok, uint32_t gslot, uint32_t tile, uint32_t grp, uint32_t lane,
-                                                RawWriter &w, uint64_t *raw, uint32_t max_chunks, Counters *counters)
+// Cold block of the scan: the wave knows that SOME lane has a candidate within thr of a guide.  `ok` = this lane's
+// plane of such candidates; bit q of it is candidate q % (1 << w_log) of the lane -- which sits at offset off0 + that of
+// `tile` (the lane's own: a window of the pruned scan straddles two tiles) -- against the guide in slot gslot + (q >>
+// w_log) (full units: w_log = 5, one guide per pass).
+__device__ __forceinline__ void note_candidates(uint32_t ok, uint32_t gslot, uint32_t w_log, uint32_t tile, uint32_t off0,
+                                                uint32_t lane, RawWriter &w, uint64_t *raw, uint32_t max_chunks,
+                                                Counters *counters)
 {
     while (true) {
         const bool has = ok != 0u;
@@ -846,11 +940,11 @@ __device__ __forceinline__ void note_candidates(uint32_t ok, uint32_t gslot, uin
             raw_acquire(w, raw, max_chunks, counters, lane);
         }
         if (has) {
-            const uint32_t j = static_cast<uint32_t>(__builtin_ctz(ok));
+            const uint32_t q = static_cast<uint32_t>(__builtin_ctz(ok));
             ok &= ok - 1u;
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(who >> 32),
                                                             __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(who), 0u));
-            w.chunk[w.fill + rank] = raw_record(gslot, tile, grp * 32u + j);
+            w.chunk[w.fill + rank] = raw_record(gslot + (q >> w_log), tile, off0 + (q & ((1u << w_log) - 1u)));
         }
         w.fill += n;
     }
@@ -875,7 +969,8 @@ __device__ __forceinline__ void note_candidates(uint32_t ok, uint32_t gslot, uin
 template <int THR, bool FINE>
 __device__ __forceinline__ void scan_range(const uint32_t *__restrict__ scan_stream, const ScanItem *__restrict__ items,
                                            const PlanInfo *__restrict__ plan, const RangeStart *__restrict__ range_start,
-                                           const uint32_t *__restrict__ gword_stream, uint64_t *raw, uint32_t max_chunks,
+                                           const uint32_t *__restrict__ gword_stream, uint4 *wave_masks,
+                                           uint64_t *raw, uint32_t max_chunks,
                                            Counters *counters, uint32_t thr, unsigned long long *stamps,
                                            uint64_t *__restrict__ scan_count, uint32_t *next_unit_p, uint32_t *waves_done_p,
                                            unsigned long long *wg_compared_p, unsigned long long t_start,
@@ -923,6 +1018,52 @@ __device__ __forceinline__ void scan_range(const uint32_t *__restrict__ scan_str
         const uint32_t g_begin = cur.g0 + (u == 0 ? first.goff : 0u);
         const uint32_t g_end = (gt == tile_last) ? cur.g0 + last.goff : cur.g1;
 
+        if (fine && cur.shape != 32u) {
+            // ---- a SHORT unit: the last 64 * shape candidates of a successor-byte group, 32 / shape guides per pass ----
+            // Lane l takes candidates [l * shape, (l + 1) * shape) of the window, i.e. field l % per of lane group
+            // first + l / per: the same eight 16-byte loads, then one byte permute per plane spreads the field over the
+            // whole register.
+            const uint32_t shape = cur.shape, per = 32u / shape, w_log = shape == 16u ? 4u : 3u;
+            const uint32_t glane = cur.group_abs + lane / per;
+            uint32_t tile = glane >> 6;
+            const uint32_t grp = glane & 63u, sub = lane & (per - 1u);
+            if (tile >= n_tiles) tile = n_tiles - 1u;
+            compared += static_cast<unsigned long long>(cur.last_cands) * (g_end - g_begin);
+            const uint4 *__restrict__ src =
+                reinterpret_cast<const uint4 *>(scan_stream + static_cast<uint64_t>(tile) * kTileCands) + grp;
+            const uint32_t sel = shape == 16u ? (sub ? 0x03020302u : 0x01000100u) : sub * 0x01010101u;
+            uint32_t c[kPlanes];
+#pragma unroll
+            for (int q = 0; q < kPlanes / 4; ++q) {
+                const uint4 t4 = src[q * 64];
+                c[4 * q + 0] = __builtin_amdgcn_perm(0u, t4.x, sel); c[4 * q + 1] = __builtin_amdgcn_perm(0u, t4.y, sel);
+                c[4 * q + 2] = __builtin_amdgcn_perm(0u, t4.z, sel); c[4 * q + 3] = __builtin_amdgcn_perm(0u, t4.w, sel);
+            }
+            // the lane's candidates that are the item's: window offsets [lo, hi), the same for every guide field
+            const int lo = static_cast<int>(cur.window & 0xFFFFu), hi = static_cast<int>(cur.window >> 16);
+            const int below = lo - static_cast<int>(lane * shape), upto = hi - static_cast<int>(lane * shape);
+            const uint32_t field = shape == 16u ? 0xFFFFu : 0xFFu;
+            const uint32_t mine = (below <= 0 ? field : below >= static_cast<int>(shape) ? 0u : (field << below) & field) &
+                                  (upto >= static_cast<int>(shape) ? field : upto <= 0 ? 0u : field >> (shape - upto));
+            const uint32_t keep = mine * (shape == 16u ? 0x00010001u : 0x01010101u);
+            const uint32_t off0 = grp * 32u + sub * shape;
+            for (uint32_t gb = g_begin; gb < g_end; gb += 8u * per) { // 8 passes' masks at a time
+                __builtin_amdgcn_wave_barrier();
+                short_unit_masks(gword_stream, gb, shape, lane, wave_masks);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const uint32_t passes = (g_end - gb + per - 1u) / per;
+                for (uint32_t i = 0; i < (passes < 8u ? passes : 8u); ++i) {
+                    const uint32_t ok = near_plane_masks<THR>(c, wave_masks + i * 8u, thr, keep);
+                    if (__ballot(ok != 0u) != 0ull) {
+                        note_candidates(ok, gb + i * per, w_log, tile, off0, lane, w, raw, max_chunks, counters);
+                        own_chunk = true;
+                    }
+                }
+            }
+            continue;
+        }
+
         // ---- one tile: 2048 candidates, tile k of the item, guide slots [g_begin, g_end) -----------
         // The unit: 2048 consecutive candidates of the bucket from lane group cur.group_abs + 64 k on; lane l takes the
         // 32 of group (first + l).  Bucket-level items start on a tile; a window of the pruned scan may start on any lane
@@ -966,7 +1107,7 @@ __device__ __forceinline__ void scan_range(const uint32_t *__restrict__ scan_str
                 if (g + uu >= g_end) break; // padding slots of the bucket's last group (scalar test, not taken: free)
                 const uint32_t ok = near_plane<THR>(c, gg.w[uu], thr, keep);
                 if (__ballot(ok != 0u) != 0ull) { // ~4 % of the (guide, tile) pairs on random data
-                    note_candidates(ok, g + uu, tile, grp, lane, w, raw, max_chunks, counters);
+                    note_candidates(ok, g + uu, 5u, tile, grp * 32u, lane, w, raw, max_chunks, counters);
                     own_chunk = true;
                 }
             }
@@ -1008,6 +1149,7 @@ __global__ __launch_bounds__(1024, 8) void k_scan(const uint32_t *__restrict__ s
     __shared__ uint32_t next_unit;
     __shared__ uint32_t waves_done;
     __shared__ unsigned long long wg_compared;
+    __shared__ uint4 tail_masks[16][64]; // per wave: the guide masks of 8 passes of a short unit (short_unit_masks)
     // stamps (diagnostics, normally null): per wave {start, end} in 100 MHz ticks, {XCC_ID, HW_ID} and the number of
     // tiles it took; nothing else reads them
     const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
@@ -1020,10 +1162,10 @@ __global__ __launch_bounds__(1024, 8) void k_scan(const uint32_t *__restrict__ s
     if (threadIdx.x == 0) atomicMin(span, t_start); // the launch's own span: first workgroup in, last one out
     // the plan of this batch: bucket-level items, or the successor-byte groups of the pruned scan (k_fine_plan)
     if (plan->fine != 0u)
-        scan_range<THR, true>(scan_stream, items_fine, plan, range_start, gword_fine, raw, max_chunks, counters, thr, stamps,
+        scan_range<THR, true>(scan_stream, items_fine, plan, range_start, gword_fine, tail_masks[threadIdx.x >> 6], raw, max_chunks, counters, thr, stamps,
                               scan_count, &next_unit, &waves_done, &wg_compared, t_start, span, n_tiles);
     else
-        scan_range<THR, false>(scan_stream, items_full, plan, range_start, gword_full, raw, max_chunks, counters, thr, stamps,
+        scan_range<THR, false>(scan_stream, items_full, plan, range_start, gword_full, tail_masks[threadIdx.x >> 6], raw, max_chunks, counters, thr, stamps,
                                scan_count, &next_unit, &waves_done, &wg_compared, t_start, span, n_tiles);
 }
 
@@ -1114,6 +1256,10 @@ __global__ __launch_bounds__(kChunkRecs, 8) void k_verify(ImageView v, Workspace
         const uint32_t offset = static_cast<uint32_t>(rec) & (kTileCands - 1u);
         const uint32_t tile = static_cast<uint32_t>(rec >> 11) & 0x3FFFFFFu;
         const uint32_t gslot = static_cast<uint32_t>(rec >> 37);
+        // sorted layouts: what the stream holds at the record's place, asked for before anything else is known about it
+        StreamRec sr_early{};
+        if (in_use && v.srec) sr_early = v.srec[static_cast<uint64_t>(tile) * kTileCands + offset];
+        else if (in_use && v.sid) sr_early.id = v.sid[static_cast<uint64_t>(tile) * kTileCands + offset];
         // the guide slot knows its guide and its bucket (pruned scan: and its successor-byte group): no search for the tile's
         uint32_t guide = kNoGuide, where = 0;
         if (in_use) {
@@ -1135,9 +1281,7 @@ __global__ __launch_bounds__(kChunkRecs, 8) void k_verify(ImageView v, Workspace
                 const uint64_t gsig = guides[guide];
                 // sorted layouts: signature, site id (and a 24-bit copy of the count) come in one stream-order record, or --
                 // compact -- the id alone, with the signature behind it in the site table
-                StreamRec sr{};
-                if (v.srec) sr = v.srec[start + pos];
-                else if (v.sid) sr.id = v.sid[start + pos];
+                StreamRec sr = sr_early;
                 const bool by_id = v.srec || v.sid; // the scoring order is (slice, site id): ImageHeader
                 const uint64_t ot = v.srec   ? sr.sig & ((1ull << 40) - 1ull)
                                     : v.sid  ? v.sites[sr.id]
@@ -1218,8 +1362,9 @@ __global__ __launch_bounds__(kChunkRecs, 8) void k_verify(ImageView v, Workspace
         if ((todo >> lane) & 1ull) rank = atomicAdd(&ws.gcount[guide], 1u);
         if (live) {
             const uint64_t slot = static_cast<uint64_t>(chunk) * (kChunkRecs - 1u) + (t - 1u); // < cap_chunks * 127 <= cap_hits
-            ws.rank[slot] = rank;
-            reinterpret_cast<double2 *>(ws.pay)[slot] = make_double2(mit_term, cfd_term);
+            HitRec hr;
+            hr.key = key; hr.mit = mit_term; hr.cfd = cfd_term; hr.rank = rank; hr.pad = 0;
+            ws.hit_raw[slot] = hr;
         }
         if (!in_use) continue;
         recs[t] = key;
@@ -1366,9 +1511,7 @@ __global__ __launch_bounds__(1024) void k_prefix_single(const uint32_t *__restri
 __global__ __launch_bounds__(kChunkRecs) void k_group_scatter(const uint64_t *__restrict__ raw,
                                                               const Counters *__restrict__ counters, uint32_t cap_chunks,
                                                               const uint32_t *__restrict__ goff,
-                                                              const uint32_t *__restrict__ rank,
-                                                              const double2 *__restrict__ pay,
-                                                              uint64_t *__restrict__ sorted, double2 *__restrict__ terms)
+                                                              const HitRec *__restrict__ hit_raw, HitRec *__restrict__ hit_grp)
 {
     short_kernel_priority();
     uint32_t n_chunks = counters->raw_chunks;
@@ -1378,13 +1521,9 @@ __global__ __launch_bounds__(kChunkRecs) void k_group_scatter(const uint64_t *__
         const uint32_t used = static_cast<uint32_t>(recs[0]);
         const uint32_t t = threadIdx.x + 1u;
         if (t >= used || t >= kChunkRecs) continue;
-        const uint64_t key = recs[t];
-        if (key == kDeadKey) continue;
-        const uint32_t guide = static_cast<uint32_t>(key >> 35);
-        const uint64_t slot = static_cast<uint64_t>(chunk) * (kChunkRecs - 1u) + (t - 1u);
-        const uint32_t to = goff[guide] + rank[slot]; // rank: k_verify's
-        sorted[to] = key;
-        terms[to] = pay[slot];
+        if (recs[t] == kDeadKey) continue;
+        const HitRec hr = hit_raw[static_cast<uint64_t>(chunk) * (kChunkRecs - 1u) + (t - 1u)];
+        hit_grp[goff[static_cast<uint32_t>(hr.key >> 35)] + hr.rank] = hr; // rank: k_verify's
     }
 }
 
@@ -1403,8 +1542,7 @@ void launch_group_hits(const Workspace &ws, uint32_t n, void *stream_)
                            ws.gcur_big, ws.counters);
     }
     hipLaunchKernelGGL(k_group_scatter, dim3(kTailGrid), dim3(kChunkRecs), 0, stream, ws.raw, ws.counters,
-                       static_cast<uint32_t>(ws.cap_chunks), ws.goff, ws.rank, reinterpret_cast<const double2 *>(ws.pay),
-                       ws.sorted, reinterpret_cast<double2 *>(ws.terms));
+                       static_cast<uint32_t>(ws.cap_chunks), ws.goff, ws.hit_raw, ws.hit_grp);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1590,10 +1728,10 @@ __global__ __launch_bounds__(64) void k_replay(ImageView v, Workspace ws, const 
             stop = accumulate_chunk(mit_term, cfd_term, cnt, p, lane, tot_mit, tot_cfd, kept);
         };
 
-        // The terms of every hit were computed by k_verify and sit next to the keys (ws.terms, same index as ws.sorted);
+        // The terms of every hit were computed by k_verify and sit next to the keys (ws.hit_grp);
         // what is left is putting them in key order and adding them up.  issl_dump_hits also wants the expanded
         // records: those are looked up here (hit_terms), the totals still come from the stored terms.
-        const double2 *__restrict__ terms2 = reinterpret_cast<const double2 *>(ws.terms);
+        const HitRec *__restrict__ grp = ws.hit_grp + h0;
         if (h <= 64) {
             // Common case: no sort.  Lane l takes key l and its terms, finds the rank of its key among the h keys by
             // counting, and drops the terms at that rank; lane r then owns the r-th hit in key order.
@@ -1601,8 +1739,9 @@ __global__ __launch_bounds__(64) void k_replay(ImageView v, Workspace ws, const 
             double2 mine = make_double2(0.0, 0.0);
             issl_hit rec{};
             if (lane < h) {
-                key = ws.sorted[h0 + lane];
-                mine = terms2[h0 + lane];
+                const HitRec hr = grp[lane];
+                key = hr.key;
+                mine = make_double2(hr.mit, hr.cfd);
                 if (out_hits) rec = hit_terms(v, gsig, g, key, calc_mit, calc_cfd, true).rec;
             }
             uint32_t rank = 0;
@@ -1624,7 +1763,7 @@ __global__ __launch_bounds__(64) void k_replay(ImageView v, Workspace ws, const 
         } else {
             // (slice, position) of every key with the key's index behind it, sorted in LDS; the terms follow by index
             uint64_t *data = keys;
-            for (uint32_t i = lane; i < h; i += 64) keys[i] = ((ws.sorted[h0 + i] & ((1ull << 35) - 1ull)) << 9) | i; // h <= 512
+            for (uint32_t i = lane; i < h; i += 64) keys[i] = ((grp[i].key & ((1ull << 35) - 1ull)) << 9) | i; // h <= 512
             __syncthreads();
             wave_sort(data, h);
             __syncthreads();
@@ -1633,7 +1772,8 @@ __global__ __launch_bounds__(64) void k_replay(ImageView v, Workspace ws, const 
                 double2 mine = make_double2(0.0, 0.0);
                 if (idx < h) {
                     const uint64_t sv = data[idx];
-                    mine = terms2[h0 + static_cast<uint32_t>(sv & 511ull)];
+                    const HitRec hr = grp[static_cast<uint32_t>(sv & 511ull)];
+                    mine = make_double2(hr.mit, hr.cfd);
                     if (out_hits)
                         out_hits[h0 + idx] = hit_terms(v, gsig, g, (static_cast<uint64_t>(g) << 35) | (sv >> 9), calc_mit, calc_cfd, true).rec;
                 }
@@ -1753,7 +1893,8 @@ __global__ __launch_bounds__(1024, 8) void k_replay_big(ImageView v, Workspace w
         const uint32_t h0 = ws.goff[g];
         const uint32_t h = ws.goff[g + 1] - h0;
         const uint64_t gsig = guides[g];
-        uint64_t *seg = ws.sorted + h0;
+        uint64_t *seg = ws.sorted + h0;            // the guide's keys in scoring order, slice by slice
+        const HitRec *__restrict__ grp = ws.hit_grp + h0; // ... as they arrived
         uint64_t *tmp = ws.raw + h0; // the raw records are dead once they are grouped; the buffer holds >= all hits
         // diagnostics (ISSL_SCAN_STAMPS, tools/replay_stamps.py): phase clocks of the first 4096 big guides
         unsigned long long *st = (ws.stamps && b < 4096u) ? ws.stamps + 65536u + 16u * b : nullptr;
@@ -1767,7 +1908,7 @@ __global__ __launch_bounds__(1024, 8) void k_replay_big(ImageView v, Workspace w
         __syncthreads();
         for (uint32_t base = 0; base < h; base += blockDim.x) {
             const uint32_t i = base + threadIdx.x;
-            const uint32_t sl = i < h ? static_cast<uint32_t>(seg[i] >> 32) & 7u : 8u;
+            const uint32_t sl = i < h ? static_cast<uint32_t>(grp[i].key >> 32) & 7u : 8u;
             for (uint32_t s2 = 0; s2 < v.n_slices; ++s2) {
                 const uint64_t m = __ballot(sl == s2);
                 if (m != 0ull && lane == 0) atomicAdd(&slice_cnt[s2], static_cast<uint32_t>(__builtin_popcountll(m)));
@@ -1782,7 +1923,7 @@ __global__ __launch_bounds__(1024, 8) void k_replay_big(ImageView v, Workspace w
         __syncthreads();
         for (uint32_t base = 0; base < h; base += blockDim.x) {
             const uint32_t i = base + threadIdx.x;
-            const uint64_t key = i < h ? seg[i] : 0ull;
+            const uint64_t key = i < h ? grp[i].key : 0ull;
             const uint32_t sl = i < h ? static_cast<uint32_t>(key >> 32) & 7u : 8u;
             for (uint32_t s2 = 0; s2 < v.n_slices; ++s2) {
                 const uint64_t m = __ballot(sl == s2);
