@@ -167,6 +167,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=24.0, help="CPU seconds for the baseline sweep")
     ap.add_argument("--no-extras", action="store_true", help="skip the 10k-guide, 64-guide and host-pointer points")
+    ap.add_argument("--dump-scores", default=None,
+                    help="rank 0 writes the scores of the last timed step, in input order, to this .npz (tests: the N>1 "
+                         "path against the single-process result)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -186,15 +189,22 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU path to time)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # ISSL_BENCH_DEVICE / ISSL_BENCH_BACKEND: rehearsal of the N>1 path on a box with ONE GPU (tests/test_multirank_one_gpu.py):
+    # every rank on the same device, collectives over gloo (RCCL refuses two ranks on one GPU)
+    dev_id = int(os.environ.get("ISSL_BENCH_DEVICE", local_rank))
+    backend = os.environ.get("ISSL_BENCH_BACKEND", "nccl")
+    torch.cuda.set_device(dev_id)
+    dev = torch.device("cuda", dev_id)
     # Under torch.distributed.run (RANK set) the process group is used even for one rank, so that the RCCL
     # path (broadcast of the image, gather of the scores, barrier, max-reduce) runs on a 1-GPU box too.
     use_dist = world > 1 or "RANK" in os.environ
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     # ---- index: rank 0 builds it on its GPU, the image is broadcast over RCCL/xGMI ----------------------------------
     timings = {}
@@ -210,7 +220,7 @@ def main():
             sigs, occ = random_sites(a.sites, seed=20261003)
         timings["synth_s"] = time.perf_counter() - t0
         t0 = time.perf_counter()
-        index = ca.IsslIndex.build_on_device(sigs, occ, device=local_rank)
+        index = ca.IsslIndex.build_on_device(sigs, occ, device=dev_id)
         timings["device_build_s"] = time.perf_counter() - t0
         del occ
     if use_dist:
@@ -226,8 +236,14 @@ def main():
         g_all = torch.from_numpy(all_guides.view(np.int64)).to(dev)
     else:
         g_all = torch.empty(n_total, dtype=torch.int64, device=dev)
+    cdev = "cpu" if backend == "gloo" else dev   # where the small control tensors of the collectives live
     if use_dist:
-        dist.broadcast(g_all, 0)
+        if backend == "gloo":
+            host = g_all.cpu()
+            dist.broadcast(host, 0)
+            g_all.copy_(host)
+        else:
+            dist.broadcast(g_all, 0)
     layout = sharding.ShardLayout(torch, n_total, world, a.chunk if world > 1 else None, dev)
     d_guides = g_all[layout.index_tensors[rank]].contiguous()
     n_mine = int(d_guides.numel())
@@ -283,6 +299,9 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     gather_s = time.perf_counter() - t_scored
+    if a.dump_scores and rank == 0:  # scores of the last timed step in input order
+        last = (gathered[0][-1], gathered[1][-1]) if use_dist else (out_mit[-1], out_cfd[-1])
+        np.savez(a.dump_scores, guides=all_guides, mit=last[0].cpu().numpy(), cfd=last[1].cpu().numpy())
     st = index.stats()
     scan_ms = st["ms_scan"]
     # Stage breakdown (bin / verify / group / replay) from a short UNTIMED pass: the timed region records only the event
@@ -297,10 +316,10 @@ def main():
     stages = index.stats()
     per_rank = None
     if use_dist:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-        mine_t = torch.tensor([scan_ms, stages["ms_total"], float(n_mine), float(st["candidates"])], dtype=torch.float64, device=dev)
+        mine_t = torch.tensor([scan_ms, stages["ms_total"], float(n_mine), float(st["candidates"])], dtype=torch.float64, device=cdev)
         allr = [torch.empty_like(mine_t) for _ in range(world)] if rank == 0 else None
         dist.gather(mine_t, allr, dst=0)
         if rank == 0:
@@ -324,7 +343,7 @@ def main():
             step(g, m, c)
         index.finish(stream)
         barrier()
-        tt = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
+        tt = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         if rank == 0:
             dt = float(tt.item())

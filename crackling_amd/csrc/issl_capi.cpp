@@ -160,6 +160,8 @@ struct Lane {
     hipEvent_t ev[6] = {};      // stage boundaries of the last batch
     hipEvent_t done = nullptr;  // end of the last batch
     hipStream_t stream = nullptr; // internal stream of asynchronous batches
+    hipStream_t tail_stream = nullptr; // lanes = 2: the batch's verify / group / replay run here (high priority), beside the
+                                // scan of the next batch on the other lane's stream
     bool ready = false;         // events and stream created
     uint32_t last_n = 0;
     uint32_t pending = 0;       // batches enqueued since the last finish
@@ -190,6 +192,7 @@ struct issl_index {
     bool have_events = false;
     issl_stats stats{};
     uint32_t n_pending = 0;  // batches enqueued and not yet finished
+    hipEvent_t prev_scan_end = nullptr; // lanes = 2: end of the previous batch's scan (scans run one after the other)
     bool list_order_only = false; // the lists of this index cannot be re-ordered (kSortNeedsListOrder)
 };
 
@@ -230,7 +233,7 @@ static int select_device(int device)
 static void free_workspace(Workspace &w)
 {
     void *ptrs[] = {w.ng, w.gfill, w.gstart, w.gword, w.gidx, w.gbucket, w.items, w.plan, w.range_start, w.counters, w.scan_count, w.scan_span, w.sticky, w.stamps, w.gcur_big, w.terms, w.sorted, w.gcount,
-                    w.goff, w.blocksum, w.d_guides, w.d_mit, w.d_cfd, w.d_kept, w.d_hitrec, w.hit_raw, w.hit_grp, w.fword, w.fmeta,
+                    w.goff, w.blocksum, w.d_guides, w.d_mit, w.d_cfd, w.d_kept, w.d_hitrec, w.pay, w.rank, w.fword, w.fmeta,
                     w.fitems, w.fcount, w.fsum};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -254,8 +257,8 @@ static int ensure_hit_capacity(Workspace &w, size_t want)
     int rc;
     if ((rc = dev_alloc(w.sorted, want))) return rc;
     if ((rc = dev_alloc(w.terms, 2 * want))) return rc;
-    if ((rc = dev_alloc(w.hit_raw, want))) return rc;
-    if ((rc = dev_alloc(w.hit_grp, want))) return rc;
+    if ((rc = dev_alloc(w.pay, 2 * want))) return rc;
+    if ((rc = dev_alloc(w.rank, want))) return rc;
     w.cap_hits = want;
     return ISSL_OK;
 }
@@ -343,7 +346,10 @@ static int ensure_workspace(issl_index *ix, size_t n, Lane &lane)
     if (!lane.ready) {
         for (auto &e : lane.ev) HIP_TRY(hipEventCreate(&e));
         HIP_TRY(hipEventCreate(&lane.done));
-        HIP_TRY(hipStreamCreateWithFlags(&lane.stream, hipStreamNonBlocking));
+        int prio_low = 0, prio_high = 0; // (numerically lowest = most urgent)
+        HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
+        HIP_TRY(hipStreamCreateWithPriority(&lane.stream, hipStreamNonBlocking, prio_low));
+        HIP_TRY(hipStreamCreateWithPriority(&lane.tail_stream, hipStreamNonBlocking, prio_high));
         lane.ready = true;
     }
     if (!w.stamps && !tn.stamps_path.empty()) { // diagnostics: per-wave start/end times of the scan
@@ -635,9 +641,11 @@ static void release_device(issl_index *ix)
         Lane &lane = *lp;
         if (lane.ready) {
             (void)hipStreamSynchronize(lane.stream);
+            (void)hipStreamSynchronize(lane.tail_stream);
             for (auto &e : lane.ev) (void)hipEventDestroy(e);
             (void)hipEventDestroy(lane.done);
             (void)hipStreamDestroy(lane.stream);
+            (void)hipStreamDestroy(lane.tail_stream);
             lane.ready = false;
         }
         free_workspace(lane.ws);
@@ -650,6 +658,7 @@ static void release_device(issl_index *ix)
         ix->have_events = false;
     }
     ix->n_pending = 0;
+    ix->prev_scan_end = nullptr;
     if (ix->d_image && ix->owns_image) (void)hipFree(ix->d_image);
     ix->d_image = nullptr;
     ix->owns_image = false;
@@ -679,8 +688,13 @@ static int new_index_from_host(std::unique_ptr<HostIndex> h, issl_index **out)
 // `staged`: record an event at every stage boundary (bin / scan / verify / group / replay times in issl_stats).  An event
 // record costs ~4 us of stream time on MI355X -- 5 % of a 10 k-guide batch for the six of them -- so the asynchronous
 // back-to-back path records only the pair around the scan and the end of the batch unless the stage_timing knob is set.
+// `pipelined` (asynchronous batches with the lanes option = 2): a software pipeline over two workspaces.  Binning and scan of
+// a batch run on the lane's stream, its verify / group / replay on the lane's high-priority tail stream; the scans of
+// consecutive batches are chained by events, so that they run one after the other at full speed while the short, latency-
+// bound tail of batch i runs beside the scan of batch i + 1 -- a step then costs max(bin + scan, tail) instead of their sum.
 static int enqueue_batch(issl_index *ix, Lane &lane, hipStream_t stream, const uint64_t *d_guides, size_t n, int max_dist,
-                         double threshold, int method, double *d_mit, double *d_cfd, bool dump, bool staged)
+                         double threshold, int method, double *d_mit, double *d_cfd, bool dump, bool staged,
+                         bool pipelined = false)
 {
     if (!ix->d_image) {
         set_error("index has no device image: call issl_index_upload first");
@@ -712,23 +726,31 @@ static int enqueue_batch(issl_index *ix, Lane &lane, hipStream_t stream, const u
     const uint32_t n32 = static_cast<uint32_t>(n);
     const uint32_t slot = ix->n_pending % kRing;
     lane.staged = staged;
+    if (pipelined && lane.pending) HIP_TRY(hipStreamWaitEvent(stream, lane.done, 0)); // the workspace's previous batch (tail stream)
     if (staged) HIP_TRY(hipEventRecord(lane.ev[0], stream));
     ws.span_slot = lane.pending % kSpanRing;
     const uint32_t prune_mode = prune_mode_for(ix->view, tn, n32, max_dist);
     launch_bin_guides(ix->view, ws, tn, d_guides, n32, prune_mode, stream);
     if (staged) HIP_TRY(hipEventRecord(lane.ev[1], stream));
+    if (pipelined && ix->prev_scan_end) HIP_TRY(hipStreamWaitEvent(stream, ix->prev_scan_end, 0)); // one scan at a time
     HIP_TRY(hipEventRecord(ix->ring[2 * slot], stream));
     launch_scan(ix->view, ws, tn, d_guides, n32, max_dist, prune_mode, stream);
     HIP_TRY(hipEventRecord(ix->ring[2 * slot + 1], stream));
     if (staged) HIP_TRY(hipEventRecord(lane.ev[2], stream));
-    launch_verify(ix->view, ws, d_guides, p, stream);
-    if (staged) HIP_TRY(hipEventRecord(lane.ev[3], stream));
-    launch_group_hits(ws, n32, stream);
-    if (staged) HIP_TRY(hipEventRecord(lane.ev[4], stream));
+    hipStream_t tail = stream;
+    if (pipelined) {
+        tail = lane.tail_stream;
+        HIP_TRY(hipStreamWaitEvent(tail, ix->ring[2 * slot + 1], 0));
+        ix->prev_scan_end = ix->ring[2 * slot + 1];
+    }
+    launch_verify(ix->view, ws, d_guides, p, tail);
+    if (staged) HIP_TRY(hipEventRecord(lane.ev[3], tail));
+    launch_group_hits(ws, n32, tail);
+    if (staged) HIP_TRY(hipEventRecord(lane.ev[4], tail));
     launch_replay(ix->view, ws, d_guides, n32, p, d_mit, d_cfd, dump ? ws.d_kept : nullptr,
-                  dump ? ws.d_hitrec : nullptr, stream);
-    if (staged) HIP_TRY(hipEventRecord(lane.ev[5], stream));
-    HIP_TRY(hipEventRecord(lane.done, stream));
+                  dump ? ws.d_hitrec : nullptr, tail);
+    if (staged) HIP_TRY(hipEventRecord(lane.ev[5], tail));
+    HIP_TRY(hipEventRecord(lane.done, tail));
     ix->n_pending += 1;
     lane.pending += 1;
     lane.last_n = n32;
@@ -747,7 +769,11 @@ static int finish_batches(issl_index *ix, hipStream_t stream)
     HIP_TRY(hipSetDevice(ix->device));
     HIP_TRY(hipStreamSynchronize(stream));
     for (Lane *lp : {&ix->lane, &ix->lane2})
-        if (lp->ready && lp->pending) HIP_TRY(hipStreamSynchronize(lp->stream));
+        if (lp->ready && lp->pending) {
+            HIP_TRY(hipStreamSynchronize(lp->stream));
+            HIP_TRY(hipStreamSynchronize(lp->tail_stream));
+        }
+    ix->prev_scan_end = nullptr;
     HIP_TRY(hipGetLastError());
     const uint32_t batches = ix->n_pending;
     ix->n_pending = 0;
@@ -1377,7 +1403,7 @@ int issl_score_device_async(issl_index *idx, const uint64_t *d_guides, size_t n,
         HIP_TRY(hipStreamWaitEvent(lane.stream, lane.ev[0], 0));
     }
     return enqueue_batch(idx, lane, lane.stream, d_guides, n, max_dist, threshold, method, d_mit, d_cfd, false,
-                         idx->tuning.stage_timing);
+                         idx->tuning.stage_timing, idx->tuning.lanes == 2);
 }
 
 int issl_score_wait(issl_index *idx, void *stream)

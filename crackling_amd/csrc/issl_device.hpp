@@ -233,14 +233,6 @@ struct RangeStart {
     uint32_t pad;
 };
 
-// One scored off-target as k_verify leaves it: 32 bytes = one aligned half sector, written and moved in one piece.
-struct alignas(32) HitRec {
-    uint64_t key;      // guide << 35 | first matching slice << 32 | site id (sorted layouts) or list position
-    double mit, cfd;   // its terms (isslScoreOfftargets.cpp:392-460)
-    uint32_t rank;     // place among its guide's hits in arrival order (k_verify's returning atomic)
-    uint32_t pad;
-};
-
 // Written by the planning kernel, read-only for the scan.
 struct PlanInfo {
     uint32_t n_items;
@@ -304,13 +296,13 @@ struct Workspace {
     uint64_t *scan_count = nullptr; // [kScanMaxBlocks] comparisons every scan workgroup actually made (real candidates x real guides)
     unsigned long long *stamps = nullptr; // [4 * kScanWaves] scan wave clocks, then replay phase clocks (ISSL_SCAN_STAMPS diagnostics)
     uint32_t *sticky = nullptr;  // [4] survives the per-batch resets: [0] raw overflow seen, [1] max chunks asked, [2] plan errors, [3] items a pruned plan wanted beyond cap_fitems
-    uint64_t *sorted = nullptr;  // [hit_cap] many-hit replay: a guide's keys in scoring order
+    uint64_t *sorted = nullptr;  // [hit_cap] keys guide<<35 | slice<<32 | site id or list position, grouped by guide
     uint32_t *gcount = nullptr;  // [G+1] hits per guide
     uint32_t *goff = nullptr;    // [G+1] exclusive prefix
     uint32_t *gcur_big = nullptr; // [G] guides handed to k_replay_big
-    double *terms = nullptr;     // [2 * hit_cap] many-hit replay: MIT/CFD terms of a guide's hits in scoring order
-    HitRec *hit_raw = nullptr;   // [hit_cap] what k_verify found out about a surviving raw record, by raw-record slot
-    HitRec *hit_grp = nullptr;   // [hit_cap] the same records grouped by guide (k_group_scatter): what the replay reads
+    double *terms = nullptr;     // [2 * hit_cap] MIT/CFD terms of the hits, grouped by guide like `sorted`
+    double *pay = nullptr;       // [2 * hit_cap] the same terms as k_verify computed them, by raw-record slot
+    uint32_t *rank = nullptr;    // [hit_cap] place of a surviving raw record inside its guide's segment, by raw-record slot
     uint32_t *blocksum = nullptr;
     uint64_t *d_guides = nullptr; // staging for the host API
     double *d_mit = nullptr, *d_cfd = nullptr;

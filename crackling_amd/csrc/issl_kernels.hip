@@ -1362,9 +1362,8 @@ __global__ __launch_bounds__(kChunkRecs, 8) void k_verify(ImageView v, Workspace
         if ((todo >> lane) & 1ull) rank = atomicAdd(&ws.gcount[guide], 1u);
         if (live) {
             const uint64_t slot = static_cast<uint64_t>(chunk) * (kChunkRecs - 1u) + (t - 1u); // < cap_chunks * 127 <= cap_hits
-            HitRec hr;
-            hr.key = key; hr.mit = mit_term; hr.cfd = cfd_term; hr.rank = rank; hr.pad = 0;
-            ws.hit_raw[slot] = hr;
+            ws.rank[slot] = rank;
+            reinterpret_cast<double2 *>(ws.pay)[slot] = make_double2(mit_term, cfd_term);
         }
         if (!in_use) continue;
         recs[t] = key;
@@ -1467,51 +1466,60 @@ __global__ __launch_bounds__(256) void k_prefix_apply(const uint32_t *__restrict
     }
 }
 
-// Whole prefix sum in one workgroup (used while n is moderate; saves two launches).
+// Whole prefix sum in one workgroup (used while n is moderate; saves two launches): every thread sums its own run of
+// consecutive counts (16-byte loads), ONE scan over the 1024 run totals, then every thread writes its run's prefixes --
+// two barriers in all, where a loop over chunks of 4096 counts paid three per chunk (0.06 ms at 100 k guides).
 __global__ __launch_bounds__(1024) void k_prefix_single(const uint32_t *__restrict__ in, uint32_t n,
                                                         uint32_t *__restrict__ out, uint32_t *__restrict__ big,
                                                         Counters *__restrict__ counters)
 {
     short_kernel_priority();
     __shared__ uint32_t wave_sum[16];
-    __shared__ uint32_t carry_s;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) carry_s = 0;
+    const uint32_t per = ((n + 1023u) / 1024u + 3u) & ~3u; // counts per thread, a multiple of 4: the runs start 16-byte aligned
+    const uint32_t i0 = threadIdx.x * per;
+    uint32_t s = 0;
+    for (uint32_t k = 0; k < per; k += 4) {
+        const uint32_t i = i0 + k;
+        uint4 q = make_uint4(0, 0, 0, 0);
+        if (i + 3 < n) q = *reinterpret_cast<const uint4 *>(in + i);
+        else { if (i < n) q.x = in[i]; if (i + 1 < n) q.y = in[i + 1]; if (i + 2 < n) q.z = in[i + 2]; }
+        s += q.x + q.y + q.z + q.w;
+        const uint32_t vals[4] = {q.x, q.y, q.z, q.w};
+        for (uint32_t j = 0; j < 4; ++j)
+            if (vals[j] > kReplayLds) big[atomicAdd(&counters->n_big, 1u)] = i + j; // guides for k_replay_big
+    }
+    uint32_t x = s; // inclusive scan of s inside the wave
+    for (uint32_t d = 1; d < 64; d <<= 1) {
+        const uint32_t y = __shfl_up(x, d, 64);
+        if (lane >= d) x += y;
+    }
+    if (lane == 63) wave_sum[wave] = x;
     __syncthreads();
-    for (uint32_t base = 0; base < n; base += 4096) {
-        const uint32_t i0 = base + threadIdx.x * 4u;
-        uint32_t val[4];
-        uint32_t s = 0;
-        for (uint32_t i = 0; i < 4; ++i) {
-            val[i] = (i0 + i < n) ? in[i0 + i] : 0u;
-            s += val[i];
-            if (val[i] > kReplayLds) big[atomicAdd(&counters->n_big, 1u)] = i0 + i; // guides for k_replay_big
-        }
-        // inclusive scan of s inside the wave
-        uint32_t x = s;
-        for (uint32_t d = 1; d < 64; d <<= 1) {
-            const uint32_t y = __shfl_up(x, d, 64);
-            if (lane >= d) x += y;
-        }
-        if (lane == 63) wave_sum[wave] = x;
-        __syncthreads();
-        uint32_t before = carry_s;
-        for (uint32_t wv = 0; wv < wave; ++wv) before += wave_sum[wv];
-        uint32_t run = before + x - s;
-        for (uint32_t i = 0; i < 4; ++i) {
-            if (i0 + i < n) out[i0 + i] = run;
-            run += val[i];
-        }
-        __syncthreads();
-        if (threadIdx.x == 1023) carry_s = run;
-        __syncthreads();
+    uint32_t run = x - s;
+    for (uint32_t wv = 0; wv < wave; ++wv) run += wave_sum[wv];
+    for (uint32_t k = 0; k < per; k += 4) {
+        const uint32_t i = i0 + k;
+        if (i >= n) break;
+        uint4 q = make_uint4(0, 0, 0, 0);
+        if (i + 3 < n) q = *reinterpret_cast<const uint4 *>(in + i);
+        else { q.x = in[i]; if (i + 1 < n) q.y = in[i + 1]; if (i + 2 < n) q.z = in[i + 2]; }
+        const uint4 o = make_uint4(run, run + q.x, run + q.x + q.y, run + q.x + q.y + q.z);
+        if (i + 3 < n) *reinterpret_cast<uint4 *>(out + i) = o;
+        else { out[i] = o.x; if (i + 1 < n) out[i + 1] = o.y; if (i + 2 < n) out[i + 2] = o.z; }
+        run += q.x + q.y + q.z + q.w;
     }
 }
 
+// (One 32-byte record {key, terms, rank} per hit instead of the three arrays -- written by k_verify, moved by this
+// kernel, read by the replay -- was measured in round 3: verify +7 %, this kernel +35 %: the passes are bound by the
+// bytes they move, not by the number of streams; profiles/r03_ab_hit_records.log.)
 __global__ __launch_bounds__(kChunkRecs) void k_group_scatter(const uint64_t *__restrict__ raw,
                                                               const Counters *__restrict__ counters, uint32_t cap_chunks,
                                                               const uint32_t *__restrict__ goff,
-                                                              const HitRec *__restrict__ hit_raw, HitRec *__restrict__ hit_grp)
+                                                              const uint32_t *__restrict__ rank,
+                                                              const double2 *__restrict__ pay,
+                                                              uint64_t *__restrict__ sorted, double2 *__restrict__ terms)
 {
     short_kernel_priority();
     uint32_t n_chunks = counters->raw_chunks;
@@ -1521,9 +1529,13 @@ __global__ __launch_bounds__(kChunkRecs) void k_group_scatter(const uint64_t *__
         const uint32_t used = static_cast<uint32_t>(recs[0]);
         const uint32_t t = threadIdx.x + 1u;
         if (t >= used || t >= kChunkRecs) continue;
-        if (recs[t] == kDeadKey) continue;
-        const HitRec hr = hit_raw[static_cast<uint64_t>(chunk) * (kChunkRecs - 1u) + (t - 1u)];
-        hit_grp[goff[static_cast<uint32_t>(hr.key >> 35)] + hr.rank] = hr; // rank: k_verify's
+        const uint64_t key = recs[t];
+        if (key == kDeadKey) continue;
+        const uint32_t guide = static_cast<uint32_t>(key >> 35);
+        const uint64_t slot = static_cast<uint64_t>(chunk) * (kChunkRecs - 1u) + (t - 1u);
+        const uint32_t to = goff[guide] + rank[slot]; // rank: k_verify's
+        sorted[to] = key;
+        terms[to] = pay[slot];
     }
 }
 
@@ -1542,7 +1554,8 @@ void launch_group_hits(const Workspace &ws, uint32_t n, void *stream_)
                            ws.gcur_big, ws.counters);
     }
     hipLaunchKernelGGL(k_group_scatter, dim3(kTailGrid), dim3(kChunkRecs), 0, stream, ws.raw, ws.counters,
-                       static_cast<uint32_t>(ws.cap_chunks), ws.goff, ws.hit_raw, ws.hit_grp);
+                       static_cast<uint32_t>(ws.cap_chunks), ws.goff, ws.rank, reinterpret_cast<const double2 *>(ws.pay),
+                       ws.sorted, reinterpret_cast<double2 *>(ws.terms));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1728,10 +1741,10 @@ __global__ __launch_bounds__(64) void k_replay(ImageView v, Workspace ws, const 
             stop = accumulate_chunk(mit_term, cfd_term, cnt, p, lane, tot_mit, tot_cfd, kept);
         };
 
-        // The terms of every hit were computed by k_verify and sit next to the keys (ws.hit_grp);
+        // The terms of every hit were computed by k_verify and sit next to the keys (ws.terms, same index as ws.sorted);
         // what is left is putting them in key order and adding them up.  issl_dump_hits also wants the expanded
         // records: those are looked up here (hit_terms), the totals still come from the stored terms.
-        const HitRec *__restrict__ grp = ws.hit_grp + h0;
+        const double2 *__restrict__ terms2 = reinterpret_cast<const double2 *>(ws.terms);
         if (h <= 64) {
             // Common case: no sort.  Lane l takes key l and its terms, finds the rank of its key among the h keys by
             // counting, and drops the terms at that rank; lane r then owns the r-th hit in key order.
@@ -1739,9 +1752,8 @@ __global__ __launch_bounds__(64) void k_replay(ImageView v, Workspace ws, const 
             double2 mine = make_double2(0.0, 0.0);
             issl_hit rec{};
             if (lane < h) {
-                const HitRec hr = grp[lane];
-                key = hr.key;
-                mine = make_double2(hr.mit, hr.cfd);
+                key = ws.sorted[h0 + lane];
+                mine = terms2[h0 + lane];
                 if (out_hits) rec = hit_terms(v, gsig, g, key, calc_mit, calc_cfd, true).rec;
             }
             uint32_t rank = 0;
@@ -1763,7 +1775,7 @@ __global__ __launch_bounds__(64) void k_replay(ImageView v, Workspace ws, const 
         } else {
             // (slice, position) of every key with the key's index behind it, sorted in LDS; the terms follow by index
             uint64_t *data = keys;
-            for (uint32_t i = lane; i < h; i += 64) keys[i] = ((grp[i].key & ((1ull << 35) - 1ull)) << 9) | i; // h <= 512
+            for (uint32_t i = lane; i < h; i += 64) keys[i] = ((ws.sorted[h0 + i] & ((1ull << 35) - 1ull)) << 9) | i; // h <= 512
             __syncthreads();
             wave_sort(data, h);
             __syncthreads();
@@ -1772,8 +1784,7 @@ __global__ __launch_bounds__(64) void k_replay(ImageView v, Workspace ws, const 
                 double2 mine = make_double2(0.0, 0.0);
                 if (idx < h) {
                     const uint64_t sv = data[idx];
-                    const HitRec hr = grp[static_cast<uint32_t>(sv & 511ull)];
-                    mine = make_double2(hr.mit, hr.cfd);
+                    mine = terms2[h0 + static_cast<uint32_t>(sv & 511ull)];
                     if (out_hits)
                         out_hits[h0 + idx] = hit_terms(v, gsig, g, (static_cast<uint64_t>(g) << 35) | (sv >> 9), calc_mit, calc_cfd, true).rec;
                 }
@@ -1893,8 +1904,7 @@ __global__ __launch_bounds__(1024, 8) void k_replay_big(ImageView v, Workspace w
         const uint32_t h0 = ws.goff[g];
         const uint32_t h = ws.goff[g + 1] - h0;
         const uint64_t gsig = guides[g];
-        uint64_t *seg = ws.sorted + h0;            // the guide's keys in scoring order, slice by slice
-        const HitRec *__restrict__ grp = ws.hit_grp + h0; // ... as they arrived
+        uint64_t *seg = ws.sorted + h0;
         uint64_t *tmp = ws.raw + h0; // the raw records are dead once they are grouped; the buffer holds >= all hits
         // diagnostics (ISSL_SCAN_STAMPS, tools/replay_stamps.py): phase clocks of the first 4096 big guides
         unsigned long long *st = (ws.stamps && b < 4096u) ? ws.stamps + 65536u + 16u * b : nullptr;
@@ -1908,7 +1918,7 @@ __global__ __launch_bounds__(1024, 8) void k_replay_big(ImageView v, Workspace w
         __syncthreads();
         for (uint32_t base = 0; base < h; base += blockDim.x) {
             const uint32_t i = base + threadIdx.x;
-            const uint32_t sl = i < h ? static_cast<uint32_t>(grp[i].key >> 32) & 7u : 8u;
+            const uint32_t sl = i < h ? static_cast<uint32_t>(seg[i] >> 32) & 7u : 8u;
             for (uint32_t s2 = 0; s2 < v.n_slices; ++s2) {
                 const uint64_t m = __ballot(sl == s2);
                 if (m != 0ull && lane == 0) atomicAdd(&slice_cnt[s2], static_cast<uint32_t>(__builtin_popcountll(m)));
@@ -1923,7 +1933,7 @@ __global__ __launch_bounds__(1024, 8) void k_replay_big(ImageView v, Workspace w
         __syncthreads();
         for (uint32_t base = 0; base < h; base += blockDim.x) {
             const uint32_t i = base + threadIdx.x;
-            const uint64_t key = i < h ? grp[i].key : 0ull;
+            const uint64_t key = i < h ? seg[i] : 0ull;
             const uint32_t sl = i < h ? static_cast<uint32_t>(key >> 32) & 7u : 8u;
             for (uint32_t s2 = 0; s2 < v.n_slices; ++s2) {
                 const uint64_t m = __ballot(sl == s2);

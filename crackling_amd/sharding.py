@@ -42,9 +42,17 @@ def shard_size(n, world, rank, chunk=DEFAULT_CHUNK):
     return mine * chunk + (rest if full % world == rank else 0)
 
 
+def _staged(dist, torch, device):
+    """True when collectives on `device` tensors have to go through host memory: the `gloo` backend moves CPU tensors
+    (its CUDA support covers only some collectives); `nccl` (= RCCL) moves device tensors as they are."""
+    return getattr(device, "type", str(device)) != "cpu" and str(dist.get_backend()).lower() == "gloo"
+
+
 def broadcast_image(dist, torch, index, device, src=0, index_cls=None, piece_bytes=1 << 30):
     """Rank `src` holds an IsslIndex (host arrays, or an image already on `device`); every rank ends up with an
     IsslIndex attached to its own copy of the image.  Returns (index, seconds spent in the broadcast proper).
+    The index passed in on rank `src` is CONSUMED when it already has a device image: that image is copied into the
+    tensor the ranks share the layout of and the library-owned copy is closed; use the returned index from then on.
 
     The image travels as ONE uint8 tensor: rank `src` builds it straight into the tensor (host arrays) or copies its
     device-built image there; the others receive and attach (issl_index_attach_image).  The broadcast itself goes in
@@ -55,7 +63,8 @@ def broadcast_image(dist, torch, index, device, src=0, index_cls=None, piece_byt
     if index_cls is None:
         from .scorer import IsslIndex as index_cls
     rank = dist.get_rank()
-    nbytes = torch.zeros(1, dtype=torch.int64, device=device)
+    staged = _staged(dist, torch, device)
+    nbytes = torch.zeros(1, dtype=torch.int64, device="cpu" if staged else device)
     if rank == src:
         nbytes[0] = index.device_bytes()
     dist.broadcast(nbytes, src)
@@ -74,7 +83,14 @@ def broadcast_image(dist, torch, index, device, src=0, index_cls=None, piece_byt
     _sync(torch, device)
     t0 = time.perf_counter()
     for at in range(0, n, piece_bytes):
-        dist.broadcast(image[at:at + piece_bytes], src)
+        piece = image[at:at + piece_bytes]
+        if staged:  # (test set-ups only: two ranks sharing one GPU over gloo)
+            host = piece.cpu()
+            dist.broadcast(host, src)
+            if rank != src:
+                piece.copy_(host)
+        else:
+            dist.broadcast(piece, src)
     _sync(torch, device)
     seconds = time.perf_counter() - t0
     return (index_cls.attach_tensor(image) if attach else index), seconds
@@ -122,10 +138,13 @@ def gather_scores(dist, torch, layout, mit, cfd, device="cpu", dst=0):
     local = torch.zeros((2,) + lead + (layout.width,), dtype=torch.float64, device=device)
     local[0, ..., :layout.sizes[rank]] = mit_t.to(device)
     local[1, ..., :layout.sizes[rank]] = cfd_t.to(device)
+    if _staged(dist, torch, device):
+        local = local.cpu()
     parts = [torch.empty_like(local) for _ in range(world)] if rank == dst else None
     dist.gather(local, parts, dst=dst)
     if rank != dst:
         return None, None
+    parts = [p.to(device) for p in parts]
     out = torch.empty((2,) + lead + (layout.n,), dtype=torch.float64, device=device)
     for r in range(world):
         out[..., layout.index_tensors[r]] = parts[r][..., :layout.sizes[r]]
