@@ -54,16 +54,26 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def kernels_sha16():
+    """What the PMC points of profiles/scan_traffic.json are stamped with: the scan kernel's source."""
+    import hashlib
+    return hashlib.sha256((ROOT / "crackling_amd" / "csrc" / "issl_kernels.hip").read_bytes()).hexdigest()[:16]
+
+
 def traffic_point(sites, guides, dist, pruned):
-    """HBM bytes per k_scan launch of this workload from a PMC profile (profiles/scan_traffic.json), or None."""
+    """(HBM bytes per k_scan launch of this workload from a PMC profile, where it came from), or (None, why not).  A
+    point measured on another build of the kernels (its `kernels_sha16` differs from the source in this tree) is stale
+    and is not used."""
     prof = ROOT / "profiles" / "scan_traffic.json"
     try:
         for rec in json.loads(prof.read_text()).get("points", []):
             if (rec.get("sites"), rec.get("guides"), rec.get("distribution"), rec.get("pruned")) == (sites, guides, dist, pruned):
-                return rec.get("hbm_bytes_per_launch")
-    except Exception:  # noqa: BLE001
-        pass
-    return None
+                if rec.get("kernels_sha16") != kernels_sha16():
+                    return None, f"stale: profiles/scan_traffic.json holds a point of kernel build {rec.get('kernels_sha16')}, this is {kernels_sha16()}"
+                return rec.get("hbm_bytes_per_launch"), rec.get("source")
+    except Exception as e:  # noqa: BLE001
+        return None, f"{type(e).__name__}: {e}"
+    return None, "no PMC point for this workload in profiles/scan_traffic.json"
 
 
 def host_description():
@@ -185,7 +195,7 @@ def main():
     import torch
     import torch.distributed as dist
     from crackling_amd import sharding
-    from synth import random_sites, random_sites_fast, random_guides_fast, markov_sites
+    from synth import random_sites, random_sites_fast, random_guides_fast, markov_sites_fast
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU path to time)")
@@ -213,7 +223,7 @@ def main():
     if rank == 0:
         t0 = time.perf_counter()
         if a.dist == "markov":
-            sigs, occ = markov_sites(a.sites, seed=20261003)
+            sigs, occ = markov_sites_fast(a.sites, seed=20261003, threads=min(16, os.cpu_count() or 8))
         elif a.sites >= 20_000_000:
             sigs, occ = random_sites_fast(a.sites, seed=20261003, threads=min(16, os.cpu_count() or 8))
         else:
@@ -341,11 +351,11 @@ def main():
         t1 = time.perf_counter()
         for _ in range(weak_steps):
             step(g, m, c)
-        index.finish(stream)
+        weak_ok = index.finish(stream)  # False: a batch ran out of scratch space and would have to be re-run
         barrier()
-        tt = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=cdev)
+        tt = torch.tensor([time.perf_counter() - t1 if weak_ok else float("inf")], dtype=torch.float64, device=cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        if rank == 0:
+        if rank == 0 and float(tt.item()) != float("inf"):
             dt = float(tt.item())
             extras["weak_scaling_point"] = {"guides_per_gpu_per_step": n_weak, "steps": weak_steps, "ms_per_step": dt * 1e3 / weak_steps,
                                             "guides_per_s_all_gpus": world * n_weak * weak_steps / dt,
@@ -368,11 +378,12 @@ def main():
                 t1 = time.perf_counter()
                 for _ in range(reps):
                     step(g, m, c)
-                index.finish(stream)
+                if not index.finish(stream):  # a batch would have to be re-run: no number for this point
+                    continue
                 dt = time.perf_counter() - t1
                 s2 = index.stats()
                 phys = s2["scan_tiles"] * TILE_BYTES
-                pmc = traffic_point(a.sites, n_small, a.dist, s2["pruned"])
+                pmc, _src = traffic_point(a.sites, n_small, a.dist, s2["pruned"])
                 extras[label] = {
                     "hbm_pmc_bytes_per_launch": pmc, "hbm_pmc_frac": (pmc / s2["ms_scan"] / 1e6 / HBM_PEAK_GBS) if pmc else None,
                     "pruned": s2["pruned"],
@@ -387,25 +398,30 @@ def main():
             # beside the scan of the next
             index.set_option("lanes", 2)
             try:
+                def step2(i):  # consecutive batches are in flight together: every one its own output buffers
+                    index.score_device_async(d_guides, out_mit[i % a.steps], out_cfd[i % a.steps], a.max_dist, a.threshold, a.method, stream=None)
                 settle(step)
                 settle(step)
-                for _ in range(4):
-                    step()
+                for i in range(4):
+                    step2(i)
                 index.finish(stream)
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
                 reps = a.steps
-                for _ in range(reps):
-                    step()
-                index.finish(stream)
+                for i in range(reps):
+                    step2(i)
+                ok2 = index.finish(stream)
                 dt = time.perf_counter() - t1
                 s2 = index.stats()
-                extras["two_lanes"] = {
-                    "guides_per_step": n_mine, "steps": reps, "ms_per_step": dt * 1e3 / reps, "guides_per_s": n_mine * reps / dt,
-                    "scan_ms": s2["ms_scan"], "scan_ms_events": s2["ms_scan_events"],
-                    "note": "option lanes=2 (not the default): throughput of back-to-back batches rises, every kernel shares "
-                            "the chip with the other lane's and takes longer (scan_ms is the launch's own span)",
-                }
+                if ok2:  # (a RETRY would mean batches to re-run: no number then)
+                    extras["two_lanes"] = {
+                        "guides_per_step": n_mine, "steps": reps, "ms_per_step": dt * 1e3 / reps, "guides_per_s": n_mine * reps / dt,
+                        "scan_ms": s2["ms_scan"], "scan_ms_events": s2["ms_scan_events"],
+                        "note": "option lanes=2 (not the default): a software pipeline over two workspaces -- the scans of "
+                                "consecutive batches one after the other, verify / group / replay of a batch on a high-priority "
+                                "stream beside the next batch's scan; every kernel then shares the chip (scan_ms is the launch's "
+                                "own span), the step shrinks by a few per cent only",
+                    }
             finally:
                 index.set_option("lanes", lanes)
             # the same batch with the pruned scan switched off: every bucket of every guide compared in full, which is
@@ -422,7 +438,8 @@ def main():
                 reps = 5
                 for _ in range(reps):
                     step()
-                index.finish(stream)
+                if not index.finish(stream):
+                    raise RuntimeError("whole-bucket point: scratch buffers grew inside the measurement")
                 dt = time.perf_counter() - t1
                 s2 = index.stats()
                 extras["whole_bucket_scan"] = {
@@ -458,17 +475,8 @@ def main():
         useful_valu_cycles = cmp_per_launch / 2048.0 * VALU_PER_2048_CMP * VALU_CYCLES_PER_INSTR
         lane_ops = cmp_per_launch * VALU_PER_2048_CMP / 32.0     # 64 lanes x instructions
         tile_bytes = st["scan_tiles"] * TILE_BYTES
-        traffic = None
-        traffic_src = None
-        prof = ROOT / "profiles" / "scan_traffic.json"
-        if prof.exists():
-            try:
-                for rec in json.loads(prof.read_text()).get("points", []):
-                    if (rec.get("sites"), rec.get("guides"), rec.get("distribution"), rec.get("pruned")) == (a.sites, n_mine, a.dist, st["pruned"]):
-                        traffic = rec.get("hbm_bytes_per_launch")
-                        traffic_src = rec.get("source")
-            except Exception:
-                traffic = None
+        traffic, traffic_src = traffic_point(a.sites, n_mine, a.dist, st["pruned"])
+        regime = extras.get("north_star_10k_guides") or {}
         out = {
             "metric": "guides/sec (whole node) + achieved HBM GB/s, 20bp/<=4mm ISSL scan",
             "value": value,
@@ -521,6 +529,14 @@ def main():
                 "algorithmic_over_hbm_peak": algo_bytes / t_scan / 1e9 / HBM_PEAK_GBS,
                 "hbm_physical_GBps": tile_bytes / t_scan / 1e9,
                 "hbm_physical_frac": tile_bytes / t_scan / 1e9 / HBM_PEAK_GBS,
+                # north_star's own point (10 000 guides per step, same index), where the scan is HBM-bound: flat copies of
+                # extras.north_star_10k_guides so that a reader of `roofline` alone has them
+                "hbm_regime_guides_per_step": regime.get("guides_per_step"),
+                "hbm_regime_scan_ms": regime.get("scan_ms"),
+                "hbm_regime_pmc_bytes_per_launch": regime.get("hbm_pmc_bytes_per_launch"),
+                "hbm_regime_frac": regime.get("hbm_pmc_frac"),
+                "hbm_regime_physical_frac": regime.get("hbm_physical_frac"),
+                "kernels_sha16": kernels_sha16(),
                 "hbm_regime": extras.get("north_star_10k_guides"),
                 "note": "avg_launch_ms is the launch's own span (first workgroup in to last workgroup out, stamped by the kernel "
                         "on the 100 MHz constant clock), avg_launch_ms_events the HIP event pair around the launch on its "

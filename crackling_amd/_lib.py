@@ -84,6 +84,7 @@ _protos = {
     "issl_index_bucket_sizes": (C.c_int, [_P, _P, C.c_size_t]),
     "issl_index_close": (C.c_int, [_P]),
     "issl_index_device_bytes": (C.c_int, [_P, C.POINTER(C.c_size_t)]),
+    "issl_device_memory": (C.c_int, [C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "issl_index_upload": (C.c_int, [_P, C.c_int]),
     "issl_index_upload_into": (C.c_int, [_P, C.c_int, _P, C.c_size_t]),
     "issl_index_attach_image": (C.c_int, [C.c_int, _P, C.c_size_t, C.POINTER(_P)]),

@@ -27,6 +27,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <string>
 #include <algorithm>
@@ -95,6 +96,9 @@ struct Resident {
     struct timespec mtime{};
     ino_t ino = 0;
     dev_t dev = 0;
+    // resident server: what the image takes of every device it sits on, and when it was last asked for
+    size_t image_bytes = 0;
+    unsigned long long last_used = 0;
 };
 
 void release(Resident &r)
@@ -111,7 +115,10 @@ constexpr long long kSortedLayoutPaysFromGuides = 750000;
 
 // Open + upload.  Several devices only when ISSL_DEVICES asks for them.  one_shot_guides: guides of the only page this
 // process will score, or -1 (resident server).
-bool make_resident(const char *issl_path, const DeviceChoice &dc, Resident &r, std::string &err, long long one_shot_guides = -1)
+// before_upload: called with the opened index (host side only) before any device memory is taken: the resident server
+// makes room there.
+bool make_resident(const char *issl_path, const DeviceChoice &dc, Resident &r, std::string &err, long long one_shot_guides = -1,
+                   const std::function<void(issl_index *)> &before_upload = nullptr)
 {
     const double t0 = now_ms();
     if (issl_index_open(issl_path, &r.idx)) { err = last_error("cannot open index"); return false; }
@@ -119,6 +126,7 @@ bool make_resident(const char *issl_path, const DeviceChoice &dc, Resident &r, s
         (void)issl_index_set_option(r.idx, "sorted_layout", "0");
     issl_index_header(r.idx, &r.hdr);
     r.load_ms = now_ms() - t0;
+    if (before_upload) before_upload(r.idx);
     const bool all = dc.all;
     const double t1 = now_ms();
     if (all || dc.list.size() > 1) {
@@ -142,6 +150,7 @@ bool make_resident(const char *issl_path, const DeviceChoice &dc, Resident &r, s
         }
         r.upload_ms = now_ms() - t1;
     }
+    (void)issl_index_device_bytes(r.idx, &r.image_bytes); // (of the layout the upload settled on)
     return true;
 }
 
@@ -321,7 +330,37 @@ int serve(const char *sock_path)
     const DeviceChoice dc = device_choice_from_env();
     long request_timeout_s = 10;
     if (const char *t = std::getenv("ISSL_SERVER_TIMEOUT_S")) request_timeout_s = std::max(1L, std::atol(t));
+    // Resident indexes, least recently used first out: before an index is uploaded, others are released until the image of
+    // its preferred (fastest) layout, the temporaries of its construction and a working reserve fit the free HBM -- an
+    // upload that found the HBM full of idle indexes would otherwise settle for a slower layout or fail.  The index a
+    // request is for is never evicted for itself; one request is served at a time, so none is in use meanwhile.
+    // ISSL_SERVER_HBM_BUDGET (bytes) caps what the server lets its indexes take together (tests, shared GPUs).
     std::map<std::string, Resident> cache;
+    unsigned long long tick = 0, evictions = 0;
+    size_t budget = 0;
+    if (const char *b = std::getenv("ISSL_SERVER_HBM_BUDGET")) budget = static_cast<size_t>(std::strtoull(b, nullptr, 10));
+    const int mem_device = dc.list.empty() ? dc.single : dc.list[0];
+    auto make_room = [&](issl_index *incoming) {
+        size_t want = 0;
+        issl_header h{};
+        if (issl_index_device_bytes(incoming, &want) || issl_index_header(incoming, &h)) return;
+        want += 24 * h.n_sites + (size_t(2) << 30); // temporaries of the sorted layout + scoring workspace
+        while (!cache.empty()) {
+            size_t free_b = 0, total_b = 0, held = 0;
+            if (issl_device_memory(mem_device, &free_b, &total_b)) return;
+            for (const auto &kv : cache) held += kv.second.image_bytes;
+            if (budget) free_b = std::min(free_b, budget > held ? budget - held : size_t(0));
+            if (free_b >= want) return;
+            auto lru = cache.begin();
+            for (auto it = cache.begin(); it != cache.end(); ++it)
+                if (it->second.last_used < lru->second.last_used) lru = it;
+            std::fprintf(stderr, "isslScoreOfftargets: releasing %s (%.1f GB, least recently used) to make room\n", lru->first.c_str(),
+                         lru->second.image_bytes / 1e9);
+            release(lru->second);
+            cache.erase(lru);
+            ++evictions;
+        }
+    };
     bool quit = false;
     while (!quit) {
         const int fd = ::accept(lfd, nullptr, nullptr);
@@ -339,6 +378,17 @@ int serve(const char *sock_path)
             if (line == "QUIT") {
                 write_all(fd, "OK 0 {}\n", 8);
                 quit = true;
+            } else if (line == "STATUS") { // what is resident, in order of last use
+                std::vector<const std::pair<const std::string, Resident> *> order;
+                for (const auto &kv : cache) order.push_back(&kv);
+                std::sort(order.begin(), order.end(), [](auto a, auto b) { return a->second.last_used < b->second.last_used; });
+                std::string body = "{\"evictions\": " + std::to_string(evictions) + ", \"resident\": [";
+                for (size_t i = 0; i < order.size(); ++i)
+                    body += std::string(i ? ", " : "") + "{\"issl\": \"" + order[i]->first + "\", \"image_bytes\": " +
+                            std::to_string(order[i]->second.image_bytes) + "}";
+                body += "]}\n";
+                const std::string head = "OK " + std::to_string(body.size()) + " {}\n";
+                write_all(fd, head.data(), head.size()) && write_all(fd, body.data(), body.size());
             } else {
                 std::vector<std::string> f;
                 size_t a = 0;
@@ -366,7 +416,7 @@ int serve(const char *sock_path)
                         if (it != cache.end() && !hit) { release(it->second); cache.erase(it); it = cache.end(); }
                         if (it == cache.end()) {
                             Resident r;
-                            if (make_resident(q.issl.c_str(), dc, r, err)) {
+                            if (make_resident(q.issl.c_str(), dc, r, err, -1, make_room)) {
                                 r.size = st.st_size;
                                 r.mtime = st.st_mtim;
                                 r.ino = st.st_ino;
@@ -374,7 +424,10 @@ int serve(const char *sock_path)
                                 it = cache.emplace(q.issl, r).first;
                             }
                         }
-                        if (it != cache.end()) ok = score_request(it->second, q, out, err, tj, hit);
+                        if (it != cache.end()) {
+                            it->second.last_used = ++tick;
+                            ok = score_request(it->second, q, out, err, tj, hit);
+                        }
                     }
                 } else {
                     err = "malformed request";
@@ -464,6 +517,25 @@ int main(int argc, char **argv)
         if (fd < 0 || ::connect(fd, reinterpret_cast<sockaddr *>(&addr), sizeof addr) != 0) return 1;
         std::string line;
         const bool ok = write_all(fd, "QUIT\n", 5) && read_line(fd, line);
+        ::close(fd);
+        return ok ? 0 : 1;
+    }
+    if (argc == 3 && !std::strcmp(argv[1], "--status")) { // what the resident server holds (JSON on stdout)
+        sockaddr_un addr;
+        const int fd = unix_socket(argv[2], addr);
+        if (fd < 0 || ::connect(fd, reinterpret_cast<sockaddr *>(&addr), sizeof addr) != 0) return 1;
+        std::string line;
+        bool ok = write_all(fd, "STATUS\n", 7) && read_line(fd, line) && line.rfind("OK ", 0) == 0;
+        if (ok) {
+            std::string body(static_cast<size_t>(std::atol(line.c_str() + 3)), '\0');
+            size_t got = 0;
+            while (got < body.size()) {
+                const ssize_t k = ::read(fd, &body[got], body.size() - got);
+                if (k <= 0) { ok = false; break; }
+                got += static_cast<size_t>(k);
+            }
+            if (ok) std::fwrite(body.data(), 1, body.size(), stdout);
+        }
         ::close(fd);
         return ok ? 0 : 1;
     }

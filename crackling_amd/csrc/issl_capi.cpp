@@ -1212,6 +1212,15 @@ int issl_index_build_on_device(const uint64_t *sigs, const uint32_t *occ, size_t
     return issl_index_build_on_device_opt(sigs, occ, n_sites, n_lines, seq_len, slice_width, device, nullptr, out);
 }
 
+int issl_device_memory(int device, size_t *free_bytes, size_t *total_bytes)
+{
+    if (!free_bytes || !total_bytes) { set_error("null argument"); return ISSL_E_ARG; }
+    int rc = select_device(device);
+    if (rc) return rc;
+    HIP_TRY(hipMemGetInfo(free_bytes, total_bytes));
+    return ISSL_OK;
+}
+
 int issl_index_upload(issl_index *idx, int device) { return upload_common(idx, device, nullptr, 0); }
 
 int issl_index_upload_into(issl_index *idx, int device, void *dev_buf, size_t bytes)

@@ -158,6 +158,9 @@ int issl_index_close(issl_index *idx);
 /* Bytes of the device image (sites + bucket entries + packed scan stream + tables). */
 int issl_index_device_bytes(const issl_index *idx, size_t *out);
 
+/* Free and total memory of `device` in bytes (hipMemGetInfo): what a resident server weighs an upload against.  (ABI 4) */
+int issl_device_memory(int device, size_t *free_bytes, size_t *total_bytes);
+
 /* Allocate the image on `device` (hipMalloc), copy and transform.  Owned by the index. */
 int issl_index_upload(issl_index *idx, int device);
 

@@ -137,6 +137,55 @@ def markov_sites(n_lines, seed, seq_len=20, at_bias=0.62, order=3):
     return sig[idx], occ
 
 
+def markov_sites_fast(n_lines, seed, threads=16, seq_len=20, at_bias=0.62, order=3):
+    """markov_sites() for hundreds of millions of lines: the same chain (same transition rows for the same seed), drawn
+    in chunks on a thread pool with a 256-step inverse-CDF table per context (probabilities rounded to 1/256: synthetic
+    data), sorted per leading four bases.  Not the same random stream as markov_sites()."""
+    from concurrent.futures import ThreadPoolExecutor
+    rng = np.random.default_rng(seed)
+    base_p = np.array([at_bias / 2, (1 - at_bias) / 2, (1 - at_bias) / 2, at_bias / 2])  # A C G T
+    n_ctx = 4 ** order
+    rows = rng.dirichlet(base_p * 6.0, size=n_ctx)
+
+    def table(p):  # 256 equally likely bytes -> base, by the cumulative probabilities
+        edges = np.round(np.cumsum(p) * 256).astype(np.int64)
+        edges[-1] = 256
+        return np.repeat(np.arange(4, dtype=np.uint8), np.diff(np.concatenate([[0], edges])))
+    first_tab = table(base_p)
+    ctx_tab = np.concatenate([table(r) for r in rows])          # [ctx * 256 + byte]
+    n_chunks = max(threads * 4, 1)
+    per = (n_lines + n_chunks - 1) // n_chunks
+
+    def chunk(c):
+        m = min(per, n_lines - c * per)
+        if m <= 0:
+            return np.empty(0, dtype=np.uint64)
+        r = np.random.default_rng([seed, 7, c])
+        key = np.zeros(m, dtype=np.uint64)                      # text-order key: position 0 in the top bits
+        ctx = np.zeros(m, dtype=np.int64)
+        for pos in range(seq_len):
+            u = r.integers(0, 256, size=m, dtype=np.uint8)
+            b = first_tab[u] if pos < order else ctx_tab[ctx * 256 + u]
+            key |= b.astype(np.uint64) << np.uint64(2 * (seq_len - 1 - pos))
+            ctx = ((ctx * 4) + b) % n_ctx
+        key.sort()
+        return key
+
+    with ThreadPoolExecutor(max_workers=threads) as pool:
+        parts = list(pool.map(chunk, range(n_chunks)))
+
+        def lead(c):  # all keys whose leading four bases are c, sorted, distinct, with their multiplicities
+            lo, hi = np.uint64(c) << np.uint64(32), np.uint64(c + 1) << np.uint64(32)
+            k = np.concatenate([p[np.searchsorted(p, lo):np.searchsorted(p, hi)] for p in parts])
+            k.sort()
+            first = np.ones(len(k), dtype=bool)
+            first[1:] = k[1:] != k[:-1]
+            idx = np.flatnonzero(first)
+            return text_order_key(k[idx], seq_len), np.diff(np.append(idx, len(k))).astype(np.uint32)  # the key map is its own inverse
+        out = list(pool.map(lead, range(256)))
+    return np.concatenate([o[0] for o in out]), np.concatenate([o[1] for o in out])
+
+
 def check_comparisons(ix, guides, prune=None):
     """Counters of the last call: what the reference would compare, what was planned, what the scan kernel counted."""
     st = ix.stats()

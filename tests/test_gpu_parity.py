@@ -950,3 +950,57 @@ def test_pruned_scan_on_groups_of_many_windows(tmp_path):
     finally:
         oracle.close()
         ix.close()
+
+
+def test_resident_server_releases_the_least_recently_used_index(tmp_path):
+    """Three indexes, room for two (ISSL_SERVER_HBM_BUDGET): asking for the third releases the one that was used longest
+    ago, the others stay resident hits; every answer equals the reference's stdout (Crackling's per-page reload of
+    config.ini:106-112 against a server that holds several genomes)."""
+    import json
+    import time
+    from conftest import Golden
+    sets = [Golden("uniform"), Golden("clustered"), Golden("bigocc")]
+    sizes = []
+    for g in sets:
+        ix = ca.IsslIndex.open(g.issl)
+        sizes.append(ix.device_bytes())
+        ix.close()
+    assert max(sizes) < 1.15 * min(sizes)
+    # the server wants image + 24 B/site of temporaries + 2 GiB of workspace free before an upload: room for two images
+    # and that reserve, not for three
+    budget = int(2.5 * max(sizes)) + 24 * 8200 + (2 << 30)
+    exe = str(ROOT / "bin" / "isslScoreOfftargets")
+    sock = str(tmp_path / "issl.sock")
+    server = subprocess.Popen([exe, "--serve", sock], stderr=subprocess.PIPE, env=dict(os.environ, ISSL_SERVER_HBM_BUDGET=str(budget)))
+    try:
+        for _ in range(100):
+            if os.path.exists(sock):
+                break
+            time.sleep(0.05)
+        env = dict(os.environ, ISSL_SERVER=sock, ISSL_TIMING="1")
+
+        def ask(g, key="and|75|4"):
+            method, thr, dist = key.split("|")
+            r = subprocess.run([exe, str(g.issl), str(g.guides_txt), dist, thr, method], capture_output=True, env=env)
+            assert r.returncode == 0 and r.stdout.decode() == g.expected[key], r.stderr.decode()
+            return b'"resident": true' in r.stderr
+
+        def status():
+            r = subprocess.run([exe, "--status", sock], capture_output=True)
+            assert r.returncode == 0, r.stderr
+            return json.loads(r.stdout)
+        a, b, c = sets
+        assert not ask(a) and not ask(b) and ask(a)            # a, b resident; a used last
+        assert status()["evictions"] == 0 and len(status()["resident"]) == 2
+        assert not ask(c)                                       # no room for three: b (least recently used) goes
+        st = status()
+        assert st["evictions"] == 1 and [os.path.basename(os.path.dirname(x["issl"])) for x in st["resident"]] == ["uniform", "bigocc"]
+        assert ask(a) and ask(c) and not ask(b)                 # b comes back, a (used before c) goes
+        assert [os.path.basename(os.path.dirname(x["issl"])) for x in status()["resident"]] == ["bigocc", "clustered"]
+    finally:
+        subprocess.run([exe, "--stop", sock], capture_output=True)
+        try:
+            server.wait(timeout=20)
+        except subprocess.TimeoutExpired:
+            server.kill()
+    assert server.returncode == 0

@@ -11,7 +11,7 @@ ROOT = pathlib.Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
 import torch
 import crackling_amd as ca
-from synth import random_sites_fast, markov_sites, random_guides_fast
+from synth import random_sites_fast, markov_sites_fast, random_guides_fast
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--sites", type=int, default=300_000_000)
@@ -24,7 +24,7 @@ ap.add_argument("--variants", default="lanes=1/lanes=2")
 a = ap.parse_args()
 
 torch.zeros(1, device="cuda:0"); torch.cuda.synchronize()
-sigs, occ = (markov_sites if a.dist == "markov" else random_sites_fast)(a.sites, seed=20261003)
+sigs, occ = (markov_sites_fast if a.dist == "markov" else random_sites_fast)(a.sites, seed=20261003)
 ix = ca.IsslIndex.build_on_device(sigs, occ, device=0)
 guides = random_guides_fast(sigs, a.guides, seed=777)
 d_g = torch.from_numpy(guides.view(np.int64)).cuda()

@@ -5,7 +5,7 @@ import numpy as np
 ROOT = pathlib.Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
 import crackling_amd as ca
-from synth import random_sites, random_sites_fast, markov_sites, random_guides
+from synth import random_sites, random_sites_fast, markov_sites, markov_sites_fast, random_guides
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--sites", type=int, default=5_000_000)
@@ -22,18 +22,18 @@ ap.add_argument("--json", default=None, help="write the best repetition (by scan
 ap.add_argument("--write-issl", default=None)
 ap.add_argument("--write-guides", default=None)
 a = ap.parse_args()
-gen = markov_sites if a.dist == "markov" else (random_sites_fast if a.fast_synth else random_sites)
+gen = (markov_sites_fast if a.fast_synth else markov_sites) if a.dist == "markov" else (random_sites_fast if a.fast_synth else random_sites)
 t = time.time(); sigs, occ = gen(a.sites, seed=1); guides = random_guides(sigs, a.guides, seed=2)
 print(f"synth {time.time()-t:.1f}s  distinct={len(sigs)}", flush=True)
 t = time.time()
-ix = ca.IsslIndex.build_on_device(sigs, occ, device=0) if a.fast_synth else ca.IsslIndex.build_from_sites(sigs, occ)
+ix = ca.IsslIndex.build_on_device(sigs, occ, device=0) if (a.fast_synth or a.dist == "markov") else ca.IsslIndex.build_from_sites(sigs, occ)
 t_build = time.time() - t; print(f"build {t_build:.1f}s", flush=True)
 if a.write_issl:
     t = time.time(); ix.write(a.write_issl); print(f"write issl {time.time()-t:.1f}s", flush=True)
 if a.write_guides:
     open(a.write_guides, "w").write("".join(s + "\n" for s in ca.decode_guides(guides)))
 t = time.time()
-if not a.fast_synth:
+if not (a.fast_synth or a.dist == "markov"):
     ix.upload(0)
 t_upload = time.time() - t
 print(f"upload {t_upload:.1f}s  image={ix.device_bytes()/1e9:.2f} GB", flush=True)

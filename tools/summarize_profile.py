@@ -56,7 +56,9 @@ if len(sys.argv) >= 6 and "scan_hbm_bytes_per_launch" in summary:
     rec = json.loads(path.read_text()) if path.exists() else {}
     points = [p for p in rec.get("points", [])
               if (p.get("sites"), p.get("guides"), p.get("distribution"), p.get("pruned")) != (sites, guides, dist, pruned)]
-    points.append({"sites": sites, "guides": guides, "distribution": dist, "pruned": pruned,
+    import hashlib
+    sha = hashlib.sha256((pathlib.Path(__file__).resolve().parent.parent / "crackling_amd" / "csrc" / "issl_kernels.hip").read_bytes()).hexdigest()[:16]
+    points.append({"sites": sites, "guides": guides, "distribution": dist, "pruned": pruned, "kernels_sha16": sha,
                    "hbm_bytes_per_launch": summary["scan_hbm_bytes_per_launch"]["total_bytes"],
                    "fetch_corrected_bytes": summary["scan_hbm_bytes_per_launch"]["fetch_corrected_bytes"],
                    "write_bytes": summary["scan_hbm_bytes_per_launch"]["write_bytes"],
