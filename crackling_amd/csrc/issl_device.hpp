@@ -269,6 +269,13 @@ constexpr uint32_t kFetchPairs = 8;     // time of fetching one 8 KiB tile, in (
                                         // (50 M sites, neighbouring groups share tiles in L2) to 12 (300 M sites)
 constexpr uint32_t kPruneMaxGuides = 1u << 20; // guides per pruned launch: 65 slots per guide + padding must fit the 27-bit slot field
 
+// What k_verify needs to know about a guide slot of the pruned plan, in one 16-byte load.
+struct alignas(16) FineMeta {
+    uint32_t guide;  // index into the batch, kNoGuide in padding slots
+    uint32_t where;  // bucket << 8 | successor byte of the group the slot belongs to
+    uint64_t gsig;   // the guide's packed signature
+};
+
 struct Workspace {
     uint32_t *ng = nullptr;      // [nb]   guides per bucket
     uint32_t *gfill = nullptr;   // [nb]
@@ -279,7 +286,7 @@ struct Workspace {
     ScanItem *items = nullptr;   // [max_items+1]
     // pruned scan: the guide arrays and the item list once more, grouped by (bucket, successor byte)
     uint32_t *fword = nullptr;   // scan words of the guides, grouped
-    uint2 *fmeta = nullptr;      // per slot {guide index (kNoGuide in padding), bucket << 8 | successor byte}
+    FineMeta *fmeta = nullptr;   // per slot: its guide (kNoGuide in padding), its group, the guide's signature
     ScanItem *fitems = nullptr;
     uint32_t *fcount = nullptr;  // [nb * 256] guides per (bucket, successor byte)
     FineSum *fsum = nullptr;     // [nb] per-bucket totals, then their exclusive prefix

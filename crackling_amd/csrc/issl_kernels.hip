@@ -606,7 +606,7 @@ __global__ __launch_bounds__(256) void k_fine_scatter(ImageView v, const uint64_
                                                       const uint32_t *__restrict__ gword, const uint32_t *__restrict__ gidx,
                                                       const uint32_t *__restrict__ fcount, const FineSum *__restrict__ fbase,
                                                       const PlanInfo *__restrict__ plan, uint32_t *__restrict__ fword,
-                                                      uint2 *__restrict__ fmeta,
+                                                      FineMeta *__restrict__ fmeta,
                                                       ScanItem *__restrict__ fitems, uint32_t item_guides, uint32_t ways,
                                                       uint32_t tail_shapes)
 {
@@ -661,19 +661,20 @@ __global__ __launch_bounds__(256) void k_fine_scatter(ImageView v, const uint64_
             }
         }
         // padding slots behind the group's guides
-        for (uint32_t k2 = c; k2 < static_cast<uint32_t>(slots); ++k2) { fmeta[slot_at + k2] = make_uint2(kNoGuide, 0u); fword[slot_at + k2] = kPadGuideWord; }
+        for (uint32_t k2 = c; k2 < static_cast<uint32_t>(slots); ++k2) { fmeta[slot_at + k2] = FineMeta{kNoGuide, 0u, 0ull}; fword[slot_at + k2] = kPadGuideWord; }
     }
     __syncthreads();
     const uint32_t g0 = gstart[b], n = gfill[b];
     for (uint32_t at = threadIdx.x; at < n * ways; at += 256) { // one (guide, way) pair per thread and step
         const uint32_t i = at / ways, way = at - i * ways;
         const uint32_t guide = gidx[g0 + i], word = gword[g0 + i];
-        const uint32_t gj = static_cast<uint32_t>(guides[guide] >> succ_shift) & 0xFFu;
+        const uint64_t gsig = guides[guide];
+        const uint32_t gj = static_cast<uint32_t>(gsig >> succ_shift) & 0xFFu;
         const uint32_t ww = fine_way(gj, way);
         if (ss[ww + 1] == ss[ww]) continue; // no candidates there: the group has no slots
         const uint32_t slot = slot_of[ww] + atomicAdd(&cursor[ww], 1u);
         fword[slot] = word;
-        fmeta[slot] = make_uint2(guide, (b << 8) | ww);
+        fmeta[slot] = FineMeta{guide, (b << 8) | ww, gsig};
     }
 }
 
@@ -1222,6 +1223,8 @@ __device__ inline void score_terms(const ImageView &v, uint64_t gsig, uint64_t o
 // Workgroups of the two passes over the raw chunks (one chunk per workgroup and step): enough of them that the
 // ~16 k first chunks of the scan waves are all in flight at once -- the passes are chains of dependent loads.
 constexpr uint32_t kTailGrid = 16384;
+constexpr uint32_t kReplayLds = 512;  // guides with more hits than this go to k_replay_big (a whole workgroup each)
+static_assert(kReplayLds <= 512, "k_replay sorts (key, 9-bit index) pairs");
 
 // Exact check of the raw records, IN PLACE: one thread per record, one chunk per 128-thread workgroup.
 // A record that survives is overwritten by its final key guide<<35 | slice<<32 | position-in-bucket,
@@ -1245,44 +1248,55 @@ __global__ __launch_bounds__(kChunkRecs, 8) void k_verify(ImageView v, Workspace
     if (n_chunks > ws.cap_chunks) n_chunks = static_cast<uint32_t>(ws.cap_chunks);
     const uint64_t low = (1ull << v.slice_width) - 1ull;
     for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+        // The passes behind the scan are chains of dependent loads at full occupancy: what they cost is the number of
+        // links.  Header and record of the chunk are asked for together (a chunk always has its 128 slots), then the
+        // stream record and the guide slot's 16 bytes together, then -- nothing more before the exact test.
         uint64_t *recs = ws.raw + static_cast<uint64_t>(chunk) * kChunkRecs;
-        const uint32_t used = static_cast<uint32_t>(recs[0]);
         const uint32_t t = threadIdx.x + 1u;
+        const uint64_t rec_any = recs[t < kChunkRecs ? t : 0u];
+        const uint32_t used = static_cast<uint32_t>(recs[0]);
         const bool in_use = t < used && t < kChunkRecs; // every lane stays: the counting below is done by the wave
-        const uint64_t rec = in_use ? recs[t] : 0ull;
+        const uint64_t rec = in_use ? rec_any : 0ull;
         uint64_t key = kDeadKey;
         double mit_term = 0.0, cfd_term = 0.0; // of a record that survives: computed here, one thread per hit, so that the
                                                // replay (one wave per guide, a chain of dependent steps) only adds them up
+        uint64_t hit_gsig = 0, hit_ot = 0;     // ... from these
+        uint32_t hit_occ = 0;
         const uint32_t offset = static_cast<uint32_t>(rec) & (kTileCands - 1u);
         const uint32_t tile = static_cast<uint32_t>(rec >> 11) & 0x3FFFFFFu;
         const uint32_t gslot = static_cast<uint32_t>(rec >> 37);
         // sorted layouts: what the stream holds at the record's place, asked for before anything else is known about it
+        const bool by_id = v.srec || v.sid; // the scoring order is (slice, site id): ImageHeader
         StreamRec sr_early{};
         if (in_use && v.srec) sr_early = v.srec[static_cast<uint64_t>(tile) * kTileCands + offset];
         else if (in_use && v.sid) sr_early.id = v.sid[static_cast<uint64_t>(tile) * kTileCands + offset];
-        // the guide slot knows its guide and its bucket (pruned scan: and its successor-byte group): no search for the tile's
+        // the guide slot knows its guide and its bucket (pruned scan: and its successor-byte group, and the guide's
+        // signature): no search for the tile's
         uint32_t guide = kNoGuide, where = 0;
+        uint64_t gsig = 0;
         if (in_use) {
-            if (prune_mode) { const uint2 m = ws.fmeta[gslot]; guide = m.x; where = m.y; }
+            if (prune_mode) { const FineMeta m = ws.fmeta[gslot]; guide = m.guide; where = m.where; gsig = m.gsig; }
             else { guide = ws.gidx[gslot]; where = ws.gbucket[gslot]; }
         }
         if (guide != kNoGuide) {
             const uint32_t bucket = prune_mode ? where >> 8 : where;
             const uint32_t slice = bucket >> v.slice_width;
-            const uint64_t start = v.bucket_start[bucket];
-            uint64_t lo_pos = 0, hi_pos = v.bucket_start[bucket + 1] - start; // beyond: zero padding of the bucket's last tile
-            if (prune_mode) { // a group's first and last tile also hold candidates of its neighbours: theirs to report
-                const uint32_t *ss = v.sub_start + static_cast<uint64_t>(bucket) * 257u + (where & 0xFFu);
-                lo_pos = ss[0];
-                hi_pos = ss[1];
+            // Is the candidate the item's?  The scan notes only candidates of the item's own window (`keep`: not the zero
+            // padding behind a bucket, not the neighbouring group that shares the tile), so on the sorted layouts, which need
+            // nothing else from the bucket tables, the question is not asked again.  The list-order layouts find their list
+            // entry through the bucket's start and check on the way.
+            uint64_t start = 0, pos = 0;
+            bool mine = true;
+            if (!by_id) {
+                start = v.bucket_start[bucket];
+                pos = static_cast<uint64_t>(tile - v.tile_first[bucket]) * kTileCands + offset; // in the stream
+                mine = pos < v.bucket_start[bucket + 1] - start;
             }
-            const uint64_t pos = static_cast<uint64_t>(tile - v.tile_first[bucket]) * kTileCands + offset; // in the stream
-            if (pos >= lo_pos && pos < hi_pos) {
-                const uint64_t gsig = guides[guide];
+            if (mine) {
+                if (!prune_mode) gsig = guides[guide];
                 // sorted layouts: signature, site id (and a 24-bit copy of the count) come in one stream-order record, or --
                 // compact -- the id alone, with the signature behind it in the site table
                 StreamRec sr = sr_early;
-                const bool by_id = v.srec || v.sid; // the scoring order is (slice, site id): ImageHeader
                 const uint64_t ot = v.srec   ? sr.sig & ((1ull << 40) - 1ull)
                                     : v.sid  ? v.sites[sr.id]
                                     : v.esig ? v.esig[start + pos]
@@ -1318,7 +1332,7 @@ __global__ __launch_bounds__(kChunkRecs, 8) void k_verify(ImageView v, Workspace
                         if (reporter == slice)
                             key = (static_cast<uint64_t>(guide) << 35) | (static_cast<uint64_t>(first) << 32) | sr.id;
                     }
-                    if (key != kDeadKey) { // the hit will be scored: its terms (:392-460)
+                    if (key != kDeadKey) { // the hit will be scored: what its terms are made of (:348)
                         uint32_t occ;
                         if (v.srec) {
                             occ = static_cast<uint32_t>(sr.sig >> 40);
@@ -1331,8 +1345,7 @@ __global__ __launch_bounds__(kChunkRecs, 8) void k_verify(ImageView v, Workspace
                         } else {
                             occ = static_cast<uint32_t>(v.entries[start + pos] >> 32);
                         }
-                        int dist;
-                        score_terms(v, gsig, ot, occ, calc_mit, calc_cfd, mit_term, cfd_term, dist);
+                        hit_gsig = gsig; hit_ot = ot; hit_occ = occ;
                     }
                 }
             }
@@ -1363,7 +1376,14 @@ __global__ __launch_bounds__(kChunkRecs, 8) void k_verify(ImageView v, Workspace
         if (live) {
             const uint64_t slot = static_cast<uint64_t>(chunk) * (kChunkRecs - 1u) + (t - 1u); // < cap_chunks * 127 <= cap_hits
             ws.rank[slot] = rank;
-            reinterpret_cast<double2 *>(ws.pay)[slot] = make_double2(mit_term, cfd_term);
+            // The terms (:392-460) -- unless the guide already has more hits than the one-wave replay takes: the many-hit
+            // replay works out the terms of the hits it walks by itself, and on skewed data most hits belong to such
+            // guides and lie behind their early exit.
+            if (rank < kReplayLds) {
+                int dist;
+                score_terms(v, hit_gsig, hit_ot, hit_occ, calc_mit, calc_cfd, mit_term, cfd_term, dist);
+                reinterpret_cast<double2 *>(ws.pay)[slot] = make_double2(mit_term, cfd_term);
+            }
         }
         if (!in_use) continue;
         recs[t] = key;
@@ -1412,8 +1432,6 @@ void launch_verify(const ImageView &v, const Workspace &ws, const uint64_t *d_gu
 // ------------------------------------------------------------------------------------------------
 
 constexpr uint32_t kScanChunk = 2048; // elements per block in the device-wide prefix sum
-constexpr uint32_t kReplayLds = 512;  // guides with more hits than this go to k_replay_big (a whole workgroup each)
-static_assert(kReplayLds <= 512, "k_replay sorts (key, 9-bit index) pairs");
 constexpr uint32_t kBigLds = 7680;    // hits per slice k_replay_big sorts in LDS (2 x 30 KiB); longer slices are sorted in HBM
 
 __global__ __launch_bounds__(256) void k_prefix_block_sums(const uint32_t *__restrict__ in, uint32_t n,
@@ -1525,17 +1543,20 @@ __global__ __launch_bounds__(kChunkRecs) void k_group_scatter(const uint64_t *__
     uint32_t n_chunks = counters->raw_chunks;
     if (n_chunks > cap_chunks) n_chunks = cap_chunks;
     for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+        // (everything that does not depend on the key is asked for at once: the pass is a chain of dependent loads)
         const uint64_t *recs = raw + static_cast<uint64_t>(chunk) * kChunkRecs;
-        const uint32_t used = static_cast<uint32_t>(recs[0]);
         const uint32_t t = threadIdx.x + 1u;
-        if (t >= used || t >= kChunkRecs) continue;
-        const uint64_t key = recs[t];
-        if (key == kDeadKey) continue;
+        const uint64_t slot = static_cast<uint64_t>(chunk) * (kChunkRecs - 1u) + (threadIdx.x < kChunkRecs - 1u ? threadIdx.x : kChunkRecs - 2u);
+        const uint64_t key = recs[t < kChunkRecs ? t : 0u];
+        const uint32_t my_rank = rank[slot];
+        const double2 my_pay = pay[slot];
+        const uint32_t used = static_cast<uint32_t>(recs[0]);
+        if (t >= used || t >= kChunkRecs || key == kDeadKey) continue;
         const uint32_t guide = static_cast<uint32_t>(key >> 35);
-        const uint64_t slot = static_cast<uint64_t>(chunk) * (kChunkRecs - 1u) + (t - 1u);
-        const uint32_t to = goff[guide] + rank[slot]; // rank: k_verify's
+        const uint32_t g0 = goff[guide];
+        const uint32_t to = g0 + my_rank; // rank: k_verify's
         sorted[to] = key;
-        terms[to] = pay[slot];
+        if (goff[guide + 1] - g0 <= kReplayLds) terms[to] = my_pay; // (the many-hit replay makes its own)
     }
 }
 
@@ -1804,14 +1825,14 @@ __global__ __launch_bounds__(64) void k_replay(ImageView v, Workspace ws, const 
 // slice) sit in LDS, every thread finds the rank of its K positions by comparing them with all `len` of them
 // (broadcast reads, no barrier inside) and writes the full keys to their final places.  A bitonic network over the same
 // keys costs ~80-90 workgroup barriers; positions are distinct, so the ranks are a permutation.
-template <uint32_t K>
+template <uint32_t K, uint32_t THREADS>
 __device__ __forceinline__ void rank_sort_slice(const uint32_t *pos_lds, uint32_t len, uint64_t high_bits,
                                                 uint64_t *__restrict__ dst)
 {
     uint32_t mine[K], rk[K];
 #pragma unroll
     for (uint32_t k = 0; k < K; ++k) {
-        const uint32_t idx = threadIdx.x + k * 1024u;
+        const uint32_t idx = threadIdx.x + k * THREADS;
         mine[k] = idx < len ? pos_lds[idx] : 0xFFFFFFFFu;
         rk[k] = 0;
     }
@@ -1829,7 +1850,7 @@ __device__ __forceinline__ void rank_sort_slice(const uint32_t *pos_lds, uint32_
     }
 #pragma unroll
     for (uint32_t k = 0; k < K; ++k)
-        if (threadIdx.x + k * 1024u < len) dst[rk[k]] = high_bits | mine[k];
+        if (threadIdx.x + k * THREADS < len) dst[rk[k]] = high_bits | mine[k];
 }
 
 // Longer slices: the same ranking, but only against the positions that share the top 8 bits (of the slice's largest
@@ -1882,14 +1903,20 @@ __device__ __forceinline__ void rank_sort_slice_grouped(const uint32_t *pos_lds,
 // Guides with many hits (dense neighbourhoods, repeats): one 1024-thread workgroup each, one slice at a time: sort
 // the slice's keys (by counting in LDS up to 8192 per slice, else a bitonic network in HBM), compute the terms of its
 // hits in parallel, let wave 0 add them up in key order with the reference's running totals and early exit.
-__global__ __launch_bounds__(1024, 8) void k_replay_big(ImageView v, Workspace ws, const uint64_t *__restrict__ guides,
+// Two builds share the list of such guides: up to kMidHits hits a 256-thread workgroup with room for 2048 hits per slice
+// in LDS (eight of them fit a CU, and a guide's phases are a chain of barriers and memory round trips: on skewed data
+// four guides in ten are of this kind, and what counts is how many are in flight), beyond that a 1024-thread workgroup
+// with 7680 (two per CU).
+constexpr uint32_t kMidHits = 2048;
+template <uint32_t THREADS, uint32_t LDS_HITS>
+__global__ __launch_bounds__(THREADS) void k_replay_big(ImageView v, Workspace ws, const uint64_t *__restrict__ guides,
                                                      ScoreParams p, double *__restrict__ out_mit,
                                                      double *__restrict__ out_cfd, uint32_t *__restrict__ out_kept,
                                                      issl_hit *__restrict__ out_hits)
 {
     short_kernel_priority();
-    __shared__ __attribute__((aligned(16))) uint32_t pos_lds[kBigLds];
-    __shared__ uint32_t grouped[kBigLds];
+    __shared__ __attribute__((aligned(16))) uint32_t pos_lds[LDS_HITS];
+    __shared__ uint32_t grouped[LDS_HITS];
     __shared__ uint32_t group_at[257], group_cur[256], max_pos;
     __shared__ uint32_t slice_cnt[8], slice_off[9], slice_cur[8];
     __shared__ uint32_t walk_stopped;
@@ -1903,6 +1930,7 @@ __global__ __launch_bounds__(1024, 8) void k_replay_big(ImageView v, Workspace w
         const uint32_t g = ws.gcur_big[b];
         const uint32_t h0 = ws.goff[g];
         const uint32_t h = ws.goff[g + 1] - h0;
+        if ((h <= kMidHits) != (THREADS < 1024u)) continue; // the other build's (uniform over the workgroup)
         const uint64_t gsig = guides[g];
         uint64_t *seg = ws.sorted + h0;
         uint64_t *tmp = ws.raw + h0; // the raw records are dead once they are grouped; the buffer holds >= all hits
@@ -1960,12 +1988,12 @@ __global__ __launch_bounds__(1024, 8) void k_replay_big(ImageView v, Workspace w
             if (len == 0) continue; // uniform over the workgroup
             if (st && threadIdx.x == 0 && s2 == 0) { st[3] = __builtin_amdgcn_s_memrealtime(); st[4] = len; }
             uint64_t *dst = seg + off;
-            if (len <= kBigLds) {
+            if (len <= LDS_HITS) {
                 for (uint32_t i = threadIdx.x; i < ((len + 3u) & ~3u); i += blockDim.x)
                     pos_lds[i] = i < len ? static_cast<uint32_t>(tmp[off + i]) : 0xFFFFFFFFu;
                 __syncthreads();
                 const uint64_t high_bits = (static_cast<uint64_t>(g) << 35) | (static_cast<uint64_t>(s2) << 32);
-                if (len <= 1024u) rank_sort_slice<1>(pos_lds, len, high_bits, dst);
+                if (len <= THREADS) rank_sort_slice<1, THREADS>(pos_lds, len, high_bits, dst);
                 else rank_sort_slice_grouped(pos_lds, grouped, group_at, group_cur, &max_pos, len, high_bits, dst);
             } else {
                 for (uint32_t i = threadIdx.x; i < len; i += blockDim.x) dst[i] = tmp[off + i];
@@ -1974,25 +2002,32 @@ __global__ __launch_bounds__(1024, 8) void k_replay_big(ImageView v, Workspace w
             }
             __syncthreads();
             if (st && threadIdx.x == 0 && s2 == 0) st[5] = __builtin_amdgcn_s_memrealtime();
-            // terms of the slice's hits by the whole workgroup, then wave 0 adds them up in key order
-            for (uint32_t i = threadIdx.x; i < len; i += blockDim.x) {
-                const HitTerms t = hit_terms(v, gsig, g, dst[i], calc_mit, calc_cfd, out_hits != nullptr);
-                ws.terms[2ull * (h0 + off + i)] = t.mit;
-                ws.terms[2ull * (h0 + off + i) + 1] = t.cfd;
-                if (out_hits) out_hits[h0 + off + i] = t.rec;
-            }
-            __syncthreads();
-            if (st && threadIdx.x == 0 && s2 == 0) st[6] = __builtin_amdgcn_s_memrealtime();
-            if (threadIdx.x < 64) {
-                for (uint32_t base = 0; base < len && !stop; base += 64) {
-                    const uint32_t idx = base + lane;
-                    const double mit_term = idx < len ? ws.terms[2ull * (h0 + off + idx)] : 0.0;
-                    const double cfd_term = idx < len ? ws.terms[2ull * (h0 + off + idx) + 1] : 0.0;
-                    accumulate(mit_term, cfd_term, (len - base < 64u) ? len - base : 64u);
+            // Terms of the slice's hits by the whole workgroup, 1024 at a time, each block added up in key order by wave 0
+            // before the next one is worked out: a guide like this usually leaves through the early exit within its first
+            // hits (:467-496), and the terms cost two or three random reads each.
+            for (uint32_t blk = 0; blk < len; blk += blockDim.x) {
+                const uint32_t i = blk + threadIdx.x;
+                if (i < len) {
+                    const HitTerms t = hit_terms(v, gsig, g, dst[i], calc_mit, calc_cfd, out_hits != nullptr);
+                    ws.terms[2ull * (h0 + off + i)] = t.mit;
+                    ws.terms[2ull * (h0 + off + i) + 1] = t.cfd;
+                    if (out_hits) out_hits[h0 + off + i] = t.rec;
                 }
-                if (lane == 0) walk_stopped = stop ? 1u : 0u;
+                __syncthreads();
+                if (st && threadIdx.x == 0 && s2 == 0 && blk == 0) st[6] = __builtin_amdgcn_s_memrealtime();
+                if (threadIdx.x < 64) {
+                    const uint32_t end = (len - blk < blockDim.x) ? len : blk + blockDim.x;
+                    for (uint32_t base = blk; base < end && !stop; base += 64) {
+                        const uint32_t idx = base + lane;
+                        const double mit_term = idx < end ? ws.terms[2ull * (h0 + off + idx)] : 0.0;
+                        const double cfd_term = idx < end ? ws.terms[2ull * (h0 + off + idx) + 1] : 0.0;
+                        accumulate(mit_term, cfd_term, (end - base < 64u) ? end - base : 64u);
+                    }
+                    if (lane == 0) walk_stopped = stop ? 1u : 0u;
+                }
+                __syncthreads();
+                if (walk_stopped != 0u) break; // uniform
             }
-            __syncthreads();
             if (walk_stopped != 0u) break; // uniform: the slices behind the exit are never sorted
         }
         if (threadIdx.x == 0) {
@@ -2013,7 +2048,9 @@ void launch_replay(const ImageView &v, const Workspace &ws, const uint64_t *d_gu
     const uint32_t grid = n < 65536u ? n : 65536u;
     hipLaunchKernelGGL(k_replay, dim3(grid), dim3(64), 0, static_cast<hipStream_t>(stream), v, ws, d_guides, n, p,
                        d_mit, d_cfd, d_kept, d_hitrec);
-    hipLaunchKernelGGL(k_replay_big, dim3(512), dim3(1024), 0, static_cast<hipStream_t>(stream), v, ws, d_guides, p,
+    hipLaunchKernelGGL((k_replay_big<256, kMidHits>), dim3(2048), dim3(256), 0, static_cast<hipStream_t>(stream), v, ws, d_guides, p,
+                       d_mit, d_cfd, d_kept, d_hitrec);
+    hipLaunchKernelGGL((k_replay_big<1024, kBigLds>), dim3(512), dim3(1024), 0, static_cast<hipStream_t>(stream), v, ws, d_guides, p,
                        d_mit, d_cfd, d_kept, d_hitrec);
 }
 
