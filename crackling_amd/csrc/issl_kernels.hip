@@ -1223,8 +1223,10 @@ __device__ inline void score_terms(const ImageView &v, uint64_t gsig, uint64_t o
 // Workgroups of the two passes over the raw chunks (one chunk per workgroup and step): enough of them that the
 // ~16 k first chunks of the scan waves are all in flight at once -- the passes are chains of dependent loads.
 constexpr uint32_t kTailGrid = 16384;
-constexpr uint32_t kReplayLds = 512;  // guides with more hits than this go to k_replay_big (a whole workgroup each)
+constexpr uint32_t kReplayLds = 512;  // guides with up to this many hits: one wave each (k_replay)
 static_assert(kReplayLds <= 512, "k_replay sorts (key, 9-bit index) pairs");
+constexpr uint32_t kMidHits = 2048;   // ... up to this many: one 256-thread workgroup each (k_replay_mid), terms from k_verify;
+                                      // beyond: k_replay_big (1024 threads, slice by slice, terms worked out as it walks)
 
 // Exact check of the raw records, IN PLACE: one thread per record, one chunk per 128-thread workgroup.
 // A record that survives is overwritten by its final key guide<<35 | slice<<32 | position-in-bucket,
@@ -1376,10 +1378,10 @@ __global__ __launch_bounds__(kChunkRecs, 8) void k_verify(ImageView v, Workspace
         if (live) {
             const uint64_t slot = static_cast<uint64_t>(chunk) * (kChunkRecs - 1u) + (t - 1u); // < cap_chunks * 127 <= cap_hits
             ws.rank[slot] = rank;
-            // The terms (:392-460) -- unless the guide already has more hits than the one-wave replay takes: the many-hit
-            // replay works out the terms of the hits it walks by itself, and on skewed data most hits belong to such
-            // guides and lie behind their early exit.
-            if (rank < kReplayLds) {
+            // The terms (:392-460) -- unless the guide already has more hits than the replays that read them take
+            // (k_replay, k_replay_mid): the many-hit replay works out the terms of the hits it walks by itself, and on
+            // skewed data most hits belong to such guides and lie behind their early exit.
+            if (rank < kMidHits) {
                 int dist;
                 score_terms(v, hit_gsig, hit_ot, hit_occ, calc_mit, calc_cfd, mit_term, cfd_term, dist);
                 reinterpret_cast<double2 *>(ws.pay)[slot] = make_double2(mit_term, cfd_term);
@@ -1556,7 +1558,7 @@ __global__ __launch_bounds__(kChunkRecs) void k_group_scatter(const uint64_t *__
         const uint32_t g0 = goff[guide];
         const uint32_t to = g0 + my_rank; // rank: k_verify's
         sorted[to] = key;
-        if (goff[guide + 1] - g0 <= kReplayLds) terms[to] = my_pay; // (the many-hit replay makes its own)
+        if (goff[guide + 1] - g0 <= kMidHits) terms[to] = my_pay; // (the many-hit replay makes its own)
     }
 }
 
@@ -1821,6 +1823,60 @@ __global__ __launch_bounds__(64) void k_replay(ImageView v, Workspace ws, const 
     }
 }
 
+// Guides with kReplayLds < hits <= kMidHits (on skewed data four guides in ten): one 256-thread workgroup each.  The
+// whole guide is sorted at once -- (slice, site id or position, index) in LDS, a bitonic network over at most 2048 keys --
+// and wave 0 walks the terms k_verify left, fetched by index, up to the early exit.  (The slice-by-slice machinery of
+// k_replay_big costs such a guide a dozen phases of barriers and memory round trips, 170 us against 25; eight of these
+// workgroups fit a CU.)
+__global__ __launch_bounds__(256) void k_replay_mid(ImageView v, Workspace ws, const uint64_t *__restrict__ guides,
+                                                    ScoreParams p, double *__restrict__ out_mit,
+                                                    double *__restrict__ out_cfd, uint32_t *__restrict__ out_kept,
+                                                    issl_hit *__restrict__ out_hits)
+{
+    short_kernel_priority();
+    __shared__ uint64_t keys[kMidHits];
+    const bool calc_mit = p.method == ISSL_METHOD_MIT || p.method == ISSL_METHOD_AND || p.method == ISSL_METHOD_OR ||
+                          p.method == ISSL_METHOD_AVG;
+    const bool calc_cfd = p.method == ISSL_METHOD_CFD || p.method == ISSL_METHOD_AND || p.method == ISSL_METHOD_OR ||
+                          p.method == ISSL_METHOD_AVG;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t n_big = ws.counters->n_big;
+    const double2 *__restrict__ terms2 = reinterpret_cast<const double2 *>(ws.terms);
+    for (uint32_t b = blockIdx.x; b < n_big; b += gridDim.x) {
+        const uint32_t g = ws.gcur_big[b];
+        const uint32_t h0 = ws.goff[g];
+        const uint32_t h = ws.goff[g + 1] - h0;
+        if (h > kMidHits) continue; // k_replay_big's (uniform over the workgroup)
+        for (uint32_t i = threadIdx.x; i < h; i += blockDim.x) keys[i] = ((ws.sorted[h0 + i] & ((1ull << 35) - 1ull)) << 11) | i;
+        __syncthreads();
+        wave_sort(keys, h);
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            const uint64_t gsig = guides[g];
+            double tot_mit = 0.0, tot_cfd = 0.0;
+            uint32_t kept = 0;
+            bool stop = false;
+            for (uint32_t base = 0; base < h && !stop; base += 64) {
+                const uint32_t idx = base + lane;
+                double2 mine = make_double2(0.0, 0.0);
+                if (idx < h) {
+                    const uint64_t sv = keys[idx];
+                    mine = terms2[h0 + static_cast<uint32_t>(sv & 2047ull)];
+                    if (out_hits)
+                        out_hits[h0 + idx] = hit_terms(v, gsig, g, (static_cast<uint64_t>(g) << 35) | (sv >> 11), calc_mit, calc_cfd, true).rec;
+                }
+                stop = accumulate_chunk(mine.x, mine.y, (h - base < 64u) ? h - base : 64u, p, lane, tot_mit, tot_cfd, kept);
+            }
+            if (lane == 0) {
+                out_mit[g] = 10000.0 / (100.0 + tot_mit); // :505
+                out_cfd[g] = 10000.0 / (100.0 + tot_cfd); // :506
+                if (out_kept) out_kept[g] = kept;
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // Sort by counting for the slices of a big guide: positions (low 32 key bits; guide and slice are common to the
 // slice) sit in LDS, every thread finds the rank of its K positions by comparing them with all `len` of them
 // (broadcast reads, no barrier inside) and writes the full keys to their final places.  A bitonic network over the same
@@ -1903,11 +1959,6 @@ __device__ __forceinline__ void rank_sort_slice_grouped(const uint32_t *pos_lds,
 // Guides with many hits (dense neighbourhoods, repeats): one 1024-thread workgroup each, one slice at a time: sort
 // the slice's keys (by counting in LDS up to 8192 per slice, else a bitonic network in HBM), compute the terms of its
 // hits in parallel, let wave 0 add them up in key order with the reference's running totals and early exit.
-// Two builds share the list of such guides: up to kMidHits hits a 256-thread workgroup with room for 2048 hits per slice
-// in LDS (eight of them fit a CU, and a guide's phases are a chain of barriers and memory round trips: on skewed data
-// four guides in ten are of this kind, and what counts is how many are in flight), beyond that a 1024-thread workgroup
-// with 7680 (two per CU).
-constexpr uint32_t kMidHits = 2048;
 template <uint32_t THREADS, uint32_t LDS_HITS>
 __global__ __launch_bounds__(THREADS) void k_replay_big(ImageView v, Workspace ws, const uint64_t *__restrict__ guides,
                                                      ScoreParams p, double *__restrict__ out_mit,
@@ -1930,7 +1981,7 @@ __global__ __launch_bounds__(THREADS) void k_replay_big(ImageView v, Workspace w
         const uint32_t g = ws.gcur_big[b];
         const uint32_t h0 = ws.goff[g];
         const uint32_t h = ws.goff[g + 1] - h0;
-        if ((h <= kMidHits) != (THREADS < 1024u)) continue; // the other build's (uniform over the workgroup)
+        if (h <= kMidHits) continue; // k_replay_mid's (uniform over the workgroup)
         const uint64_t gsig = guides[g];
         uint64_t *seg = ws.sorted + h0;
         uint64_t *tmp = ws.raw + h0; // the raw records are dead once they are grouped; the buffer holds >= all hits
@@ -2048,7 +2099,7 @@ void launch_replay(const ImageView &v, const Workspace &ws, const uint64_t *d_gu
     const uint32_t grid = n < 65536u ? n : 65536u;
     hipLaunchKernelGGL(k_replay, dim3(grid), dim3(64), 0, static_cast<hipStream_t>(stream), v, ws, d_guides, n, p,
                        d_mit, d_cfd, d_kept, d_hitrec);
-    hipLaunchKernelGGL((k_replay_big<256, kMidHits>), dim3(2048), dim3(256), 0, static_cast<hipStream_t>(stream), v, ws, d_guides, p,
+    hipLaunchKernelGGL(k_replay_mid, dim3(2048), dim3(256), 0, static_cast<hipStream_t>(stream), v, ws, d_guides, p,
                        d_mit, d_cfd, d_kept, d_hitrec);
     hipLaunchKernelGGL((k_replay_big<1024, kBigLds>), dim3(512), dim3(1024), 0, static_cast<hipStream_t>(stream), v, ws, d_guides, p,
                        d_mit, d_cfd, d_kept, d_hitrec);
