@@ -1823,11 +1823,13 @@ __global__ __launch_bounds__(64) void k_replay(ImageView v, Workspace ws, const 
     }
 }
 
-// Guides with kReplayLds < hits <= kMidHits (on skewed data four guides in ten): one 256-thread workgroup each.  The
-// whole guide is sorted at once -- (slice, site id or position, index) in LDS, a bitonic network over at most 2048 keys --
-// and wave 0 walks the terms k_verify left, fetched by index, up to the early exit.  (The slice-by-slice machinery of
-// k_replay_big costs such a guide a dozen phases of barriers and memory round trips, 170 us against 25; eight of these
-// workgroups fit a CU.)
+// Guides with kReplayLds < hits <= kMidHits (on skewed data four guides in ten): one 256-thread workgroup each, all keys
+// -- (slice, site id or position, index of the hit) -- in LDS, the terms k_verify left fetched by index.  Such a guide
+// usually leaves through the early exit (:467-496) within its first hits, so the smallest keys are tried first: the keys
+// are counted by their top eight bits, the leading groups that hold at least 512 of them (at most kMidHead) are gathered,
+// sorted (a bitonic network over <= 1024 keys) and walked; only a guide that survives them pays for the network over all
+// its keys (66 stages of barriers for 2048: 170 us per guide, which made this kernel the longest of the skewed step).
+constexpr uint32_t kMidHead = 1024;
 __global__ __launch_bounds__(256) void k_replay_mid(ImageView v, Workspace ws, const uint64_t *__restrict__ guides,
                                                     ScoreParams p, double *__restrict__ out_mit,
                                                     double *__restrict__ out_cfd, uint32_t *__restrict__ out_kept,
@@ -1835,6 +1837,11 @@ __global__ __launch_bounds__(256) void k_replay_mid(ImageView v, Workspace ws, c
 {
     short_kernel_priority();
     __shared__ uint64_t keys[kMidHits];
+    __shared__ uint64_t head[kMidHead];
+    __shared__ uint32_t hist[256];
+    __shared__ uint32_t top_s, head_groups, head_count, head_fill, stopped_s;
+    __shared__ double carry_mit, carry_cfd;
+    __shared__ uint32_t carry_kept;
     const bool calc_mit = p.method == ISSL_METHOD_MIT || p.method == ISSL_METHOD_AND || p.method == ISSL_METHOD_OR ||
                           p.method == ISSL_METHOD_AVG;
     const bool calc_cfd = p.method == ISSL_METHOD_CFD || p.method == ISSL_METHOD_AND || p.method == ISSL_METHOD_OR ||
@@ -1847,31 +1854,73 @@ __global__ __launch_bounds__(256) void k_replay_mid(ImageView v, Workspace ws, c
         const uint32_t h0 = ws.goff[g];
         const uint32_t h = ws.goff[g + 1] - h0;
         if (h > kMidHits) continue; // k_replay_big's (uniform over the workgroup)
-        for (uint32_t i = threadIdx.x; i < h; i += blockDim.x) keys[i] = ((ws.sorted[h0 + i] & ((1ull << 35) - 1ull)) << 11) | i;
+        const uint64_t gsig = guides[g];
+        hist[threadIdx.x] = 0;
+        if (threadIdx.x == 0) { top_s = 0; head_fill = 0; stopped_s = 0; carry_mit = 0.0; carry_cfd = 0.0; carry_kept = 0; }
         __syncthreads();
-        wave_sort(keys, h);
+        uint32_t m = 0;
+        for (uint32_t i = threadIdx.x; i < h; i += blockDim.x) {
+            const uint64_t k35 = ws.sorted[h0 + i] & ((1ull << 35) - 1ull);
+            keys[i] = (k35 << 11) | i;
+            const uint32_t k32 = static_cast<uint32_t>(k35 >> 3);
+            m = k32 > m ? k32 : m;
+        }
+        atomicMax(&top_s, m);
         __syncthreads();
-        if (threadIdx.x < 64) {
-            const uint64_t gsig = guides[g];
-            double tot_mit = 0.0, tot_cfd = 0.0;
-            uint32_t kept = 0;
-            bool stop = false;
-            for (uint32_t base = 0; base < h && !stop; base += 64) {
-                const uint32_t idx = base + lane;
-                double2 mine = make_double2(0.0, 0.0);
-                if (idx < h) {
-                    const uint64_t sv = keys[idx];
-                    mine = terms2[h0 + static_cast<uint32_t>(sv & 2047ull)];
-                    if (out_hits)
-                        out_hits[h0 + idx] = hit_terms(v, gsig, g, (static_cast<uint64_t>(g) << 35) | (sv >> 11), calc_mit, calc_cfd, true).rec;
+        const uint32_t top = top_s;
+        const uint32_t shift = top < 256u ? 0u : 24u - static_cast<uint32_t>(__builtin_clz(top)); // group = key >> (14 + shift) < 256
+        for (uint32_t i = threadIdx.x; i < h; i += blockDim.x) atomicAdd(&hist[static_cast<uint32_t>(keys[i] >> 14) >> shift], 1u);
+        __syncthreads();
+        if (threadIdx.x == 0) { // the leading groups that together hold >= 512 keys (or all of them)
+            uint32_t run = 0, nb = 0;
+            while (nb < 256u && run < 512u) run += hist[nb++];
+            head_groups = nb;
+            head_count = run;
+        }
+        __syncthreads();
+        // Walks keys sorted[from .. to) of `arr` (in key order) with the running totals carried in LDS by wave 0.
+        auto walk = [&](const uint64_t *arr, uint32_t from, uint32_t to) {
+            if (threadIdx.x < 64) {
+                double tot_mit = carry_mit, tot_cfd = carry_cfd;
+                uint32_t kept = carry_kept;
+                bool stop = false;
+                for (uint32_t base = from; base < to && !stop; base += 64) {
+                    const uint32_t idx = base + lane;
+                    double2 mine = make_double2(0.0, 0.0);
+                    if (idx < to) {
+                        const uint64_t sv = arr[idx];
+                        mine = terms2[h0 + static_cast<uint32_t>(sv & 2047ull)];
+                        if (out_hits)
+                            out_hits[h0 + idx] = hit_terms(v, gsig, g, (static_cast<uint64_t>(g) << 35) | (sv >> 11), calc_mit, calc_cfd, true).rec;
+                    }
+                    stop = accumulate_chunk(mine.x, mine.y, (to - base < 64u) ? to - base : 64u, p, lane, tot_mit, tot_cfd, kept);
                 }
-                stop = accumulate_chunk(mine.x, mine.y, (h - base < 64u) ? h - base : 64u, p, lane, tot_mit, tot_cfd, kept);
+                if (lane == 0) { carry_mit = tot_mit; carry_cfd = tot_cfd; carry_kept = kept; stopped_s = stop ? 1u : 0u; }
             }
-            if (lane == 0) {
-                out_mit[g] = 10000.0 / (100.0 + tot_mit); // :505
-                out_cfd[g] = 10000.0 / (100.0 + tot_cfd); // :506
-                if (out_kept) out_kept[g] = kept;
+            __syncthreads();
+        };
+        uint32_t walked = 0;
+        const uint32_t cnt = head_count, nb = head_groups;
+        if (cnt <= kMidHead && cnt < h) {
+            for (uint32_t i = threadIdx.x; i < h; i += blockDim.x) {
+                const uint64_t k = keys[i];
+                if ((static_cast<uint32_t>(k >> 14) >> shift) < nb) head[atomicAdd(&head_fill, 1u)] = k;
             }
+            __syncthreads();
+            wave_sort(head, cnt);
+            __syncthreads();
+            walk(head, 0u, cnt);
+            walked = cnt;
+        }
+        if (stopped_s == 0u) { // (uniform) all keys after all
+            wave_sort(keys, h);
+            __syncthreads();
+            walk(keys, walked, h);
+        }
+        if (threadIdx.x == 0) {
+            out_mit[g] = 10000.0 / (100.0 + carry_mit); // :505
+            out_cfd[g] = 10000.0 / (100.0 + carry_cfd); // :506
+            if (out_kept) out_kept[g] = carry_kept;
         }
         __syncthreads();
     }
@@ -1959,6 +2008,7 @@ __device__ __forceinline__ void rank_sort_slice_grouped(const uint32_t *pos_lds,
 // Guides with many hits (dense neighbourhoods, repeats): one 1024-thread workgroup each, one slice at a time: sort
 // the slice's keys (by counting in LDS up to 8192 per slice, else a bitonic network in HBM), compute the terms of its
 // hits in parallel, let wave 0 add them up in key order with the reference's running totals and early exit.
+constexpr uint32_t kBigSmall = 16384;
 template <uint32_t THREADS, uint32_t LDS_HITS>
 __global__ __launch_bounds__(THREADS) void k_replay_big(ImageView v, Workspace ws, const uint64_t *__restrict__ guides,
                                                      ScoreParams p, double *__restrict__ out_mit,
@@ -1970,7 +2020,7 @@ __global__ __launch_bounds__(THREADS) void k_replay_big(ImageView v, Workspace w
     __shared__ uint32_t grouped[LDS_HITS];
     __shared__ uint32_t group_at[257], group_cur[256], max_pos;
     __shared__ uint32_t slice_cnt[8], slice_off[9], slice_cur[8];
-    __shared__ uint32_t walk_stopped;
+    __shared__ uint32_t walk_stopped, head_groups, head_count, head_fill;
     const bool calc_mit = p.method == ISSL_METHOD_MIT || p.method == ISSL_METHOD_AND || p.method == ISSL_METHOD_OR ||
                           p.method == ISSL_METHOD_AVG;
     const bool calc_cfd = p.method == ISSL_METHOD_CFD || p.method == ISSL_METHOD_AND || p.method == ISSL_METHOD_OR ||
@@ -1981,7 +2031,10 @@ __global__ __launch_bounds__(THREADS) void k_replay_big(ImageView v, Workspace w
         const uint32_t g = ws.gcur_big[b];
         const uint32_t h0 = ws.goff[g];
         const uint32_t h = ws.goff[g + 1] - h0;
-        if (h <= kMidHits) continue; // k_replay_mid's (uniform over the workgroup)
+        // k_replay_mid's, or the other build's: up to kBigSmall hits a 256-thread workgroup with 2048 hits per slice in
+        // LDS (eight per CU: what such a guide costs is a chain of barriers and memory round trips, and what counts is
+        // how many are in flight), beyond that 1024 threads with 7680 (two per CU).  (uniform over the workgroup)
+        if (h <= kMidHits || (h <= kBigSmall) != (THREADS < 1024u)) continue;
         const uint64_t gsig = guides[g];
         uint64_t *seg = ws.sorted + h0;
         uint64_t *tmp = ws.raw + h0; // the raw records are dead once they are grouped; the buffer holds >= all hits
@@ -2039,46 +2092,94 @@ __global__ __launch_bounds__(THREADS) void k_replay_big(ImageView v, Workspace w
             if (len == 0) continue; // uniform over the workgroup
             if (st && threadIdx.x == 0 && s2 == 0) { st[3] = __builtin_amdgcn_s_memrealtime(); st[4] = len; }
             uint64_t *dst = seg + off;
+            const uint64_t high_bits = (static_cast<uint64_t>(g) << 35) | (static_cast<uint64_t>(s2) << 32);
+            // Terms of hits [from, to) of the slice (dst[] holds them in key order) by the whole workgroup, a block of
+            // blockDim.x at a time, each block added up in key order by wave 0 before the next one is worked out: a
+            // guide like this usually leaves through the early exit within its first hits (:467-496), and the terms
+            // cost two or three random reads each.  Leaves walk_stopped set when the exit was taken.
+            auto walk = [&](uint32_t from, uint32_t to) {
+                for (uint32_t blk = from; blk < to; blk += blockDim.x) {
+                    const uint32_t i = blk + threadIdx.x;
+                    if (i < to) {
+                        const HitTerms t = hit_terms(v, gsig, g, dst[i], calc_mit, calc_cfd, out_hits != nullptr);
+                        ws.terms[2ull * (h0 + off + i)] = t.mit;
+                        ws.terms[2ull * (h0 + off + i) + 1] = t.cfd;
+                        if (out_hits) out_hits[h0 + off + i] = t.rec;
+                    }
+                    __syncthreads();
+                    if (threadIdx.x < 64) {
+                        const uint32_t end = (to - blk < blockDim.x) ? to : blk + blockDim.x;
+                        for (uint32_t base = blk; base < end && !stop; base += 64) {
+                            const uint32_t idx = base + lane;
+                            const double mit_term = idx < end ? ws.terms[2ull * (h0 + off + idx)] : 0.0;
+                            const double cfd_term = idx < end ? ws.terms[2ull * (h0 + off + idx) + 1] : 0.0;
+                            accumulate(mit_term, cfd_term, (end - base < 64u) ? end - base : 64u);
+                        }
+                        if (lane == 0) walk_stopped = stop ? 1u : 0u;
+                    }
+                    __syncthreads();
+                    if (walk_stopped != 0u) break; // uniform
+                }
+            };
+            auto sort_in_lds = [&](uint32_t n) { // pos_lds[0 .. n) -> dst[0 .. n) in key order
+                if (n <= THREADS) rank_sort_slice<1, THREADS>(pos_lds, n, high_bits, dst);
+                else rank_sort_slice_grouped(pos_lds, grouped, group_at, group_cur, &max_pos, n, high_bits, dst);
+                __syncthreads();
+            };
+            uint32_t walked = 0;
+            if (threadIdx.x == 0) walk_stopped = 0;
+            __syncthreads();
             if (len <= LDS_HITS) {
                 for (uint32_t i = threadIdx.x; i < ((len + 3u) & ~3u); i += blockDim.x)
                     pos_lds[i] = i < len ? static_cast<uint32_t>(tmp[off + i]) : 0xFFFFFFFFu;
                 __syncthreads();
-                const uint64_t high_bits = (static_cast<uint64_t>(g) << 35) | (static_cast<uint64_t>(s2) << 32);
-                if (len <= THREADS) rank_sort_slice<1, THREADS>(pos_lds, len, high_bits, dst);
-                else rank_sort_slice_grouped(pos_lds, grouped, group_at, group_cur, &max_pos, len, high_bits, dst);
+                sort_in_lds(len);
             } else {
-                for (uint32_t i = threadIdx.x; i < len; i += blockDim.x) dst[i] = tmp[off + i];
+                // A slice too long for the LDS (a repeat: tens of thousands of hits).  Such a guide all but always leaves
+                // through the early exit within the hits with the smallest ids, so those are tried first: the positions are
+                // counted by their top eight bits, the leading groups that fit the LDS together are gathered, sorted and
+                // walked; only a guide that survives them pays for the sort of the whole slice (a bitonic network in HBM:
+                // ~140 stages of memory round trips, which used to set the kernel's duration).
+                if (threadIdx.x < 256) group_cur[threadIdx.x] = 0;
+                if (threadIdx.x == 0) { max_pos = 0; head_fill = 0; }
                 __syncthreads();
-                wave_sort(dst, len);
-            }
-            __syncthreads();
-            if (st && threadIdx.x == 0 && s2 == 0) st[5] = __builtin_amdgcn_s_memrealtime();
-            // Terms of the slice's hits by the whole workgroup, 1024 at a time, each block added up in key order by wave 0
-            // before the next one is worked out: a guide like this usually leaves through the early exit within its first
-            // hits (:467-496), and the terms cost two or three random reads each.
-            for (uint32_t blk = 0; blk < len; blk += blockDim.x) {
-                const uint32_t i = blk + threadIdx.x;
-                if (i < len) {
-                    const HitTerms t = hit_terms(v, gsig, g, dst[i], calc_mit, calc_cfd, out_hits != nullptr);
-                    ws.terms[2ull * (h0 + off + i)] = t.mit;
-                    ws.terms[2ull * (h0 + off + i) + 1] = t.cfd;
-                    if (out_hits) out_hits[h0 + off + i] = t.rec;
+                uint32_t m = 0;
+                for (uint32_t i = threadIdx.x; i < len; i += blockDim.x) { const uint32_t q = static_cast<uint32_t>(tmp[off + i]); m = q > m ? q : m; }
+                atomicMax(&max_pos, m);
+                __syncthreads();
+                const uint32_t top = max_pos;
+                const uint32_t shift = top < 256u ? 0u : 24u - static_cast<uint32_t>(__builtin_clz(top));
+                for (uint32_t i = threadIdx.x; i < len; i += blockDim.x) atomicAdd(&group_cur[static_cast<uint32_t>(tmp[off + i]) >> shift], 1u);
+                __syncthreads();
+                if (threadIdx.x == 0) { // leading groups that fit together
+                    uint32_t run = 0, nb = 0;
+                    while (nb < 256u && run + group_cur[nb] <= LDS_HITS) run += group_cur[nb++];
+                    head_groups = nb;
+                    head_count = run;
                 }
                 __syncthreads();
-                if (st && threadIdx.x == 0 && s2 == 0 && blk == 0) st[6] = __builtin_amdgcn_s_memrealtime();
-                if (threadIdx.x < 64) {
-                    const uint32_t end = (len - blk < blockDim.x) ? len : blk + blockDim.x;
-                    for (uint32_t base = blk; base < end && !stop; base += 64) {
-                        const uint32_t idx = base + lane;
-                        const double mit_term = idx < end ? ws.terms[2ull * (h0 + off + idx)] : 0.0;
-                        const double cfd_term = idx < end ? ws.terms[2ull * (h0 + off + idx) + 1] : 0.0;
-                        accumulate(mit_term, cfd_term, (end - base < 64u) ? end - base : 64u);
+                const uint32_t nb = head_groups, cnt = head_count;
+                if (cnt != 0u) {
+                    for (uint32_t i = threadIdx.x; i < len; i += blockDim.x) {
+                        const uint32_t q = static_cast<uint32_t>(tmp[off + i]);
+                        if ((q >> shift) < nb) pos_lds[atomicAdd(&head_fill, 1u)] = q;
                     }
-                    if (lane == 0) walk_stopped = stop ? 1u : 0u;
+                    __syncthreads();
+                    for (uint32_t i = cnt + threadIdx.x; i < ((cnt + 3u) & ~3u); i += blockDim.x) pos_lds[i] = 0xFFFFFFFFu;
+                    __syncthreads();
+                    sort_in_lds(cnt);
+                    walk(0u, cnt);
+                    walked = cnt;
                 }
-                __syncthreads();
-                if (walk_stopped != 0u) break; // uniform
+                if (walk_stopped == 0u && walked < len) { // (uniform) the whole slice after all
+                    for (uint32_t i = threadIdx.x; i < len; i += blockDim.x) dst[i] = tmp[off + i];
+                    __syncthreads();
+                    wave_sort(dst, len);
+                    __syncthreads();
+                }
             }
+            if (st && threadIdx.x == 0 && s2 == 0) st[5] = __builtin_amdgcn_s_memrealtime();
+            if (walk_stopped == 0u) walk(walked, len);
             if (walk_stopped != 0u) break; // uniform: the slices behind the exit are never sorted
         }
         if (threadIdx.x == 0) {
@@ -2100,6 +2201,8 @@ void launch_replay(const ImageView &v, const Workspace &ws, const uint64_t *d_gu
     hipLaunchKernelGGL(k_replay, dim3(grid), dim3(64), 0, static_cast<hipStream_t>(stream), v, ws, d_guides, n, p,
                        d_mit, d_cfd, d_kept, d_hitrec);
     hipLaunchKernelGGL(k_replay_mid, dim3(2048), dim3(256), 0, static_cast<hipStream_t>(stream), v, ws, d_guides, p,
+                       d_mit, d_cfd, d_kept, d_hitrec);
+    hipLaunchKernelGGL((k_replay_big<256, 2048>), dim3(2048), dim3(256), 0, static_cast<hipStream_t>(stream), v, ws, d_guides, p,
                        d_mit, d_cfd, d_kept, d_hitrec);
     hipLaunchKernelGGL((k_replay_big<1024, kBigLds>), dim3(512), dim3(1024), 0, static_cast<hipStream_t>(stream), v, ws, d_guides, p,
                        d_mit, d_cfd, d_kept, d_hitrec);

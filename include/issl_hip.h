@@ -179,17 +179,24 @@ int issl_index_image(const issl_index *idx, void **dev_ptr, size_t *bytes);
  * how an index that was built on the device gets into the tensor a framework broadcasts. */
 int issl_index_copy_image_to(const issl_index *idx, void *dev_dst, size_t bytes);
 
-/* Index larger than the free HBM (BASELINE configs[4]; the format's 32-bit ids, isslScoreOfftargets.cpp:347, allow
- * 4.29 G sites = 292 GB of image).  Only the scan stream (20 B/site) is read by the scan; the site table and the slice
- * lists (isslScoreOfftargets.cpp:200-204,235-240; 48 B/site) are touched for the ~2e-5 of the comparisons that come
- * within max_dist.  issl_index_upload / issl_index_build_on_device therefore fall back, in this order, to an image
- * without the sorted layout's maps, without the optional in-list signatures, and to an image whose cold sections stay
- * in pinned, mapped HOST memory (option host_cold / ISSL_FORCE_HOST_COLD=1 forces that layout; the kernels rebuild
- * signatures from the scan stream and read host memory only for occurrence counts >= 255 and for issl_dump_hits;
- * results are identical).  issl_index_cold() returns that host buffer (NULL / 0 when everything is in HBM); another
- * device of the same process adopts a copy of the hot image plus the SAME host buffer with
- * issl_index_attach_image_cold (issl_node does this).  Images with host-resident cold sections cannot be attached in
- * another process. */
+/* Image layouts, and indexes larger than the free HBM (BASELINE configs[4]; the format's 32-bit ids,
+ * isslScoreOfftargets.cpp:347, allow 4.29 G sites).  Only the scan stream (20 B/site) is read by the scan; everything else
+ * is touched for the ~2e-5 of the comparisons that come within max_dist.  issl_index_upload / issl_index_build_on_device
+ * try, in this order, until one fits the free HBM:
+ *   sorted        every bucket ordered by the byte of the next slice (what the pruned scan needs) + 16-byte stream records,
+ *                 site table, counts, slice lists: 152 B/site
+ *   compact       the same order with 4-byte site ids per stream position: 92 B/site, or -- slice lists in pinned, mapped
+ *                 HOST memory, where only issl_dump_hits and issl_index_write read them -- 52 B/site: an index at the
+ *                 format's limit of 4.29 G sites takes 223 GB of a 288 GB GPU (3 G lines: 152 GB, measured)
+ *   list order    (indexes whose lists do not ascend by site id, or whose five lists disagree about a site's count: no
+ *                 builder writes such, the reference does not care; no pruned scan then) with / without in-list
+ *                 signatures 108 / 68 B/site, or with site table and lists in host memory 25 B/site (the kernels rebuild
+ *                 signatures from the scan stream and read host memory only for counts >= 255 and for issl_dump_hits)
+ * Options sorted_layout / compact / inline_sigs / host_cold force a choice (or the upload fails); results are identical
+ * in every layout.  An index with a site in a bucket its signature does not select, or twice in one slice, is refused
+ * (ISSL_E_FORMAT).  issl_index_cold() returns the host buffer of an image with host-resident sections (NULL / 0 when
+ * everything is in HBM); another device of the same process adopts a copy of the hot image plus the SAME host buffer
+ * with issl_index_attach_image_cold (issl_node does this).  Such images cannot be attached in another process. */
 int issl_index_cold(const issl_index *idx, void **host_ptr, size_t *bytes);
 int issl_index_attach_image_cold(int device, void *dev_buf, size_t bytes, void *cold_host, size_t cold_bytes,
                                  issl_index **out);
@@ -199,20 +206,25 @@ int issl_index_attach_image_cold(int device, void *dev_buf, size_t bytes, void *
  *   scan_blocks (ISSL_SCAN_BLOCKS) workgroups of the scan launch      item_guides (ISSL_ITEM_GUIDES) guides per scan item
  *   scan_generic (ISSL_SCAN_GENERIC) 0|1 runtime-threshold scan       stage_timing (ISSL_STAGE_TIMING) 0|1 events at every stage
  *   raw_chunks (ISSL_RAW_CHUNKS) initial raw-record buffer
- *   inline_sigs (ISSL_INLINE_SIGS) -1|0|1, host_cold (ISSL_FORCE_HOST_COLD) -1|0|1, sorted_layout (ISSL_SORTED_LAYOUT)
- *     -1|0|1: image layout, read at upload.  The sorted layout stores every bucket ordered by the byte of the next slice
- *     (+100 B per site of position maps) and is what the pruned scan needs; -1 = whenever it fits the free HBM
+ *   sorted_layout (ISSL_SORTED_LAYOUT), compact (ISSL_COMPACT), inline_sigs (ISSL_INLINE_SIGS), host_cold
+ *     (ISSL_FORCE_HOST_COLD), each -1|0|1: image layout, read at upload (see above; -1 = automatic).  compact=1 with
+ *     host_cold=1: the compact sorted image with its slice lists in host memory; host_cold=1 alone: the list-order image
+ *     with site table and lists in host memory
+ *   tail_shapes (ISSL_TAIL_SHAPES) 0|1 (default 1): the short last unit of a successor-byte group runs 2 / 4 guides per
+ *     pass on 16 / 8 candidates per lane
  *   prune (ISSL_PRUNE) -1|0|1: scan only the successor-byte groups of a bucket that can hold a site within max_dist (13
  *     of 256 for max_dist <= 4, 1 of 256 for <= 2; same hits and scores as the reference's scan of the whole bucket,
  *     isslScoreOfftargets.cpp:344): -1 = a planning kernel decides per batch from the two plans' estimated times,
  *     0 = never, 1 = whenever the image is sorted and max_dist <= 4
- *   lanes (ISSL_LANES) 1|2: workspaces and streams that the batches of issl_score_device_async alternate between
- *     (default 1).  With 2, the short kernels behind one batch's scan run beside the next batch's scan (+7-11 % guides/s
- *     for back-to-back batches); outputs of two consecutive batches must then be different buffers
+ *   lanes (ISSL_LANES) 1|2: workspaces that the batches of issl_score_device_async alternate between (default 1).  With
+ *     2 the batches form a software pipeline: scans one after the other, verify / group / replay of a batch on a
+ *     high-priority stream beside the next batch's scan (a few per cent more guides/s for back-to-back batches);
+ *     outputs of two consecutive batches must then be different buffers
  *   scan_stamps (ISSL_SCAN_STAMPS) file for per-wave clocks (diagnostics) */
 int issl_index_set_option(issl_index *idx, const char *key, const char *value);
-/* Current value of an integer knob; also the read-only keys cold_on_host, has_inline_sigs, is_sorted and dense_mit
- * (layout of the uploaded image: 0/1, -1 before an upload). */
+/* Current value of an integer knob; also the read-only keys is_sorted, is_compact, cold_on_host, cold_sections (0, 1 =
+ * slice lists, 3 = lists + site table in host memory), has_inline_sigs and dense_mit (layout of the uploaded image, -1
+ * before an upload). */
 int issl_index_get_option(const issl_index *idx, const char *key, long long *value);
 
 /* ---- guides (A2, isslScoreOfftargets.cpp:63-71,82-89,275-305) ---------------------------- */

@@ -556,6 +556,9 @@ def test_guides_with_thousands_of_hits(tmp_path):
     per_guide = np.bincount(hits[:, 0], minlength=len(guides))
     assert per_guide.max() > 2048 and per_guide[1] > 512 and 64 < per_guide[3] <= 512 and per_guide[2] <= 64
     assert np.count_nonzero((hits[:, 0] == 4) & (hits[:, 1] == 0)) > 7680  # the HBM sort of one slice
+    for thr in (50.0, 75.0, 99.0):   # ... and the hits scored before the early exit (the head of such a slice is tried first)
+        _, _, ohits = oracle.score(guides, 4, thr, "and", want_hits=True)
+        assert np.array_equal(ix.dump_hits(guides, 4, thr, "and"), ohits), thr
     ix.close()
 
 
