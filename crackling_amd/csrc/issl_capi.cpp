@@ -205,11 +205,15 @@ struct issl_index {
         }                                                                                          \
     } while (0)
 
+// 20 bp sequences cut into slices of 8, 4 or 2 bits (5, 10 or 20 slices): what isslCreateIndex can write correctly (it
+// keeps slice values in a uint8_t, isslCreateIndex.cpp:228, and 40 bits only divide into whole positions for these
+// widths).  Width 8 -- the README's recommendation, Crackling's default -- gets the sorted layouts and the pruned scan;
+// the narrower ones the list-order layouts in HBM and the scan of whole buckets (the reference's own loop, :330-344).
 static int supported_geometry(const Geometry &g)
 {
-    if (g.seq_len == 20 && g.slice_width == 8 && g.n_slices == 5) return ISSL_OK;
-    set_error("unsupported index geometry: the gfx950 scan kernels implement 20 bp sequences with five "
-              "8-bit slices (got seq_len=" + std::to_string(g.seq_len) + " slice_width=" +
+    if (g.seq_len == 20 && (g.slice_width == 8 || g.slice_width == 4 || g.slice_width == 2) && g.n_slices * g.slice_width == 40) return ISSL_OK;
+    set_error("unsupported index geometry: the gfx950 scan kernels implement 20 bp sequences in slices of 8, 4 or 2 bits "
+              "(got seq_len=" + std::to_string(g.seq_len) + " slice_width=" +
               std::to_string(g.slice_width) + " slices=" + std::to_string(g.n_slices) + ")");
     return ISSL_E_UNSUPPORTED;
 }
@@ -602,6 +606,14 @@ static std::vector<LayoutSpec> layout_choices(const Tuning &tn, const Geometry &
 {
     std::vector<LayoutSpec> c;
     auto spec = [](bool esig, uint32_t cold, uint32_t sorted) { LayoutSpec s; s.inline_sigs = esig; s.cold = cold; s.sorted = sorted; return s; };
+    const bool narrow = g.slice_width != 8; // list order in HBM only: the sorted layouts order by a successor BYTE, and the
+                                            // host-cold layout rebuilds signatures from 16 stream positions + the bucket's byte
+    if (narrow) {
+        if (tn.sorted_layout == 1 || tn.compact == 1 || tn.host_cold == 1) return c;
+        if (want_inline_sigs(tn, g)) c.push_back(spec(true, 0, 0));
+        if (tn.inline_sigs != 1) c.push_back(spec(false, 0, 0));
+        return c;
+    }
     const bool may_sort = !list_order_only && tn.sorted_layout != 0 && tn.inline_sigs != 1;
     const bool must_sort = tn.sorted_layout == 1 || tn.compact == 1;
     if (may_sort || must_sort) {
@@ -700,8 +712,10 @@ static int enqueue_batch(issl_index *ix, Lane &lane, hipStream_t stream, const u
         set_error("index has no device image: call issl_index_upload first");
         return ISSL_E_STATE;
     }
-    if (n > kMaxBatch) { // guide slots are 27-bit fields of the raw records: 5 slots per guide + padding
-        set_error("at most 2^24 guides per device batch (issl_score splits larger batches itself)");
+    // guide slots are 27-bit fields of the raw records: one slot per guide and slice + padding
+    const size_t max_batch = std::min<size_t>(kMaxBatch, ((size_t(1) << 27) - kGuideGroup * ix->hdr.n_buckets) / std::max<uint64_t>(ix->hdr.n_slices, 1));
+    if (n > max_batch) {
+        set_error("at most " + std::to_string(max_batch) + " guides per device batch on this index (issl_score splits larger batches itself)");
         return ISSL_E_ARG;
     }
     HIP_TRY(hipSetDevice(ix->device));

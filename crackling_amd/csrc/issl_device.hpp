@@ -201,6 +201,10 @@ constexpr uint32_t kMaxRanges = kScanMaxBlocks;  // one equal-cost range per wor
 constexpr uint32_t kSpanRing = 64;              // batches per lane whose scan spans are kept until the next finish
 constexpr uint32_t kChunkRecs = 128;            // raw-record chunk: 1 KiB, slot 0 is the fill count
 constexpr uint64_t kDeadKey = ~0ull;            // raw slot that did not survive the exact check
+// Key of a scored off-target: guide << 37 | first matching slice << 32 | site id (sorted layouts) or position in the
+// bucket's list -- the reference's scoring order inside a guide (isslScoreOfftargets.cpp:330,344) is the numeric order
+// of the low 37 bits.  Five bits of slice: up to 20 slices (slice width 2).
+constexpr uint32_t kKeySliceShift = 32, kKeyGuideShift = 37, kKeySliceMask = 31, kMaxSlices = 20;
 
 // One unit of scan work: a run of tiles of one bucket against one group of guides.  Full scan: all tiles of the bucket
 // against <= 512 of the guides whose slice value selects it.  Pruned scan: the tiles that hold one successor-byte group

@@ -49,11 +49,14 @@ __host__ __device__ inline uint32_t gather_even16(uint32_t x)
 // equal for every candidate and guide of the bucket), then split the remaining 16 positions into
 // low-bit plane (bits 0..15) and high-bit plane (bits 16..31).  Two words differ at position p
 // iff bit p of (x | x>>16) is set, x = a ^ b.
-__host__ __device__ inline uint32_t scan_word(uint64_t sig, uint32_t s)
+// Narrower slices (width 4 / 2: the reference scorer takes any width, :261-270,330-341) leave 18 / 19 other positions:
+// the scan word keeps the first 16 of them, so the scan's count is a lower bound of the distance there -- it notes a
+// superset of the hits and k_verify's exact test on the whole signatures decides, as it does anyway.
+__host__ __device__ inline uint32_t scan_word(uint64_t sig, uint32_t s, uint32_t width = 8u)
 {
-    const uint32_t sh = 8u * s;
+    const uint32_t sh = width * s;
     const uint64_t low = sig & ((1ull << sh) - 1ull);
-    const uint64_t high = (sig >> (sh + 8u)) << sh;
+    const uint64_t high = (sig >> (sh + width)) << sh;
     const uint32_t rem = static_cast<uint32_t>(low | high);
     return gather_even16(rem) | (gather_even16(rem >> 1) << 16);
 }
@@ -111,7 +114,7 @@ __global__ __launch_bounds__(256) void k_pack_scan_stream(ImageView v, uint32_t 
             if (pos < len && (v.srec || v.sid)) {
                 // sorted layouts: the stream holds the candidates v.srec / v.sid list (built and checked by launch_sort_slice)
                 const uint64_t at = static_cast<uint64_t>(t) * kTileCands + k0 + lane; // the maps are indexed like the stream
-                w = scan_word(v.srec ? v.srec[at].sig & ((1ull << 40) - 1ull) : v.sites[v.sid[at]], slice);
+                w = scan_word(v.srec ? v.srec[at].sig & ((1ull << 40) - 1ull) : v.sites[v.sid[at]], slice, v.slice_width);
             } else if (pos < len) {
                 const uint64_t e = v.entries[start + pos];
                 const uint64_t id = e & 0xFFFFFFFFull;
@@ -126,7 +129,7 @@ __global__ __launch_bounds__(256) void k_pack_scan_stream(ImageView v, uint32_t 
                         const uint64_t bit = static_cast<uint64_t>(slice) * v.n_sites + id;
                         if (atomicOr(&seen[bit >> 5], 1u << (bit & 31u)) & (1u << (bit & 31u))) atomicOr(error_flag, 4u);
                     }
-                    w = scan_word(sig, slice);
+                    w = scan_word(sig, slice, v.slice_width);
                     if (esig_out) esig_out[start + pos] = sig;
                     if (occ8_out) occ8_out[start + pos] = static_cast<uint8_t>((e >> 32) < 255ull ? (e >> 32) : 255ull);
                 } else {
@@ -412,11 +415,11 @@ __global__ __launch_bounds__(256) void k_guide_scatter(const uint64_t *__restric
     const uint32_t g = blockIdx.x * 256 + threadIdx.x;
     const uint32_t low = (1u << slice_width) - 1u;
     uint64_t sig = 0;
-    uint32_t rank[8];
+    uint32_t rank[kMaxSlices];
     if (g < n) {
         sig = guides[g];
 #pragma unroll
-        for (uint32_t s = 0; s < 8; ++s) {
+        for (uint32_t s = 0; s < kMaxSlices; ++s) {
             if (s < n_slices) {
                 const uint32_t key = static_cast<uint32_t>(sig >> (slice_width * s)) & low;
                 rank[s] = atomicAdd(&hist[(s << slice_width) + key], 1u);
@@ -429,12 +432,12 @@ __global__ __launch_bounds__(256) void k_guide_scatter(const uint64_t *__restric
     __syncthreads();
     if (g < n) {
 #pragma unroll
-        for (uint32_t s = 0; s < 8; ++s) {
+        for (uint32_t s = 0; s < kMaxSlices; ++s) {
             if (s < n_slices) {
                 const uint32_t key = static_cast<uint32_t>(sig >> (slice_width * s)) & low;
                 const uint32_t b = (s << slice_width) + key;
                 const uint32_t slot = gstart[b] + base[b] + rank[s];
-                gword[slot] = scan_word(sig, s);
+                gword[slot] = scan_word(sig, s, slice_width);
                 gidx[slot] = g;
                 gbucket[slot] = b;
             }
@@ -1316,7 +1319,7 @@ __global__ __launch_bounds__(kChunkRecs, 8) void k_verify(ImageView v, Workspace
                             // list-order layouts: the key carries the position in the bucket's list, which is the stream
                             // position; sorted layouts: the site id (lists ascend by id, so the order is the same)
                             const uint64_t lp = by_id ? sr.id : pos;
-                            key = (static_cast<uint64_t>(guide) << 35) | (static_cast<uint64_t>(slice) << 32) | lp;
+                            key = (static_cast<uint64_t>(guide) << kKeyGuideShift) | (static_cast<uint64_t>(slice) << kKeySliceShift) | lp;
                         }
                     } else {
                         // Pruned scan: the guide meets this site once in every exactly matching slice whose successor
@@ -1332,7 +1335,7 @@ __global__ __launch_bounds__(kChunkRecs, 8) void k_verify(ImageView v, Workspace
                             if (static_cast<uint32_t>(__builtin_popcountll((mm >> (v.slice_width * nx)) & low)) <= tol) reporter = j;
                         }
                         if (reporter == slice)
-                            key = (static_cast<uint64_t>(guide) << 35) | (static_cast<uint64_t>(first) << 32) | sr.id;
+                            key = (static_cast<uint64_t>(guide) << kKeyGuideShift) | (static_cast<uint64_t>(first) << kKeySliceShift) | sr.id;
                     }
                     if (key != kDeadKey) { // the hit will be scored: what its terms are made of (:348)
                         uint32_t occ;
@@ -1554,7 +1557,7 @@ __global__ __launch_bounds__(kChunkRecs) void k_group_scatter(const uint64_t *__
         const double2 my_pay = pay[slot];
         const uint32_t used = static_cast<uint32_t>(recs[0]);
         if (t >= used || t >= kChunkRecs || key == kDeadKey) continue;
-        const uint32_t guide = static_cast<uint32_t>(key >> 35);
+        const uint32_t guide = static_cast<uint32_t>(key >> kKeyGuideShift);
         const uint32_t g0 = goff[guide];
         const uint32_t to = g0 + my_rank; // rank: k_verify's
         sorted[to] = key;
@@ -1691,7 +1694,7 @@ __device__ inline HitTerms hit_terms(const ImageView &v, uint64_t gsig, uint32_t
     t.mit = 0.0;
     t.cfd = 0.0;
     const uint64_t low = (1ull << v.slice_width) - 1ull;
-    const uint32_t slice = static_cast<uint32_t>(key >> 32) & 7u;
+    const uint32_t slice = static_cast<uint32_t>(key >> kKeySliceShift) & kKeySliceMask;
     uint32_t pos = static_cast<uint32_t>(key);
     const uint32_t bucket = (slice << v.slice_width) + static_cast<uint32_t>((gsig >> (v.slice_width * slice)) & low);
     const uint64_t at = v.bucket_start[bucket] + pos;
@@ -1798,7 +1801,7 @@ __global__ __launch_bounds__(64) void k_replay(ImageView v, Workspace ws, const 
         } else {
             // (slice, position) of every key with the key's index behind it, sorted in LDS; the terms follow by index
             uint64_t *data = keys;
-            for (uint32_t i = lane; i < h; i += 64) keys[i] = ((ws.sorted[h0 + i] & ((1ull << 35) - 1ull)) << 9) | i; // h <= 512
+            for (uint32_t i = lane; i < h; i += 64) keys[i] = ((ws.sorted[h0 + i] & ((1ull << kKeyGuideShift) - 1ull)) << 9) | i; // h <= 512
             __syncthreads();
             wave_sort(data, h);
             __syncthreads();
@@ -1809,7 +1812,7 @@ __global__ __launch_bounds__(64) void k_replay(ImageView v, Workspace ws, const 
                     const uint64_t sv = data[idx];
                     mine = terms2[h0 + static_cast<uint32_t>(sv & 511ull)];
                     if (out_hits)
-                        out_hits[h0 + idx] = hit_terms(v, gsig, g, (static_cast<uint64_t>(g) << 35) | (sv >> 9), calc_mit, calc_cfd, true).rec;
+                        out_hits[h0 + idx] = hit_terms(v, gsig, g, (static_cast<uint64_t>(g) << kKeyGuideShift) | (sv >> 9), calc_mit, calc_cfd, true).rec;
                 }
                 accumulate(mine.x, mine.y, (h - base < 64u) ? h - base : 64u);
             }
@@ -1860,16 +1863,16 @@ __global__ __launch_bounds__(256) void k_replay_mid(ImageView v, Workspace ws, c
         __syncthreads();
         uint32_t m = 0;
         for (uint32_t i = threadIdx.x; i < h; i += blockDim.x) {
-            const uint64_t k35 = ws.sorted[h0 + i] & ((1ull << 35) - 1ull);
-            keys[i] = (k35 << 11) | i;
-            const uint32_t k32 = static_cast<uint32_t>(k35 >> 3);
+            const uint64_t k37 = ws.sorted[h0 + i] & ((1ull << kKeyGuideShift) - 1ull);
+            keys[i] = (k37 << 11) | i;
+            const uint32_t k32 = static_cast<uint32_t>(k37 >> 5);
             m = k32 > m ? k32 : m;
         }
         atomicMax(&top_s, m);
         __syncthreads();
         const uint32_t top = top_s;
-        const uint32_t shift = top < 256u ? 0u : 24u - static_cast<uint32_t>(__builtin_clz(top)); // group = key >> (14 + shift) < 256
-        for (uint32_t i = threadIdx.x; i < h; i += blockDim.x) atomicAdd(&hist[static_cast<uint32_t>(keys[i] >> 14) >> shift], 1u);
+        const uint32_t shift = top < 256u ? 0u : 24u - static_cast<uint32_t>(__builtin_clz(top)); // group = key >> (16 + shift) < 256
+        for (uint32_t i = threadIdx.x; i < h; i += blockDim.x) atomicAdd(&hist[static_cast<uint32_t>(keys[i] >> 16) >> shift], 1u);
         __syncthreads();
         if (threadIdx.x == 0) { // the leading groups that together hold >= 512 keys (or all of them)
             uint32_t run = 0, nb = 0;
@@ -1891,7 +1894,7 @@ __global__ __launch_bounds__(256) void k_replay_mid(ImageView v, Workspace ws, c
                         const uint64_t sv = arr[idx];
                         mine = terms2[h0 + static_cast<uint32_t>(sv & 2047ull)];
                         if (out_hits)
-                            out_hits[h0 + idx] = hit_terms(v, gsig, g, (static_cast<uint64_t>(g) << 35) | (sv >> 11), calc_mit, calc_cfd, true).rec;
+                            out_hits[h0 + idx] = hit_terms(v, gsig, g, (static_cast<uint64_t>(g) << kKeyGuideShift) | (sv >> 11), calc_mit, calc_cfd, true).rec;
                     }
                     stop = accumulate_chunk(mine.x, mine.y, (to - base < 64u) ? to - base : 64u, p, lane, tot_mit, tot_cfd, kept);
                 }
@@ -1904,7 +1907,7 @@ __global__ __launch_bounds__(256) void k_replay_mid(ImageView v, Workspace ws, c
         if (cnt <= kMidHead && cnt < h) {
             for (uint32_t i = threadIdx.x; i < h; i += blockDim.x) {
                 const uint64_t k = keys[i];
-                if ((static_cast<uint32_t>(k >> 14) >> shift) < nb) head[atomicAdd(&head_fill, 1u)] = k;
+                if ((static_cast<uint32_t>(k >> 16) >> shift) < nb) head[atomicAdd(&head_fill, 1u)] = k;
             }
             __syncthreads();
             wave_sort(head, cnt);
@@ -2019,7 +2022,7 @@ __global__ __launch_bounds__(THREADS) void k_replay_big(ImageView v, Workspace w
     __shared__ __attribute__((aligned(16))) uint32_t pos_lds[LDS_HITS];
     __shared__ uint32_t grouped[LDS_HITS];
     __shared__ uint32_t group_at[257], group_cur[256], max_pos;
-    __shared__ uint32_t slice_cnt[8], slice_off[9], slice_cur[8];
+    __shared__ uint32_t slice_cnt[kMaxSlices], slice_off[kMaxSlices + 1], slice_cur[kMaxSlices];
     __shared__ uint32_t walk_stopped, head_groups, head_count, head_fill;
     const bool calc_mit = p.method == ISSL_METHOD_MIT || p.method == ISSL_METHOD_AND || p.method == ISSL_METHOD_OR ||
                           p.method == ISSL_METHOD_AVG;
@@ -2046,11 +2049,11 @@ __global__ __launch_bounds__(THREADS) void k_replay_big(ImageView v, Workspace w
         // totals pass the threshold, :467-496): split the keys by slice (bits 32..34) and sort and walk one slice at
         // a time -- a fifth of the sorting work per step, in LDS up to 8192 hits PER SLICE, and none at all for the
         // slices behind the exit.
-        if (threadIdx.x < 8) { slice_cnt[threadIdx.x] = 0; slice_cur[threadIdx.x] = 0; }
+        if (threadIdx.x < kMaxSlices) { slice_cnt[threadIdx.x] = 0; slice_cur[threadIdx.x] = 0; }
         __syncthreads();
         for (uint32_t base = 0; base < h; base += blockDim.x) {
             const uint32_t i = base + threadIdx.x;
-            const uint32_t sl = i < h ? static_cast<uint32_t>(seg[i] >> 32) & 7u : 8u;
+            const uint32_t sl = i < h ? static_cast<uint32_t>(seg[i] >> kKeySliceShift) & kKeySliceMask : kKeySliceMask;
             for (uint32_t s2 = 0; s2 < v.n_slices; ++s2) {
                 const uint64_t m = __ballot(sl == s2);
                 if (m != 0ull && lane == 0) atomicAdd(&slice_cnt[s2], static_cast<uint32_t>(__builtin_popcountll(m)));
@@ -2059,14 +2062,14 @@ __global__ __launch_bounds__(THREADS) void k_replay_big(ImageView v, Workspace w
         __syncthreads();
         if (threadIdx.x == 0) {
             uint32_t run = 0;
-            for (uint32_t s2 = 0; s2 < 8; ++s2) { slice_off[s2] = run; run += slice_cnt[s2]; }
-            slice_off[8] = run;
+            for (uint32_t s2 = 0; s2 < kMaxSlices; ++s2) { slice_off[s2] = run; run += slice_cnt[s2]; }
+            slice_off[kMaxSlices] = run;
         }
         __syncthreads();
         for (uint32_t base = 0; base < h; base += blockDim.x) {
             const uint32_t i = base + threadIdx.x;
             const uint64_t key = i < h ? seg[i] : 0ull;
-            const uint32_t sl = i < h ? static_cast<uint32_t>(key >> 32) & 7u : 8u;
+            const uint32_t sl = i < h ? static_cast<uint32_t>(key >> kKeySliceShift) & kKeySliceMask : kKeySliceMask;
             for (uint32_t s2 = 0; s2 < v.n_slices; ++s2) {
                 const uint64_t m = __ballot(sl == s2);
                 if (m == 0ull) continue;
@@ -2092,7 +2095,7 @@ __global__ __launch_bounds__(THREADS) void k_replay_big(ImageView v, Workspace w
             if (len == 0) continue; // uniform over the workgroup
             if (st && threadIdx.x == 0 && s2 == 0) { st[3] = __builtin_amdgcn_s_memrealtime(); st[4] = len; }
             uint64_t *dst = seg + off;
-            const uint64_t high_bits = (static_cast<uint64_t>(g) << 35) | (static_cast<uint64_t>(s2) << 32);
+            const uint64_t high_bits = (static_cast<uint64_t>(g) << kKeyGuideShift) | (static_cast<uint64_t>(s2) << kKeySliceShift);
             // Terms of hits [from, to) of the slice (dst[] holds them in key order) by the whole workgroup, a block of
             // blockDim.x at a time, each block added up in key order by wave 0 before the next one is worked out: a
             // guide like this usually leaves through the early exit within its first hits (:467-496), and the terms

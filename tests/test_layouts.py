@@ -9,6 +9,8 @@ Layouts:
   host_cold     stream in list order, site table and lists in pinned host memory (occ8 + plane rebuild)
 The sorted layouts score in (slice, site id) order, the list-order ones in (slice, list position) order; on indexes whose
 lists ascend by id -- every builder's -- the two are the reference's order (isslScoreOfftargets.cpp:330-348)."""
+import pathlib
+
 import numpy as np
 import pytest
 
@@ -67,6 +69,47 @@ def test_every_layout_reproduces_the_reference(name, layout):
                 assert np.array_equal(hits, want), (thr, prune)
     finally:
         ix.close()
+
+
+@pytest.mark.parametrize("layout", [None, "list_esig", "list"])
+@pytest.mark.parametrize("name", ["width4", "width2"])
+def test_narrow_slices_reproduce_the_reference(name, layout):
+    """Indexes with 4- and 2-bit slices (10 / 20 slices per site; isslScoreOfftargets.cpp:261-270,330-341 is generic in
+    both): list-order image in HBM, scan of whole buckets -- the scan word keeps 16 of the 18 / 19 positions outside the
+    slice, the exact test decides.  Stdout and hit lists of the compiled reference, max distances 2, 4 and 6; the layouts
+    that need 8-bit slices are refused."""
+    g = Golden(name)
+    ix = ca.IsslIndex.open(g.issl) if layout is None else _open(g.issl, layout)
+    ix.upload(0)
+    assert ix.get_option("is_sorted") == 0 and ix.get_option("cold_on_host") == 0
+    assert ix.header["slice_width"] == int(name[5:]) and ix.header["n_slices"] == 40 // int(name[5:])
+    sigs = ca.encode_guides([s.encode() for s in g.guides])
+    try:
+        for key, want in g.expected.items():
+            method, thr, dist = key.split("|")
+            mit, cfd = ix.score(sigs, int(dist), float(thr), method)
+            assert ca.format_scores(sigs, mit, cfd, method) == want, key
+            st = ix.stats()
+            assert st["pruned"] == 0 and st["candidates"] == st["reference_comparisons"] == ix.count_candidates(sigs)
+        for thr in g.hit_thresholds():
+            assert np.array_equal(ix.dump_hits(sigs, 4, float(thr), "and"), g.hits(thr)), thr
+    finally:
+        ix.close()
+    if layout is None:
+        for forced in ("sorted", "compact", "host_cold"):
+            bad = _open(g.issl, forced)
+            with pytest.raises(ca.IsslError):
+                bad.upload(0)
+            bad.close()
+        odd = ca.IsslIndex.build_from_text(g.sites_txt.read_bytes(), slice_width=5)   # 5-bit slices cut positions in two
+        with pytest.raises(ca.IsslError) as e:
+            odd.upload(0)
+        assert "unsupported index geometry" in str(e.value)
+        odd.close()
+        exe = pathlib.Path(__file__).resolve().parent.parent / "bin" / "isslScoreOfftargets"
+        import subprocess
+        r = subprocess.run([str(exe), str(g.issl), str(g.guides_txt), "4", "75", "and"], capture_output=True)
+        assert r.returncode == 0 and r.stdout.decode() == g.expected["and|75|4"]
 
 
 def test_layout_sizes(golden_uniform):

@@ -66,6 +66,22 @@ def test_oracle_matches_reference_on_large_counts_and_signed_tables(golden_extra
         assert np.array_equal(hits, g.hits(thr)), thr
 
 
+def test_oracle_and_builder_match_reference_on_narrow_slices(golden_width):
+    """Slice widths 4 and 2 (isslCreateIndex.cpp:212-234, isslScoreOfftargets.cpp:261-270,330-341): the host builder's
+    bytes have the digest of the reference-built index (checked when the fixture rebuilds it), the oracle reproduces the
+    reference's stdout and hit lists on it."""
+    g = golden_width
+    ix = ou.OracleIndex(g.issl)
+    sigs = ou.encode(g.guides)
+    for key, want in g.expected.items():
+        method, thr, dist = key.split("|")
+        mit, cfd = ix.score(sigs, int(dist), float(thr), method, threads=1)
+        assert ou.format_tsv([l.split("\t")[0] for l in want.splitlines()], mit, cfd, method) == want, key
+    for thr in g.hit_thresholds():
+        _, _, hits = ix.score(sigs, 4, float(thr), "and", threads=1, want_hits=True)
+        assert np.array_equal(hits, g.hits(thr)), thr
+
+
 def test_oracle_thread_count_invariance(golden_uniform):
     ix = ou.OracleIndex(golden_uniform.issl)
     sigs = ou.encode(golden_uniform.guides)
