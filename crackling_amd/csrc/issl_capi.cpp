@@ -236,7 +236,7 @@ static int select_device(int device)
 
 static void free_workspace(Workspace &w)
 {
-    void *ptrs[] = {w.ng, w.gfill, w.gstart, w.gword, w.gidx, w.gbucket, w.items, w.plan, w.range_start, w.counters, w.scan_count, w.scan_span, w.sticky, w.stamps, w.gcur_big, w.terms, w.sorted, w.gcount,
+    void *ptrs[] = {w.ng, w.gfill, w.gstart, w.gword, w.gidx, w.gbucket, w.items, w.plan, w.range_start, w.counters, w.scan_count, w.scan_span, w.sticky, w.stamps, w.gcur_big, w.gcur_big2, w.terms, w.sorted, w.gcount,
                     w.goff, w.blocksum, w.d_guides, w.d_mit, w.d_cfd, w.d_kept, w.d_hitrec, w.pay, w.rank, w.fword, w.fmeta,
                     w.fitems, w.fcount, w.fsum};
     for (void *p : ptrs)
@@ -310,6 +310,7 @@ static int ensure_workspace(issl_index *ix, size_t n, Lane &lane)
         if ((rc = dev_alloc(w.gcount, cap + 1))) return rc;
         if ((rc = dev_alloc(w.goff, cap + 1))) return rc;
         if ((rc = dev_alloc(w.gcur_big, cap + 1))) return rc;
+        if ((rc = dev_alloc(w.gcur_big2, cap + 1))) return rc;
         if ((rc = dev_alloc(w.blocksum, (cap + 1) / 2048 + 2))) return rc;
         if ((rc = dev_alloc(w.d_guides, cap))) return rc;
         if ((rc = dev_alloc(w.d_mit, cap))) return rc;

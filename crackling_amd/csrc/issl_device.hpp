@@ -256,7 +256,8 @@ struct PlanInfo {
 // Updated by the scan with atomics.
 struct Counters {
     uint32_t next_range;  // ticket counter of the scan's dynamic tail
-    uint32_t n_big;       // guides with more than kReplayLds hits (k_replay_big's list)
+    uint32_t n_big;       // guides with more than kReplayLds hits (the list k_replay_mid and k_replay_big share)
+    uint32_t n_big2;      // guides k_replay_mid hands on to k_replay_big (a slice too long for its buffers)
     uint32_t raw_chunks;  // chunks of the raw record buffer handed out
     uint32_t raw_overflow; // set when the raw buffer was too small
 };
@@ -310,7 +311,8 @@ struct Workspace {
     uint64_t *sorted = nullptr;  // [hit_cap] keys guide<<35 | slice<<32 | site id or list position, grouped by guide
     uint32_t *gcount = nullptr;  // [G+1] hits per guide
     uint32_t *goff = nullptr;    // [G+1] exclusive prefix
-    uint32_t *gcur_big = nullptr; // [G] guides handed to k_replay_big
+    uint32_t *gcur_big = nullptr; // [G] guides with more than kReplayLds hits
+    uint32_t *gcur_big2 = nullptr; // [G] ... that k_replay_mid hands on to k_replay_big
     double *terms = nullptr;     // [2 * hit_cap] MIT/CFD terms of the hits, grouped by guide like `sorted`
     double *pay = nullptr;       // [2 * hit_cap] the same terms as k_verify computed them, by raw-record slot
     uint32_t *rank = nullptr;    // [hit_cap] place of a surviving raw record inside its guide's segment, by raw-record slot

@@ -1826,25 +1826,26 @@ __global__ __launch_bounds__(64) void k_replay(ImageView v, Workspace ws, const 
     }
 }
 
-// Guides with kReplayLds < hits <= kMidHits (on skewed data four guides in ten): one 256-thread workgroup each, all keys
-// -- (slice, site id or position, index of the hit) -- in LDS, the terms k_verify left fetched by index.  Such a guide
-// usually leaves through the early exit (:467-496) within its first hits, so the smallest keys are tried first: the keys
-// are counted by their top eight bits, the leading groups that hold at least 512 of them (at most kMidHead) are gathered,
-// sorted (a bitonic network over <= 1024 keys) and walked; only a guide that survives them pays for the network over all
-// its keys (66 stages of barriers for 2048: 170 us per guide, which made this kernel the longest of the skewed step).
-constexpr uint32_t kMidHead = 1024;
+// Guides with kReplayLds < hits <= kMidHits (on skewed data four guides in ten): one 256-thread workgroup each, the terms
+// k_verify left fetched by the hit's index.  One slice at a time, as the reference walks them (:330): the slice's keys are
+// gathered into LDS, every thread ranks up to four of them by counting (no barrier inside: a bitonic network over 2048
+// keys costs 66 barrier-separated stages, 170 us per guide), fetches their terms -- all of the slice's at once -- and
+// drops them at their ranks; wave 0 then walks the terms in LDS.  Such a guide usually leaves through the early exit
+// (:467-496) inside its first slice (median: 295 hits walked of 1024 found), and the slices behind the exit are never
+// touched.  A guide with a slice of more than kMidSlice hits is handed on to k_replay_big (second list).
+constexpr uint32_t kMidSlice = 1024;
 __global__ __launch_bounds__(256) void k_replay_mid(ImageView v, Workspace ws, const uint64_t *__restrict__ guides,
                                                     ScoreParams p, double *__restrict__ out_mit,
                                                     double *__restrict__ out_cfd, uint32_t *__restrict__ out_kept,
                                                     issl_hit *__restrict__ out_hits)
 {
     short_kernel_priority();
-    __shared__ uint64_t keys[kMidHits];
-    __shared__ uint64_t head[kMidHead];
-    __shared__ uint32_t hist[256];
-    __shared__ uint32_t top_s, head_groups, head_count, head_fill, stopped_s;
+    __shared__ __attribute__((aligned(16))) uint32_t head[kMidSlice]; // the slice's keys: site ids or positions (distinct) ...
+    __shared__ uint16_t head_idx[kMidSlice];                           // ... and the index of the hit each belongs to
+    __shared__ double tm[kMidSlice], tc[kMidSlice];                    // its terms in key order
+    __shared__ uint32_t slice_cnt[kMaxSlices];
+    __shared__ uint32_t head_fill, stopped_s, carry_kept;
     __shared__ double carry_mit, carry_cfd;
-    __shared__ uint32_t carry_kept;
     const bool calc_mit = p.method == ISSL_METHOD_MIT || p.method == ISSL_METHOD_AND || p.method == ISSL_METHOD_OR ||
                           p.method == ISSL_METHOD_AVG;
     const bool calc_cfd = p.method == ISSL_METHOD_CFD || p.method == ISSL_METHOD_AND || p.method == ISSL_METHOD_OR ||
@@ -1858,72 +1859,107 @@ __global__ __launch_bounds__(256) void k_replay_mid(ImageView v, Workspace ws, c
         const uint32_t h = ws.goff[g + 1] - h0;
         if (h > kMidHits) continue; // k_replay_big's (uniform over the workgroup)
         const uint64_t gsig = guides[g];
-        hist[threadIdx.x] = 0;
-        if (threadIdx.x == 0) { top_s = 0; head_fill = 0; stopped_s = 0; carry_mit = 0.0; carry_cfd = 0.0; carry_kept = 0; }
+        const uint64_t *__restrict__ gkeys = ws.sorted + h0;
+        // diagnostics (ISSL_SCAN_STAMPS): phase clocks of the first 4096 listed guides, like k_replay_big's
+        unsigned long long *st = (ws.stamps && b < 4096u) ? ws.stamps + 65536u + 16u * b : nullptr;
+        if (st && threadIdx.x == 0) { st[0] = __builtin_amdgcn_s_memrealtime(); st[1] = h; st[15] = blockIdx.x; st[14] = 1; }
+        if (threadIdx.x < kMaxSlices) slice_cnt[threadIdx.x] = 0;
+        if (threadIdx.x == 0) { stopped_s = 0; carry_mit = 0.0; carry_cfd = 0.0; carry_kept = 0; }
         __syncthreads();
-        uint32_t m = 0;
-        for (uint32_t i = threadIdx.x; i < h; i += blockDim.x) {
-            const uint64_t k37 = ws.sorted[h0 + i] & ((1ull << kKeyGuideShift) - 1ull);
-            keys[i] = (k37 << 11) | i;
-            const uint32_t k32 = static_cast<uint32_t>(k37 >> 5);
-            m = k32 > m ? k32 : m;
+        // the guide's keys, eight per thread, all asked for at once and kept in registers: every later phase works from
+        // them (a phase that goes back to memory costs a round trip of microseconds, and a guide is a chain of phases)
+        uint64_t mykey[kMidHits / 256];
+#pragma unroll
+        for (uint32_t k = 0; k < kMidHits / 256; ++k) mykey[k] = k * 256u + threadIdx.x < h ? gkeys[k * 256u + threadIdx.x] : ~0ull;
+#pragma unroll
+        for (uint32_t k = 0; k < kMidHits / 256; ++k) { // hits per slice (one LDS atomic per wave and slice present)
+            if (k * 256u >= h) break;
+            const uint32_t sl = mykey[k] != ~0ull ? static_cast<uint32_t>(mykey[k] >> kKeySliceShift) & kKeySliceMask : kKeySliceMask;
+            for (uint32_t s2 = 0; s2 < v.n_slices; ++s2) {
+                const uint64_t mm = __ballot(sl == s2);
+                if (mm != 0ull && lane == 0) atomicAdd(&slice_cnt[s2], static_cast<uint32_t>(__builtin_popcountll(mm)));
+            }
         }
-        atomicMax(&top_s, m);
         __syncthreads();
-        const uint32_t top = top_s;
-        const uint32_t shift = top < 256u ? 0u : 24u - static_cast<uint32_t>(__builtin_clz(top)); // group = key >> (16 + shift) < 256
-        for (uint32_t i = threadIdx.x; i < h; i += blockDim.x) atomicAdd(&hist[static_cast<uint32_t>(keys[i] >> 16) >> shift], 1u);
-        __syncthreads();
-        if (threadIdx.x == 0) { // the leading groups that together hold >= 512 keys (or all of them)
-            uint32_t run = 0, nb = 0;
-            while (nb < 256u && run < 512u) run += hist[nb++];
-            head_groups = nb;
-            head_count = run;
+        uint32_t longest = 0;
+        for (uint32_t s2 = 0; s2 < v.n_slices; ++s2) longest = slice_cnt[s2] > longest ? slice_cnt[s2] : longest;
+        if (longest > kMidSlice) { // (uniform) a slice that does not fit: the slice-by-slice kernel with the larger buffers
+            if (threadIdx.x == 0) ws.gcur_big2[atomicAdd(&ws.counters->n_big2, 1u)] = g;
+            continue;
         }
-        __syncthreads();
-        // Walks keys sorted[from .. to) of `arr` (in key order) with the running totals carried in LDS by wave 0.
-        auto walk = [&](const uint64_t *arr, uint32_t from, uint32_t to) {
-            if (threadIdx.x < 64) {
+        if (st && threadIdx.x == 0) st[2] = __builtin_amdgcn_s_memrealtime();
+        uint32_t walked = 0; // hits of the slices done so far (= where this slice's hits start in scoring order)
+        for (uint32_t s2 = 0; s2 < v.n_slices; ++s2) {
+            const uint32_t len = slice_cnt[s2];
+            if (len == 0) continue;
+            if (threadIdx.x == 0) head_fill = 0;
+            __syncthreads();
+#pragma unroll
+            for (uint32_t k = 0; k < kMidHits / 256; ++k) { // gather the slice's keys (one cursor bump per wave)
+                if (k * 256u >= h) break;
+                const uint64_t key = mykey[k];
+                const bool mine = key != ~0ull && (static_cast<uint32_t>(key >> kKeySliceShift) & kKeySliceMask) == s2;
+                const uint64_t mm = __ballot(mine);
+                if (mm == 0ull) continue;
+                uint32_t at = 0;
+                if (lane == 0) at = atomicAdd(&head_fill, static_cast<uint32_t>(__builtin_popcountll(mm)));
+                at = __builtin_amdgcn_readfirstlane(at);
+                if (mine) {
+                    const uint32_t to = at + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mm >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mm), 0u));
+                    head[to] = static_cast<uint32_t>(key);
+                    head_idx[to] = static_cast<uint16_t>(k * 256u + threadIdx.x);
+                }
+            }
+            __syncthreads();
+            if (threadIdx.x < 4u && len + threadIdx.x < ((len + 3u) & ~3u)) head[len + threadIdx.x] = 0xFFFFFFFFu; // (read four at a time)
+            __syncthreads();
+            {   // rank by counting (the keys are distinct: ids / positions are), then the terms to their ranks
+                uint32_t mine[4], rk[4] = {0, 0, 0, 0};
+#pragma unroll
+                for (uint32_t k = 0; k < 4; ++k) mine[k] = threadIdx.x + k * 256u < len ? head[threadIdx.x + k * 256u] : 0xFFFFFFFFu;
+                const uint4 *quads = reinterpret_cast<const uint4 *>(head);
+#pragma unroll 4
+                for (uint32_t j = 0; j < (len + 3u) / 4u; ++j) {
+                    const uint4 q = quads[j];
+#pragma unroll
+                    for (uint32_t k = 0; k < 4; ++k)
+                        rk[k] += (q.x < mine[k] ? 1u : 0u) + (q.y < mine[k] ? 1u : 0u) + (q.z < mine[k] ? 1u : 0u) + (q.w < mine[k] ? 1u : 0u);
+                }
+#pragma unroll
+                for (uint32_t k = 0; k < 4; ++k) {
+                    if (threadIdx.x + k * 256u >= len) continue;
+                    const uint32_t idx = head_idx[threadIdx.x + k * 256u];
+                    const double2 t2 = terms2[h0 + idx];
+                    tm[rk[k]] = t2.x;
+                    tc[rk[k]] = t2.y;
+                    if (out_hits)
+                        out_hits[h0 + walked + rk[k]] = hit_terms(v, gsig, g, (static_cast<uint64_t>(g) << kKeyGuideShift) |
+                                                                      (static_cast<uint64_t>(s2) << kKeySliceShift) | mine[k],
+                                                                  calc_mit, calc_cfd, true).rec;
+                }
+            }
+            __syncthreads();
+            if (st && threadIdx.x == 0 && walked == 0) { st[3] = __builtin_amdgcn_s_memrealtime(); st[4] = len; }
+            if (threadIdx.x < 64) { // wave 0 walks the slice
                 double tot_mit = carry_mit, tot_cfd = carry_cfd;
                 uint32_t kept = carry_kept;
                 bool stop = false;
-                for (uint32_t base = from; base < to && !stop; base += 64) {
+                for (uint32_t base = 0; base < len && !stop; base += 64) {
                     const uint32_t idx = base + lane;
-                    double2 mine = make_double2(0.0, 0.0);
-                    if (idx < to) {
-                        const uint64_t sv = arr[idx];
-                        mine = terms2[h0 + static_cast<uint32_t>(sv & 2047ull)];
-                        if (out_hits)
-                            out_hits[h0 + idx] = hit_terms(v, gsig, g, (static_cast<uint64_t>(g) << kKeyGuideShift) | (sv >> 11), calc_mit, calc_cfd, true).rec;
-                    }
-                    stop = accumulate_chunk(mine.x, mine.y, (to - base < 64u) ? to - base : 64u, p, lane, tot_mit, tot_cfd, kept);
+                    stop = accumulate_chunk(idx < len ? tm[idx] : 0.0, idx < len ? tc[idx] : 0.0, (len - base < 64u) ? len - base : 64u, p,
+                                            lane, tot_mit, tot_cfd, kept);
                 }
                 if (lane == 0) { carry_mit = tot_mit; carry_cfd = tot_cfd; carry_kept = kept; stopped_s = stop ? 1u : 0u; }
             }
             __syncthreads();
-        };
-        uint32_t walked = 0;
-        const uint32_t cnt = head_count, nb = head_groups;
-        if (cnt <= kMidHead && cnt < h) {
-            for (uint32_t i = threadIdx.x; i < h; i += blockDim.x) {
-                const uint64_t k = keys[i];
-                if ((static_cast<uint32_t>(k >> 16) >> shift) < nb) head[atomicAdd(&head_fill, 1u)] = k;
-            }
-            __syncthreads();
-            wave_sort(head, cnt);
-            __syncthreads();
-            walk(head, 0u, cnt);
-            walked = cnt;
-        }
-        if (stopped_s == 0u) { // (uniform) all keys after all
-            wave_sort(keys, h);
-            __syncthreads();
-            walk(keys, walked, h);
+            walked += len;
+            if (stopped_s != 0u) break; // (uniform) the slices behind the exit are never touched
         }
         if (threadIdx.x == 0) {
             out_mit[g] = 10000.0 / (100.0 + carry_mit); // :505
             out_cfd[g] = 10000.0 / (100.0 + carry_cfd); // :506
             if (out_kept) out_kept[g] = carry_kept;
+            if (st) { st[7] = __builtin_amdgcn_s_memrealtime(); st[8] = carry_kept; st[9] = walked; }
         }
         __syncthreads();
     }
@@ -1965,19 +2001,22 @@ __device__ __forceinline__ void rank_sort_slice(const uint32_t *pos_lds, uint32_
 // position): one counting pass groups the positions by those bits in `grouped`, then every position is ranked inside
 // its group -- len * len / 256 comparisons on evenly spread positions instead of len * len.
 __device__ __forceinline__ void rank_sort_slice_grouped(const uint32_t *pos_lds, uint32_t *grouped, uint32_t *group_at /*[257]*/,
-                                                        uint32_t *group_cur /*[256]*/, uint32_t *max_pos, uint32_t len,
-                                                        uint64_t high_bits, uint64_t *__restrict__ dst)
+                                                        uint32_t *group_cur /*[256]*/, uint32_t *max_pos, uint32_t *min_pos,
+                                                        uint32_t len, uint64_t high_bits, uint64_t *__restrict__ dst)
 {
     if (threadIdx.x < 256) group_cur[threadIdx.x] = 0;
-    if (threadIdx.x == 0) *max_pos = 0;
+    if (threadIdx.x == 0) { *max_pos = 0; *min_pos = 0xFFFFFFFFu; }
     __syncthreads();
-    uint32_t m = 0;
-    for (uint32_t i = threadIdx.x; i < len; i += blockDim.x) m = pos_lds[i] > m ? pos_lds[i] : m;
+    uint32_t m = 0, mn = 0xFFFFFFFFu;
+    for (uint32_t i = threadIdx.x; i < len; i += blockDim.x) { const uint32_t q = pos_lds[i]; m = q > m ? q : m; mn = q < mn ? q : mn; }
     atomicMax(max_pos, m);
+    atomicMin(min_pos, mn);
     __syncthreads();
-    const uint32_t top = *max_pos;
-    const uint32_t shift = top < 256u ? 0u : 24u - static_cast<uint32_t>(__builtin_clz(top)); // group = pos >> shift < 256
-    for (uint32_t i = threadIdx.x; i < len; i += blockDim.x) atomicAdd(&group_cur[pos_lds[i] >> shift], 1u);
+    // (the hits of a guide in one slice share the slice's bases: on a text-sorted index their ids lie in a narrow range far
+    // from zero, so the groups divide the range they span, not the values)
+    const uint32_t low = *min_pos, top = *max_pos - low;
+    const uint32_t shift = top < 256u ? 0u : 24u - static_cast<uint32_t>(__builtin_clz(top)); // group = (pos - low) >> shift < 256
+    for (uint32_t i = threadIdx.x; i < len; i += blockDim.x) atomicAdd(&group_cur[(pos_lds[i] - low) >> shift], 1u);
     __syncthreads();
     if (threadIdx.x < 64) { // exclusive scan of the 256 group sizes by one wave, 4 per lane
         uint32_t v4[4], sum = 0;
@@ -1996,12 +2035,12 @@ __device__ __forceinline__ void rank_sort_slice_grouped(const uint32_t *pos_lds,
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < len; i += blockDim.x) {
         const uint32_t pos = pos_lds[i];
-        grouped[atomicAdd(&group_cur[pos >> shift], 1u)] = pos;
+        grouped[atomicAdd(&group_cur[(pos - low) >> shift], 1u)] = pos;
     }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < len; i += blockDim.x) {
         const uint32_t pos = grouped[i];
-        const uint32_t g0 = group_at[pos >> shift], g1 = group_at[(pos >> shift) + 1u];
+        const uint32_t g0 = group_at[(pos - low) >> shift], g1 = group_at[((pos - low) >> shift) + 1u];
         uint32_t rk = g0;
         for (uint32_t j = g0; j < g1; ++j) rk += grouped[j] < pos ? 1u : 0u;
         dst[rk] = high_bits | pos;
@@ -2021,7 +2060,7 @@ __global__ __launch_bounds__(THREADS) void k_replay_big(ImageView v, Workspace w
     short_kernel_priority();
     __shared__ __attribute__((aligned(16))) uint32_t pos_lds[LDS_HITS];
     __shared__ uint32_t grouped[LDS_HITS];
-    __shared__ uint32_t group_at[257], group_cur[256], max_pos;
+    __shared__ uint32_t group_at[257], group_cur[256], max_pos, min_pos;
     __shared__ uint32_t slice_cnt[kMaxSlices], slice_off[kMaxSlices + 1], slice_cur[kMaxSlices];
     __shared__ uint32_t walk_stopped, head_groups, head_count, head_fill;
     const bool calc_mit = p.method == ISSL_METHOD_MIT || p.method == ISSL_METHOD_AND || p.method == ISSL_METHOD_OR ||
@@ -2029,15 +2068,17 @@ __global__ __launch_bounds__(THREADS) void k_replay_big(ImageView v, Workspace w
     const bool calc_cfd = p.method == ISSL_METHOD_CFD || p.method == ISSL_METHOD_AND || p.method == ISSL_METHOD_OR ||
                           p.method == ISSL_METHOD_AVG;
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t n_big = ws.counters->n_big;
-    for (uint32_t b = blockIdx.x; b < n_big; b += gridDim.x) {
-        const uint32_t g = ws.gcur_big[b];
+    const uint32_t n_big = ws.counters->n_big, n_big2 = ws.counters->n_big2;
+    for (uint32_t b = blockIdx.x; b < n_big + n_big2; b += gridDim.x) {
+        // first the list of all guides with more than kReplayLds hits, then the ones k_replay_mid handed on
+        const bool handed_on = b >= n_big;
+        const uint32_t g = handed_on ? ws.gcur_big2[b - n_big] : ws.gcur_big[b];
         const uint32_t h0 = ws.goff[g];
         const uint32_t h = ws.goff[g + 1] - h0;
         // k_replay_mid's, or the other build's: up to kBigSmall hits a 256-thread workgroup with 2048 hits per slice in
         // LDS (eight per CU: what such a guide costs is a chain of barriers and memory round trips, and what counts is
         // how many are in flight), beyond that 1024 threads with 7680 (two per CU).  (uniform over the workgroup)
-        if (h <= kMidHits || (h <= kBigSmall) != (THREADS < 1024u)) continue;
+        if ((h <= kMidHits && !handed_on) || (h <= kBigSmall) != (THREADS < 1024u)) continue;
         const uint64_t gsig = guides[g];
         uint64_t *seg = ws.sorted + h0;
         uint64_t *tmp = ws.raw + h0; // the raw records are dead once they are grouped; the buffer holds >= all hits
@@ -2126,55 +2167,62 @@ __global__ __launch_bounds__(THREADS) void k_replay_big(ImageView v, Workspace w
             };
             auto sort_in_lds = [&](uint32_t n) { // pos_lds[0 .. n) -> dst[0 .. n) in key order
                 if (n <= THREADS) rank_sort_slice<1, THREADS>(pos_lds, n, high_bits, dst);
-                else rank_sort_slice_grouped(pos_lds, grouped, group_at, group_cur, &max_pos, n, high_bits, dst);
+                else rank_sort_slice_grouped(pos_lds, grouped, group_at, group_cur, &max_pos, &min_pos, n, high_bits, dst);
                 __syncthreads();
             };
             uint32_t walked = 0;
             if (threadIdx.x == 0) walk_stopped = 0;
             __syncthreads();
-            if (len <= LDS_HITS) {
-                for (uint32_t i = threadIdx.x; i < ((len + 3u) & ~3u); i += blockDim.x)
-                    pos_lds[i] = i < len ? static_cast<uint32_t>(tmp[off + i]) : 0xFFFFFFFFu;
-                __syncthreads();
-                sort_in_lds(len);
-            } else {
-                // A slice too long for the LDS (a repeat: tens of thousands of hits).  Such a guide all but always leaves
-                // through the early exit within the hits with the smallest ids, so those are tried first: the positions are
-                // counted by their top eight bits, the leading groups that fit the LDS together are gathered, sorted and
-                // walked; only a guide that survives them pays for the sort of the whole slice (a bitonic network in HBM:
-                // ~140 stages of memory round trips, which used to set the kernel's duration).
+            if (len > THREADS) {
+                // A guide like this all but always leaves through the early exit within the hits with the smallest ids of
+                // its first slice (median: ~250 hits walked of thousands found), so those are tried first: the slice's
+                // positions are counted by their top eight bits, the leading groups that hold at least 384 of them are
+                // gathered, ranked by counting and walked; only a guide that survives them pays for the order of the whole
+                // slice (a ranking inside unevenly filled groups in LDS; beyond the LDS a bitonic network in HBM of ~140
+                // stages of memory round trips, which used to set the kernel's duration).
                 if (threadIdx.x < 256) group_cur[threadIdx.x] = 0;
-                if (threadIdx.x == 0) { max_pos = 0; head_fill = 0; }
+                if (threadIdx.x == 0) { max_pos = 0; min_pos = 0xFFFFFFFFu; head_fill = 0; }
                 __syncthreads();
-                uint32_t m = 0;
-                for (uint32_t i = threadIdx.x; i < len; i += blockDim.x) { const uint32_t q = static_cast<uint32_t>(tmp[off + i]); m = q > m ? q : m; }
+                uint32_t m = 0, mn = 0xFFFFFFFFu;
+                for (uint32_t i = threadIdx.x; i < len; i += blockDim.x) { const uint32_t q = static_cast<uint32_t>(tmp[off + i]); m = q > m ? q : m; mn = q < mn ? q : mn; }
                 atomicMax(&max_pos, m);
+                atomicMin(&min_pos, mn);
                 __syncthreads();
-                const uint32_t top = max_pos;
+                const uint32_t low = min_pos, top = max_pos - low; // (groups of the RANGE the slice's ids span: see rank_sort_slice_grouped)
                 const uint32_t shift = top < 256u ? 0u : 24u - static_cast<uint32_t>(__builtin_clz(top));
-                for (uint32_t i = threadIdx.x; i < len; i += blockDim.x) atomicAdd(&group_cur[static_cast<uint32_t>(tmp[off + i]) >> shift], 1u);
+                for (uint32_t i = threadIdx.x; i < len; i += blockDim.x) atomicAdd(&group_cur[(static_cast<uint32_t>(tmp[off + i]) - low) >> shift], 1u);
                 __syncthreads();
-                if (threadIdx.x == 0) { // leading groups that fit together
+                if (threadIdx.x == 0) {
                     uint32_t run = 0, nb = 0;
-                    while (nb < 256u && run + group_cur[nb] <= LDS_HITS) run += group_cur[nb++];
+                    while (nb < 256u && run < 384u) run += group_cur[nb++];
                     head_groups = nb;
                     head_count = run;
                 }
                 __syncthreads();
                 const uint32_t nb = head_groups, cnt = head_count;
-                if (cnt != 0u) {
+                constexpr uint32_t kHeadMax = 4u * THREADS < LDS_HITS ? 4u * THREADS : LDS_HITS; // what rank_sort_slice<4> takes
+                if (cnt <= kHeadMax && cnt < len) {
                     for (uint32_t i = threadIdx.x; i < len; i += blockDim.x) {
                         const uint32_t q = static_cast<uint32_t>(tmp[off + i]);
-                        if ((q >> shift) < nb) pos_lds[atomicAdd(&head_fill, 1u)] = q;
+                        if (((q - low) >> shift) < nb) pos_lds[atomicAdd(&head_fill, 1u)] = q;
                     }
                     __syncthreads();
                     for (uint32_t i = cnt + threadIdx.x; i < ((cnt + 3u) & ~3u); i += blockDim.x) pos_lds[i] = 0xFFFFFFFFu;
                     __syncthreads();
-                    sort_in_lds(cnt);
+                    if (cnt <= THREADS) rank_sort_slice<1, THREADS>(pos_lds, cnt, high_bits, dst);
+                    else rank_sort_slice<4, THREADS>(pos_lds, cnt, high_bits, dst);
+                    __syncthreads();
                     walk(0u, cnt);
                     walked = cnt;
                 }
-                if (walk_stopped == 0u && walked < len) { // (uniform) the whole slice after all
+            }
+            if (walk_stopped == 0u && walked < len) { // (uniform) the whole slice in key order
+                if (len <= LDS_HITS) {
+                    for (uint32_t i = threadIdx.x; i < ((len + 3u) & ~3u); i += blockDim.x)
+                        pos_lds[i] = i < len ? static_cast<uint32_t>(tmp[off + i]) : 0xFFFFFFFFu;
+                    __syncthreads();
+                    sort_in_lds(len);
+                } else {
                     for (uint32_t i = threadIdx.x; i < len; i += blockDim.x) dst[i] = tmp[off + i];
                     __syncthreads();
                     wave_sort(dst, len);
