@@ -507,10 +507,9 @@ __global__ __launch_bounds__(256) void k_fine_count(ImageView v, const uint64_t 
     cnt[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t g0 = gstart[b], n = gfill[b];
-    for (uint32_t at = threadIdx.x; at < n * ways; at += 256) { // one (guide, way) pair per thread and step
-        const uint32_t i = at / ways, way = at - i * ways;
+    for (uint32_t i = threadIdx.x; i < n; i += 256) { // one guide per thread and step: its loads once, its ways from registers
         const uint32_t gj = static_cast<uint32_t>(guides[gidx[g0 + i]] >> succ_shift) & 0xFFu;
-        atomicAdd(&cnt[fine_way(gj, way)], 1u);
+        for (uint32_t way = 0; way < ways; ++way) atomicAdd(&cnt[fine_way(gj, way)], 1u);
     }
     __syncthreads();
     const uint32_t w = threadIdx.x, c = cnt[w];
@@ -616,7 +615,7 @@ __global__ __launch_bounds__(256) void k_fine_scatter(ImageView v, const uint64_
     short_kernel_priority();
     if (!plan->fine) return; // the bucket-level plan stays
     __shared__ uint64_t lds[256];
-    __shared__ uint32_t slot_of[256], cursor[256];
+    __shared__ uint32_t slot_of[256], cursor[256], has_cands[256];
     const uint32_t b = blockIdx.x, slice = b >> v.slice_width;
     const uint32_t succ_shift = v.slice_width * ((slice + 1u) % v.n_slices);
     const uint32_t w = threadIdx.x;
@@ -666,18 +665,23 @@ __global__ __launch_bounds__(256) void k_fine_scatter(ImageView v, const uint64_
         // padding slots behind the group's guides
         for (uint32_t k2 = c; k2 < static_cast<uint32_t>(slots); ++k2) { fmeta[slot_at + k2] = FineMeta{kNoGuide, 0u, 0ull}; fword[slot_at + k2] = kPadGuideWord; }
     }
+    has_cands[w] = s1 > s0 ? 1u : 0u;
     __syncthreads();
+    // One guide per thread and step: its index, scan word and signature are loaded once (a chain of two round trips),
+    // its 13 (or 1) places come from registers and LDS.  (One (guide, way) pair per thread and step repeated that chain
+    // 13 times over: 0.18 ms at 100 k guides, two thirds of the binning.)
     const uint32_t g0 = gstart[b], n = gfill[b];
-    for (uint32_t at = threadIdx.x; at < n * ways; at += 256) { // one (guide, way) pair per thread and step
-        const uint32_t i = at / ways, way = at - i * ways;
+    for (uint32_t i = threadIdx.x; i < n; i += 256) {
         const uint32_t guide = gidx[g0 + i], word = gword[g0 + i];
         const uint64_t gsig = guides[guide];
         const uint32_t gj = static_cast<uint32_t>(gsig >> succ_shift) & 0xFFu;
-        const uint32_t ww = fine_way(gj, way);
-        if (ss[ww + 1] == ss[ww]) continue; // no candidates there: the group has no slots
-        const uint32_t slot = slot_of[ww] + atomicAdd(&cursor[ww], 1u);
-        fword[slot] = word;
-        fmeta[slot] = FineMeta{guide, (b << 8) | ww, gsig};
+        for (uint32_t way = 0; way < ways; ++way) {
+            const uint32_t ww = fine_way(gj, way);
+            if (!has_cands[ww]) continue; // no candidates there: the group has no slots
+            const uint32_t slot = slot_of[ww] + atomicAdd(&cursor[ww], 1u);
+            fword[slot] = word;
+            fmeta[slot] = FineMeta{guide, (b << 8) | ww, gsig};
+        }
     }
 }
 
