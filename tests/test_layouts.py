@@ -112,6 +112,40 @@ def test_narrow_slices_reproduce_the_reference(name, layout):
         assert r.returncode == 0 and r.stdout.decode() == g.expected["and|75|4"]
 
 
+def test_compact_image_with_host_lists_built_on_the_device_and_shared_by_a_node(golden_uniform, tmp_path):
+    """The layout of an index beyond the HBM end to end at golden size: built ON the device from signatures + counts with
+    the slice lists going to pinned host memory, written back out (the lists come from that host copy) byte-identical to
+    the reference-built .issl, scored, and shared by a node of two replicas that adopt the hot image and the ONE host
+    buffer."""
+    g = golden_uniform
+    host = ca.IsslIndex.open(g.issl)
+    n = host.header["n_sites"]
+    data = g.issl.read_bytes()
+    off_sites = 48 + 16 * host.header["n_scores"]
+    sigs = np.frombuffer(data, dtype=np.uint64, count=n, offset=off_sites).copy()
+    entries0 = np.frombuffer(data, dtype=np.uint64, count=n, offset=off_sites + 8 * n + 8 * 5 * 256)   # slice 0's lists
+    occ = np.zeros(n, dtype=np.uint32)
+    occ[(entries0 & np.uint64(0xFFFFFFFF)).astype(np.int64)] = (entries0 >> np.uint64(32)).astype(np.uint32)
+    host.close()
+    ix = ca.IsslIndex.build_on_device(sigs, occ, device=0, n_lines=int(occ.sum()), options={"compact": 1, "host_cold": 1})
+    _check_layout(ix, "compact_cold")
+    assert ix.cold()[1] >= 40 * n
+    out = tmp_path / "roundtrip.issl"
+    ix.write(out)
+    assert out.read_bytes() == data
+    guides = ca.encode_guides([s.encode() for s in g.guides])
+    mit, cfd = ix.score(guides, 4, 75.0, "and")
+    assert ca.format_scores(guides, mit, cfd, "and") == g.expected["and|75|4"]
+    assert np.array_equal(ix.dump_hits(guides, 4, 0.0, "and"), g.hits(0))
+    node = ca.IsslNode(ix, devices=[0, 0])
+    try:
+        mit, cfd = node.score(guides, 4, 75.0, "and")
+        assert ca.format_scores(guides, mit, cfd, "and") == g.expected["and|75|4"]
+    finally:
+        node.close()
+        ix.close()
+
+
 def test_layout_sizes(golden_uniform):
     """HBM bytes per layout, in the order an upload tries them (issl_index_device_bytes needs no device)."""
     size = {}
