@@ -187,3 +187,37 @@ def test_scan_word_packing_host_model():
         mm = ((x & 0xAAAAAAAAAAAAAAAA) >> 1) | (x & 0x5555555555555555)
         y = scan_word(a, s) ^ scan_word(b, s)
         assert bin((y | (y >> 16)) & 0xFFFF).count("1") == bin(mm).count("1")
+
+
+def test_image_layouts_and_their_sizes(golden_uniform):
+    """The layouts an upload tries, in order, and what each keeps in HBM per site (issl_index_device_bytes needs no
+    device): the sections that differ between them (at scale: sorted 152 B per site, compact 92, compact with the slice
+    lists in host memory 52; list order 108 / 68, with site table and lists in host memory 25)."""
+    n = 8000
+    sizes = {}
+    for name, opts in {"sorted": {"sorted_layout": 1, "compact": 0, "host_cold": 0}, "compact": {"compact": 1, "host_cold": 0},
+                       "compact_cold": {"compact": 1, "host_cold": 1}, "list_esig": {"sorted_layout": 0, "inline_sigs": 1, "host_cold": 0},
+                       "list": {"sorted_layout": 0, "inline_sigs": 0, "host_cold": 0}, "host_cold": {"sorted_layout": 0, "host_cold": 1}}.items():
+        ix = ca.IsslIndex.open(golden_uniform.issl)
+        for k, v in opts.items():
+            ix.set_option(k, v)
+        sizes[name] = ix.device_bytes()
+        ix.close()
+    auto = ca.IsslIndex.open(golden_uniform.issl)
+    assert auto.device_bytes() == sizes["sorted"]          # what an upload tries first
+    auto.close()
+    ref = ca.IsslIndex.open(golden_uniform.issl)
+    tiles = int(((ref.bucket_sizes() + 2047) // 2048).sum())     # every bucket is padded to whole tiles of 2048 candidates
+    ref.close()
+    slack = 16 * 256                                             # (sections are 256-byte aligned)
+    assert abs((sizes["sorted"] - sizes["compact"]) - 12 * 2048 * tiles) <= slack         # 16-byte records vs 4-byte ids per stream position
+    assert abs((sizes["compact"] - sizes["compact_cold"]) - 40 * n) <= slack               # the slice lists
+    assert abs((sizes["list_esig"] - sizes["list"]) - 40 * n) <= slack                     # the in-list signatures
+    assert abs((sizes["list"] - sizes["host_cold"]) - (48 - 5) * n) <= slack               # site table + lists out, one byte per entry in
+    assert abs((sizes["compact_cold"] - sizes["host_cold"]) - (4 * 2048 * tiles + 12 * n - 5 * n)) <= slack + 4 * 1280 * 257 + 256
+    bad = ca.IsslIndex.open(golden_uniform.issl)
+    bad.set_option("sorted_layout", 0).set_option("compact", 1)
+    bad.set_option("inline_sigs", 1)
+    with pytest.raises(ca.IsslError):
+        ca.IsslIndex.open(golden_uniform.issl).set_option("compact", 2)
+    bad.close()
