@@ -23,23 +23,25 @@ namespace issl {
 //   sites          u64[N]      packed signatures                (:200-204)
 //   entries        u64[N*S]    bucket contents occ<<32|id       (:235-240)
 //   mit_dense      f64[2^20]   local MIT scores indexed by the 20 mismatch flags (when the table allows it)
-//   esig           u64[N*S]    (optional) the signature of the site behind every list entry, in list order: the
-//                              exact check and the replay then need one HBM access per hit instead of two
-//                              dependent ones (entries -> sites); written while the scan stream is packed
-//   scan           u32[tiles*kTileCands]  the scan stream: for every bucket, in bucket order, the
-//                              candidate signature with its own slice removed, 16 positions, even
-//                              bits in the low half-word and odd bits in the high half-word;
-//                              each bucket zero-padded to a whole number of tiles.
+//   scan           u32[tiles*kTileCands]  the scan stream: for every bucket, in bucket order, the candidate signature
+//                              with its own slice removed, 16 positions, bit-sliced (32 candidates per plane word,
+//                              plane_word()); each bucket zero-padded to a whole number of tiles
+//   sorted layouts (every bucket ordered by the byte of the successor slice; what the pruned scan needs):
+//     sub_start    u32[nb*257] inside every bucket, the first stream position of every successor-byte value
+//     srec         StreamRec[tiles*kTileCands]  per stream position: signature | 24-bit count, site id, list position; or
+//     sid          u32[tiles*kTileCands]        (compact) per stream position: the site id alone
+//     site_occ     u32[N]      occurrence count by site id
+//   list-order layouts:
+//     esig         u64[N*S]    (optional) the signature of the site behind every list entry, in list order
+//     occ8         u8[N*S]     (host-cold only) min(occurrences, 255) per list entry
 //
-// Hot and cold.  The scan reads ONLY `scan` (20 B per site); `sites` / `entries` / `esig` (48-88 B per site) are read
-// for the ~2e-5 of the comparisons that come within max_dist (k_verify, k_replay).  When the whole image does not
-// fit the free HBM (the format's 32-bit ids allow 4.29 G sites = 292 GB, and a resident server keeps several
-// indexes) the cold sections live in mapped, pinned HOST memory instead (`cold_on_host`): their offsets are then
-// relative to that second buffer, `total_bytes` covers the hot part only, and the kernels reach them across PCIe
-// through the same ImageView pointers -- but rarely: the candidate's signature is rebuilt from its 32 bit planes in
-// the scan stream (8 loads of 16 B from HBM; the slice's own byte is the bucket number), and the occurrence count comes
-// from `occ8`, one saturating byte per list entry kept in HBM with the hot part (5 B per site).  Host memory is read
-// only for occurrence counts >= 255 and for the site ids of issl_dump_hits.
+// Hot and cold.  The scan reads ONLY `scan` (20 B per site); everything else is read for the ~2e-5 of the comparisons
+// that come within max_dist (k_verify, the replay kernels).  Sections may live in mapped, pinned HOST memory
+// (`cold_on_host`, layout_choices() in issl_capi.cpp): the slice lists of a compact sorted image -- which scoring never
+// reads: 52 B per site stay in HBM, so that every index the format can express (4.29 G sites) is scored from one GPU's
+// HBM --, or site table AND lists of a list-order image (25 B per site in HBM: there the candidate's signature is rebuilt
+// from its 32 bit planes in the scan stream, the count comes from `occ8`, and host memory is read only for counts >= 255
+// and for issl_dump_hits).  Their offsets are then relative to that second buffer and `total_bytes` covers the HBM part.
 constexpr uint64_t kImageMagic = 0x314C535349444D41ull; // "AMDISSL1"
 constexpr uint32_t kImageVersion = 7;
 constexpr uint32_t kTileCands = 2048; // candidates per scan tile: one wave, 64 lanes x 32 registers
