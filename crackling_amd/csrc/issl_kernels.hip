@@ -1,18 +1,21 @@
 // HIP kernels of the ISSL off-target scorer for gfx950 (MI355X).  Wave = 64 lanes.
 //
 // Pipeline for one batch of guides (reference: src/ISSL/isslScoreOfftargets.cpp:307-511):
-//   bin_*      group the guides of the batch by (slice, slice value) = by index bucket       (A3)
-//   scan       every bucket tile against every guide of that bucket: XOR, fold, popcount     (A4-A6)
-//              -> append (guide, slice, position) keys of candidates within max_dist that were
-//                 not already met in an earlier slice (replaces the seen-bitmap, A7)
-//   group_*    counting sort of the keys by guide
-//   replay     per guide: order its keys by (slice, position) = the reference's scan order, then
-//              accumulate MIT / CFD sequentially with the reference's early exit            (A8-A11)
+//   bin_*      group the guides of the batch by (slice, slice value) = by index bucket; on a sorted image
+//              once more by (bucket, byte of the successor slice) for the pruned scan                 (A3)
+//   scan       bucket tiles (pruned: the units of the successor-byte groups that can hold a hit) against
+//              the guides placed there: XOR, fold, popcount, bit-sliced; candidates within max_dist are
+//              NOTED as 8-byte records (guide slot, tile, offset)                                     (A4-A6)
+//   verify     every record: exact test on the whole signatures, first-matching-slice rule (replaces
+//              the seen-bitmap, A7), key (guide, slice, site id or list position), MIT / CFD terms    (A7-A9)
+//   group_*    counting sort of the keys and terms by guide
+//   replay     per guide: its hits in key order = the reference's scan order, terms added sequentially
+//              with the reference's early exit                                                        (A10-A11)
 //
-// The scan is the bandwidth/ALU-critical kernel.  It streams 4 B per candidate (the signature
-// with the bucket's own slice removed, stored bit-sliced: 32 candidates per 32-bit plane) and keeps
-// a tile of 2048 candidates in registers while the guide words of the bucket arrive through scalar
-// loads, so one HBM read of a bucket tile serves every guide of the batch that falls into this bucket.
+// The scan is the ALU-critical kernel.  It streams 4 B per candidate (the signature with the bucket's own
+// slice removed, stored bit-sliced: 32 candidates per 32-bit plane) and keeps a tile of 2048 candidates in
+// registers while the guide words of the item arrive through scalar loads, so one HBM read of a tile serves
+// every guide of the batch that is placed there.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -1484,7 +1487,13 @@ __global__ __launch_bounds__(256) void k_prefix_apply(const uint32_t *__restrict
     for (uint32_t i = 0; i < 8; ++i) {
         val[i] = (base + i < n) ? in[base + i] : 0u;
         s += val[i];
-        if (val[i] > kReplayLds) big[atomicAdd(&counters->n_big, 1u)] = base + i; // guides for k_replay_big
+    }
+    uint32_t nb = 0;
+    for (uint32_t i = 0; i < 8; ++i) nb += val[i] > kReplayLds;
+    if (nb != 0u) { // guides for k_replay_mid / k_replay_big: one reservation per thread
+        uint32_t at = atomicAdd(&counters->n_big, nb);
+        for (uint32_t i = 0; i < 8; ++i)
+            if (val[i] > kReplayLds) big[at++] = base + i;
     }
     uint64_t run = block_exclusive_scan(s, lds, nullptr) + sums[blockIdx.x];
     for (uint32_t i = 0; i < 8; ++i) {
@@ -1495,36 +1504,38 @@ __global__ __launch_bounds__(256) void k_prefix_apply(const uint32_t *__restrict
 
 // Whole prefix sum in one workgroup (used while n is moderate; saves two launches): every thread sums its own run of
 // consecutive counts (16-byte loads), ONE scan over the 1024 run totals, then every thread writes its run's prefixes --
-// two barriers in all, where a loop over chunks of 4096 counts paid three per chunk (0.06 ms at 100 k guides).
+// two barriers in all, where a loop over chunks of 4096 counts paid three per chunk (0.06 ms at 100 k guides).  The list
+// of guides with more than kReplayLds hits comes out of the same scan (their number rides in a second scanned word), in
+// guide order and without an atomic: on indexes where most guides are such (skewed genomes, the 3 G-line index) one
+// returning atomic per guide from a single workgroup cost more than the rest of the grouping (2 ms per 100 k guides).
 __global__ __launch_bounds__(1024) void k_prefix_single(const uint32_t *__restrict__ in, uint32_t n,
                                                         uint32_t *__restrict__ out, uint32_t *__restrict__ big,
                                                         Counters *__restrict__ counters)
 {
     short_kernel_priority();
-    __shared__ uint32_t wave_sum[16];
+    __shared__ uint32_t wave_sum[16], wave_big[16];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t per = ((n + 1023u) / 1024u + 3u) & ~3u; // counts per thread, a multiple of 4: the runs start 16-byte aligned
     const uint32_t i0 = threadIdx.x * per;
-    uint32_t s = 0;
+    uint32_t s = 0, b = 0;
     for (uint32_t k = 0; k < per; k += 4) {
         const uint32_t i = i0 + k;
         uint4 q = make_uint4(0, 0, 0, 0);
         if (i + 3 < n) q = *reinterpret_cast<const uint4 *>(in + i);
         else { if (i < n) q.x = in[i]; if (i + 1 < n) q.y = in[i + 1]; if (i + 2 < n) q.z = in[i + 2]; }
         s += q.x + q.y + q.z + q.w;
-        const uint32_t vals[4] = {q.x, q.y, q.z, q.w};
-        for (uint32_t j = 0; j < 4; ++j)
-            if (vals[j] > kReplayLds) big[atomicAdd(&counters->n_big, 1u)] = i + j; // guides for k_replay_big
+        b += (q.x > kReplayLds) + (q.y > kReplayLds) + (q.z > kReplayLds) + (q.w > kReplayLds);
     }
-    uint32_t x = s; // inclusive scan of s inside the wave
+    uint32_t x = s, xb = b; // inclusive scans of s and b inside the wave
     for (uint32_t d = 1; d < 64; d <<= 1) {
-        const uint32_t y = __shfl_up(x, d, 64);
-        if (lane >= d) x += y;
+        const uint32_t y = __shfl_up(x, d, 64), yb = __shfl_up(xb, d, 64);
+        if (lane >= d) { x += y; xb += yb; }
     }
-    if (lane == 63) wave_sum[wave] = x;
+    if (lane == 63) { wave_sum[wave] = x; wave_big[wave] = xb; }
     __syncthreads();
-    uint32_t run = x - s;
-    for (uint32_t wv = 0; wv < wave; ++wv) run += wave_sum[wv];
+    uint32_t run = x - s, brun = xb - b;
+    for (uint32_t wv = 0; wv < wave; ++wv) { run += wave_sum[wv]; brun += wave_big[wv]; }
+    if (threadIdx.x == 1023u) counters->n_big = brun + b;
     for (uint32_t k = 0; k < per; k += 4) {
         const uint32_t i = i0 + k;
         if (i >= n) break;
@@ -1535,6 +1546,10 @@ __global__ __launch_bounds__(1024) void k_prefix_single(const uint32_t *__restri
         if (i + 3 < n) *reinterpret_cast<uint4 *>(out + i) = o;
         else { out[i] = o.x; if (i + 1 < n) out[i + 1] = o.y; if (i + 2 < n) out[i + 2] = o.z; }
         run += q.x + q.y + q.z + q.w;
+        if (q.x > kReplayLds) big[brun++] = i; // guides for k_replay_mid / k_replay_big
+        if (q.y > kReplayLds) big[brun++] = i + 1;
+        if (q.z > kReplayLds) big[brun++] = i + 2;
+        if (q.w > kReplayLds) big[brun++] = i + 3;
     }
 }
 

@@ -20,6 +20,7 @@ guides = random_guides_fast(sigs, a.guides, seed=777)
 ix.score(guides, 4, a.thr, "and"); st = ix.stats()
 print("hits found", st["hits"], "per guide", st["hits"] / a.guides, flush=True)
 kept_total = 0; per_guide_kept = []; found = []
+exit_slice = []; found_by_slice = []; kept_by_slice = []
 step = 4096
 for lo in range(0, a.guides, step):
     g = guides[lo:lo + step]
@@ -29,6 +30,10 @@ for lo in range(0, a.guides, step):
     ix.score(g, 4, 0.0, "and")  # threshold 0: no exit -> all hits counted
     h0 = ix.dump_hits(g, 4, 0.0, "and")
     found.append(np.bincount(h0[:, 0], minlength=len(g)))
+    # per slice: hits found / scored, and the slice the last scored hit of every guide lies in
+    fs = np.zeros((len(g), 5), np.int64); np.add.at(fs, (h0[:, 0], np.minimum(h0[:, 1], 4)), 1); found_by_slice.append(fs)
+    ks = np.zeros((len(g), 5), np.int64); np.add.at(ks, (h[:, 0], np.minimum(h[:, 1], 4)), 1); kept_by_slice.append(ks)
+    last = np.full(len(g), -1, np.int64); np.maximum.at(last, h[:, 0], h[:, 1].astype(np.int64)); exit_slice.append(last)
     if lo // step % 5 == 0:
         print(lo, "kept so far", int(np.concatenate(per_guide_kept).sum()), "found", int(np.concatenate(found).sum()), flush=True)
 kept = np.concatenate(per_guide_kept); found = np.concatenate(found)
@@ -41,3 +46,11 @@ for q in (50, 90, 99, 99.9):
 big = found > 512
 print(f"guides with > 512 hits: {big.sum()} holding {found[big].sum() / found.sum():.1%} of the hits; of them exit early: {(exited & big).sum()}")
 # slice of the exit: first matching slice of the last scored hit
+fs = np.concatenate(found_by_slice); ks = np.concatenate(kept_by_slice); last = np.concatenate(exit_slice)
+print("hits found by slice", fs.sum(0).tolist(), "scored by slice", ks.sum(0).tolist())
+for s_ in range(5):
+    ex = exited & (last == s_)
+    # a split after slice s_: phase 1 does slices 0..s_ for everybody, phase 2 the rest for the guides still running
+    p1 = fs[:, :s_ + 1].sum(); still = ~(exited & (last <= s_)); p2 = fs[still][:, s_ + 1:].sum()
+    print(f"  exit in slice {s_}: {ex.sum()} guides; split after slice {s_}: phase 1 finds {p1} hits, phase 2 {p2} "
+          f"({(p1 + p2) / fs.sum():.1%} of all), guides in phase 2: {still.sum()} ({still.mean():.1%})")
