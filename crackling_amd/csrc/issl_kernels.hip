@@ -1904,6 +1904,7 @@ __global__ __launch_bounds__(256) void k_replay_mid(ImageView v, Workspace ws, c
         for (uint32_t s2 = 0; s2 < v.n_slices; ++s2) longest = slice_cnt[s2] > longest ? slice_cnt[s2] : longest;
         if (longest > kMidSlice) { // (uniform) a slice that does not fit: the slice-by-slice kernel with the larger buffers
             if (threadIdx.x == 0) ws.gcur_big2[atomicAdd(&ws.counters->n_big2, 1u)] = g;
+            __syncthreads(); // (the next guide's reset of slice_cnt must not overtake a wave that is still reading it)
             continue;
         }
         if (st && threadIdx.x == 0) st[2] = __builtin_amdgcn_s_memrealtime();

@@ -562,6 +562,52 @@ def test_guides_with_thousands_of_hits(tmp_path):
     ix.close()
 
 
+def test_replay_workgroups_that_take_several_mid_size_guides(tmp_path):
+    """More guides with 513..2048 hits than k_replay_mid has workgroups (2048), so that a workgroup takes a second
+    guide after its first -- and the first ones are guides it hands on to k_replay_big (one slice list longer than the
+    1024 hits it ranks in LDS): what follows such a guide in the same workgroup must not see its leftovers."""
+    rng = np.random.default_rng(4242)
+    n_hand, n_mid = 128, 2100
+    centres = rng.integers(0, 1 << 40, size=n_hand + n_mid, dtype=np.uint64)
+
+    def variants(c, count, first_pos):
+        """`count` signatures with 1..4 substitutions of `c` at positions first_pos..19 (per centre, vectorised)."""
+        out = np.repeat(c, count)
+        k = rng.integers(1, 5, size=len(out))
+        for j in range(4):
+            pos = rng.integers(first_pos, 20, size=len(out)).astype(np.uint64)
+            sub = rng.integers(1, 4, size=len(out)).astype(np.uint64)
+            out = np.where(j < k, out ^ (sub << (np.uint64(2) * pos)), out)
+        return out
+
+    sig = np.concatenate([variants(centres[:n_hand], 1800, 4),   # slice 0 of the guide matches exactly: one long list
+                          variants(centres[:n_hand], 100, 0),
+                          variants(centres[n_hand:], 800, 0),
+                          rng.integers(0, 1 << 40, size=50000, dtype=np.uint64)])
+    sig = np.unique(sig)
+    sig = sig[np.argsort(text_order_key(sig), kind="stable")]
+    occ = rng.integers(1, 3, size=len(sig)).astype(np.uint32)
+    ix = ca.IsslIndex.build_from_sites(sig, occ)
+    p = tmp_path / "mid.issl"
+    ix.write(p)
+    ix.upload(0)
+    oracle = ou.OracleIndex(p)
+    guides = centres
+    hits = ix.dump_hits(guides, 4, 0.0, "and")
+    per_guide = np.bincount(hits[:, 0], minlength=len(guides))
+    in_slice0 = np.bincount(hits[hits[:, 1] == 0, 0], minlength=len(guides))
+    assert (per_guide > 512).all() and (per_guide <= 2048).all()          # every guide is k_replay_mid's to begin with
+    assert (in_slice0[:n_hand] > 1024).all() and (in_slice0[n_hand:] <= 1024).all()
+    assert len(guides) > 2048 + n_hand                                      # guides 2048.. follow a handed-on one
+    for thr in (75.0, 0.0):
+        for rep in range(2):
+            mit, cfd = ix.score(guides, 4, thr, "and")
+            omit, ocfd = oracle.score(guides, 4, thr, "and")
+            bad = np.flatnonzero((mit.view(np.uint64) != omit.view(np.uint64)) | (cfd.view(np.uint64) != ocfd.view(np.uint64)))
+            assert len(bad) == 0, (thr, rep, bad[:10].tolist())
+    ix.close()
+
+
 def test_node_sharding_and_rccl_broadcast(golden_uniform, monkeypatch):
     """In-process multi-GPU orchestration on the one GPU of the test box: (a) two replicas on device 0 (peer-copy
     path: RCCL refuses a device listed twice) exercise sharding, host threads and the gather into the caller's

@@ -18,7 +18,7 @@ import pytest
 
 import crackling_amd as ca
 import oracle_util as ou
-from synth import random_sites_fast, random_guides, random_guides_fast, text_order_key, check_comparisons
+from synth import random_sites_fast, markov_sites_fast, random_guides, random_guides_fast, text_order_key, check_comparisons
 
 
 def test_fast_generator_is_sorted_and_distinct():
@@ -126,7 +126,7 @@ class ScalePoint:
     is the one asked for or the point does not run: it FAILS when the box is an MI355X-class GPU (>= 40 GB of free HBM)
     that cannot hold it -- a green suite means the full size ran -- and is skipped, with the reason, on a smaller GPU."""
 
-    def __init__(self, n_lines, n_guides, options=None, n_check=None, what="configs[2]"):
+    def __init__(self, n_lines, n_guides, options=None, n_check=None, what="configs[2]", dist="uniform"):
         from concurrent.futures import ThreadPoolExecutor
         import conftest
         self.threads = min(32, os.cpu_count() or 8)
@@ -144,7 +144,12 @@ class ScalePoint:
             pytest.fail(f"{what}: {n_lines} lines need ~{host_need / 1e9:.0f} GB of host memory (limit {limit / 1e9:.0f}) and "
                         f"~{n_lines * per_site_hbm / 1e9:.0f} GB of HBM (free {free_hbm / 1e9:.0f}); the point does not shrink")
         self.n_lines, self.n_guides = n_lines, n_guides
-        t = time.time(); self.sigs, self.occ = random_sites_fast(self.n_lines, seed=11, threads=self.threads); self.t_synth = time.time() - t
+        t = time.time()
+        if dist == "markov":  # AT-rich order-3 Markov chain: a skewed index (bench.py --dist markov)
+            self.sigs, self.occ = markov_sites_fast(self.n_lines, seed=20261003)
+        else:
+            self.sigs, self.occ = random_sites_fast(self.n_lines, seed=11, threads=self.threads)
+        self.t_synth = time.time() - t
         self.guides = random_guides_fast(self.sigs, self.n_guides, seed=12)
         t = time.time(); self.ix = ca.IsslIndex.build_on_device(self.sigs, self.occ, device=0, options=options); self.t_build = time.time() - t
         note = (f"{what}: {self.n_lines} lines ({len(self.sigs)} distinct sites) x {self.n_guides} guides, image "
@@ -342,6 +347,58 @@ def test_cold_sections_in_host_memory_at_scale(monkeypatch, tmp_path):
     got2 = again.score(guides[:5000], 4, 75.0, "and")
     assert np.array_equal(got2[0].view(np.uint64), want[0][:5000].view(np.uint64))
     again.close()
+
+
+@pytest.mark.gpu
+def test_skewed_index_at_scale(tmp_path):
+    """configs[2]'s size on a skewed index (the AT-rich Markov chain of `bench.py --dist markov`: seven times the hits,
+    43 % of the guides with more than 512 of them, 58 % leave through the early exit): the replay kernels for many-hit
+    guides carry the load here and their workgroups take many guides each.  A sample against the oracle; the whole batch
+    scored repeatedly, in pieces, with whole buckets and as back-to-back asynchronous batches on one and two lanes (what
+    bench.py times) -- all bit-identical."""
+    import torch
+    sp = ScalePoint(SCALE_SIZE[0], SCALE_SIZE[1], what="configs[2] on a skewed index", dist="markov")
+    ix, guides = sp.ix, sp.guides
+    try:
+        omit, ocfd = sp.oracle_on_neighbourhoods(tmp_path, 75.0)
+        mit, cfd = ix.score(guides, 4, 75.0, "and")
+        st = ix.stats()
+        assert np.array_equal(mit[sp.pick].view(np.uint64), omit.view(np.uint64))
+        assert np.array_equal(cfd[sp.pick].view(np.uint64), ocfd.view(np.uint64))
+        assert st["pruned"] == 2 and st["hits"] > 300 * len(guides)
+        want = (mit.view(np.uint64).copy(), cfd.view(np.uint64).copy())
+
+        def same(m, c, what):
+            bad = np.flatnonzero((m.view(np.uint64) != want[0]) | (c.view(np.uint64) != want[1]))
+            assert len(bad) == 0, (what, len(bad), bad[:8].tolist())
+
+        for rep in range(3):
+            same(*ix.score(guides, 4, 75.0, "and"), f"rep {rep}")
+        piece = 5000
+        pm = np.empty(len(guides)); pc = np.empty(len(guides))
+        for lo in range(0, len(guides), piece):
+            pm[lo:lo + piece], pc[lo:lo + piece] = ix.score(guides[lo:lo + piece], 4, 75.0, "and")
+        same(pm, pc, "pieces")
+        ix.set_option("prune", 0)
+        same(*ix.score(guides, 4, 75.0, "and"), "whole buckets")
+        ix.set_option("prune", -1)
+        d_g = torch.from_numpy(guides.view(np.int64)).cuda()
+        steps = 6
+        out_m = torch.empty(steps, len(guides), dtype=torch.float64, device="cuda:0"); out_c = torch.empty_like(out_m)
+        for lanes in (1, 2):
+            ix.set_option("lanes", lanes)
+            out_m.zero_(); out_c.zero_()
+            while True:
+                for i in range(steps):
+                    ix.score_device_async(d_g, out_m[i], out_c[i], 4, 75.0, "and", stream=None)
+                if ix.finish(None):
+                    break
+            hm, hc = out_m.cpu().numpy(), out_c.cpu().numpy()
+            for i in range(steps):
+                same(hm[i], hc[i], f"lanes {lanes} step {i}")
+        ix.set_option("lanes", 1)
+    finally:
+        ix.close()
 
 
 def _beyond_hbm_lines():
