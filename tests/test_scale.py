@@ -350,6 +350,72 @@ def test_cold_sections_in_host_memory_at_scale(monkeypatch, tmp_path):
 
 
 @pytest.mark.gpu
+def test_many_hit_guides_several_per_replay_workgroup(tmp_path):
+    """More guides of every many-hit class than the replay kernel of that class has workgroups: 2300 guides with 2049 ..
+    16384 hits (k_replay_big<256>: 2048 workgroups) and 560 with more (k_replay_big<1024>: 512), besides 2300 of
+    k_replay_mid's, so that every workgroup takes a second guide after its first.  The batch is scored whole, in pieces
+    small enough that no workgroup meets two guides, and -- a sample -- by the oracle on the guides' neighbourhoods."""
+    rng = np.random.default_rng(20261004)
+    classes = [(2300, 900, 513, 2048), (2300, 3600, 2049, 16384), (560, 24000, 16385, 1 << 30)]  # guides, draws, hits from .. to
+    centres = rng.integers(0, 1 << 40, size=sum(c[0] for c in classes), dtype=np.uint64)
+
+    def variants(c, count, k_from):
+        out = np.repeat(c, count)
+        k = rng.integers(k_from, 5, size=len(out))
+        for j in range(4):
+            pos = rng.integers(0, 20, size=len(out)).astype(np.uint64)
+            sub = rng.integers(1, 4, size=len(out)).astype(np.uint64)
+            out = np.where(j < k, out ^ (sub << (np.uint64(2) * pos)), out)
+        return out
+
+    parts, at = [rng.integers(0, 1 << 40, size=200000, dtype=np.uint64)], 0
+    for n, draws, _, _ in classes:
+        parts.append(variants(centres[at:at + n], draws, 3 if draws > 20000 else 1)); at += n
+    sig = np.unique(np.concatenate(parts))
+    sig = sig[np.argsort(text_order_key(sig), kind="stable")]
+    occ = rng.integers(1, 3, size=len(sig)).astype(np.uint32)
+    order = rng.permutation(len(centres))   # the classes mixed through the batch
+    guides = centres[order]
+    ix = ca.IsslIndex.build_on_device(sig, occ, device=0)
+    try:
+        mit, cfd = ix.score(guides, 4, 0.0, "and")
+        hits = ix.stats()["hits"]
+        got = ix.dump_hits(guides[:512], 4, 0.0, "and")
+        per_guide = np.bincount(got[:, 0], minlength=512)
+        at = 0
+        for n, _, lo, hi in classes:   # every guide of the sample lies in its class
+            mine = np.flatnonzero((order[:512] >= at) & (order[:512] < at + n)); at += n
+            assert len(mine) and (per_guide[mine] >= lo).all() and (per_guide[mine] <= hi).all(), (lo, hi, per_guide[mine].min(), per_guide[mine].max())
+        for thr, method in ((0.0, "and"), (75.0, "and"), (90.0, "or"), (50.0, "mit")):
+            mit, cfd = ix.score(guides, 4, thr, method)
+            for rep in range(2):
+                m2, c2 = ix.score(guides, 4, thr, method)
+                assert np.array_equal(m2.view(np.uint64), mit.view(np.uint64)) and np.array_equal(c2.view(np.uint64), cfd.view(np.uint64)), (thr, method, rep)
+            pm = np.empty(len(guides)); pc = np.empty(len(guides))
+            piece = 64
+            for lo in range(0, len(guides), piece):
+                pm[lo:lo + piece], pc[lo:lo + piece] = ix.score(guides[lo:lo + piece], 4, thr, method)
+            bad = np.flatnonzero((pm.view(np.uint64) != mit.view(np.uint64)) | (pc.view(np.uint64) != cfd.view(np.uint64)))
+            assert len(bad) == 0, (thr, method, len(bad), bad[:8].tolist())
+            # the oracle on the neighbourhoods of a sample (brute force over the site table)
+            pick = np.linspace(0, len(guides) - 1, 36).astype(np.int64)
+            if thr in (0.0, 75.0):
+                near = [_neighbours(sig, g, 4) for g in guides[pick]]
+                keep = np.unique(np.concatenate(near + [np.arange(0, len(sig), 4000)]))
+                mini = ca.IsslIndex.build_from_sites(sig[keep], occ[keep])
+                path = tmp_path / "mini_many.issl"
+                mini.write(path); mini.close()
+                oracle = ou.OracleIndex(path)
+                omit, ocfd = oracle.score(guides[pick], 4, thr, method)
+                oracle.close()
+                assert np.array_equal(mit[pick].view(np.uint64), omit.view(np.uint64)), (thr, method)
+                assert np.array_equal(cfd[pick].view(np.uint64), ocfd.view(np.uint64)), (thr, method)
+        print(f"many-hit batch: {len(guides)} guides, {len(sig)} sites, {hits} hits", flush=True)
+    finally:
+        ix.close()
+
+
+@pytest.mark.gpu
 def test_skewed_index_at_scale(tmp_path):
     """configs[2]'s size on a skewed index (the AT-rich Markov chain of `bench.py --dist markov`: seven times the hits,
     43 % of the guides with more than 512 of them, 58 % leave through the early exit): the replay kernels for many-hit
@@ -382,6 +448,15 @@ def test_skewed_index_at_scale(tmp_path):
         ix.set_option("prune", 0)
         same(*ix.score(guides, 4, 75.0, "and"), "whole buckets")
         ix.set_option("prune", -1)
+        for method, thr, max_dist in (("or", 90.0, 4), ("mit", 50.0, 4), ("cfd", 75.0, 3), ("avg", 60.0, 4), ("and", 0.0, 4)):
+            wm, wc = ix.score(guides, max_dist, thr, method)   # other exits, other distances: whole batch = pieces = oracle sample
+            for lo in range(0, len(guides), 20000):
+                qm, qc = ix.score(guides[lo:lo + 20000], max_dist, thr, method)
+                assert np.array_equal(qm.view(np.uint64), wm[lo:lo + 20000].view(np.uint64)), (method, thr, lo)
+                assert np.array_equal(qc.view(np.uint64), wc[lo:lo + 20000].view(np.uint64)), (method, thr, lo)
+            om, oc = sp.oracle_on_neighbourhoods(tmp_path, thr, method=method, max_dist=max_dist)
+            assert np.array_equal(wm[sp.pick].view(np.uint64), om.view(np.uint64)), (method, thr)
+            assert np.array_equal(wc[sp.pick].view(np.uint64), oc.view(np.uint64)), (method, thr)
         d_g = torch.from_numpy(guides.view(np.int64)).cuda()
         steps = 6
         out_m = torch.empty(steps, len(guides), dtype=torch.float64, device="cuda:0"); out_c = torch.empty_like(out_m)
