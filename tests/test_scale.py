@@ -350,7 +350,10 @@ def test_cold_sections_in_host_memory_at_scale(monkeypatch, tmp_path):
 
 
 @pytest.mark.gpu
-def test_many_hit_guides_several_per_replay_workgroup(tmp_path):
+@pytest.mark.parametrize("options", [None, {"compact": 1}, {"compact": 1, "host_cold": 1}, {"sorted_layout": 0},
+                                     {"sorted_layout": 0, "inline_sigs": 0}, {"sorted_layout": 0, "host_cold": 1}],
+                         ids=["sorted", "compact", "compact-lists-cold", "list-order", "list-order-no-inline", "list-order-cold"])
+def test_many_hit_guides_several_per_replay_workgroup(tmp_path, options):
     """More guides of every many-hit class than the replay kernel of that class has workgroups: 2300 guides with 2049 ..
     16384 hits (k_replay_big<256>: 2048 workgroups) and 560 with more (k_replay_big<1024>: 512), besides 2300 of
     k_replay_mid's, so that every workgroup takes a second guide after its first.  The batch is scored whole, in pieces
@@ -376,8 +379,11 @@ def test_many_hit_guides_several_per_replay_workgroup(tmp_path):
     occ = rng.integers(1, 3, size=len(sig)).astype(np.uint32)
     order = rng.permutation(len(centres))   # the classes mixed through the batch
     guides = centres[order]
-    ix = ca.IsslIndex.build_on_device(sig, occ, device=0)
+    ix = ca.IsslIndex.build_on_device(sig, occ, device=0, options=options)
     try:
+        assert ix.get_option("is_sorted") == (0 if options and options.get("sorted_layout") == 0 else 1)
+        assert ix.get_option("is_compact") == (1 if options and options.get("compact") == 1 else 0)
+        assert (ix.get_option("cold_on_host") == 1) == bool(options and options.get("host_cold") == 1)
         mit, cfd = ix.score(guides, 4, 0.0, "and")
         hits = ix.stats()["hits"]
         got = ix.dump_hits(guides[:512], 4, 0.0, "and")
