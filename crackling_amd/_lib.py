@@ -2,7 +2,8 @@
 import ctypes as C
 import os
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libissl_hip.so")
+# ISSL_HIP_LIBRARY: another build of the same library (A/B of kernel variants, tools/ablate.py); default: the in-tree one
+LIB_PATH = os.environ.get("ISSL_HIP_LIBRARY") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libissl_hip.so")
 
 
 class IsslError(RuntimeError):

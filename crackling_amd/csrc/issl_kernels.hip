@@ -1363,28 +1363,27 @@ __global__ __launch_bounds__(kChunkRecs, 8) void k_verify(ImageView v, Workspace
             }
         }
         // Count the hit for its guide.  The count doubles as the hit's place in the guide's segment, so that the grouping
-        // pass scatters without a second atomic (ws.rank, by raw-record slot).  A dense guide's hits
-        // come in runs (one scan wave, consecutive tiles): lanes that share the guide of the first live lane take ONE
-        // atomic together while such runs are at least 4 lanes long; everybody else adds for itself.
+        // pass scatters without a second atomic (ws.rank, by raw-record slot).  The hits of a guide in one unit lie side by
+        // side in the chunk (the scan wave notes them guide by guide): every RUN of neighbouring lanes with the same guide
+        // takes one atomic, issued by its first lane -- no loop, every run of the wave in the same instruction.  (The
+        // atomics are half of this kernel's time on a skewed index: profiles/r03_ablation_verify.log.)
         const bool live = key != kDeadKey;
         const uint32_t lane = threadIdx.x & 63u;
+        const uint32_t prev_guide = static_cast<uint32_t>(__shfl_up(static_cast<int>(live ? guide : kNoGuide), 1, 64));
+        const bool continues = live && lane != 0u && prev_guide == guide;    // (a dead lane never equals a live one: kNoGuide)
+        const uint64_t starts = __ballot(!continues);                        // first lanes of runs, and the dead lanes
         uint32_t rank = 0;
-        uint64_t todo = __ballot(live);
-        while (todo != 0ull) {
-            const int leader = __builtin_ctzll(todo);
-            const uint32_t g0 = __builtin_amdgcn_readlane(guide, leader);
-            const uint64_t same = __ballot(live && guide == g0) & todo;
-            const uint32_t cnt = static_cast<uint32_t>(__builtin_popcountll(same));
-            if (cnt < 4u) break;
+        if (starts == ~0ull) { // (uniform over the wave) no runs, the usual case on an even index: everybody for itself
+            if (live) rank = atomicAdd(&ws.gcount[guide], 1u);
+        } else {
+            const uint64_t upto = (lane == 63u ? 0ull : (~0ull << (lane + 1u))); // the lanes above this one
+            const uint32_t head = 63u - static_cast<uint32_t>(__builtin_clzll(starts & ~upto)); // lane 0 always starts: never empty
+            const uint64_t later = starts & upto;
+            const uint32_t next = later ? static_cast<uint32_t>(__builtin_ctzll(later)) : 64u;
             uint32_t base = 0;
-            if (static_cast<int>(lane) == leader) base = atomicAdd(&ws.gcount[g0], cnt);
-            base = __builtin_amdgcn_readlane(base, leader);
-            if ((same >> lane) & 1ull)
-                rank = base + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(same >> 32),
-                                                        __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(same), 0u));
-            todo &= ~same;
+            if (live && !continues) base = atomicAdd(&ws.gcount[guide], next - lane); // the run is [lane, next)
+            rank = static_cast<uint32_t>(__shfl(static_cast<int>(base), static_cast<int>(head), 64)) + (lane - head);
         }
-        if ((todo >> lane) & 1ull) rank = atomicAdd(&ws.gcount[guide], 1u);
         if (live) {
             const uint64_t slot = static_cast<uint64_t>(chunk) * (kChunkRecs - 1u) + (t - 1u); // < cap_chunks * 127 <= cap_hits
             ws.rank[slot] = rank;

@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Builds variants of libissl_hip.so with pieces of a kernel cut out (timing experiments, never shipped):
+
+    python tools/ablate.py build            # here (hipcc cross-compiles): build/ablate/libissl_hip_<name>.so
+    python tools/ablate.py run [bench args] # on the GPU box: bench.py once per variant, stage times side by side
+
+A variant is a list of (old, new) text replacements applied to a COPY of csrc/issl_kernels.hip; the results of a cut
+kernel are wrong by construction -- only its duration is read."""
+import json, os, pathlib, subprocess, sys
+ROOT = pathlib.Path(__file__).resolve().parent.parent
+CSRC = ROOT / "crackling_amd" / "csrc"
+OUT = ROOT / "build" / "ablate"
+
+VARIANTS = {
+    "base": [],
+    # k_verify
+    "verify_no_atomic": [("if ((todo >> lane) & 1ull) rank = atomicAdd(&ws.gcount[guide], 1u);", "if ((todo >> lane) & 1ull) rank = lane;"),
+                         ("if (static_cast<int>(lane) == leader) base = atomicAdd(&ws.gcount[g0], cnt);", "if (static_cast<int>(lane) == leader) base = cnt;")],
+    "verify_no_terms": [("            if (rank < kMidHits) {\n                int dist;", "            if (false) {\n                int dist;")],
+    "verify_no_srec": [("if (in_use && v.srec) sr_early = v.srec[static_cast<uint64_t>(tile) * kTileCands + offset];",
+                        "if (in_use && v.srec) { sr_early.sig = rec * 0x9E3779B97F4A7C15ull; sr_early.id = static_cast<uint32_t>(rec); }")],
+    "verify_srec_only": [("        if (guide != kNoGuide) {\n            const uint32_t bucket = prune_mode ? where >> 8 : where;",
+                          "        if (guide != kNoGuide && sr_early.sig == 0x123456789ull) {\n            const uint32_t bucket = prune_mode ? where >> 8 : where;")],
+    "verify_no_rank_pay_store": [("            ws.rank[slot] = rank;", "            if (rank == 0xFFFFFFFFu) ws.rank[slot] = rank;"),
+                                 ("                reinterpret_cast<double2 *>(ws.pay)[slot] = make_double2(mit_term, cfd_term);",
+                                  "                if (mit_term == 1e300) reinterpret_cast<double2 *>(ws.pay)[slot] = make_double2(mit_term, cfd_term);")],
+}
+
+
+def build():
+    OUT.mkdir(parents=True, exist_ok=True)
+    src = (CSRC / "issl_kernels.hip").read_text()
+    flags = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "--offload-arch=gfx950", f"-I{CSRC}", f"-I{ROOT / 'include'}"]
+    objs = []
+    for f in ("issl_extract.hip", "issl_build.hip", "issl_capi.cpp", "issl_node.cpp", "issl_host.cpp"):  # once for all variants
+        o = OUT / (f + ".o")
+        subprocess.check_call(["/opt/rocm/bin/hipcc"] + flags + ["-c", "-o", str(o), str(CSRC / f)])
+        objs.append(str(o))
+    for name, edits in VARIANTS.items():
+        text = src
+        for old, new in edits:
+            assert text.count(old) == 1, (name, old[:60], text.count(old))
+            text = text.replace(old, new)
+        tmp = OUT / f"issl_kernels_{name}.hip"
+        tmp.write_text(text)
+        print(name, flush=True)
+        subprocess.check_call(["/opt/rocm/bin/hipcc"] + flags + ["-c", "-o", str(OUT / f"k_{name}.o"), str(tmp)])
+        subprocess.check_call(["/opt/rocm/bin/hipcc"] + flags + ["-shared", "-o", str(OUT / f"libissl_hip_{name}.so"), str(OUT / f"k_{name}.o")] + objs + ["-lpthread", "-ldl"])
+        tmp.unlink()
+
+
+def run(args):
+    for name in VARIANTS:
+        lib = OUT / f"libissl_hip_{name}.so"
+        env = dict(os.environ, ISSL_HIP_LIBRARY=str(lib))
+        r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--no-extras", "--no-cpu-baseline", "--steps", "5", "--warmup", "2"] + args,
+                           env=env, capture_output=True, text=True)
+        try:
+            d = json.loads(r.stdout.strip().splitlines()[-1])
+            print(f"{name:28s} step {d['ms_per_step']:7.3f} ms  " + "  ".join(f"{k} {v:.3f}" for k, v in d["kernel_ms"].items()), flush=True)
+        except Exception as e:  # a cut kernel may upset a later stage: report and go on
+            print(f"{name:28s} failed: {e}; {r.stderr.strip().splitlines()[-1:] }", flush=True)
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "build":
+        build()
+    else:
+        run(sys.argv[2:])
