@@ -110,13 +110,14 @@ Tuning Tuning::from_env()
     t.compact = -1;
     t.prune = -1;
     t.tail_shapes = 1;
+    t.hit_slots = 1;
     t.lanes = 1;
     static const char *const keys[][2] = {
         {"ISSL_SCAN_BLOCKS", "scan_blocks"}, {"ISSL_ITEM_GUIDES", "item_guides"},
         {"ISSL_SCAN_GENERIC", "scan_generic"}, {"ISSL_STAGE_TIMING", "stage_timing"}, {"ISSL_RAW_CHUNKS", "raw_chunks"},
         {"ISSL_INLINE_SIGS", "inline_sigs"}, {"ISSL_FORCE_HOST_COLD", "host_cold"}, {"ISSL_SCAN_STAMPS", "scan_stamps"},
         {"ISSL_SORTED_LAYOUT", "sorted_layout"}, {"ISSL_PRUNE", "prune"}, {"ISSL_LANES", "lanes"},
-        {"ISSL_COMPACT", "compact"}, {"ISSL_TAIL_SHAPES", "tail_shapes"},
+        {"ISSL_COMPACT", "compact"}, {"ISSL_TAIL_SHAPES", "tail_shapes"}, {"ISSL_HIT_SLOTS", "hit_slots"},
     };
     for (const auto &k : keys)
         if (const char *e = std::getenv(k[0])) (void)t.set(k[1], e); // values out of range leave the default
@@ -142,6 +143,7 @@ bool Tuning::set(const char *key, const char *value)
     else if (k == "prune") { if (!is_int || n < -1 || n > 1) return false; prune = static_cast<int>(n); }
     else if (k == "lanes") { if (!is_int || n < 1 || n > 2) return false; lanes = static_cast<int>(n); }
     else if (k == "tail_shapes") { if (!is_int || n < 0 || n > 1) return false; tail_shapes = static_cast<int>(n); }
+    else if (k == "hit_slots") { if (!is_int || n < 0 || n > 1) return false; hit_slots = static_cast<int>(n); }
     else if (k == "scan_stamps") stamps_path = value;
     else return false;
     return true;
@@ -151,6 +153,7 @@ bool Tuning::set(const char *key, const char *value)
 
 constexpr uint32_t kRing = 64;
 constexpr size_t kMaxBatch = size_t(1) << 24; // guides per pipeline launch
+constexpr size_t kSlotBytesMax = size_t(8) << 30; // hit slots of a workspace: up to 8 GiB (512 k guides per batch)
 
 // One complete workspace + the internal stream that asynchronous batches run on.  (Rotating consecutive batches through
 // several of these so that the short kernels of one batch run in the shadow of the next scan was measured in round 1
@@ -238,7 +241,7 @@ static void free_workspace(Workspace &w)
 {
     void *ptrs[] = {w.ng, w.gfill, w.gstart, w.gword, w.gidx, w.gbucket, w.items, w.plan, w.range_start, w.counters, w.scan_count, w.scan_span, w.sticky, w.stamps, w.gcur_big, w.gcur_big2, w.terms, w.sorted, w.gcount,
                     w.goff, w.blocksum, w.d_guides, w.d_mit, w.d_cfd, w.d_kept, w.d_hitrec, w.pay, w.rank, w.fword, w.fmeta,
-                    w.fitems, w.fcount, w.fsum};
+                    w.fitems, w.fcount, w.fsum, w.slots};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (w.raw) (void)hipFree(w.raw);
@@ -316,6 +319,14 @@ static int ensure_workspace(issl_index *ix, size_t n, Lane &lane)
         if ((rc = dev_alloc(w.d_mit, cap))) return rc;
         if ((rc = dev_alloc(w.d_cfd, cap))) return rc;
         if ((rc = dev_alloc(w.d_kept, cap))) return rc;
+        // hit slots (Workspace): kSlotHits x 32 bytes per guide -- 1.6 GB for 100 k guides; batches beyond kSlotBytesMax (or a
+        // device short of memory) go without, every hit then passes through the grouping pass
+        if (w.slots) { (void)hipFree(w.slots); w.slots = nullptr; }
+        w.cap_slot_guides = 0;
+        if (cap * kSlotHits * sizeof(SlotRec) <= kSlotBytesMax) {
+            if (hipMalloc(reinterpret_cast<void **>(&w.slots), cap * kSlotHits * sizeof(SlotRec)) == hipSuccess) w.cap_slot_guides = cap;
+            else { (void)hipGetLastError(); w.slots = nullptr; }
+        }
         w.cap_guides = cap;
         w.cap_gslots = slots;
         w.cap_items = items;
@@ -734,6 +745,8 @@ static int enqueue_batch(issl_index *ix, Lane &lane, hipStream_t stream, const u
         if (rc) return rc;
         ws.cap_hitrec = ws.cap_hits;
     }
+    // issl_dump_hits wants every hit of the batch in one array in guide order: no hit slots there
+    ws.slot_hits = (!dump && tn.hit_slots && ws.cap_slot_guides >= n) ? kSlotHits : 0u;
     ScoreParams p;
     p.max_dist = max_dist;
     p.method = method;
@@ -838,7 +851,7 @@ static int finish_batches(issl_index *ix, hipStream_t stream)
     PlanInfo pl{};
     uint32_t total_hits = 0;
     HIP_TRY(hipMemcpy(&pl, lane.ws.plan, sizeof pl, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(&total_hits, lane.ws.goff + lane.last_n, sizeof total_hits, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&total_hits, &lane.ws.counters->total_hits, sizeof total_hits, hipMemcpyDeviceToHost));
     // comparisons the scan workgroups of the last batch counted while they made them
     std::vector<uint64_t> counted(ix->tuning.scan_blocks);
     HIP_TRY(hipMemcpy(counted.data(), lane.ws.scan_count, 8 * counted.size(), hipMemcpyDeviceToHost));
@@ -1081,6 +1094,7 @@ int issl_index_get_option(const issl_index *idx, const char *key, long long *val
     else if (k == "prune") *value = t.prune;
     else if (k == "lanes") *value = t.lanes;
     else if (k == "tail_shapes") *value = t.tail_shapes;
+    else if (k == "hit_slots") *value = t.hit_slots;
     else if (k == "is_sorted") *value = idx->d_image ? ((idx->hdr.off_srec || idx->hdr.off_sid) ? 1 : 0) : -1; // read-only
     else if (k == "is_compact") *value = idx->d_image ? (idx->hdr.off_sid ? 1 : 0) : -1;                   // read-only
     else if (k == "cold_on_host") *value = idx->d_image ? (idx->hdr.cold_on_host ? 1 : 0) : -1;            // read-only: layout in use

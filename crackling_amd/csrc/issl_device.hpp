@@ -146,6 +146,7 @@ struct Tuning {
                             //                    0 never, 1 whenever possible
     int tail_shapes;        // ISSL_TAIL_SHAPES   1 (default): the short last unit of a successor-byte group runs 2 / 4 guides
                             //                    per pass on 16 / 8 candidates per lane; 0: every unit is a full one (A/B)
+    int hit_slots;          // ISSL_HIT_SLOTS     1 (default): Workspace::slot_hits = kSlotHits when the arrays fit; 0: never (A/B, tests)
     int lanes;              // ISSL_LANES         1|2 (default 1): workspaces + streams that asynchronous batches alternate
                             //                    between (2: the short kernels of one batch fill the wave slots the scan of
                             //                    the next leaves)
@@ -262,6 +263,7 @@ struct Counters {
     uint32_t n_big2;      // guides k_replay_mid hands on to k_replay_big (a slice too long for its buffers)
     uint32_t raw_chunks;  // chunks of the raw record buffer handed out
     uint32_t raw_overflow; // set when the raw buffer was too small
+    uint32_t total_hits;  // scored off-targets of the batch before any early exit (sum of the per-guide counts)
 };
 
 // Per bucket, pruned scan: what its successor-byte groups add to the plan (k_fine_count -> k_fine_plan -> k_fine_scatter).
@@ -271,6 +273,13 @@ struct FineSum {
     uint32_t places;      // guides placed in the bucket's groups (every guide counts once per group it visits)
 };
 
+constexpr uint32_t kSlotHits = 512;     // = kReplayLds: what k_replay takes
+// One hit in a guide's slots: terms and key in ONE aligned 32-byte record -- k_verify scatters them, and a write that
+// fills a whole 32-byte sector goes out as it is, where an 8- and a 16-byte piece of two arrays cost two partial ones.
+struct alignas(32) SlotRec {
+    double mit, cfd;
+    uint64_t key, pad;
+};
 constexpr uint32_t kFineWays = 13;      // successor bytes within one mismatch of a guide's: itself + 4 positions x 3 bases
 constexpr uint32_t kFetchPairs = 8;     // time of fetching one 8 KiB tile, in (guide, tile) comparisons of the chip: measured 7
                                         // (50 M sites, neighbouring groups share tiles in L2) to 12 (300 M sites)
@@ -318,6 +327,13 @@ struct Workspace {
     double *terms = nullptr;     // [2 * hit_cap] MIT/CFD terms of the hits, grouped by guide like `sorted`
     double *pay = nullptr;       // [2 * hit_cap] the same terms as k_verify computed them, by raw-record slot
     uint32_t *rank = nullptr;    // [hit_cap] place of a surviving raw record inside its guide's segment, by raw-record slot
+    // Hit slots: the first slot_hits (0 or kSlotHits) hits of every guide go straight from k_verify to a place of their own,
+    // slots[guide * slot_hits + rank]; only guides with more hits than that take part in the grouping pass
+    // (on an even index: none -- the pass and its buffers drop out of the step).  0: every hit is grouped (issl_dump_hits,
+    // batches too large for the slot arrays, the hit_slots knob).
+    SlotRec *slots = nullptr;       // [cap_slot_guides * kSlotHits]
+    uint32_t slot_hits = 0;
+    size_t cap_slot_guides = 0;
     uint32_t *blocksum = nullptr;
     uint64_t *d_guides = nullptr; // staging for the host API
     double *d_mit = nullptr, *d_cfd = nullptr;

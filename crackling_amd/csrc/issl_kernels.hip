@@ -1384,7 +1384,16 @@ __global__ __launch_bounds__(kChunkRecs, 8) void k_verify(ImageView v, Workspace
             if (live && !continues) base = atomicAdd(&ws.gcount[guide], next - lane); // the run is [lane, next)
             rank = static_cast<uint32_t>(__shfl(static_cast<int>(base), static_cast<int>(head), 64)) + (lane - head);
         }
-        if (live) {
+        if (live && rank < ws.slot_hits) {
+            // hit slots (Workspace): the hit goes to its final place at once and takes no part in the grouping pass
+            int dist;
+            score_terms(v, hit_gsig, hit_ot, hit_occ, calc_mit, calc_cfd, mit_term, cfd_term, dist);
+            const uint64_t at = static_cast<uint64_t>(guide) * ws.slot_hits + rank;
+            SlotRec r;
+            r.mit = mit_term; r.cfd = cfd_term; r.key = key; r.pad = 0;
+            ws.slots[at] = r;
+            key = kDeadKey;
+        } else if (live) {
             const uint64_t slot = static_cast<uint64_t>(chunk) * (kChunkRecs - 1u) + (t - 1u); // < cap_chunks * 127 <= cap_hits
             ws.rank[slot] = rank;
             // The terms (:392-460) -- unless the guide already has more hits than the replays that read them take
@@ -1445,15 +1454,18 @@ void launch_verify(const ImageView &v, const Workspace &ws, const uint64_t *d_gu
 constexpr uint32_t kScanChunk = 2048; // elements per block in the device-wide prefix sum
 constexpr uint32_t kBigLds = 7680;    // hits per slice k_replay_big sorts in LDS (2 x 30 KiB); longer slices are sorted in HBM
 
+// What a guide's hits take in the grouped arrays: nothing when they all sit in its hit slots (Workspace::slot_hits).
+__device__ __forceinline__ uint32_t grouped_hits(uint32_t count, uint32_t slot_hits) { return count <= slot_hits ? 0u : count; }
+
 __global__ __launch_bounds__(256) void k_prefix_block_sums(const uint32_t *__restrict__ in, uint32_t n,
-                                                           uint32_t *__restrict__ sums)
+                                                           uint32_t *__restrict__ sums, uint32_t slot_hits)
 {
     short_kernel_priority();
     __shared__ uint64_t lds[256];
     const uint32_t base = blockIdx.x * kScanChunk + threadIdx.x * 8u;
     uint64_t s = 0;
     for (uint32_t i = 0; i < 8; ++i)
-        if (base + i < n) s += in[base + i];
+        if (base + i < n) s += grouped_hits(in[base + i], slot_hits);
     uint64_t total;
     (void)block_exclusive_scan(s, lds, &total);
     if (threadIdx.x == 0) sums[blockIdx.x] = static_cast<uint32_t>(total);
@@ -1476,24 +1488,31 @@ __global__ __launch_bounds__(256) void k_prefix_of_sums(uint32_t *__restrict__ s
 
 __global__ __launch_bounds__(256) void k_prefix_apply(const uint32_t *__restrict__ in, uint32_t n,
                                                       const uint32_t *__restrict__ sums, uint32_t *__restrict__ out,
-                                                      uint32_t *__restrict__ big, Counters *__restrict__ counters)
+                                                      uint32_t *__restrict__ big, Counters *__restrict__ counters,
+                                                      uint32_t slot_hits)
 {
     short_kernel_priority();
     __shared__ uint64_t lds[256];
     const uint32_t base = blockIdx.x * kScanChunk + threadIdx.x * 8u;
     uint32_t val[8];
     uint64_t s = 0;
+    uint32_t nb = 0, all = 0;
     for (uint32_t i = 0; i < 8; ++i) {
-        val[i] = (base + i < n) ? in[base + i] : 0u;
+        const uint32_t c = (base + i < n) ? in[base + i] : 0u;
+        all += c;
+        nb += c > kReplayLds;
+        val[i] = grouped_hits(c, slot_hits);
         s += val[i];
     }
-    uint32_t nb = 0;
-    for (uint32_t i = 0; i < 8; ++i) nb += val[i] > kReplayLds;
     if (nb != 0u) { // guides for k_replay_mid / k_replay_big: one reservation per thread
         uint32_t at = atomicAdd(&counters->n_big, nb);
         for (uint32_t i = 0; i < 8; ++i)
-            if (val[i] > kReplayLds) big[at++] = base + i;
+            if (base + i < n && in[base + i] > kReplayLds) big[at++] = base + i;
     }
+    uint64_t total_all;
+    (void)block_exclusive_scan(all, lds, &total_all);
+    if (threadIdx.x == 0 && total_all) atomicAdd(&counters->total_hits, static_cast<uint32_t>(total_all));
+    __syncthreads();
     uint64_t run = block_exclusive_scan(s, lds, nullptr) + sums[blockIdx.x];
     for (uint32_t i = 0; i < 8; ++i) {
         if (base + i < n) out[base + i] = static_cast<uint32_t>(run);
@@ -1507,44 +1526,54 @@ __global__ __launch_bounds__(256) void k_prefix_apply(const uint32_t *__restrict
 // of guides with more than kReplayLds hits comes out of the same scan (their number rides in a second scanned word), in
 // guide order and without an atomic: on indexes where most guides are such (skewed genomes, the 3 G-line index) one
 // returning atomic per guide from a single workgroup cost more than the rest of the grouping (2 ms per 100 k guides).
+// With hit slots only those guides have anything in the grouped arrays (grouped_hits); the sum of all counts goes to
+// counters->total_hits.
 __global__ __launch_bounds__(1024) void k_prefix_single(const uint32_t *__restrict__ in, uint32_t n,
                                                         uint32_t *__restrict__ out, uint32_t *__restrict__ big,
-                                                        Counters *__restrict__ counters)
+                                                        Counters *__restrict__ counters, uint32_t slot_hits)
 {
     short_kernel_priority();
-    __shared__ uint32_t wave_sum[16], wave_big[16];
+    __shared__ uint32_t wave_sum[16], wave_big[16], wave_all[16];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t per = ((n + 1023u) / 1024u + 3u) & ~3u; // counts per thread, a multiple of 4: the runs start 16-byte aligned
     const uint32_t i0 = threadIdx.x * per;
-    uint32_t s = 0, b = 0;
+    uint32_t s = 0, b = 0, all = 0;
     for (uint32_t k = 0; k < per; k += 4) {
         const uint32_t i = i0 + k;
         uint4 q = make_uint4(0, 0, 0, 0);
         if (i + 3 < n) q = *reinterpret_cast<const uint4 *>(in + i);
         else { if (i < n) q.x = in[i]; if (i + 1 < n) q.y = in[i + 1]; if (i + 2 < n) q.z = in[i + 2]; }
-        s += q.x + q.y + q.z + q.w;
+        all += q.x + q.y + q.z + q.w;
+        s += grouped_hits(q.x, slot_hits) + grouped_hits(q.y, slot_hits) + grouped_hits(q.z, slot_hits) + grouped_hits(q.w, slot_hits);
         b += (q.x > kReplayLds) + (q.y > kReplayLds) + (q.z > kReplayLds) + (q.w > kReplayLds);
     }
-    uint32_t x = s, xb = b; // inclusive scans of s and b inside the wave
+    uint32_t x = s, xb = b, xa = all; // inclusive scans of s and b inside the wave (and the sum of `all`)
     for (uint32_t d = 1; d < 64; d <<= 1) {
-        const uint32_t y = __shfl_up(x, d, 64), yb = __shfl_up(xb, d, 64);
-        if (lane >= d) { x += y; xb += yb; }
+        const uint32_t y = __shfl_up(x, d, 64), yb = __shfl_up(xb, d, 64), ya = __shfl_up(xa, d, 64);
+        if (lane >= d) { x += y; xb += yb; xa += ya; }
     }
-    if (lane == 63) { wave_sum[wave] = x; wave_big[wave] = xb; }
+    if (lane == 63) { wave_sum[wave] = x; wave_big[wave] = xb; wave_all[wave] = xa; }
     __syncthreads();
     uint32_t run = x - s, brun = xb - b;
     for (uint32_t wv = 0; wv < wave; ++wv) { run += wave_sum[wv]; brun += wave_big[wv]; }
-    if (threadIdx.x == 1023u) counters->n_big = brun + b;
+    if (threadIdx.x == 1023u) {
+        counters->n_big = brun + b;
+        uint32_t total = 0;
+        for (uint32_t wv = 0; wv < 16; ++wv) total += wave_all[wv];
+        counters->total_hits = total;
+    }
     for (uint32_t k = 0; k < per; k += 4) {
         const uint32_t i = i0 + k;
         if (i >= n) break;
         uint4 q = make_uint4(0, 0, 0, 0);
         if (i + 3 < n) q = *reinterpret_cast<const uint4 *>(in + i);
         else { q.x = in[i]; if (i + 1 < n) q.y = in[i + 1]; if (i + 2 < n) q.z = in[i + 2]; }
-        const uint4 o = make_uint4(run, run + q.x, run + q.x + q.y, run + q.x + q.y + q.z);
+        const uint32_t ex = grouped_hits(q.x, slot_hits), ey = grouped_hits(q.y, slot_hits), ez = grouped_hits(q.z, slot_hits),
+                       ew = grouped_hits(q.w, slot_hits);
+        const uint4 o = make_uint4(run, run + ex, run + ex + ey, run + ex + ey + ez);
         if (i + 3 < n) *reinterpret_cast<uint4 *>(out + i) = o;
         else { out[i] = o.x; if (i + 1 < n) out[i + 1] = o.y; if (i + 2 < n) out[i + 2] = o.z; }
-        run += q.x + q.y + q.z + q.w;
+        run += ex + ey + ez + ew;
         if (q.x > kReplayLds) big[brun++] = i; // guides for k_replay_mid / k_replay_big
         if (q.y > kReplayLds) big[brun++] = i + 1;
         if (q.z > kReplayLds) big[brun++] = i + 2;
@@ -1557,12 +1586,16 @@ __global__ __launch_bounds__(1024) void k_prefix_single(const uint32_t *__restri
 // bytes they move, not by the number of streams; profiles/r03_ab_hit_records.log.)
 __global__ __launch_bounds__(kChunkRecs) void k_group_scatter(const uint64_t *__restrict__ raw,
                                                               const Counters *__restrict__ counters, uint32_t cap_chunks,
+                                                              const uint32_t *__restrict__ gcount,
                                                               const uint32_t *__restrict__ goff,
                                                               const uint32_t *__restrict__ rank,
                                                               const double2 *__restrict__ pay,
-                                                              uint64_t *__restrict__ sorted, double2 *__restrict__ terms)
+                                                              uint64_t *__restrict__ sorted, double2 *__restrict__ terms,
+                                                              uint32_t slot_hits)
 {
     short_kernel_priority();
+    // hit slots: only guides with more hits than fit their slots left anything to group -- on an even index none
+    if (slot_hits >= kReplayLds && counters->n_big == 0u) return;
     uint32_t n_chunks = counters->raw_chunks;
     if (n_chunks > cap_chunks) n_chunks = cap_chunks;
     for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
@@ -1576,10 +1609,9 @@ __global__ __launch_bounds__(kChunkRecs) void k_group_scatter(const uint64_t *__
         const uint32_t used = static_cast<uint32_t>(recs[0]);
         if (t >= used || t >= kChunkRecs || key == kDeadKey) continue;
         const uint32_t guide = static_cast<uint32_t>(key >> kKeyGuideShift);
-        const uint32_t g0 = goff[guide];
-        const uint32_t to = g0 + my_rank; // rank: k_verify's
+        const uint32_t to = goff[guide] + my_rank; // rank: k_verify's
         sorted[to] = key;
-        if (goff[guide + 1] - g0 <= kMidHits) terms[to] = my_pay; // (the many-hit replay makes its own)
+        if (gcount[guide] <= kMidHits) terms[to] = my_pay; // (the many-hit replay makes its own)
     }
 }
 
@@ -1589,17 +1621,17 @@ void launch_group_hits(const Workspace &ws, uint32_t n, void *stream_)
     const uint32_t m = n + 1; // gcount[n] = 0 so that goff[n] = total
     if (m <= (1u << 18)) {
         hipLaunchKernelGGL(k_prefix_single, dim3(1), dim3(1024), 0, stream, ws.gcount, m, ws.goff, ws.gcur_big,
-                           ws.counters);
+                           ws.counters, ws.slot_hits);
     } else {
         const uint32_t blocks = (m + kScanChunk - 1) / kScanChunk;
-        hipLaunchKernelGGL(k_prefix_block_sums, dim3(blocks), dim3(256), 0, stream, ws.gcount, m, ws.blocksum);
+        hipLaunchKernelGGL(k_prefix_block_sums, dim3(blocks), dim3(256), 0, stream, ws.gcount, m, ws.blocksum, ws.slot_hits);
         hipLaunchKernelGGL(k_prefix_of_sums, dim3(1), dim3(256), 0, stream, ws.blocksum, blocks);
         hipLaunchKernelGGL(k_prefix_apply, dim3(blocks), dim3(256), 0, stream, ws.gcount, m, ws.blocksum, ws.goff,
-                           ws.gcur_big, ws.counters);
+                           ws.gcur_big, ws.counters, ws.slot_hits);
     }
     hipLaunchKernelGGL(k_group_scatter, dim3(kTailGrid), dim3(kChunkRecs), 0, stream, ws.raw, ws.counters,
-                       static_cast<uint32_t>(ws.cap_chunks), ws.goff, ws.rank, reinterpret_cast<const double2 *>(ws.pay),
-                       ws.sorted, reinterpret_cast<double2 *>(ws.terms));
+                       static_cast<uint32_t>(ws.cap_chunks), ws.gcount, ws.goff, ws.rank, reinterpret_cast<const double2 *>(ws.pay),
+                       ws.sorted, reinterpret_cast<double2 *>(ws.terms), ws.slot_hits);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1772,9 +1804,16 @@ __global__ __launch_bounds__(64) void k_replay(ImageView v, Workspace ws, const 
     const uint32_t lane = threadIdx.x;
 
     for (uint32_t g = blockIdx.x; g < n; g += gridDim.x) {
-        const uint32_t h0 = ws.goff[g];
-        const uint32_t h = ws.goff[g + 1] - h0;
-        if (h > kReplayLds) continue; // k_replay_big's
+        const uint32_t h = ws.gcount[g];
+        if (h > kReplayLds) continue; // k_replay_mid's, k_replay_big's
+        // the guide's keys and terms: in its hit slots, or (no slots: issl_dump_hits, ...) its segment of the grouped arrays
+        const bool slots = ws.slot_hits >= kReplayLds;
+        const uint32_t h0 = slots ? 0u : ws.goff[g];
+        const SlotRec *__restrict__ srec = ws.slots + static_cast<uint64_t>(g) * ws.slot_hits;
+        const uint64_t *__restrict__ skeys = ws.sorted + h0;
+        const double2 *__restrict__ sterms = reinterpret_cast<const double2 *>(ws.terms) + h0;
+        auto key_of = [&](uint32_t i) { return slots ? srec[i].key : skeys[i]; };
+        auto terms_of = [&](uint32_t i) { return slots ? *reinterpret_cast<const double2 *>(&srec[i].mit) : sterms[i]; };
         const uint64_t gsig = guides[g];
         double tot_mit = 0.0, tot_cfd = 0.0;
         uint32_t kept = 0;
@@ -1788,7 +1827,6 @@ __global__ __launch_bounds__(64) void k_replay(ImageView v, Workspace ws, const 
         // The terms of every hit were computed by k_verify and sit next to the keys (ws.terms, same index as ws.sorted);
         // what is left is putting them in key order and adding them up.  issl_dump_hits also wants the expanded
         // records: those are looked up here (hit_terms), the totals still come from the stored terms.
-        const double2 *__restrict__ terms2 = reinterpret_cast<const double2 *>(ws.terms);
         if (h <= 64) {
             // Common case: no sort.  Lane l takes key l and its terms, finds the rank of its key among the h keys by
             // counting, and drops the terms at that rank; lane r then owns the r-th hit in key order.
@@ -1796,8 +1834,8 @@ __global__ __launch_bounds__(64) void k_replay(ImageView v, Workspace ws, const 
             double2 mine = make_double2(0.0, 0.0);
             issl_hit rec{};
             if (lane < h) {
-                key = ws.sorted[h0 + lane];
-                mine = terms2[h0 + lane];
+                key = key_of(lane);
+                mine = terms_of(lane);
                 if (out_hits) rec = hit_terms(v, gsig, g, key, calc_mit, calc_cfd, true).rec;
             }
             uint32_t rank = 0;
@@ -1819,7 +1857,7 @@ __global__ __launch_bounds__(64) void k_replay(ImageView v, Workspace ws, const 
         } else {
             // (slice, position) of every key with the key's index behind it, sorted in LDS; the terms follow by index
             uint64_t *data = keys;
-            for (uint32_t i = lane; i < h; i += 64) keys[i] = ((ws.sorted[h0 + i] & ((1ull << kKeyGuideShift) - 1ull)) << 9) | i; // h <= 512
+            for (uint32_t i = lane; i < h; i += 64) keys[i] = ((key_of(i) & ((1ull << kKeyGuideShift) - 1ull)) << 9) | i; // h <= 512
             __syncthreads();
             wave_sort(data, h);
             __syncthreads();
@@ -1828,7 +1866,7 @@ __global__ __launch_bounds__(64) void k_replay(ImageView v, Workspace ws, const 
                 double2 mine = make_double2(0.0, 0.0);
                 if (idx < h) {
                     const uint64_t sv = data[idx];
-                    mine = terms2[h0 + static_cast<uint32_t>(sv & 511ull)];
+                    mine = terms_of(static_cast<uint32_t>(sv & 511ull));
                     if (out_hits)
                         out_hits[h0 + idx] = hit_terms(v, gsig, g, (static_cast<uint64_t>(g) << kKeyGuideShift) | (sv >> 9), calc_mit, calc_cfd, true).rec;
                 }
@@ -1873,10 +1911,13 @@ __global__ __launch_bounds__(256) void k_replay_mid(ImageView v, Workspace ws, c
     const double2 *__restrict__ terms2 = reinterpret_cast<const double2 *>(ws.terms);
     for (uint32_t b = blockIdx.x; b < n_big; b += gridDim.x) {
         const uint32_t g = ws.gcur_big[b];
-        const uint32_t h0 = ws.goff[g];
-        const uint32_t h = ws.goff[g + 1] - h0;
+        const uint32_t h = ws.gcount[g];
         if (h > kMidHits) continue; // k_replay_big's (uniform over the workgroup)
+        const uint32_t h0 = ws.goff[g];
         const uint64_t gsig = guides[g];
+        // hit i of the guide: in its hit slots below slot_hits, in its segment of the grouped arrays from there on
+        const uint32_t in_slots = ws.slot_hits;
+        const SlotRec *__restrict__ srec = ws.slots + static_cast<uint64_t>(g) * in_slots;
         const uint64_t *__restrict__ gkeys = ws.sorted + h0;
         // diagnostics (ISSL_SCAN_STAMPS): phase clocks of the first 4096 listed guides, like k_replay_big's
         unsigned long long *st = (ws.stamps && b < 4096u) ? ws.stamps + 65536u + 16u * b : nullptr;
@@ -1888,7 +1929,10 @@ __global__ __launch_bounds__(256) void k_replay_mid(ImageView v, Workspace ws, c
         // them (a phase that goes back to memory costs a round trip of microseconds, and a guide is a chain of phases)
         uint64_t mykey[kMidHits / 256];
 #pragma unroll
-        for (uint32_t k = 0; k < kMidHits / 256; ++k) mykey[k] = k * 256u + threadIdx.x < h ? gkeys[k * 256u + threadIdx.x] : ~0ull;
+        for (uint32_t k = 0; k < kMidHits / 256; ++k) {
+            const uint32_t i = k * 256u + threadIdx.x;
+            mykey[k] = i < h ? (i < in_slots ? srec[i].key : gkeys[i]) : ~0ull;
+        }
 #pragma unroll
         for (uint32_t k = 0; k < kMidHits / 256; ++k) { // hits per slice (one LDS atomic per wave and slice present)
             if (k * 256u >= h) break;
@@ -1948,7 +1992,7 @@ __global__ __launch_bounds__(256) void k_replay_mid(ImageView v, Workspace ws, c
                 for (uint32_t k = 0; k < 4; ++k) {
                     if (threadIdx.x + k * 256u >= len) continue;
                     const uint32_t idx = head_idx[threadIdx.x + k * 256u];
-                    const double2 t2 = terms2[h0 + idx];
+                    const double2 t2 = idx < in_slots ? *reinterpret_cast<const double2 *>(&srec[idx].mit) : terms2[h0 + idx];
                     tm[rk[k]] = t2.x;
                     tc[rk[k]] = t2.y;
                     if (out_hits)
@@ -2092,8 +2136,8 @@ __global__ __launch_bounds__(THREADS) void k_replay_big(ImageView v, Workspace w
         // first the list of all guides with more than kReplayLds hits, then the ones k_replay_mid handed on
         const bool handed_on = b >= n_big;
         const uint32_t g = handed_on ? ws.gcur_big2[b - n_big] : ws.gcur_big[b];
+        const uint32_t h = ws.gcount[g];
         const uint32_t h0 = ws.goff[g];
-        const uint32_t h = ws.goff[g + 1] - h0;
         // k_replay_mid's, or the other build's: up to kBigSmall hits a 256-thread workgroup with 2048 hits per slice in
         // LDS (eight per CU: what such a guide costs is a chain of barriers and memory round trips, and what counts is
         // how many are in flight), beyond that 1024 threads with 7680 (two per CU).  (uniform over the workgroup)
@@ -2110,6 +2154,8 @@ __global__ __launch_bounds__(THREADS) void k_replay_big(ImageView v, Workspace w
         // a time -- a fifth of the sorting work per step, in LDS up to 8192 hits PER SLICE, and none at all for the
         // slices behind the exit.
         if (threadIdx.x < kMaxSlices) { slice_cnt[threadIdx.x] = 0; slice_cur[threadIdx.x] = 0; }
+        // hit slots: the guide's first slot_hits keys join the rest in its segment (h > slot_hits here: all of them are there)
+        for (uint32_t i = threadIdx.x; i < ws.slot_hits; i += blockDim.x) seg[i] = ws.slots[static_cast<uint64_t>(g) * ws.slot_hits + i].key;
         __syncthreads();
         for (uint32_t base = 0; base < h; base += blockDim.x) {
             const uint32_t i = base + threadIdx.x;

@@ -354,8 +354,15 @@ def test_scheduling_knobs_do_not_change_results(config0):
             assert np.array_equal(gm, wm) and np.array_equal(gc, wc), (sched, blocks, prune)
             st = check_comparisons(ix, batch, prune)
             assert st["reference_comparisons"] == expected and st["pruned"] == 2 * prune, (sched, blocks, prune)
+        ix.set_option("item_guides", 512).set_option("scan_blocks", 1024)
+        for slots, prune in ((0, 0), (0, 1), (1, 1)):   # without / with the per-guide hit slots (Workspace::slot_hits)
+            ix.set_option("hit_slots", slots).set_option("prune", prune)
+            for thr in (75.0, 0.0):
+                gm, gc = ix.score(batch, 4, thr, "and")
+                om, oc = oracle.score(batch, 4, thr, "and")
+                assert np.array_equal(gm.view(np.uint64), om.view(np.uint64)) and np.array_equal(gc.view(np.uint64), oc.view(np.uint64)), (slots, prune, thr)
     finally:
-        ix.set_option("item_guides", 512).set_option("scan_blocks", 1024).set_option("prune", -1)
+        ix.set_option("item_guides", 512).set_option("scan_blocks", 1024).set_option("prune", -1).set_option("hit_slots", 1)
     _, _, ohits = oracle.score(batch, 4, 0.0, "and", want_hits=True)
     assert np.array_equal(want, ohits)
     with pytest.raises(ca.IsslError):
@@ -911,6 +918,7 @@ def test_random_small_indexes_differential():
             layout = dict(LAYOUTS[name])
             if name in SORTED:
                 layout["prune"] = int(rng.integers(-1, 2)) if trial % 2 else 1
+            layout["hit_slots"] = int(rng.integers(0, 2))   # hits straight to per-guide slots, or all through the grouping pass
             for key, value in layout.items():
                 ix.set_option(key, value)
             ix.upload(0)

@@ -403,6 +403,10 @@ def test_many_hit_guides_several_per_replay_workgroup(tmp_path, options):
                 pm[lo:lo + piece], pc[lo:lo + piece] = ix.score(guides[lo:lo + piece], 4, thr, method)
             bad = np.flatnonzero((pm.view(np.uint64) != mit.view(np.uint64)) | (pc.view(np.uint64) != cfd.view(np.uint64)))
             assert len(bad) == 0, (thr, method, len(bad), bad[:8].tolist())
+            ix.set_option("hit_slots", 0)   # every hit through the grouping pass (no per-guide slots): the same scores
+            m0, c0 = ix.score(guides, 4, thr, method)
+            ix.set_option("hit_slots", 1)
+            assert np.array_equal(m0.view(np.uint64), mit.view(np.uint64)) and np.array_equal(c0.view(np.uint64), cfd.view(np.uint64)), (thr, method)
             # the oracle on the neighbourhoods of a sample (brute force over the site table)
             pick = np.linspace(0, len(guides) - 1, 36).astype(np.int64)
             if thr in (0.0, 75.0):
@@ -453,7 +457,9 @@ def test_skewed_index_at_scale(tmp_path):
         same(pm, pc, "pieces")
         ix.set_option("prune", 0)
         same(*ix.score(guides, 4, 75.0, "and"), "whole buckets")
-        ix.set_option("prune", -1)
+        ix.set_option("prune", -1).set_option("hit_slots", 0)
+        same(*ix.score(guides, 4, 75.0, "and"), "no hit slots")
+        ix.set_option("hit_slots", 1)
         for method, thr, max_dist in (("or", 90.0, 4), ("mit", 50.0, 4), ("cfd", 75.0, 3), ("avg", 60.0, 4), ("and", 0.0, 4)):
             wm, wc = ix.score(guides, max_dist, thr, method)   # other exits, other distances: whole batch = pieces = oracle sample
             for lo in range(0, len(guides), 20000):
