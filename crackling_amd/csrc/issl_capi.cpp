@@ -851,7 +851,11 @@ static int finish_batches(issl_index *ix, hipStream_t stream)
     PlanInfo pl{};
     uint32_t total_hits = 0;
     HIP_TRY(hipMemcpy(&pl, lane.ws.plan, sizeof pl, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(&total_hits, &lane.ws.counters->total_hits, sizeof total_hits, hipMemcpyDeviceToHost));
+    {   // scored off-targets of the last batch before any early exit: the per-guide counts k_verify left
+        std::vector<uint32_t> counts(lane.last_n);
+        if (lane.last_n) HIP_TRY(hipMemcpy(counts.data(), lane.ws.gcount, 4 * counts.size(), hipMemcpyDeviceToHost));
+        for (uint32_t c : counts) total_hits += c;
+    }
     // comparisons the scan workgroups of the last batch counted while they made them
     std::vector<uint64_t> counted(ix->tuning.scan_blocks);
     HIP_TRY(hipMemcpy(counted.data(), lane.ws.scan_count, 8 * counted.size(), hipMemcpyDeviceToHost));

@@ -263,7 +263,7 @@ struct Counters {
     uint32_t n_big2;      // guides k_replay_mid hands on to k_replay_big (a slice too long for its buffers)
     uint32_t raw_chunks;  // chunks of the raw record buffer handed out
     uint32_t raw_overflow; // set when the raw buffer was too small
-    uint32_t total_hits;  // scored off-targets of the batch before any early exit (sum of the per-guide counts)
+    uint32_t overflowed;  // hit slots: guides whose hits outgrew their slots (k_verify); 0 = nothing to group
 };
 
 // Per bucket, pruned scan: what its successor-byte groups add to the plan (k_fine_count -> k_fine_plan -> k_fine_scatter).

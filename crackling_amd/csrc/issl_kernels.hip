@@ -1394,6 +1394,7 @@ __global__ __launch_bounds__(kChunkRecs, 8) void k_verify(ImageView v, Workspace
             ws.slots[at] = r;
             key = kDeadKey;
         } else if (live) {
+            if (rank == ws.slot_hits && rank != 0u) atomicAdd(&ws.counters->overflowed, 1u); // the guide's first hit beyond its slots
             const uint64_t slot = static_cast<uint64_t>(chunk) * (kChunkRecs - 1u) + (t - 1u); // < cap_chunks * 127 <= cap_hits
             ws.rank[slot] = rank;
             // The terms (:392-460) -- unless the guide already has more hits than the replays that read them take
@@ -1496,10 +1497,9 @@ __global__ __launch_bounds__(256) void k_prefix_apply(const uint32_t *__restrict
     const uint32_t base = blockIdx.x * kScanChunk + threadIdx.x * 8u;
     uint32_t val[8];
     uint64_t s = 0;
-    uint32_t nb = 0, all = 0;
+    uint32_t nb = 0;
     for (uint32_t i = 0; i < 8; ++i) {
         const uint32_t c = (base + i < n) ? in[base + i] : 0u;
-        all += c;
         nb += c > kReplayLds;
         val[i] = grouped_hits(c, slot_hits);
         s += val[i];
@@ -1509,10 +1509,6 @@ __global__ __launch_bounds__(256) void k_prefix_apply(const uint32_t *__restrict
         for (uint32_t i = 0; i < 8; ++i)
             if (base + i < n && in[base + i] > kReplayLds) big[at++] = base + i;
     }
-    uint64_t total_all;
-    (void)block_exclusive_scan(all, lds, &total_all);
-    if (threadIdx.x == 0 && total_all) atomicAdd(&counters->total_hits, static_cast<uint32_t>(total_all));
-    __syncthreads();
     uint64_t run = block_exclusive_scan(s, lds, nullptr) + sums[blockIdx.x];
     for (uint32_t i = 0; i < 8; ++i) {
         if (base + i < n) out[base + i] = static_cast<uint32_t>(run);
@@ -1526,42 +1522,37 @@ __global__ __launch_bounds__(256) void k_prefix_apply(const uint32_t *__restrict
 // of guides with more than kReplayLds hits comes out of the same scan (their number rides in a second scanned word), in
 // guide order and without an atomic: on indexes where most guides are such (skewed genomes, the 3 G-line index) one
 // returning atomic per guide from a single workgroup cost more than the rest of the grouping (2 ms per 100 k guides).
-// With hit slots only those guides have anything in the grouped arrays (grouped_hits); the sum of all counts goes to
-// counters->total_hits.
+// With hit slots only those guides have anything in the grouped arrays (grouped_hits), and when k_verify saw no guide
+// outgrow its slots there is nothing to do at all.
 __global__ __launch_bounds__(1024) void k_prefix_single(const uint32_t *__restrict__ in, uint32_t n,
                                                         uint32_t *__restrict__ out, uint32_t *__restrict__ big,
                                                         Counters *__restrict__ counters, uint32_t slot_hits)
 {
     short_kernel_priority();
-    __shared__ uint32_t wave_sum[16], wave_big[16], wave_all[16];
+    if (slot_hits >= kReplayLds && counters->overflowed == 0u) return; // (n_big stays 0: k_group_scatter and the replays of many-hit guides return at once)
+    __shared__ uint32_t wave_sum[16], wave_big[16];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t per = ((n + 1023u) / 1024u + 3u) & ~3u; // counts per thread, a multiple of 4: the runs start 16-byte aligned
     const uint32_t i0 = threadIdx.x * per;
-    uint32_t s = 0, b = 0, all = 0;
+    uint32_t s = 0, b = 0;
     for (uint32_t k = 0; k < per; k += 4) {
         const uint32_t i = i0 + k;
         uint4 q = make_uint4(0, 0, 0, 0);
         if (i + 3 < n) q = *reinterpret_cast<const uint4 *>(in + i);
         else { if (i < n) q.x = in[i]; if (i + 1 < n) q.y = in[i + 1]; if (i + 2 < n) q.z = in[i + 2]; }
-        all += q.x + q.y + q.z + q.w;
         s += grouped_hits(q.x, slot_hits) + grouped_hits(q.y, slot_hits) + grouped_hits(q.z, slot_hits) + grouped_hits(q.w, slot_hits);
         b += (q.x > kReplayLds) + (q.y > kReplayLds) + (q.z > kReplayLds) + (q.w > kReplayLds);
     }
-    uint32_t x = s, xb = b, xa = all; // inclusive scans of s and b inside the wave (and the sum of `all`)
+    uint32_t x = s, xb = b; // inclusive scans of s and b inside the wave
     for (uint32_t d = 1; d < 64; d <<= 1) {
-        const uint32_t y = __shfl_up(x, d, 64), yb = __shfl_up(xb, d, 64), ya = __shfl_up(xa, d, 64);
-        if (lane >= d) { x += y; xb += yb; xa += ya; }
+        const uint32_t y = __shfl_up(x, d, 64), yb = __shfl_up(xb, d, 64);
+        if (lane >= d) { x += y; xb += yb; }
     }
-    if (lane == 63) { wave_sum[wave] = x; wave_big[wave] = xb; wave_all[wave] = xa; }
+    if (lane == 63) { wave_sum[wave] = x; wave_big[wave] = xb; }
     __syncthreads();
     uint32_t run = x - s, brun = xb - b;
     for (uint32_t wv = 0; wv < wave; ++wv) { run += wave_sum[wv]; brun += wave_big[wv]; }
-    if (threadIdx.x == 1023u) {
-        counters->n_big = brun + b;
-        uint32_t total = 0;
-        for (uint32_t wv = 0; wv < 16; ++wv) total += wave_all[wv];
-        counters->total_hits = total;
-    }
+    if (threadIdx.x == 1023u) counters->n_big = brun + b;
     for (uint32_t k = 0; k < per; k += 4) {
         const uint32_t i = i0 + k;
         if (i >= n) break;

@@ -14,16 +14,16 @@ OUT = ROOT / "build" / "ablate"
 VARIANTS = {
     "base": [],
     # k_verify
-    "verify_no_atomic": [("if ((todo >> lane) & 1ull) rank = atomicAdd(&ws.gcount[guide], 1u);", "if ((todo >> lane) & 1ull) rank = lane;"),
-                         ("if (static_cast<int>(lane) == leader) base = atomicAdd(&ws.gcount[g0], cnt);", "if (static_cast<int>(lane) == leader) base = cnt;")],
-    "verify_no_terms": [("            if (rank < kMidHits) {\n                int dist;", "            if (false) {\n                int dist;")],
+    "verify_no_atomic": [("            if (live) rank = atomicAdd(&ws.gcount[guide], 1u);", "            if (live) rank = lane;"),
+                         ("if (live && !continues) base = atomicAdd(&ws.gcount[guide], next - lane);", "if (live && !continues) base = next - lane;")],
+    "verify_no_terms": [("            score_terms(v, hit_gsig, hit_ot, hit_occ, calc_mit, calc_cfd, mit_term, cfd_term, dist);\n            const uint64_t at",
+                         "            dist = 0;\n            const uint64_t at")],
     "verify_no_srec": [("if (in_use && v.srec) sr_early = v.srec[static_cast<uint64_t>(tile) * kTileCands + offset];",
                         "if (in_use && v.srec) { sr_early.sig = rec * 0x9E3779B97F4A7C15ull; sr_early.id = static_cast<uint32_t>(rec); }")],
     "verify_srec_only": [("        if (guide != kNoGuide) {\n            const uint32_t bucket = prune_mode ? where >> 8 : where;",
                           "        if (guide != kNoGuide && sr_early.sig == 0x123456789ull) {\n            const uint32_t bucket = prune_mode ? where >> 8 : where;")],
-    "verify_no_rank_pay_store": [("            ws.rank[slot] = rank;", "            if (rank == 0xFFFFFFFFu) ws.rank[slot] = rank;"),
-                                 ("                reinterpret_cast<double2 *>(ws.pay)[slot] = make_double2(mit_term, cfd_term);",
-                                  "                if (mit_term == 1e300) reinterpret_cast<double2 *>(ws.pay)[slot] = make_double2(mit_term, cfd_term);")],
+    "verify_no_slot_store": [("            ws.slots[at] = r;", "            if (rank == 0xFFFFFFFFu) ws.slots[at] = r;")],
+    "verify_no_key_store": [("        if (!in_use) continue;\n        recs[t] = key;", "        if (!in_use) continue;\n        if (key != kDeadKey) recs[t] = key;")],
 }
 
 
