@@ -212,6 +212,9 @@ int issl_index_attach_image_cold(int device, void *dev_buf, size_t bytes, void *
  *     with site table and lists in host memory
  *   tail_shapes (ISSL_TAIL_SHAPES) 0|1 (default 1): the short last unit of a successor-byte group runs 2 / 4 guides per
  *     pass on 16 / 8 candidates per lane
+ *   hit_slots (ISSL_HIT_SLOTS) 0|1 (default 1): the first 512 hits of every guide go straight from the exact test to a
+ *     32-byte record of their own (1.6 GB of scratch per 100 000 guides of a batch; batches beyond 512 k guides, a
+ *     device short of memory and issl_dump_hits go without); 0: every hit passes through the grouping pass
  *   prune (ISSL_PRUNE) -1|0|1: scan only the successor-byte groups of a bucket that can hold a site within max_dist (13
  *     of 256 for max_dist <= 4, 1 of 256 for <= 2; same hits and scores as the reference's scan of the whole bucket,
  *     isslScoreOfftargets.cpp:344): -1 = a planning kernel decides per batch from the two plans' estimated times,
