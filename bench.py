@@ -462,6 +462,48 @@ def main():
             dt = (time.perf_counter() - t1) / reps
             extras["host_pointer_entry"] = {"ms_per_step": dt * 1e3, "guides_per_s": n_mine / dt,
                                             "note": "issl_score(): guides in and scores out over PCIe, one synchronisation per call"}
+            # the same line on a SKEWED index of the same size (`--dist markov` run by itself gives the full record): an
+            # AT-rich order-3 Markov chain, seven times the hits, most guides leave through the early exit -- the tail's
+            # kernels carry the step there
+            if a.dist == "uniform" and a.sites >= 50_000_000:
+                t1 = time.perf_counter()
+                sk_sigs, sk_occ = markov_sites_fast(a.sites, seed=20261003, threads=min(16, os.cpu_count() or 8))
+                sk_index = ca.IsslIndex.build_on_device(sk_sigs, sk_occ, device=dev_id)
+                sk_guides = random_guides_fast(sk_sigs, n_mine, seed=777)
+                sk_setup = time.perf_counter() - t1
+                try:
+                    sk_d = torch.from_numpy(sk_guides.view(np.int64)).to(dev)
+
+                    def sk_step(i=0):
+                        sk_index.score_device_async(sk_d, out_mit[i % a.steps], out_cfd[i % a.steps], a.max_dist, a.threshold, a.method, stream=None)
+
+                    for _ in range(4):  # (scratch buffers settle: a batch that needs larger ones is repeated)
+                        sk_step()
+                        while not sk_index.finish(stream):
+                            sk_step()
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    reps = max(5, min(a.steps, 10))
+                    for i in range(reps):
+                        sk_step(i)
+                    ok_sk = sk_index.finish(stream)
+                    dt = time.perf_counter() - t1
+                    sk_index.set_option("stage_timing", 1)
+                    for _ in range(2):
+                        sk_step()
+                    sk_index.finish(stream)
+                    s2 = sk_index.stats()
+                    if ok_sk:
+                        extras["skewed_index"] = {
+                            "distribution": "markov", "distinct_sites": int(len(sk_sigs)), "guides_per_step": n_mine, "steps": reps,
+                            "ms_per_step": dt * 1e3 / reps, "guides_per_s": n_mine * reps / dt, "hits_per_step": s2["hits"],
+                            "kernel_ms": {"bin": s2["ms_bin"], "scan": s2["ms_scan"], "verify": s2["ms_verify"], "group": s2["ms_group"],
+                                          "replay": s2["ms_replay"], "pipeline": s2["ms_total"]},
+                            "setup_s": sk_setup,
+                        }
+                finally:
+                    sk_index.close()
+                    del sk_sigs, sk_occ
         except Exception as e:  # noqa: BLE001
             extras["error"] = f"{type(e).__name__}: {e}"
 

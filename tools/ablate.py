@@ -23,6 +23,11 @@ VARIANTS = {
     "verify_srec_only": [("        if (guide != kNoGuide) {\n            const uint32_t bucket = prune_mode ? where >> 8 : where;",
                           "        if (guide != kNoGuide && sr_early.sig == 0x123456789ull) {\n            const uint32_t bucket = prune_mode ? where >> 8 : where;")],
     "verify_no_slot_store": [("            ws.slots[at] = r;", "            if (rank == 0xFFFFFFFFu) ws.slots[at] = r;")],
+    # not cuts but alternatives (results stay right): streaming hints on the random accesses of k_verify
+    "verify_srec_nontemporal": [("if (in_use && v.srec) sr_early = v.srec[static_cast<uint64_t>(tile) * kTileCands + offset];",
+                                 "if (in_use && v.srec) { typedef unsigned int v4u __attribute__((ext_vector_type(4))); const v4u q4 = __builtin_nontemporal_load(reinterpret_cast<const v4u *>(v.srec + static_cast<uint64_t>(tile) * kTileCands + offset)); sr_early = *reinterpret_cast<const StreamRec *>(&q4); }")],
+    "verify_slot_nontemporal": [("            ws.slots[at] = r;",
+                                 "            { typedef unsigned int v4u __attribute__((ext_vector_type(4))); const v4u *r4 = reinterpret_cast<const v4u *>(&r); v4u *d4 = reinterpret_cast<v4u *>(ws.slots + at); __builtin_nontemporal_store(r4[0], d4); __builtin_nontemporal_store(r4[1], d4 + 1); }")],
     "verify_no_key_store": [("        if (!in_use) continue;\n        recs[t] = key;", "        if (!in_use) continue;\n        if (key != kDeadKey) recs[t] = key;")],
 }
 
@@ -36,7 +41,10 @@ def build():
         o = OUT / (f + ".o")
         subprocess.check_call(["/opt/rocm/bin/hipcc"] + flags + ["-c", "-o", str(o), str(CSRC / f)])
         objs.append(str(o))
+    only = os.environ.get("ABLATE_ONLY")
     for name, edits in VARIANTS.items():
+        if only and name not in only.split(","):
+            continue
         text = src
         for old, new in edits:
             assert text.count(old) == 1, (name, old[:60], text.count(old))
@@ -50,7 +58,10 @@ def build():
 
 
 def run(args):
+    only = os.environ.get("ABLATE_ONLY")
     for name in VARIANTS:
+        if only and name not in only.split(","):
+            continue
         lib = OUT / f"libissl_hip_{name}.so"
         env = dict(os.environ, ISSL_HIP_LIBRARY=str(lib))
         r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--no-extras", "--no-cpu-baseline", "--steps", "5", "--warmup", "2"] + args,
