@@ -1660,14 +1660,19 @@ __device__ inline double bcast_f64(double x, int lane)
     return __longlong_as_double((static_cast<uint64_t>(hi) << 32) | lo);
 }
 
-// Adds the terms held by lanes 0..cnt-1 (cnt <= 64; lanes beyond hold 0.0) to the running totals in lane order (:394,
-// :460) and applies the exit test of :467-496 after every hit.  The sums are a serial chain of f64 additions -- the
-// order is part of the result -- but the test is not: every lane keeps the totals as they stood after ITS hit, the
-// tests run side by side afterwards, and the first lane that passes decides where the walk stops.  (Testing inside
-// the chain costs a compare, a branch and their latencies per hit: ~200 cycles against ~50.)
+// Adds the terms of a chunk of cnt <= 64 hits to the running totals in walking order (:394, :460) and applies the exit test
+// of :467-496 after every hit.  `chunk_lds`: the chunk's terms in LDS, {mit, cfd} per hit in walking order, zeros behind the
+// last hit up to a multiple of 8; lane l also holds the terms of hit l (0.0 beyond cnt).  The sums are a serial chain of
+// f64 additions -- the order is part of the result -- read from LDS, every lane the same 16 bytes: one load and two
+// additions per hit (passing them from lane to lane through scalar registers cost four readlanes more; the walk shares
+// its SIMD with seven other waves, what it costs is instructions: replay 0.37 -> 0.30 ms, 4.2 -> 3.5 on the skewed index).
+// The exit test is not part of the chain: every lane keeps the totals as they stood after ITS hit, the tests run side by
+// side afterwards, and the first lane that passes decides where the walk stops.  (Testing inside the chain costs a
+// compare, a branch and their latencies per hit: ~200 cycles against ~50.)
 // Returns true when the walk stops; `kept` counts the hits that were scored, the totals are those at that point.
 __device__ __forceinline__ bool accumulate_chunk(double mit_term, double cfd_term, uint32_t cnt, const ScoreParams &p,
-                                                 uint32_t lane, double &tot_mit, double &tot_cfd, uint32_t &kept)
+                                                 uint32_t lane, double &tot_mit, double &tot_cfd, uint32_t &kept,
+                                                 const double2 *chunk_lds)
 {
     auto passes = [&](double m, double c) {
         if (p.method == ISSL_METHOD_AND) return m > p.maximum_sum && c > p.maximum_sum;
@@ -1685,9 +1690,10 @@ __device__ __forceinline__ bool accumulate_chunk(double mit_term, double cfd_ter
         double tm = tot_mit, tc = tot_cfd;
         for (uint32_t l0 = 0; l0 < cnt; l0 += 8) {
 #pragma unroll
-            for (uint32_t l = 0; l < 8; ++l) { // x + 0.0 == x: the empty lanes of the last group change nothing
-                tm += bcast_f64(mit_term, static_cast<int>(l0 + l));
-                tc += bcast_f64(cfd_term, static_cast<int>(l0 + l));
+            for (uint32_t l = 0; l < 8; ++l) { // x + 0.0 == x: the zeros behind the last hit change nothing
+                const double2 t = chunk_lds[l0 + l];
+                tm += t.x;
+                tc += t.y;
             }
         }
         const bool grows = __ballot(lane < cnt && !(mit_term >= 0.0 && cfd_term >= 0.0)) == 0ull;
@@ -1702,8 +1708,9 @@ __device__ __forceinline__ bool accumulate_chunk(double mit_term, double cfd_ter
     for (uint32_t l0 = 0; l0 < cnt; l0 += 8) {
 #pragma unroll
         for (uint32_t l = 0; l < 8; ++l) {
-            tm += bcast_f64(mit_term, static_cast<int>(l0 + l));
-            tc += bcast_f64(cfd_term, static_cast<int>(l0 + l));
+            const double2 t = chunk_lds[l0 + l];
+            tm += t.x;
+            tc += t.y;
             if (lane == l0 + l) { mine_m = tm; mine_c = tc; }
         }
     }
@@ -1787,7 +1794,7 @@ __global__ __launch_bounds__(64) void k_replay(ImageView v, Workspace ws, const 
 {
     short_kernel_priority();
     __shared__ uint64_t keys[kReplayLds];
-    __shared__ double ord_mit[64], ord_cfd[64];
+    __shared__ __attribute__((aligned(16))) double2 ord[64]; // the terms of the chunk being walked, in key order
     const bool calc_mit = p.method == ISSL_METHOD_MIT || p.method == ISSL_METHOD_AND || p.method == ISSL_METHOD_OR ||
                           p.method == ISSL_METHOD_AVG;
     const bool calc_cfd = p.method == ISSL_METHOD_CFD || p.method == ISSL_METHOD_AND || p.method == ISSL_METHOD_OR ||
@@ -1812,7 +1819,7 @@ __global__ __launch_bounds__(64) void k_replay(ImageView v, Workspace ws, const 
 
         // Running totals in key order, same operations as the reference's (:394,:460), early exit of :467-496.
         auto accumulate = [&](double mit_term, double cfd_term, uint32_t cnt) {
-            stop = accumulate_chunk(mit_term, cfd_term, cnt, p, lane, tot_mit, tot_cfd, kept);
+            stop = accumulate_chunk(mit_term, cfd_term, cnt, p, lane, tot_mit, tot_cfd, kept, ord);
         };
 
         // The terms of every hit were computed by k_verify and sit next to the keys (ws.terms, same index as ws.sorted);
@@ -1837,14 +1844,14 @@ __global__ __launch_bounds__(64) void k_replay(ImageView v, Workspace ws, const 
                 rank += (other < key) ? 1u : 0u;
             }
             if (lane < h) {
-                ord_mit[rank] = mine.x;
-                ord_cfd[rank] = mine.y;
+                ord[rank] = mine;
                 if (out_hits) out_hits[h0 + rank] = rec;
+            } else {
+                ord[lane] = make_double2(0.0, 0.0); // (ranks are below h: nobody else writes here)
             }
             __syncthreads();
-            const double mit_term = lane < h ? ord_mit[lane] : 0.0;
-            const double cfd_term = lane < h ? ord_cfd[lane] : 0.0;
-            accumulate(mit_term, cfd_term, h);
+            const double2 t = ord[lane];
+            accumulate(t.x, t.y, h);
         } else {
             // (slice, position) of every key with the key's index behind it, sorted in LDS; the terms follow by index
             uint64_t *data = keys;
@@ -1861,6 +1868,9 @@ __global__ __launch_bounds__(64) void k_replay(ImageView v, Workspace ws, const 
                     if (out_hits)
                         out_hits[h0 + idx] = hit_terms(v, gsig, g, (static_cast<uint64_t>(g) << kKeyGuideShift) | (sv >> 9), calc_mit, calc_cfd, true).rec;
                 }
+                __syncthreads(); // (the walk of the chunk before has read `ord`)
+                ord[lane] = mine;
+                __syncthreads();
                 accumulate(mine.x, mine.y, (h - base < 64u) ? h - base : 64u);
             }
         }
@@ -1889,7 +1899,7 @@ __global__ __launch_bounds__(256) void k_replay_mid(ImageView v, Workspace ws, c
     short_kernel_priority();
     __shared__ __attribute__((aligned(16))) uint32_t head[kMidSlice]; // the slice's keys: site ids or positions (distinct) ...
     __shared__ uint16_t head_idx[kMidSlice];                           // ... and the index of the hit each belongs to
-    __shared__ double tm[kMidSlice], tc[kMidSlice];                    // its terms in key order
+    __shared__ __attribute__((aligned(16))) double2 tmc[kMidSlice];    // its terms {mit, cfd} in key order
     __shared__ uint32_t slice_cnt[kMaxSlices];
     __shared__ uint32_t head_fill, stopped_s, carry_kept;
     __shared__ double carry_mit, carry_cfd;
@@ -1984,13 +1994,13 @@ __global__ __launch_bounds__(256) void k_replay_mid(ImageView v, Workspace ws, c
                     if (threadIdx.x + k * 256u >= len) continue;
                     const uint32_t idx = head_idx[threadIdx.x + k * 256u];
                     const double2 t2 = idx < in_slots ? *reinterpret_cast<const double2 *>(&srec[idx].mit) : terms2[h0 + idx];
-                    tm[rk[k]] = t2.x;
-                    tc[rk[k]] = t2.y;
+                    tmc[rk[k]] = t2;
                     if (out_hits)
                         out_hits[h0 + walked + rk[k]] = hit_terms(v, gsig, g, (static_cast<uint64_t>(g) << kKeyGuideShift) |
                                                                       (static_cast<uint64_t>(s2) << kKeySliceShift) | mine[k],
                                                                   calc_mit, calc_cfd, true).rec;
                 }
+                if (threadIdx.x < 8u && len + threadIdx.x < ((len + 7u) & ~7u)) tmc[len + threadIdx.x] = make_double2(0.0, 0.0); // (walked eight at a time)
             }
             __syncthreads();
             if (st && threadIdx.x == 0 && walked == 0) { st[3] = __builtin_amdgcn_s_memrealtime(); st[4] = len; }
@@ -2000,8 +2010,9 @@ __global__ __launch_bounds__(256) void k_replay_mid(ImageView v, Workspace ws, c
                 bool stop = false;
                 for (uint32_t base = 0; base < len && !stop; base += 64) {
                     const uint32_t idx = base + lane;
-                    stop = accumulate_chunk(idx < len ? tm[idx] : 0.0, idx < len ? tc[idx] : 0.0, (len - base < 64u) ? len - base : 64u, p,
-                                            lane, tot_mit, tot_cfd, kept);
+                    const double2 mine2 = idx < len ? tmc[idx] : make_double2(0.0, 0.0);
+                    stop = accumulate_chunk(mine2.x, mine2.y, (len - base < 64u) ? len - base : 64u, p, lane, tot_mit, tot_cfd, kept,
+                                            tmc + base);
                 }
                 if (lane == 0) { carry_mit = tot_mit; carry_cfd = tot_cfd; carry_kept = kept; stopped_s = stop ? 1u : 0u; }
             }
@@ -2117,6 +2128,7 @@ __global__ __launch_bounds__(THREADS) void k_replay_big(ImageView v, Workspace w
     __shared__ uint32_t group_at[257], group_cur[256], max_pos, min_pos;
     __shared__ uint32_t slice_cnt[kMaxSlices], slice_off[kMaxSlices + 1], slice_cur[kMaxSlices];
     __shared__ uint32_t walk_stopped, head_groups, head_count, head_fill;
+    __shared__ __attribute__((aligned(16))) double2 walk_terms[64]; // wave 0: the terms of the 64 hits it is adding up
     const bool calc_mit = p.method == ISSL_METHOD_MIT || p.method == ISSL_METHOD_AND || p.method == ISSL_METHOD_OR ||
                           p.method == ISSL_METHOD_AVG;
     const bool calc_cfd = p.method == ISSL_METHOD_CFD || p.method == ISSL_METHOD_AND || p.method == ISSL_METHOD_OR ||
@@ -2184,8 +2196,12 @@ __global__ __launch_bounds__(THREADS) void k_replay_big(ImageView v, Workspace w
         double tot_mit = 0.0, tot_cfd = 0.0;
         uint32_t kept = 0;
         bool stop = false;
-        auto accumulate = [&](double mit_term, double cfd_term, uint32_t cnt) {
-            stop = accumulate_chunk(mit_term, cfd_term, cnt, p, lane, tot_mit, tot_cfd, kept);
+        auto accumulate = [&](double mit_term, double cfd_term, uint32_t cnt) { // (wave 0 only)
+            __builtin_amdgcn_wave_barrier();
+            walk_terms[lane] = make_double2(mit_term, cfd_term);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            stop = accumulate_chunk(mit_term, cfd_term, cnt, p, lane, tot_mit, tot_cfd, kept, walk_terms);
         };
         for (uint32_t s2 = 0; s2 < v.n_slices; ++s2) {
             const uint32_t off = slice_off[s2], len = slice_cnt[s2];
