@@ -420,6 +420,17 @@ def test_many_hit_guides_several_per_replay_workgroup(tmp_path, options):
                 oracle.close()
                 assert np.array_equal(mit[pick].view(np.uint64), omit.view(np.uint64)), (thr, method)
                 assert np.array_equal(cfd[pick].view(np.uint64), ocfd.view(np.uint64)), (thr, method)
+        # the same guides at the end of a batch of more than 2^18: the three-kernel prefix sum over the hit counts instead of
+        # the one-workgroup one (with and without hit slots)
+        filler = rng.integers(0, 1 << 40, size=(1 << 18) + 1000, dtype=np.uint64)
+        long_batch = np.concatenate([filler, guides])
+        want_m, want_c = ix.score(guides, 4, 75.0, "and")
+        for slots in (1, 0):
+            ix.set_option("hit_slots", slots)
+            lm, lc = ix.score(long_batch, 4, 75.0, "and")
+            assert np.array_equal(lm[len(filler):].view(np.uint64), want_m.view(np.uint64)), slots
+            assert np.array_equal(lc[len(filler):].view(np.uint64), want_c.view(np.uint64)), slots
+        ix.set_option("hit_slots", 1)
         print(f"many-hit batch: {len(guides)} guides, {len(sig)} sites, {hits} hits", flush=True)
     finally:
         ix.close()
