@@ -319,7 +319,7 @@ struct Workspace {
     uint64_t *scan_count = nullptr; // [kScanMaxBlocks] comparisons every scan workgroup actually made (real candidates x real guides)
     unsigned long long *stamps = nullptr; // [4 * kScanWaves] scan wave clocks, then replay phase clocks (ISSL_SCAN_STAMPS diagnostics)
     uint32_t *sticky = nullptr;  // [4] survives the per-batch resets: [0] raw overflow seen, [1] max chunks asked, [2] plan errors, [3] items a pruned plan wanted beyond cap_fitems
-    uint64_t *sorted = nullptr;  // [hit_cap] keys guide<<35 | slice<<32 | site id or list position, grouped by guide
+    uint64_t *sorted = nullptr;  // [hit_cap] keys guide<<37 | slice<<32 | site id or list position, grouped by guide (with hit slots: of the guides that outgrew them)
     uint32_t *gcount = nullptr;  // [G+1] hits per guide
     uint32_t *goff = nullptr;    // [G+1] exclusive prefix
     uint32_t *gcur_big = nullptr; // [G] guides with more than kReplayLds hits

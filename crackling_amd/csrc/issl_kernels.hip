@@ -7,8 +7,10 @@
 //              the guides placed there: XOR, fold, popcount, bit-sliced; candidates within max_dist are
 //              NOTED as 8-byte records (guide slot, tile, offset)                                     (A4-A6)
 //   verify     every record: exact test on the whole signatures, first-matching-slice rule (replaces
-//              the seen-bitmap, A7), key (guide, slice, site id or list position), MIT / CFD terms    (A7-A9)
-//   group_*    counting sort of the keys and terms by guide
+//              the seen-bitmap, A7), key (guide, slice, site id or list position), MIT / CFD terms;
+//              the first 512 hits of a guide go straight to its hit slots (Workspace)                 (A7-A9)
+//   group_*    counting sort by guide of the keys and terms that lie beyond their guide's slots
+//              (nothing on an index where no guide has more than 512 hits)
 //   replay     per guide: its hits in key order = the reference's scan order, terms added sequentially
 //              with the reference's early exit                                                        (A10-A11)
 //
@@ -753,8 +755,8 @@ struct alignas(4 * kGuideGroup) GuideGroup {
 // 8-byte record (guide slot, tile, offset in tile), with plain stores into a chunk of the raw buffer
 // that the wave owns -- no dependent load, no returning atomic on the hot path (one hit per ~50k
 // comparisons is frequent enough that a latency chain per hit would dominate the kernel).
-// k_verify then checks every record exactly, applies the first-matching-slice rule and appends the
-// final keys.  Chunk = kChunkRecs slots of 8 bytes, slot 0 = number of used slots (header included).
+// k_verify then checks every record exactly, applies the first-matching-slice rule and turns the
+// survivors into keys.  Chunk = kChunkRecs slots of 8 bytes, slot 0 = number of used slots (header included).
 __device__ __forceinline__ uint64_t raw_record(uint32_t gslot, uint32_t tile, uint32_t offset)
 {
     return (static_cast<uint64_t>(gslot) << 37) | (static_cast<uint64_t>(tile) << 11) | offset;
@@ -1239,8 +1241,10 @@ constexpr uint32_t kMidHits = 2048;   // ... up to this many: one 256-thread wor
                                       // beyond: k_replay_big (1024 threads, slice by slice, terms worked out as it walks)
 
 // Exact check of the raw records, IN PLACE: one thread per record, one chunk per 128-thread workgroup.
-// A record that survives is overwritten by its final key guide<<35 | slice<<32 | position-in-bucket,
-// every other slot by kDeadKey; the per-guide hit counts are accumulated for the grouping pass.
+// A record that survives becomes a hit: key guide<<37 | slice<<32 | site id (list-order layouts: position in the
+// bucket's list), rank inside its guide from the per-guide counter, MIT / CFD terms.  With hit slots the first
+// ws.slot_hits hits of a guide are written to its slots; what lies beyond overwrites the record with its key for the
+// grouping pass; every other slot of the chunk becomes kDeadKey.
 __global__ __launch_bounds__(kChunkRecs, 8) void k_verify(ImageView v, Workspace ws, const uint64_t *__restrict__ guides,
                                                        ScoreParams p)
 {
@@ -1822,7 +1826,7 @@ __global__ __launch_bounds__(64) void k_replay(ImageView v, Workspace ws, const 
             stop = accumulate_chunk(mit_term, cfd_term, cnt, p, lane, tot_mit, tot_cfd, kept, ord);
         };
 
-        // The terms of every hit were computed by k_verify and sit next to the keys (ws.terms, same index as ws.sorted);
+        // The terms of every hit were computed by k_verify and sit next to the keys (key_of / terms_of above);
         // what is left is putting them in key order and adding them up.  issl_dump_hits also wants the expanded
         // records: those are looked up here (hit_terms), the totals still come from the stored terms.
         if (h <= 64) {
