@@ -344,7 +344,7 @@ int serve(const char *sock_path)
         size_t want = 0;
         issl_header h{};
         if (issl_index_device_bytes(incoming, &want) || issl_index_header(incoming, &h)) return;
-        want += 24 * h.n_sites + (size_t(2) << 30); // temporaries of the sorted layout + scoring workspace
+        want += 24 * h.n_sites + (size_t(10) << 30); // temporaries of the sorted layout + scoring workspace (hit slots: up to 8 GiB)
         while (!cache.empty()) {
             size_t free_b = 0, total_b = 0, held = 0;
             if (issl_device_memory(mem_device, &free_b, &total_b)) return;

@@ -1023,9 +1023,9 @@ def test_resident_server_releases_the_least_recently_used_index(tmp_path):
         sizes.append(ix.device_bytes())
         ix.close()
     assert max(sizes) < 1.15 * min(sizes)
-    # the server wants image + 24 B/site of temporaries + 2 GiB of workspace free before an upload: room for two images
+    # the server wants image + 24 B/site of temporaries + 10 GiB of workspace free before an upload: room for two images
     # and that reserve, not for three
-    budget = int(2.5 * max(sizes)) + 24 * 8200 + (2 << 30)
+    budget = int(2.5 * max(sizes)) + 24 * 8200 + (10 << 30)
     exe = str(ROOT / "bin" / "isslScoreOfftargets")
     sock = str(tmp_path / "issl.sock")
     server = subprocess.Popen([exe, "--serve", sock], stderr=subprocess.PIPE, env=dict(os.environ, ISSL_SERVER_HBM_BUDGET=str(budget)))
