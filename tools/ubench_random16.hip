@@ -52,6 +52,35 @@ __global__ __launch_bounds__(128) void k_reads(const uint8_t *__restrict__ table
     if (acc == 0x12345678u) sink[0] = acc; // (never: keeps the loads)
 }
 
+// random WRITES of `BYTES` (16 or 32: one or two dwordx4 into one 32-byte sector) -- k_verify's slot records
+template <int BYTES>
+__global__ __launch_bounds__(128) void k_writes(uint8_t *__restrict__ table, uint64_t n_slots32, uint64_t n_writes)
+{
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n_writes; i += stride) {
+        const uint64_t slot = mix(i ^ 0x9E3779B97F4A7C15ull) % n_slots32;
+        v4u *p = reinterpret_cast<v4u *>(table + slot * 32ull);
+        const v4u val = {static_cast<unsigned int>(i), 1u, 2u, 3u};
+        p[0] = val;
+        if (BYTES == 32) p[1] = val;
+    }
+}
+
+template <int BYTES> static void run_writes(const char *name, uint8_t *table, uint64_t n_slots32, uint64_t n_writes)
+{
+    hipEvent_t a, b;
+    CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
+    hipLaunchKernelGGL(k_writes<BYTES>, dim3(16384), dim3(128), 0, 0, table, n_slots32, n_writes / 8);
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipEventRecord(a));
+    hipLaunchKernelGGL(k_writes<BYTES>, dim3(16384), dim3(128), 0, 0, table, n_slots32, n_writes);
+    CHECK(hipEventRecord(b));
+    CHECK(hipEventSynchronize(b));
+    float ms = 0;
+    CHECK(hipEventElapsedTime(&ms, a, b));
+    printf("%-44s %8.3f ms  %7.2f G writes/s\n", name, ms, n_writes / ms / 1e6);
+}
+
 template <int MODE> static void run(const char *name, const uint8_t *table, uint64_t n_slots16, uint64_t n_reads, uint32_t *sink)
 {
     hipEvent_t a, b;
@@ -90,5 +119,8 @@ int main(int argc, char **argv)
     run<5>("16 B, last of its 128-B line", table, slots, n_reads, sink);
     run<6>("16 B, lane pairs share a 32-B sector", table, slots, n_reads, sink);
     run<7>("32 B per lane (both halves of a sector)", table, slots, n_reads, sink);
+    run_writes<32>("random 32-B writes (one sector each), 22 GiB", table, bytes / 32, n_reads);
+    run_writes<16>("random 16-B writes", table, bytes / 32, n_reads);
+    run_writes<32>("random 32-B writes into 1.6 GB (the hit slots' extent)", table, (1600ull << 20) / 32, n_reads);
     return 0;
 }
