@@ -245,6 +245,7 @@ static void free_workspace(Workspace &w)
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (w.raw) (void)hipFree(w.raw);
+    if (w.raw_used) (void)hipFree(w.raw_used);
     w = Workspace{};
 }
 
@@ -275,6 +276,7 @@ static int ensure_raw_capacity(Workspace &w, size_t chunks)
     if (chunks <= w.cap_chunks) return ISSL_OK;
     int rc = dev_alloc(w.raw, (chunks + 1) * kChunkRecs); // +1: spare chunk that absorbs writes after exhaustion
     if (rc) return rc;
+    if ((rc = dev_alloc(w.raw_used, chunks + 1))) return rc;
     w.cap_chunks = chunks;
     return ISSL_OK;
 }

@@ -310,6 +310,7 @@ struct Workspace {
     PlanInfo *plan = nullptr;
     RangeStart *range_start = nullptr; // [kMaxRanges + 1]
     uint64_t *raw = nullptr;     // [(cap_chunks+1) * kChunkRecs] raw records of the scan, chunked
+    uint32_t *raw_used = nullptr; // [cap_chunks+1] slots in use per chunk (slot 0, which holds nothing, included)
     size_t cap_chunks = 0;
     Counters *counters = nullptr;
     unsigned long long *scan_span = nullptr; // [2 * kSpanRing] first start / last end of the scan workgroups of the lane's

@@ -227,8 +227,11 @@ __global__ __launch_bounds__(256) void k_guide_hist(Workspace ws, const uint64_t
     const uint32_t stride = gridDim.x * 256;
     for (uint32_t k = g; k < n_slots; k += stride) { ws.gidx[k] = kNoGuide; ws.gword[k] = kPadGuideWord; }
     for (uint32_t k = g; k <= n; k += stride) ws.gcount[k] = 0;
-    // chunk headers: a chunk nobody writes must read as empty; chunks [0, n_scan_waves) belong to the scan waves
-    for (uint32_t k = g; k < ws.cap_chunks; k += stride) ws.raw[static_cast<uint64_t>(k) * kChunkRecs] = 0;
+    // chunk fill counts: a chunk nobody writes must read as empty; chunks [0, n_scan_waves) belong to the scan waves.  (The
+    // counts have an array of their own: cleared in one sweep, where a header word inside every 1 KiB chunk cost a cache
+    // line per chunk -- 0.2 ms on a skewed index, whose raw buffer has grown -- and out of the way of k_replay_big, which
+    // uses the raw buffer as scratch.)
+    for (uint32_t k = g; k <= ws.cap_chunks; k += stride) ws.raw_used[k] = 0;
     if (g == 0) {
         Counters c{};
         c.raw_chunks = n_scan_waves;
@@ -756,7 +759,7 @@ struct alignas(4 * kGuideGroup) GuideGroup {
 // that the wave owns -- no dependent load, no returning atomic on the hot path (one hit per ~50k
 // comparisons is frequent enough that a latency chain per hit would dominate the kernel).
 // k_verify then checks every record exactly, applies the first-matching-slice rule and turns the
-// survivors into keys.  Chunk = kChunkRecs slots of 8 bytes, slot 0 = number of used slots (header included).
+// survivors into keys.  Chunk = kChunkRecs slots of 8 bytes, slot 0 unused; raw_used[chunk] = slots in use (slot 0 included).
 __device__ __forceinline__ uint64_t raw_record(uint32_t gslot, uint32_t tile, uint32_t offset)
 {
     return (static_cast<uint64_t>(gslot) << 37) | (static_cast<uint64_t>(tile) << 11) | offset;
@@ -771,9 +774,9 @@ struct RawWriter {
                        // its record stores; a wave with few hits never reserves a chunk it does not use
 };
 
-__device__ __forceinline__ void raw_retire(const RawWriter &w, uint32_t lane)
+__device__ __forceinline__ void raw_retire(const RawWriter &w, uint32_t lane, const uint64_t *raw, uint32_t *raw_used)
 {
-    if (lane == 0) w.chunk[0] = w.fill;
+    if (lane == 0) raw_used[(w.chunk - raw) / kChunkRecs] = w.fill;
 }
 
 __device__ __forceinline__ void raw_acquire(RawWriter &w, uint64_t *raw, uint32_t max_chunks, Counters *counters,
@@ -940,8 +943,8 @@ __device__ __forceinline__ uint32_t count_near(const uint32_t (&m)[16], uint32_t
 // `tile` (the lane's own: a window of the pruned scan straddles two tiles) -- against the guide in slot gslot + (q >>
 // w_log) (full units: w_log = 5, one guide per pass).
 __device__ __forceinline__ void note_candidates(uint32_t ok, uint32_t gslot, uint32_t w_log, uint32_t tile, uint32_t off0,
-                                                uint32_t lane, RawWriter &w, uint64_t *raw, uint32_t max_chunks,
-                                                Counters *counters)
+                                                uint32_t lane, RawWriter &w, uint64_t *raw, uint32_t *raw_used,
+                                                uint32_t max_chunks, Counters *counters)
 {
     while (true) {
         const bool has = ok != 0u;
@@ -949,7 +952,7 @@ __device__ __forceinline__ void note_candidates(uint32_t ok, uint32_t gslot, uin
         if (who == 0ull) break;
         const uint32_t n = static_cast<uint32_t>(__builtin_popcountll(who));
         if (w.fill + n > kChunkRecs) {
-            raw_retire(w, lane);
+            raw_retire(w, lane, raw, raw_used);
             raw_acquire(w, raw, max_chunks, counters, lane);
         }
         if (has) {
@@ -983,7 +986,7 @@ template <int THR, bool FINE>
 __device__ __forceinline__ void scan_range(const uint32_t *__restrict__ scan_stream, const ScanItem *__restrict__ items,
                                            const PlanInfo *__restrict__ plan, const RangeStart *__restrict__ range_start,
                                            const uint32_t *__restrict__ gword_stream, uint4 *wave_masks,
-                                           uint64_t *raw, uint32_t max_chunks,
+                                           uint64_t *raw, uint32_t *raw_used, uint32_t max_chunks,
                                            Counters *counters, uint32_t thr, unsigned long long *stamps,
                                            uint64_t *__restrict__ scan_count, uint32_t *next_unit_p, uint32_t *waves_done_p,
                                            unsigned long long *wg_compared_p, unsigned long long t_start,
@@ -1069,7 +1072,7 @@ __device__ __forceinline__ void scan_range(const uint32_t *__restrict__ scan_str
                 for (uint32_t i = 0; i < (passes < 8u ? passes : 8u); ++i) {
                     const uint32_t ok = near_plane_masks<THR>(c, wave_masks + i * 8u, thr, keep);
                     if (__ballot(ok != 0u) != 0ull) {
-                        note_candidates(ok, gb + i * per, w_log, tile, off0, lane, w, raw, max_chunks, counters);
+                        note_candidates(ok, gb + i * per, w_log, tile, off0, lane, w, raw, raw_used, max_chunks, counters);
                         own_chunk = true;
                     }
                 }
@@ -1120,14 +1123,14 @@ __device__ __forceinline__ void scan_range(const uint32_t *__restrict__ scan_str
                 if (g + uu >= g_end) break; // padding slots of the bucket's last group (scalar test, not taken: free)
                 const uint32_t ok = near_plane<THR>(c, gg.w[uu], thr, keep);
                 if (__ballot(ok != 0u) != 0ull) { // ~4 % of the (guide, tile) pairs on random data
-                    note_candidates(ok, g + uu, 5u, tile, grp * 32u, lane, w, raw, max_chunks, counters);
+                    note_candidates(ok, g + uu, 5u, tile, grp * 32u, lane, w, raw, raw_used, max_chunks, counters);
                     own_chunk = true;
                 }
             }
         }
     }
     if (own_chunk) {
-        raw_retire(w, lane);
+        raw_retire(w, lane, raw, raw_used);
         if (no_own_chunk && lane == 0) counters->raw_overflow = 1u;
     }
     // comparisons of the workgroup: summed in LDS, stored (not added: no reset needed) by its last wave
@@ -1155,7 +1158,7 @@ __global__ __launch_bounds__(1024, 8) void k_scan(const uint32_t *__restrict__ s
                                                   const RangeStart *__restrict__ range_start,
                                                   const uint32_t *__restrict__ gword_full,
                                                   const uint32_t *__restrict__ gword_fine, uint64_t *raw,
-                                                  uint32_t max_chunks, Counters *counters, uint32_t thr,
+                                                  uint32_t *raw_used, uint32_t max_chunks, Counters *counters, uint32_t thr,
                                                   unsigned long long *stamps, uint64_t *__restrict__ scan_count,
                                                   unsigned long long *span, uint32_t n_tiles)
 {
@@ -1175,10 +1178,10 @@ __global__ __launch_bounds__(1024, 8) void k_scan(const uint32_t *__restrict__ s
     if (threadIdx.x == 0) atomicMin(span, t_start); // the launch's own span: first workgroup in, last one out
     // the plan of this batch: bucket-level items, or the successor-byte groups of the pruned scan (k_fine_plan)
     if (plan->fine != 0u)
-        scan_range<THR, true>(scan_stream, items_fine, plan, range_start, gword_fine, tail_masks[threadIdx.x >> 6], raw, max_chunks, counters, thr, stamps,
+        scan_range<THR, true>(scan_stream, items_fine, plan, range_start, gword_fine, tail_masks[threadIdx.x >> 6], raw, raw_used, max_chunks, counters, thr, stamps,
                               scan_count, &next_unit, &waves_done, &wg_compared, t_start, span, n_tiles);
     else
-        scan_range<THR, false>(scan_stream, items_full, plan, range_start, gword_full, tail_masks[threadIdx.x >> 6], raw, max_chunks, counters, thr, stamps,
+        scan_range<THR, false>(scan_stream, items_full, plan, range_start, gword_full, tail_masks[threadIdx.x >> 6], raw, raw_used, max_chunks, counters, thr, stamps,
                                scan_count, &next_unit, &waves_done, &wg_compared, t_start, span, n_tiles);
 }
 
@@ -1270,7 +1273,7 @@ __global__ __launch_bounds__(kChunkRecs, 8) void k_verify(ImageView v, Workspace
         uint64_t *recs = ws.raw + static_cast<uint64_t>(chunk) * kChunkRecs;
         const uint32_t t = threadIdx.x + 1u;
         const uint64_t rec_any = recs[t < kChunkRecs ? t : 0u];
-        const uint32_t used = static_cast<uint32_t>(recs[0]);
+        const uint32_t used = ws.raw_used[chunk];
         const bool in_use = t < used && t < kChunkRecs; // every lane stays: the counting below is done by the wave
         const uint64_t rec = in_use ? rec_any : 0ull;
         uint64_t key = kDeadKey;
@@ -1422,7 +1425,7 @@ static void launch_scan_thr(const ImageView &v, const Workspace &ws, const Tunin
     // pruned scan: the items and guide words grouped by (bucket, successor byte); the plan says which list counts
     hipLaunchKernelGGL(k_scan<THR>, dim3(tn.scan_blocks), dim3(1024), 0, stream, v.scan, ws.items,
                        prune_mode ? ws.fitems : ws.items, ws.plan, ws.range_start, ws.gword, prune_mode ? ws.fword : ws.gword,
-                       ws.raw, static_cast<uint32_t>(ws.cap_chunks), ws.counters, thr, ws.stamps, ws.scan_count,
+                       ws.raw, ws.raw_used, static_cast<uint32_t>(ws.cap_chunks), ws.counters, thr, ws.stamps, ws.scan_count,
                        ws.scan_span + 2u * ws.span_slot, v.n_tiles);
 }
 
@@ -1580,6 +1583,7 @@ __global__ __launch_bounds__(1024) void k_prefix_single(const uint32_t *__restri
 // kernel, read by the replay -- was measured in round 3: verify +7 %, this kernel +35 %: the passes are bound by the
 // bytes they move, not by the number of streams; profiles/r03_ab_hit_records.log.)
 __global__ __launch_bounds__(kChunkRecs) void k_group_scatter(const uint64_t *__restrict__ raw,
+                                                              const uint32_t *__restrict__ raw_used,
                                                               const Counters *__restrict__ counters, uint32_t cap_chunks,
                                                               const uint32_t *__restrict__ gcount,
                                                               const uint32_t *__restrict__ goff,
@@ -1601,7 +1605,7 @@ __global__ __launch_bounds__(kChunkRecs) void k_group_scatter(const uint64_t *__
         const uint64_t key = recs[t < kChunkRecs ? t : 0u];
         const uint32_t my_rank = rank[slot];
         const double2 my_pay = pay[slot];
-        const uint32_t used = static_cast<uint32_t>(recs[0]);
+        const uint32_t used = raw_used[chunk];
         if (t >= used || t >= kChunkRecs || key == kDeadKey) continue;
         const uint32_t guide = static_cast<uint32_t>(key >> kKeyGuideShift);
         const uint32_t to = goff[guide] + my_rank; // rank: k_verify's
@@ -1624,7 +1628,7 @@ void launch_group_hits(const Workspace &ws, uint32_t n, void *stream_)
         hipLaunchKernelGGL(k_prefix_apply, dim3(blocks), dim3(256), 0, stream, ws.gcount, m, ws.blocksum, ws.goff,
                            ws.gcur_big, ws.counters, ws.slot_hits);
     }
-    hipLaunchKernelGGL(k_group_scatter, dim3(kTailGrid), dim3(kChunkRecs), 0, stream, ws.raw, ws.counters,
+    hipLaunchKernelGGL(k_group_scatter, dim3(kTailGrid), dim3(kChunkRecs), 0, stream, ws.raw, ws.raw_used, ws.counters,
                        static_cast<uint32_t>(ws.cap_chunks), ws.gcount, ws.goff, ws.rank, reinterpret_cast<const double2 *>(ws.pay),
                        ws.sorted, reinterpret_cast<double2 *>(ws.terms), ws.slot_hits);
 }
