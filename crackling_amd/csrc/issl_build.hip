@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void k_fill_maps(const uint64_t *__restrict__ 
         const uint64_t at = static_cast<uint64_t>(tile_first[bucket]) * kTileCands + (t0 + i - bucket_start[bucket]);
         if (srec) {
             StreamRec r;
-            r.sig = (sites[id] & ((1ull << 40) - 1ull)) | ((occ < kOccSaturated ? occ : kOccSaturated) << 40);
+            r.sig = (sites[id] & kSigMask) | ((occ < kOccSaturated ? occ : kOccSaturated) << 40);
             r.id = id; r.pos = p;
             srec[at] = r;
         } else {
@@ -111,6 +111,25 @@ __global__ __launch_bounds__(256) void k_sub_start(const uint64_t *__restrict__ 
 }
 
 } // namespace
+
+// Sorted layouts, last step of their construction: a 24-bit copy of every site's occurrence count into the 24 bits of its
+// signature word that the 20-mer leaves free (the same packing as StreamRec::sig).  Whoever goes from a site id to the site
+// -- k_verify on the compact layout, the many-hit replay on both -- then has signature and count in ONE random read instead
+// of two; counts from kOccSaturated on are still looked up in site_occ.  Every reader of `sites` masks the upper bits.
+__global__ __launch_bounds__(256) void k_tag_sites(uint64_t *__restrict__ sites, const uint32_t *__restrict__ site_occ, uint64_t n_sites)
+{
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x; i < n_sites; i += static_cast<uint64_t>(gridDim.x) * 256) {
+        const uint64_t occ = site_occ[i];
+        sites[i] = (sites[i] & kSigMask) | ((occ < kOccSaturated ? occ : kOccSaturated) << 40);
+    }
+}
+
+void launch_tag_sites(uint64_t *d_sites, const uint32_t *d_site_occ, uint64_t n_sites)
+{
+    if (n_sites == 0) return;
+    const uint32_t grid = static_cast<uint32_t>(std::min<uint64_t>((n_sites + 255) / 256, 1u << 16));
+    hipLaunchKernelGGL(k_tag_sites, dim3(grid), dim3(256), 0, nullptr, d_sites, d_site_occ, n_sites);
+}
 
 int SortTemp::alloc(uint64_t n_sites)
 {

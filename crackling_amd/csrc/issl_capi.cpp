@@ -530,6 +530,8 @@ static int finish_upload(issl_index *ix, const DeviceBuildInput *dbi = nullptr)
         t0 = wall_ms();
         launch_pack_scan_stream(ix->view, scan_out, nullptr, nullptr, flag, nullptr, nullptr);
         HIP_TRY(hipGetLastError());
+        launch_tag_sites(d_sites, d_site_occ, n); // (last: from here on `sites` carries a 24-bit copy of the counts)
+        HIP_TRY(hipGetLastError());
     } else if (!ix->hdr.cold_on_host) {
         // Plain copies from the (file-mapped) host arrays: measured 48 GB/s on a 14 GB index, where a 12-thread
         // pipeline through pinned staging buffers reached 24 GB/s.
@@ -991,6 +993,7 @@ int issl_index_write(const issl_index *idx, const char *path)
     const uint8_t *base = static_cast<const uint8_t *>(idx->d_image);
     const uint8_t *cold = static_cast<const uint8_t *>(idx->h_cold);
     std::vector<uint8_t> stage;
+    bool sig_words = false;
     auto stream_out = [&](uint64_t off, uint64_t bytes, bool in_host) {
         if (in_host) { // the section already sits in host memory
             ok = ok && std::fwrite(cold + off, 1, bytes, fp) == bytes;
@@ -999,11 +1002,17 @@ int issl_index_write(const issl_index *idx, const char *path)
         stage.resize(size_t(64) << 20);
         for (uint64_t at = 0; ok && at < bytes; at += stage.size()) {
             const size_t len = static_cast<size_t>(std::min<uint64_t>(stage.size(), bytes - at));
-            ok = hipMemcpy(stage.data(), base + off + at, len, hipMemcpyDeviceToHost) == hipSuccess &&
-                 std::fwrite(stage.data(), 1, len, fp) == len;
+            ok = hipMemcpy(stage.data(), base + off + at, len, hipMemcpyDeviceToHost) == hipSuccess;
+            if (ok && sig_words) { // the site table of a sorted image carries a copy of the counts above the signatures
+                uint64_t *w = reinterpret_cast<uint64_t *>(stage.data());
+                for (size_t i = 0; i < len / 8; ++i) w[i] &= kSigMask;
+            }
+            ok = ok && std::fwrite(stage.data(), 1, len, fp) == len;
         }
     };
+    sig_words = idx->hdr.off_sub_start != 0;
     stream_out(idx->hdr.off_sites, 8 * idx->geo.n_sites, (idx->hdr.cold_on_host & 2u) != 0);
+    sig_words = false;
     ok = ok && std::fwrite(idx->host->sizes, 8, idx->geo.n_buckets(), fp) == idx->geo.n_buckets();
     stream_out(idx->hdr.off_entries, 8 * idx->geo.n_sites * idx->geo.n_slices, (idx->hdr.cold_on_host & 1u) != 0);
     ok = (std::fclose(fp) == 0) && ok;

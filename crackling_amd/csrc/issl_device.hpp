@@ -20,7 +20,7 @@ namespace issl {
 //                              [tile_first[b], tile_first[b+1]); a tile is kTileCands candidates)
 //   score_mask     u64[ns]     sorted unique mismatch masks     (isslScoreOfftargets.cpp:188-197)
 //   score_val      f64[ns]     their local MIT scores
-//   sites          u64[N]      packed signatures                (:200-204)
+//   sites          u64[N]      packed signatures                (:200-204); sorted layouts: | min(count, 2^24-1) << 40 (k_tag_sites)
 //   entries        u64[N*S]    bucket contents occ<<32|id       (:235-240)
 //   mit_dense      f64[2^20]   local MIT scores indexed by the 20 mismatch flags (when the table allows it)
 //   scan           u32[tiles*kTileCands]  the scan stream: for every bucket, in bucket order, the candidate signature
@@ -43,7 +43,7 @@ namespace issl {
 // from its 32 bit planes in the scan stream, the count comes from `occ8`, and host memory is read only for counts >= 255
 // and for issl_dump_hits).  Their offsets are then relative to that second buffer and `total_bytes` covers the HBM part.
 constexpr uint64_t kImageMagic = 0x314C535349444D41ull; // "AMDISSL1"
-constexpr uint32_t kImageVersion = 7;
+constexpr uint32_t kImageVersion = 8;
 constexpr uint32_t kTileCands = 2048; // candidates per scan tile: one wave, 64 lanes x 32 registers
 constexpr uint32_t kHeaderBytes = 4096;
 
@@ -82,7 +82,8 @@ static_assert(sizeof(ImageHeader) <= kHeaderBytes, "header must fit its block");
 
 // Kernel-side view (raw pointers into the image).
 // Sorted layout: what k_verify needs to know about the candidate at a stream position, in one 16-byte load.
-constexpr uint32_t kOccSaturated = 0xFFFFFFu; // StreamRec: occurrence counts from here on are read from the list entry
+constexpr uint32_t kOccSaturated = 0xFFFFFFu; // StreamRec (and the site table of the sorted layouts): occurrence counts from here on are looked up
+constexpr uint64_t kSigMask = (1ull << 40) - 1ull; // the 20-mer's bits of a signature word
 struct alignas(16) StreamRec {
     uint64_t sig;  // packed signature of the site (bits 0..39) | min(occurrences, kOccSaturated) << 40
     uint32_t id;   // site id (low half of the list entry)
@@ -187,6 +188,7 @@ int launch_sort_slice(SortTemp &t, const uint64_t *d_sites, const uint64_t *d_li
                       StreamRec *d_srec, uint32_t *d_sid, uint32_t *d_site_occ, uint32_t *d_flag);
 // Synchronises and reads the flag word: ISSL_OK, ISSL_E_FORMAT (an id beyond the site table), kSortNeedsListOrder.
 int finish_sort(uint32_t *d_flag);
+void launch_tag_sites(uint64_t *d_sites, const uint32_t *d_site_occ, uint64_t n_sites);
 
 // ---- scoring workspace -------------------------------------------------------------------------
 constexpr uint32_t kGuideGroup = 8;    // guide words fetched per scalar load

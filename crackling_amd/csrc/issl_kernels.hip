@@ -119,12 +119,12 @@ __global__ __launch_bounds__(256) void k_pack_scan_stream(ImageView v, uint32_t 
             if (pos < len && (v.srec || v.sid)) {
                 // sorted layouts: the stream holds the candidates v.srec / v.sid list (built and checked by launch_sort_slice)
                 const uint64_t at = static_cast<uint64_t>(t) * kTileCands + k0 + lane; // the maps are indexed like the stream
-                w = scan_word(v.srec ? v.srec[at].sig & ((1ull << 40) - 1ull) : v.sites[v.sid[at]], slice, v.slice_width);
+                w = scan_word(v.srec ? v.srec[at].sig & kSigMask : v.sites[v.sid[at]] & kSigMask, slice, v.slice_width);
             } else if (pos < len) {
                 const uint64_t e = v.entries[start + pos];
                 const uint64_t id = e & 0xFFFFFFFFull;
                 if (id < v.n_sites) {
-                    const uint64_t sig = v.sites[id];
+                    const uint64_t sig = v.sites[id] & kSigMask;
                     // Every slice must list every site once, in the bucket its signature selects: the scan compares the
                     // 16 positions outside the slice and the first-matching-slice rule stands in for the reference's
                     // seen-bitmap (:385-390) on exactly that premise.  `seen`: one bit per (slice, site).
@@ -1316,8 +1316,8 @@ __global__ __launch_bounds__(kChunkRecs, 8) void k_verify(ImageView v, Workspace
                 // sorted layouts: signature, site id (and a 24-bit copy of the count) come in one stream-order record, or --
                 // compact -- the id alone, with the signature behind it in the site table
                 StreamRec sr = sr_early;
-                const uint64_t ot = v.srec   ? sr.sig & ((1ull << 40) - 1ull)
-                                    : v.sid  ? v.sites[sr.id]
+                if (v.sid) sr.sig = v.sites[sr.id]; // (the site table of a sorted layout: signature | 24-bit count << 40, like a stream record)
+                const uint64_t ot = by_id    ? sr.sig & kSigMask
                                     : v.esig ? v.esig[start + pos]
                                     : v.occ8 ? candidate_signature(v, bucket, tile, offset) // cold sections in host memory
                                              : v.sites[v.entries[start + pos] & 0xFFFFFFFFull];
@@ -1353,11 +1353,9 @@ __global__ __launch_bounds__(kChunkRecs, 8) void k_verify(ImageView v, Workspace
                     }
                     if (key != kDeadKey) { // the hit will be scored: what its terms are made of (:348)
                         uint32_t occ;
-                        if (v.srec) {
+                        if (by_id) {
                             occ = static_cast<uint32_t>(sr.sig >> 40);
                             if (occ == kOccSaturated) occ = v.site_occ[sr.id];
-                        } else if (v.sid) {
-                            occ = v.site_occ[sr.id];
                         } else if (v.occ8) {
                             occ = v.occ8[start + pos];
                             if (occ == 255u) occ = static_cast<uint32_t>(v.entries[start + pos] >> 32); // (host memory)
@@ -1760,8 +1758,10 @@ __device__ inline HitTerms hit_terms(const ImageView &v, uint64_t gsig, uint32_t
         // sorted layouts: the key's low word is the site id; issl_dump_hits also wants the position in the bucket's list
         // (:344): the lists ascend by id, so a binary search finds it (in host memory when the lists live there)
         id = pos;
-        ot = v.sites[id];
-        occ = v.site_occ[id];
+        const uint64_t site = v.sites[id]; // signature | min(count, kOccSaturated) << 40 (k_tag_sites)
+        ot = site & kSigMask;
+        occ = static_cast<uint32_t>(site >> 40);
+        if (occ == kOccSaturated) occ = v.site_occ[id];
         pos = 0;
         if (want_id) {
             const uint64_t *list = v.entries + v.bucket_start[bucket];
