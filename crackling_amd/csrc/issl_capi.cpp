@@ -241,7 +241,7 @@ static void free_workspace(Workspace &w)
 {
     void *ptrs[] = {w.ng, w.gfill, w.gstart, w.gword, w.gidx, w.gbucket, w.items, w.plan, w.range_start, w.counters, w.scan_count, w.scan_span, w.sticky, w.stamps, w.gcur_big, w.gcur_big2, w.terms, w.sorted, w.gcount,
                     w.goff, w.blocksum, w.d_guides, w.d_mit, w.d_cfd, w.d_kept, w.d_hitrec, w.pay, w.rank, w.fword, w.fmeta,
-                    w.fitems, w.fcount, w.fsum, w.slots};
+                    w.fitems, w.fcount, w.fcount0, w.fsum, w.slots};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (w.raw) (void)hipFree(w.raw);
@@ -346,6 +346,7 @@ static int ensure_workspace(issl_index *ix, size_t n, Lane &lane)
             if ((rc = dev_alloc(w.fmeta, fslots))) return rc;
             if ((rc = dev_alloc(w.fitems, fitems + 1))) return rc;
             if ((rc = dev_alloc(w.fcount, nb * 256))) return rc;
+            if ((rc = dev_alloc(w.fcount0, nb * 256))) return rc;
             if ((rc = dev_alloc(w.fsum, nb))) return rc;
             w.cap_fslots = fslots;
             w.cap_fitems = fitems;

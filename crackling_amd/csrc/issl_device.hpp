@@ -230,7 +230,8 @@ struct ScanItem {
                          // pass; 16 / 8 = the SHORT last unit of a successor-byte group (<= 1024 / <= 512 candidates):
                          // every register then holds the lane's 16 / 8 candidates two / four times over and a pass
                          // compares two / four guides at once, with masks the wave makes in LDS (short_unit_masks)
-    uint32_t pad;
+    uint32_t gmid;       // pruned scan: the group's class-0 guides (successor byte = the group's own) sit in the slots from
+                         // here on, its class-1 guides (one mismatch there) in front of them (fine_word, issl_kernels.hip)
 };
 static_assert(sizeof(ScanItem) == 48, "scan items are fetched with scalar loads");
 
@@ -307,6 +308,7 @@ struct Workspace {
     FineMeta *fmeta = nullptr;   // per slot: its guide (kNoGuide in padding), its group, the guide's signature
     ScanItem *fitems = nullptr;
     uint32_t *fcount = nullptr;  // [nb * 256] guides per (bucket, successor byte)
+    uint32_t *fcount0 = nullptr; // [nb * 256] ... of them the ones whose own successor byte it is (class 0)
     FineSum *fsum = nullptr;     // [nb] per-bucket totals, then their exclusive prefix
     size_t cap_fslots = 0, cap_fitems = 0;
     PlanInfo *plan = nullptr;

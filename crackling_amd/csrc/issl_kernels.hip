@@ -365,7 +365,7 @@ __global__ __launch_bounds__(256) void k_plan(ImageView v, uint32_t *__restrict_
                 it.last_cands = static_cast<uint32_t>(blen - static_cast<uint64_t>(nt - 1u) * kTileCands);
                 it.group_abs = v.tile_first[b] * 64u;
                 it.window = it.last_cands << 16;
-                it.shape = 32; it.pad = 0;
+                it.shape = 32; it.gmid = 0;
                 items[item_at++] = it;
                 cost_at += static_cast<uint64_t>(nt) * (len * kGuideCost + kTileFixedCost);
                 tile_at += nt;
@@ -381,7 +381,7 @@ __global__ __launch_bounds__(256) void k_plan(ImageView v, uint32_t *__restrict_
             ScanItem end;
             end.bucket = 0; end.g0 = 0; end.g1 = 0; end.n_tiles = 0; end.cost0 = tot_cost;
             end.tile0 = static_cast<uint32_t>(tot_tiles); end.last_cands = 0; end.group_abs = 0; end.window = 0;
-            end.shape = 32; end.pad = 0;
+            end.shape = 32; end.gmid = 0;
             items[tot_items] = end;
         }
         plan->n_items = overflow ? 0u : static_cast<uint32_t>(tot_items);
@@ -500,23 +500,47 @@ __device__ __forceinline__ uint32_t fine_way(uint32_t gj, uint32_t way)
     return gj ^ (d << (2u * q));
 }
 
+// The pruned scan compares 12 positions, not 16.  An item of its plan is ONE (bucket, successor byte) group: inside the
+// item's window every candidate carries the same four bases in the successor slice, and how far a guide is from them is
+// known when the guide is placed -- 0 mismatches in its own group (way 0, "class 0"), 1 in the twelve others (ways 1..12,
+// "class 1").  The scan therefore leaves the successor slice's planes in memory (two of the eight 16-byte loads per lane,
+// scan_word: positions 4 s' .. 4 s' + 3 of the 16, s' = fine_quad(slice)) and counts the other 12 positions against
+// max_dist - class; the reference's test :376-382 on the full signatures is k_verify's.  Guide word of the pruned plan:
+// bits 0..11 the low code bits of the 12 positions in scan-word order, bits 12..23 the high ones, bit 24 the class.
+// A group's slots hold its class-1 guides first (from a multiple of 8 on), its class-0 guides behind them from
+// ScanItem::gmid on: full units run the two classes as two loops with their own compiled tests, short units take the
+// class bit as a thirteenth plane.
+constexpr uint32_t kFineFlag = 1u << 24;
+__host__ __device__ __forceinline__ uint32_t fine_quad(uint32_t slice) { return slice < 4u ? slice : 0u; }
+__host__ __device__ __forceinline__ uint32_t fine_word(uint32_t word, uint32_t slice)
+{
+    const uint32_t sh = 4u * fine_quad(slice);
+    const uint32_t lo = word & 0xFFFFu, hi = word >> 16;
+    const uint32_t lo12 = (lo & ((1u << sh) - 1u)) | ((lo >> (sh + 4u)) << sh);
+    const uint32_t hi12 = (hi & ((1u << sh) - 1u)) | ((hi >> (sh + 4u)) << sh);
+    return lo12 | (hi12 << 12);
+}
+
 // Per bucket: guides per successor byte, and what the bucket's groups add to the plan.
 __global__ __launch_bounds__(256) void k_fine_count(ImageView v, const uint64_t *__restrict__ guides,
                                                     const uint32_t *__restrict__ gstart, const uint32_t *__restrict__ gfill,
                                                     const uint32_t *__restrict__ gidx, uint32_t *__restrict__ fcount,
+                                                    uint32_t *__restrict__ fcount0,
                                                     FineSum *__restrict__ fsum, uint32_t item_guides, uint32_t ways,
                                                     uint32_t tail_shapes)
 {
     short_kernel_priority();
-    __shared__ uint32_t cnt[256];
+    __shared__ uint32_t cnt[256], cnt0[256];
     __shared__ uint64_t lds[256];
     const uint32_t b = blockIdx.x, slice = b >> v.slice_width;
     const uint32_t succ_shift = v.slice_width * ((slice + 1u) % v.n_slices);
     cnt[threadIdx.x] = 0;
+    cnt0[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t g0 = gstart[b], n = gfill[b];
     for (uint32_t i = threadIdx.x; i < n; i += 256) { // one guide per thread and step: its loads once, its ways from registers
         const uint32_t gj = static_cast<uint32_t>(guides[gidx[g0 + i]] >> succ_shift) & 0xFFu;
+        atomicAdd(&cnt0[gj], 1u); // class 0: the guide's successor byte is the group's own (fine_class)
         for (uint32_t way = 0; way < ways; ++way) atomicAdd(&cnt[fine_way(gj, way)], 1u);
     }
     __syncthreads();
@@ -524,6 +548,7 @@ __global__ __launch_bounds__(256) void k_fine_count(ImageView v, const uint64_t 
     const uint32_t *ss = v.sub_start + static_cast<uint64_t>(b) * 257u;
     const uint32_t s0 = ss[w], s1 = ss[w + 1];
     fcount[static_cast<uint64_t>(b) * 256u + w] = (s1 > s0) ? c : 0u; // a group without candidates takes no guides
+    fcount0[static_cast<uint64_t>(b) * 256u + w] = (s1 > s0) ? cnt0[w] : 0u;
     uint64_t cost = 0, cand = 0, slots = 0, items = 0, units = 0;
     if (c && s1 > s0) {
         const GroupUnits gu = group_units(s0, s1, tail_shapes);
@@ -597,7 +622,7 @@ __global__ __launch_bounds__(256) void k_fine_plan(FineSum *__restrict__ fsum, u
             ScanItem end;
             end.bucket = 0; end.g0 = 0; end.g1 = 0; end.n_tiles = 0; end.cost0 = t_cost;
             end.tile0 = static_cast<uint32_t>(t_units); end.last_cands = 0; end.group_abs = 0; end.window = 0;
-            end.shape = 32; end.pad = 0;
+            end.shape = 32; end.gmid = 0;
             fitems[t_items] = end;
             plan->n_items = static_cast<uint32_t>(t_items);
             plan->total_cost = t_cost;
@@ -614,7 +639,8 @@ __global__ __launch_bounds__(256) void k_fine_plan(FineSum *__restrict__ fsum, u
 __global__ __launch_bounds__(256) void k_fine_scatter(ImageView v, const uint64_t *__restrict__ guides,
                                                       const uint32_t *__restrict__ gstart, const uint32_t *__restrict__ gfill,
                                                       const uint32_t *__restrict__ gword, const uint32_t *__restrict__ gidx,
-                                                      const uint32_t *__restrict__ fcount, const FineSum *__restrict__ fbase,
+                                                      const uint32_t *__restrict__ fcount, const uint32_t *__restrict__ fcount0,
+                                                      const FineSum *__restrict__ fbase,
                                                       const PlanInfo *__restrict__ plan, uint32_t *__restrict__ fword,
                                                       FineMeta *__restrict__ fmeta,
                                                       ScanItem *__restrict__ fitems, uint32_t item_guides, uint32_t ways,
@@ -623,11 +649,12 @@ __global__ __launch_bounds__(256) void k_fine_scatter(ImageView v, const uint64_
     short_kernel_priority();
     if (!plan->fine) return; // the bucket-level plan stays
     __shared__ uint64_t lds[256];
-    __shared__ uint32_t slot_of[256], cursor[256], has_cands[256];
+    __shared__ uint32_t slot_of[256], slot0_of[256], cursor[256], cursor0[256], has_cands[256];
     const uint32_t b = blockIdx.x, slice = b >> v.slice_width;
     const uint32_t succ_shift = v.slice_width * ((slice + 1u) % v.n_slices);
     const uint32_t w = threadIdx.x;
     const uint32_t c = fcount[static_cast<uint64_t>(b) * 256u + w];
+    const uint32_t c1 = c - fcount0[static_cast<uint64_t>(b) * 256u + w]; // class 1 first, class 0 behind it (fine_class)
     const uint32_t *ss = v.sub_start + static_cast<uint64_t>(b) * 257u;
     const uint32_t s0 = ss[w], s1 = ss[w + 1];
     uint64_t cost = 0, slots = 0, items = 0;
@@ -645,7 +672,9 @@ __global__ __launch_bounds__(256) void k_fine_scatter(ImageView v, const uint64_
     const uint32_t slot_at = base.slots + static_cast<uint32_t>(block_exclusive_scan(slots, lds, nullptr));
     uint32_t item_at = base.items + static_cast<uint32_t>(block_exclusive_scan(items, lds, nullptr));
     slot_of[w] = slot_at;
+    slot0_of[w] = slot_at + c1;
     cursor[w] = 0;
+    cursor0[w] = 0;
     if (c) {
         const uint64_t blen = v.bucket_start[b + 1] - v.bucket_start[b];
         for (uint32_t done = 0; done < c; done += item_guides) {
@@ -665,7 +694,7 @@ __global__ __launch_bounds__(256) void k_fine_scatter(ImageView v, const uint64_
                 it.last_cands = after < cap ? static_cast<uint32_t>(after) : cap;
                 it.group_abs = v.tile_first[b] * 64u + (wstart >> 5);
                 it.window = (t == 0 ? s0 - gu.s0a : 0u) | ((s1 - wstart < cap ? s1 - wstart : cap) << 16);
-                it.shape = shape; it.pad = 0;
+                it.shape = shape; it.gmid = slot_at + c1;
                 fitems[item_at++] = it;
                 cost_at += static_cast<uint64_t>(len) * (shape >> 3) + kTileFixedCost;
             }
@@ -683,11 +712,12 @@ __global__ __launch_bounds__(256) void k_fine_scatter(ImageView v, const uint64_
         const uint32_t guide = gidx[g0 + i], word = gword[g0 + i];
         const uint64_t gsig = guides[guide];
         const uint32_t gj = static_cast<uint32_t>(gsig >> succ_shift) & 0xFFu;
+        const uint32_t word12 = fine_word(word, slice);
         for (uint32_t way = 0; way < ways; ++way) {
             const uint32_t ww = fine_way(gj, way);
             if (!has_cands[ww]) continue; // no candidates there: the group has no slots
-            const uint32_t slot = slot_of[ww] + atomicAdd(&cursor[ww], 1u);
-            fword[slot] = word;
+            const uint32_t slot = way ? slot_of[ww] + atomicAdd(&cursor[ww], 1u) : slot0_of[ww] + atomicAdd(&cursor0[ww], 1u);
+            fword[slot] = word12 | (way ? kFineFlag : 0u);
             fmeta[slot] = FineMeta{guide, (b << 8) | ww, gsig};
         }
     }
@@ -733,12 +763,12 @@ void launch_bin_guides(const ImageView &v, const Workspace &ws, const Tuning &tn
     if (prune_mode) { // regroup by (bucket, successor byte); k_fine_plan decides which of the two plans the scan follows
         const uint32_t ways = prune_mode == 1 ? 1u : kFineWays;
         hipLaunchKernelGGL(k_fine_count, dim3(nb), dim3(256), 0, stream, v, d_guides, ws.gstart, ws.gfill, ws.gidx, ws.fcount,
-                           ws.fsum, tn.item_guides, ways, static_cast<uint32_t>(tn.tail_shapes));
+                           ws.fcount0, ws.fsum, tn.item_guides, ways, static_cast<uint32_t>(tn.tail_shapes));
         hipLaunchKernelGGL(k_fine_plan, dim3(1), dim3(256), 0, stream, ws.fsum, nb, ws.fitems,
                            static_cast<uint32_t>(ws.cap_fitems), static_cast<uint32_t>(ws.cap_fslots), ws.plan, tn.scan_blocks,
                            prune_mode, tn.prune == 1 ? 1u : 0u, ws.sticky);
         hipLaunchKernelGGL(k_fine_scatter, dim3(nb), dim3(256), 0, stream, v, d_guides, ws.gstart, ws.gfill, ws.gword, ws.gidx,
-                           ws.fcount, ws.fsum, ws.plan, ws.fword, ws.fmeta, ws.fitems, tn.item_guides, ways,
+                           ws.fcount, ws.fcount0, ws.fsum, ws.plan, ws.fword, ws.fmeta, ws.fitems, tn.item_guides, ways,
                            static_cast<uint32_t>(tn.tail_shapes));
         hipLaunchKernelGGL(k_fine_ranges, dim3(range_blocks), dim3(256), 0, stream, ws.plan, ws.fitems, ws.range_start);
     }
@@ -938,6 +968,99 @@ __device__ __forceinline__ uint32_t count_near(const uint32_t (&m)[16], uint32_t
     return keep & ~gt;
 }
 
+// ---- the pruned scan's test: 12 positions (fine_word) -------------------------------------------------------------
+// The planes of candidates whose 12 mismatch planes m[] (+ the class plane f when EXTRA) count up to at most B
+// (B = 0..4 compiled in; B < 0: runtime `thr`).  count = n0 + 2 n1 + 4 S4 with S4 the number of set planes among the
+// three of weight 4 (k4[0], k4[1], a2 & b2), so the compiled budgets need the weight-2 sums a2, b2 only through a handful
+// of three-input functions: 41 vector operations per pass for B = 3 (the class-1 guides of max_dist 4: twelve of
+// thirteen), 46 for B = 4, against 62 for the 16-position test.
+template <int B, bool EXTRA>
+__device__ __forceinline__ uint32_t count_near12(const uint32_t (&m)[12], uint32_t f, uint32_t thr, uint32_t keep)
+{
+    uint32_t s0, s1, s2, s3, t, n0, a2, b2, k2[6], k40, k41;
+    full_add(m[0], m[1], m[2], s0, k2[0]);
+    full_add(m[3], m[4], m[5], s1, k2[1]);
+    full_add(m[6], m[7], m[8], s2, k2[2]);
+    full_add(m[9], m[10], m[11], s3, k2[3]);
+    full_add(s0, s1, s2, t, k2[4]);
+    if (EXTRA) full_add(t, s3, f, n0, k2[5]);
+    else half_add(t, s3, n0, k2[5]);
+    full_add(k2[0], k2[1], k2[2], a2, k40);
+    full_add(k2[3], k2[4], k2[5], b2, k41);
+    // bitop3 tables: bit (4a + 2b + c) of the constant is f(a, b, c)
+    if (B >= 0 && B <= 3) {
+        const uint32_t r1 = __builtin_amdgcn_bitop3_b32(k40, k41, keep, 0x02);              // ~(a | b) & c: no weight-4 plane among the first two
+        if (B == 3) return __builtin_amdgcn_bitop3_b32(r1, a2, b2, 0x70);                   // a & ~(b & c): S4 == 0
+        if (B == 1) return __builtin_amdgcn_bitop3_b32(r1, a2, b2, 0x10);                   // a & ~(b | c): S4 == 0 and n1 == 0
+        if (B == 0) return __builtin_amdgcn_bitop3_b32(__builtin_amdgcn_bitop3_b32(r1, a2, b2, 0x10), n0, n0, 0x30); // ... and n0 == 0
+        const uint32_t r2 = __builtin_amdgcn_bitop3_b32(r1, a2, b2, 0x70);
+        return __builtin_amdgcn_bitop3_b32(r2, a2 ^ b2, n0, 0x70);                          // B == 2: S4 == 0 and not (n1 and n0)
+    }
+    const uint32_t k42 = a2 & b2;
+    if (B == 4) { // count <= 4  <=>  not (S4 >= 2 or (S4 >= 1 and (n1 or n0)))
+        const uint32_t w = __builtin_amdgcn_bitop3_b32(a2, b2, n0, 0xBE);                   // (a ^ b) | c
+        const uint32_t p = __builtin_amdgcn_bitop3_b32(k40, k41, k42, 0xE8);                // majority
+        const uint32_t o = __builtin_amdgcn_bitop3_b32(k40, k41, k42, 0xFE);                // a | b | c
+        const uint32_t x = __builtin_amdgcn_bitop3_b32(o, w, keep, 0x2A);                   // ~(a & b) & c
+        return __builtin_amdgcn_bitop3_b32(x, p, p, 0x30);                                  // a & ~b
+    }
+    // runtime budget: count = n0 + 2 n1 + 4 n2 + 8 n3 (<= 13), compared MSB first with the uniform thr (< 16)
+    uint32_t n2, n3;
+    full_add(k40, k41, k42, n2, n3);
+    const uint32_t n[4] = {n0, a2 ^ b2, n2, n3};
+    uint32_t gt = 0u, eq = ~0u;
+#pragma unroll
+    for (int b = 3; b >= 0; --b) {
+        if ((thr >> b) & 1u) {
+            eq &= n[b];
+        } else {
+            gt |= eq & n[b];
+            eq &= ~n[b];
+        }
+    }
+    return keep & ~gt;
+}
+
+// Full unit of the pruned scan: the lane's 32 candidates (c[0..11] low, c[12..23] high code bits of the 12 positions)
+// against one guide word of the pruned plan (fine_word), budget B.
+template <int B>
+__device__ __forceinline__ uint32_t near_plane12(const uint32_t (&c)[24], uint32_t gw, uint32_t thr, uint32_t keep)
+{
+    uint32_t m[12];
+#pragma unroll
+    for (int p = 0; p < 12; ++p) {
+        const uint32_t g0 = 0u - ((gw >> p) & 1u);
+        const uint32_t g1 = 0u - ((gw >> (12 + p)) & 1u);
+        m[p] = (c[p] ^ g0) | (c[12 + p] ^ g1);
+    }
+    return count_near12<B, false>(m, 0u, thr, keep);
+}
+
+// Short unit of the pruned scan: two / four guides per pass, the masks from the wave's LDS (short_unit_masks: word p of a
+// pass = bit p of its guides' words, spread over their fields; word 24 = the class bits: a plane of weight one).
+template <int B>
+__device__ __forceinline__ uint32_t near_plane12_masks(const uint32_t (&c)[24], const uint4 *gm /*LDS, 8 x uint4*/,
+                                                       uint32_t thr, uint32_t keep)
+{
+    uint32_t m[12];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const uint4 lo = gm[q], hi = gm[3 + q];
+        asm volatile("" ::: "memory"); // (keeps the next loads behind these: at most two steps' masks are live)
+        m[4 * q + 0] = (c[4 * q + 0] ^ lo.x) | (c[12 + 4 * q + 0] ^ hi.x);
+        m[4 * q + 1] = (c[4 * q + 1] ^ lo.y) | (c[12 + 4 * q + 1] ^ hi.y);
+        m[4 * q + 2] = (c[4 * q + 2] ^ lo.z) | (c[12 + 4 * q + 2] ^ hi.z);
+        m[4 * q + 3] = (c[4 * q + 3] ^ lo.w) | (c[12 + 4 * q + 3] ^ hi.w);
+    }
+    const uint32_t f = reinterpret_cast<const uint32_t *>(gm)[24];
+    return count_near12<B, true>(m, f, thr, keep);
+}
+
+// Guide words that start at any slot (a class boundary is no multiple of 8): a scalar load needs its address dword-aligned only.
+struct alignas(4) GuideGroupAny {
+    uint32_t w[kGuideGroup];
+};
+
 // Cold block of the scan: the wave knows that SOME lane has a candidate within thr of a guide.  `ok` = this lane's
 // plane of such candidates; bit q of it is candidate q % (1 << w_log) of the lane -- which sits at offset off0 + that of
 // `tile` (the lane's own: a window of the pruned scan straddles two tiles) -- against the guide in slot gslot + (q >>
@@ -1034,45 +1157,116 @@ __device__ __forceinline__ void scan_range(const uint32_t *__restrict__ scan_str
         const uint32_t g_begin = cur.g0 + (u == 0 ? first.goff : 0u);
         const uint32_t g_end = (gt == tile_last) ? cur.g0 + last.goff : cur.g1;
 
-        if (fine && cur.shape != 32u) {
-            // ---- a SHORT unit: the last 64 * shape candidates of a successor-byte group, 32 / shape guides per pass ----
-            // Lane l takes candidates [l * shape, (l + 1) * shape) of the window, i.e. field l % per of lane group
-            // first + l / per: the same eight 16-byte loads, then one byte permute per plane spreads the field over the
-            // whole register.
-            const uint32_t shape = cur.shape, per = 32u / shape, w_log = shape == 16u ? 4u : 3u;
-            const uint32_t glane = cur.group_abs + lane / per;
+        if constexpr (FINE) {
+            // The planes the unit needs: 12 of the 16 positions (fine_word) -- the successor slice's four sit in plane quads
+            // sq and 4 + sq of the tile and stay in memory.
+            const uint32_t sq = fine_quad(cur.bucket >> 16); // bucket << 8 | successor byte, 8-bit slices: slice = bucket >> 8
+            const uint32_t q0 = sq == 0u ? 1u : 0u, q1 = sq <= 1u ? 2u : 1u, q2 = sq <= 2u ? 3u : 2u;
+            if (cur.shape != 32u) {
+                // ---- a SHORT unit: the last 64 * shape candidates of a successor-byte group, 32 / shape guides per pass ----
+                // Lane l takes candidates [l * shape, (l + 1) * shape) of the window, i.e. field l % per of lane group
+                // first + l / per: the same 16-byte loads, then one byte permute per plane spreads the field over the
+                // whole register.
+                const uint32_t shape = cur.shape, per = 32u / shape, w_log = shape == 16u ? 4u : 3u;
+                const uint32_t glane = cur.group_abs + lane / per;
+                uint32_t tile = glane >> 6;
+                const uint32_t grp = glane & 63u, sub = lane & (per - 1u);
+                if (tile >= n_tiles) tile = n_tiles - 1u;
+                compared += static_cast<unsigned long long>(cur.last_cands) * (g_end - g_begin);
+                const uint4 *__restrict__ src =
+                    reinterpret_cast<const uint4 *>(scan_stream + static_cast<uint64_t>(tile) * kTileCands) + grp;
+                const uint32_t sel = shape == 16u ? (sub ? 0x03020302u : 0x01000100u) : sub * 0x01010101u;
+                uint32_t c[24];
+                {
+                    const uint4 a0 = src[q0 * 64u], a1 = src[q1 * 64u], a2 = src[q2 * 64u];
+                    const uint4 b0 = src[(4u + q0) * 64u], b1 = src[(4u + q1) * 64u], b2 = src[(4u + q2) * 64u];
+                    const uint4 t6[6] = {a0, a1, a2, b0, b1, b2};
+#pragma unroll
+                    for (int q = 0; q < 6; ++q) {
+                        c[4 * q + 0] = __builtin_amdgcn_perm(0u, t6[q].x, sel); c[4 * q + 1] = __builtin_amdgcn_perm(0u, t6[q].y, sel);
+                        c[4 * q + 2] = __builtin_amdgcn_perm(0u, t6[q].z, sel); c[4 * q + 3] = __builtin_amdgcn_perm(0u, t6[q].w, sel);
+                    }
+                }
+                // the lane's candidates that are the item's: window offsets [lo, hi), the same for every guide field
+                const int lo = static_cast<int>(cur.window & 0xFFFFu), hi = static_cast<int>(cur.window >> 16);
+                const int below = lo - static_cast<int>(lane * shape), upto = hi - static_cast<int>(lane * shape);
+                const uint32_t field = shape == 16u ? 0xFFFFu : 0xFFu;
+                const uint32_t mine = (below <= 0 ? field : below >= static_cast<int>(shape) ? 0u : (field << below) & field) &
+                                      (upto >= static_cast<int>(shape) ? field : upto <= 0 ? 0u : field >> (shape - upto));
+                const uint32_t keep = mine * (shape == 16u ? 0x00010001u : 0x01010101u);
+                const uint32_t off0 = grp * 32u + sub * shape;
+                for (uint32_t gb = g_begin; gb < g_end; gb += 8u * per) { // 8 passes' masks at a time
+                    __builtin_amdgcn_wave_barrier();
+                    short_unit_masks(gword_stream, gb, shape, lane, wave_masks);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    const uint32_t passes = (g_end - gb + per - 1u) / per;
+                    for (uint32_t i = 0; i < (passes < 8u ? passes : 8u); ++i) {
+                        const uint32_t ok = near_plane12_masks<THR>(c, wave_masks + i * 8u, thr, keep);
+                        if (__ballot(ok != 0u) != 0ull) {
+                            note_candidates(ok, gb + i * per, w_log, tile, off0, lane, w, raw, raw_used, max_chunks, counters);
+                            own_chunk = true;
+                        }
+                    }
+                }
+                continue;
+            }
+            // ---- a full unit: 2048 consecutive candidates of the bucket from lane group cur.group_abs on; lane l takes the
+            // 32 of group (first + l).  A window may start on any lane group and then straddles two tiles -- the same
+            // 16-byte loads per lane, from two places.  (A window at the very end of the stream would reach past it:
+            // those lanes read the last tile instead, and `keep` hides them.)
+            const uint32_t glane = cur.group_abs + lane;
             uint32_t tile = glane >> 6;
-            const uint32_t grp = glane & 63u, sub = lane & (per - 1u);
+            const uint32_t grp = glane & 63u;
             if (tile >= n_tiles) tile = n_tiles - 1u;
             compared += static_cast<unsigned long long>(cur.last_cands) * (g_end - g_begin);
             const uint4 *__restrict__ src =
                 reinterpret_cast<const uint4 *>(scan_stream + static_cast<uint64_t>(tile) * kTileCands) + grp;
-            const uint32_t sel = shape == 16u ? (sub ? 0x03020302u : 0x01000100u) : sub * 0x01010101u;
-            uint32_t c[kPlanes];
-#pragma unroll
-            for (int q = 0; q < kPlanes / 4; ++q) {
-                const uint4 t4 = src[q * 64];
-                c[4 * q + 0] = __builtin_amdgcn_perm(0u, t4.x, sel); c[4 * q + 1] = __builtin_amdgcn_perm(0u, t4.y, sel);
-                c[4 * q + 2] = __builtin_amdgcn_perm(0u, t4.z, sel); c[4 * q + 3] = __builtin_amdgcn_perm(0u, t4.w, sel);
+            uint32_t c[24];
+            {
+                const uint4 a0 = src[q0 * 64u], a1 = src[q1 * 64u], a2 = src[q2 * 64u];
+                const uint4 b0 = src[(4u + q0) * 64u], b1 = src[(4u + q1) * 64u], b2 = src[(4u + q2) * 64u];
+                c[0] = a0.x; c[1] = a0.y; c[2] = a0.z; c[3] = a0.w; c[4] = a1.x; c[5] = a1.y; c[6] = a1.z; c[7] = a1.w;
+                c[8] = a2.x; c[9] = a2.y; c[10] = a2.z; c[11] = a2.w;
+                c[12] = b0.x; c[13] = b0.y; c[14] = b0.z; c[15] = b0.w; c[16] = b1.x; c[17] = b1.y; c[18] = b1.z; c[19] = b1.w;
+                c[20] = b2.x; c[21] = b2.y; c[22] = b2.z; c[23] = b2.w;
             }
-            // the lane's candidates that are the item's: window offsets [lo, hi), the same for every guide field
+            // the lane's candidates that are the item's: offsets [lo, hi) of the unit
             const int lo = static_cast<int>(cur.window & 0xFFFFu), hi = static_cast<int>(cur.window >> 16);
-            const int below = lo - static_cast<int>(lane * shape), upto = hi - static_cast<int>(lane * shape);
-            const uint32_t field = shape == 16u ? 0xFFFFu : 0xFFu;
-            const uint32_t mine = (below <= 0 ? field : below >= static_cast<int>(shape) ? 0u : (field << below) & field) &
-                                  (upto >= static_cast<int>(shape) ? field : upto <= 0 ? 0u : field >> (shape - upto));
-            const uint32_t keep = mine * (shape == 16u ? 0x00010001u : 0x01010101u);
-            const uint32_t off0 = grp * 32u + sub * shape;
-            for (uint32_t gb = g_begin; gb < g_end; gb += 8u * per) { // 8 passes' masks at a time
-                __builtin_amdgcn_wave_barrier();
-                short_unit_masks(gword_stream, gb, shape, lane, wave_masks);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                const uint32_t passes = (g_end - gb + per - 1u) / per;
-                for (uint32_t i = 0; i < (passes < 8u ? passes : 8u); ++i) {
-                    const uint32_t ok = near_plane_masks<THR>(c, wave_masks + i * 8u, thr, keep);
+            const int below = lo - static_cast<int>(lane * 32u), upto = hi - static_cast<int>(lane * 32u);
+            const uint32_t keep = (below <= 0 ? ~0u : below >= 32 ? 0u : ~0u << below) &
+                                  (upto >= 32 ? ~0u : upto <= 0 ? 0u : ~0u >> (32 - upto));
+            if (stamps) { // diagnostics: how long the planes take to arrive once they are requested
+                const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                plane_wait += __builtin_amdgcn_s_memrealtime() - t1;
+            }
+            // class 1 (one mismatch in the successor slice): budget THR - 1 over the 12 positions; then class 0: budget THR
+            const uint32_t gmid = cur.gmid < g_begin ? g_begin : cur.gmid > g_end ? g_end : cur.gmid;
+            if constexpr (THR < 0 || THR >= 1) {
+                if (THR >= 0 || thr >= 1u) {
+                    for (uint32_t g = g_begin; g < gmid; g += kGuideGroup) {
+                        const GuideGroupAny gg = *reinterpret_cast<const GuideGroupAny *>(gword_stream + g);
+#pragma unroll
+                        for (uint32_t uu = 0; uu < kGuideGroup; ++uu) {
+                            if (g + uu >= gmid) break;
+                            const uint32_t ok = near_plane12<(THR < 0 ? -1 : THR - 1)>(c, gg.w[uu], thr - 1u, keep);
+                            if (__ballot(ok != 0u) != 0ull) {
+                                note_candidates(ok, g + uu, 5u, tile, grp * 32u, lane, w, raw, raw_used, max_chunks, counters);
+                                own_chunk = true;
+                            }
+                        }
+                    }
+                }
+            }
+            for (uint32_t g = gmid; g < g_end; g += kGuideGroup) {
+                const GuideGroupAny gg = *reinterpret_cast<const GuideGroupAny *>(gword_stream + g);
+#pragma unroll
+                for (uint32_t uu = 0; uu < kGuideGroup; ++uu) {
+                    if (g + uu >= g_end) break;
+                    const uint32_t ok = near_plane12<THR>(c, gg.w[uu], thr, keep);
                     if (__ballot(ok != 0u) != 0ull) {
-                        note_candidates(ok, gb + i * per, w_log, tile, off0, lane, w, raw, raw_used, max_chunks, counters);
+                        note_candidates(ok, g + uu, 5u, tile, grp * 32u, lane, w, raw, raw_used, max_chunks, counters);
                         own_chunk = true;
                     }
                 }
@@ -1086,13 +1280,7 @@ __device__ __forceinline__ void scan_range(const uint32_t *__restrict__ scan_str
         // group and then straddles two tiles -- the same eight 16-byte loads per lane, from two places.  (A window at the
         // very end of the stream would reach past it: those lanes read the last tile instead, and `keep` hides them.)
         const uint32_t glane = cur.group_abs + (k << 6) + lane;
-        uint32_t tile = glane >> 6, grp = glane & 63u;
-        if (fine) {
-            if (tile >= n_tiles) tile = n_tiles - 1u;
-        } else {
-            tile = __builtin_amdgcn_readfirstlane(tile); // (whole tiles: uniform)
-            grp = lane;
-        }
+        const uint32_t tile = __builtin_amdgcn_readfirstlane(glane >> 6), grp = lane; // (whole tiles: uniform)
         // comparisons made here: the unit's real candidates (only a bucket's last one is short) x the real guides
         compared += static_cast<unsigned long long>((k + 1u == cur.n_tiles) ? cur.last_cands : kTileCands) * (g_end - g_begin);
         const uint4 *__restrict__ src =
