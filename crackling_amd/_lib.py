@@ -80,6 +80,7 @@ _protos = {
     "issl_index_build_from_sites": (C.c_int, [_P, _P, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(_P)]),
     "issl_index_build_on_device": (C.c_int, [_P, _P, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, C.POINTER(_P)]),
     "issl_index_build_on_device_opt": (C.c_int, [_P, _P, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, C.c_char_p, C.POINTER(_P)]),
+    "issl_index_build_from_device_sites": (C.c_int, [_P, _P, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, C.c_char_p, C.POINTER(_P)]),
     "issl_index_write": (C.c_int, [_P, C.c_char_p]),
     "issl_index_header": (C.c_int, [_P, C.POINTER(Header)]),
     "issl_index_bucket_sizes": (C.c_int, [_P, _P, C.c_size_t]),

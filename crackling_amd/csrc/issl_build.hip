@@ -216,6 +216,48 @@ int finish_sort(uint32_t *d_flag)
     return ISSL_OK;
 }
 
+namespace {
+__global__ __launch_bounds__(256) void k_bucket_sizes(const uint64_t *__restrict__ sites, uint64_t n_sites, uint32_t slice_width,
+                                                      uint32_t n_slices, unsigned long long *__restrict__ sizes)
+{
+    __shared__ uint32_t hist[kMaxSlices << 8]; // 20 KiB: widths up to 8 bits, up to 20 slices
+    const uint32_t nb = n_slices << slice_width, low = (1u << slice_width) - 1u;
+    // a workgroup's share stays below 2^32 sites: 32-bit counters in LDS
+    for (uint32_t b = threadIdx.x; b < nb; b += 256) hist[b] = 0;
+    __syncthreads();
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x; i < n_sites; i += static_cast<uint64_t>(gridDim.x) * 256) {
+        const uint64_t sig = sites[i];
+        for (uint32_t s = 0; s < n_slices; ++s) atomicAdd(&hist[(s << slice_width) + (static_cast<uint32_t>(sig >> (slice_width * s)) & low)], 1u);
+    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < nb; b += 256)
+        if (hist[b]) atomicAdd(&sizes[b], static_cast<unsigned long long>(hist[b]));
+}
+} // namespace
+
+int launch_bucket_sizes(const uint64_t *d_sites, uint64_t n_sites, uint32_t slice_width, uint32_t n_slices, uint64_t *h_sizes)
+{
+    if (slice_width == 0 || slice_width > 8 || n_slices == 0 || n_slices > kMaxSlices) {
+        set_error("bucket sizes on the device: slices of 1..8 bits, up to 20 of them");
+        return ISSL_E_UNSUPPORTED;
+    }
+    const uint32_t nb = n_slices << slice_width;
+    unsigned long long *d_sizes = nullptr;
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&d_sizes), 8ull * nb);
+    if (e == hipSuccess) e = hipMemset(d_sizes, 0, 8ull * nb);
+    if (e == hipSuccess) {
+        const uint32_t grid = static_cast<uint32_t>(std::min<uint64_t>((n_sites + 255) / 256, 4096));
+        hipLaunchKernelGGL(k_bucket_sizes, dim3(std::max(grid, 1u)), dim3(256), 0, nullptr, d_sites, n_sites, slice_width, n_slices, d_sizes);
+        e = hipMemcpy(h_sizes, d_sizes, 8ull * nb, hipMemcpyDeviceToHost);
+    }
+    if (d_sizes) (void)hipFree(d_sizes);
+    if (e != hipSuccess) {
+        set_error(std::string("HIP error: ") + hipGetErrorString(e) + " (bucket sizes of a site table on the device)");
+        return ISSL_E_DEVICE;
+    }
+    return ISSL_OK;
+}
+
 int launch_build_entries(const uint64_t *d_sites, const uint32_t *d_occ, uint64_t n_sites, uint32_t slice_begin,
                          uint32_t slice_end, uint32_t slice_width, uint64_t *d_entries)
 {

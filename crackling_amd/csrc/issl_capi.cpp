@@ -40,7 +40,9 @@ void layout_image(ImageHeader &h, const Geometry &g, uint64_t n_scores_unique, u
     h.n_scores_unique = n_scores_unique;
     h.n_tiles = n_tiles;
     h.tile_cands = kTileCands;
-    const uint64_t sites_b = align256(8 * g.n_sites), lists_b = align256(8 * g.n_sites * g.n_slices);
+    const bool no_lists = spec.no_lists && spec.sorted != 0 && spec.cold == 0;
+    const uint64_t sites_b = align256(8 * g.n_sites), lists_b = no_lists ? 0 : align256(8 * g.n_sites * g.n_slices);
+    h.lists_absent = no_lists ? 1 : 0;
     const bool esig = spec.inline_sigs && spec.cold == 0 && spec.sorted == 0; // in-list signatures: list-order layouts in HBM
     uint64_t off = kHeaderBytes, cold_off = 0;
     h.off_bucket_start = off; off = align256(off + 8 * (h.n_buckets + 1));
@@ -76,7 +78,7 @@ ImageView make_view(const ImageHeader &h, void *base, void *cold)
     v.score_val = reinterpret_cast<const double *>(p + h.off_score_val);
     v.mit_dense = h.off_mit_dense ? reinterpret_cast<const double *>(p + h.off_mit_dense) : nullptr;
     v.sites = reinterpret_cast<const uint64_t *>(((h.cold_on_host & 2u) ? c : p) + h.off_sites);
-    v.entries = reinterpret_cast<const uint64_t *>(((h.cold_on_host & 1u) ? c : p) + h.off_entries);
+    v.entries = h.lists_absent ? nullptr : reinterpret_cast<const uint64_t *>(((h.cold_on_host & 1u) ? c : p) + h.off_entries);
     v.esig = h.off_esig ? reinterpret_cast<const uint64_t *>(p + h.off_esig) : nullptr;
     v.occ8 = h.off_occ8 ? reinterpret_cast<const uint8_t *>(p + h.off_occ8) : nullptr;
     v.sub_start = h.off_sub_start ? reinterpret_cast<const uint32_t *>(p + h.off_sub_start) : nullptr;
@@ -106,6 +108,7 @@ Tuning Tuning::from_env()
     t.raw_chunks = 0;
     t.inline_sigs = -1;
     t.host_cold = -1;
+    t.keep_lists = -1;
     t.sorted_layout = -1;
     t.compact = -1;
     t.prune = -1;
@@ -118,6 +121,7 @@ Tuning Tuning::from_env()
         {"ISSL_INLINE_SIGS", "inline_sigs"}, {"ISSL_FORCE_HOST_COLD", "host_cold"}, {"ISSL_SCAN_STAMPS", "scan_stamps"},
         {"ISSL_SORTED_LAYOUT", "sorted_layout"}, {"ISSL_PRUNE", "prune"}, {"ISSL_LANES", "lanes"},
         {"ISSL_COMPACT", "compact"}, {"ISSL_TAIL_SHAPES", "tail_shapes"}, {"ISSL_HIT_SLOTS", "hit_slots"},
+        {"ISSL_KEEP_LISTS", "keep_lists"},
     };
     for (const auto &k : keys)
         if (const char *e = std::getenv(k[0])) (void)t.set(k[1], e); // values out of range leave the default
@@ -138,6 +142,7 @@ bool Tuning::set(const char *key, const char *value)
     else if (k == "raw_chunks") { if (!is_int || n < 0) return false; raw_chunks = static_cast<size_t>(n); }
     else if (k == "inline_sigs") { if (!is_int || n < -1 || n > 1) return false; inline_sigs = static_cast<int>(n); }
     else if (k == "host_cold") { if (!is_int || n < -1 || n > 1) return false; host_cold = static_cast<int>(n); }
+    else if (k == "keep_lists") { if (!is_int || n < -1 || n > 1) return false; keep_lists = static_cast<int>(n); }
     else if (k == "sorted_layout") { if (!is_int || n < -1 || n > 1) return false; sorted_layout = static_cast<int>(n); }
     else if (k == "compact") { if (!is_int || n < -1 || n > 1) return false; compact = static_cast<int>(n); }
     else if (k == "prune") { if (!is_int || n < -1 || n > 1) return false; prune = static_cast<int>(n); }
@@ -414,6 +419,7 @@ static void upload_note(const issl_index *ix, const char *what, double t0)
 struct DeviceBuildInput {
     const uint64_t *sigs;
     const uint32_t *occ;
+    bool on_device; // the two arrays are device memory of the upload's device (issl_index_build_from_device_sites)
 };
 
 struct DevTemp { // device allocation freed on every path out of a function
@@ -427,6 +433,7 @@ static int finish_upload(issl_index *ix, const DeviceBuildInput *dbi = nullptr)
     const HostIndex &h = *ix->host;
     const Geometry &g = h.geo;
     const uint64_t nb = g.n_buckets();
+    const hipMemcpyKind dbi_kind = (dbi && dbi->on_device) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
     uint8_t *base = static_cast<uint8_t *>(ix->d_image);
     std::vector<uint64_t> bstart(nb + 1);
     std::vector<uint32_t> tfirst(nb + 1);
@@ -459,14 +466,14 @@ static int finish_upload(issl_index *ix, const DeviceBuildInput *dbi = nullptr)
     uint32_t *scan_out = reinterpret_cast<uint32_t *>(base + ix->hdr.off_scan);
     if (dbi && !ix->hdr.off_sub_start) { // (the sorted layouts keep the counts in the image)
         HIP_TRY(hipMalloc(&occ_mem.p, 4 * g.n_sites));
-        HIP_TRY(hipMemcpy(occ_mem.p, dbi->occ, 4 * g.n_sites, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(occ_mem.p, dbi->occ, 4 * g.n_sites, dbi_kind));
     }
     const uint32_t *d_occ = static_cast<const uint32_t *>(occ_mem.p);
     DevTemp seen_mem; // list-order layouts: one bit per (slice, site) -- every slice must list every site once
     uint32_t *seen = nullptr;
     if (!ix->hdr.off_sub_start) {
         const uint64_t words = (g.n_sites * g.n_slices + 31) / 32 + 1;
-        HIP_TRY(hipMalloc(&seen_mem.p, 4 * words));
+        if (hipMalloc(&seen_mem.p, 4 * words) != hipSuccess) { (void)hipGetLastError(); seen_mem.p = nullptr; return kSortNoRoom; } // the next layout
         HIP_TRY(hipMemset(seen_mem.p, 0, 4 * words));
         seen = static_cast<uint32_t *>(seen_mem.p);
     }
@@ -478,17 +485,20 @@ static int finish_upload(issl_index *ix, const DeviceBuildInput *dbi = nullptr)
         const uint64_t n = g.n_sites;
         uint64_t *d_sites = reinterpret_cast<uint64_t *>(base + ix->hdr.off_sites);
         uint32_t *d_site_occ = reinterpret_cast<uint32_t *>(base + ix->hdr.off_site_occ);
-        HIP_TRY(hipMemcpy(d_sites, dbi ? dbi->sigs : h.sites, 8 * n, hipMemcpyHostToDevice));
-        if (dbi) HIP_TRY(hipMemcpy(d_site_occ, dbi->occ, 4 * n, hipMemcpyHostToDevice)); // (k_fill_maps writes the same again)
+        HIP_TRY(hipMemcpy(d_sites, dbi ? dbi->sigs : h.sites, 8 * n, dbi ? dbi_kind : hipMemcpyHostToDevice));
+        if (dbi) HIP_TRY(hipMemcpy(d_site_occ, dbi->occ, 4 * n, dbi_kind)); // (k_fill_maps writes the same again)
         upload_note(ix, "sites", t0);
         t0 = wall_ms();
         SortTemp st;
         int src = st.alloc(n);
         if (src) return src;
-        const bool lists_cold = (ix->hdr.cold_on_host & 1u) != 0;
+        // lists in pinned host memory, or nowhere (lists_absent): either way a slice's list exists on the device only while
+        // the slice is worked on, in one 8 B/site temporary
+        const bool lists_kept_cold = (ix->hdr.cold_on_host & 1u) != 0;
+        const bool lists_cold = lists_kept_cold || ix->hdr.lists_absent != 0;
         DevTemp list_mem;
         uint64_t *d_entries = lists_cold ? nullptr : reinterpret_cast<uint64_t *>(base + ix->hdr.off_entries);
-        uint64_t *c_entries = lists_cold ? reinterpret_cast<uint64_t *>(static_cast<uint8_t *>(ix->h_cold) + ix->hdr.off_entries) : nullptr;
+        uint64_t *c_entries = lists_kept_cold ? reinterpret_cast<uint64_t *>(static_cast<uint8_t *>(ix->h_cold) + ix->hdr.off_entries) : nullptr;
         if (lists_cold) {
             if (hipMalloc(&list_mem.p, std::max<uint64_t>(8 * n, 8)) != hipSuccess) { (void)hipGetLastError(); list_mem.p = nullptr; return kSortNoRoom; }
         } else if (dbi) { // isslCreateIndex.cpp:218-234 on the device
@@ -509,10 +519,12 @@ static int finish_upload(issl_index *ix, const DeviceBuildInput *dbi = nullptr)
                     int brc = launch_build_entries(d_sites, d_site_occ, n, static_cast<uint32_t>(sl), static_cast<uint32_t>(sl + 1),
                                                    static_cast<uint32_t>(g.slice_width), t_list);
                     if (brc) return brc;
-                    HIP_TRY(hipMemcpy(c_entries + sl * n, t_list, 8 * n, hipMemcpyDeviceToHost));
-                } else {
+                    if (c_entries) HIP_TRY(hipMemcpy(c_entries + sl * n, t_list, 8 * n, hipMemcpyDeviceToHost));
+                } else if (c_entries) {
                     std::memcpy(c_entries + sl * n, h.entries + sl * n, 8 * n);
                     HIP_TRY(hipMemcpy(t_list, c_entries + sl * n, 8 * n, hipMemcpyHostToDevice));
+                } else {
+                    HIP_TRY(hipMemcpy(t_list, h.entries + sl * n, 8 * n, hipMemcpyHostToDevice));
                 }
             }
             src = launch_sort_slice(st, d_sites, d_list, reinterpret_cast<const uint64_t *>(base + ix->hdr.off_bucket_start),
@@ -536,7 +548,7 @@ static int finish_upload(issl_index *ix, const DeviceBuildInput *dbi = nullptr)
     } else if (!ix->hdr.cold_on_host) {
         // Plain copies from the (file-mapped) host arrays: measured 48 GB/s on a 14 GB index, where a 12-thread
         // pipeline through pinned staging buffers reached 24 GB/s.
-        HIP_TRY(hipMemcpy(base + ix->hdr.off_sites, dbi ? dbi->sigs : h.sites, 8 * g.n_sites, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(base + ix->hdr.off_sites, dbi ? dbi->sigs : h.sites, 8 * g.n_sites, dbi ? dbi_kind : hipMemcpyHostToDevice));
         upload_note(ix, "sites", t0);
         t0 = wall_ms();
         if (dbi) { // isslCreateIndex.cpp:218-234 on the device
@@ -567,7 +579,8 @@ static int finish_upload(issl_index *ix, const DeviceBuildInput *dbi = nullptr)
         HIP_TRY(hipMalloc(&sites_mem.p, std::max<uint64_t>(8 * n, 8)));
         HIP_TRY(hipMalloc(&list_mem.p, std::max<uint64_t>(8 * n, 8)));
         uint64_t *t_sites = static_cast<uint64_t *>(sites_mem.p), *t_list = static_cast<uint64_t *>(list_mem.p);
-        std::memcpy(c_sites, dbi ? dbi->sigs : h.sites, 8 * n);
+        if (dbi && dbi->on_device) HIP_TRY(hipMemcpy(c_sites, dbi->sigs, 8 * n, hipMemcpyDeviceToHost));
+        else std::memcpy(c_sites, dbi ? dbi->sigs : h.sites, 8 * n);
         HIP_TRY(hipMemcpy(t_sites, c_sites, 8 * n, hipMemcpyHostToDevice));
         upload_note(ix, "sites (pinned host copy + temporary device copy)", t0);
         t0 = wall_ms();
@@ -622,25 +635,28 @@ static bool want_inline_sigs(const Tuning &tn, const Geometry &g)
 static std::vector<LayoutSpec> layout_choices(const Tuning &tn, const Geometry &g, bool list_order_only)
 {
     std::vector<LayoutSpec> c;
-    auto spec = [](bool esig, uint32_t cold, uint32_t sorted) { LayoutSpec s; s.inline_sigs = esig; s.cold = cold; s.sorted = sorted; return s; };
+    auto spec = [](bool esig, uint32_t cold, uint32_t sorted, bool no_lists = false) { LayoutSpec s; s.inline_sigs = esig; s.cold = cold; s.sorted = sorted; s.no_lists = no_lists; return s; };
     const bool narrow = g.slice_width != 8; // list order in HBM only: the sorted layouts order by a successor BYTE, and the
                                             // host-cold layout rebuilds signatures from 16 stream positions + the bucket's byte
     if (narrow) {
-        if (tn.sorted_layout == 1 || tn.compact == 1 || tn.host_cold == 1) return c;
+        if (tn.sorted_layout == 1 || tn.compact == 1 || tn.host_cold == 1 || tn.keep_lists == 0) return c;
         if (want_inline_sigs(tn, g)) c.push_back(spec(true, 0, 0));
         if (tn.inline_sigs != 1) c.push_back(spec(false, 0, 0));
         return c;
     }
     const bool may_sort = !list_order_only && tn.sorted_layout != 0 && tn.inline_sigs != 1;
-    const bool must_sort = tn.sorted_layout == 1 || tn.compact == 1;
+    const bool must_sort = tn.sorted_layout == 1 || tn.compact == 1 || tn.keep_lists == 0; // (only a sorted image can do without its lists)
     if (may_sort || must_sort) {
         if (tn.host_cold == 1) {
-            if (tn.compact == 1 || tn.sorted_layout == 1) c.push_back(spec(false, 1, 2));
+            if ((tn.compact == 1 || tn.sorted_layout == 1) && tn.keep_lists != 0) c.push_back(spec(false, 1, 2));
         } else {
-            if (tn.compact != 1) c.push_back(spec(false, 0, 1));
+            if (tn.compact != 1 && tn.keep_lists != 0) c.push_back(spec(false, 0, 1));
             if (tn.compact != 0) {
-                c.push_back(spec(false, 0, 2));
-                if (tn.host_cold == -1) c.push_back(spec(false, 1, 2));
+                if (tn.keep_lists != 0) c.push_back(spec(false, 0, 2));
+                // the smallest image: compact and without its slice lists -- 52 B/site, self-contained (nothing in host
+                // memory, so it can still be broadcast and attached elsewhere); the variant with the lists in pinned
+                // host memory (40 B/site there) is made on request only (host_cold=1)
+                if (tn.keep_lists != 1) c.push_back(spec(false, 0, 2, true));
             }
         }
     }
@@ -995,15 +1011,11 @@ int issl_index_write(const issl_index *idx, const char *path)
     const uint8_t *cold = static_cast<const uint8_t *>(idx->h_cold);
     std::vector<uint8_t> stage;
     bool sig_words = false;
-    auto stream_out = [&](uint64_t off, uint64_t bytes, bool in_host) {
-        if (in_host) { // the section already sits in host memory
-            ok = ok && std::fwrite(cold + off, 1, bytes, fp) == bytes;
-            return;
-        }
+    auto stream_dev = [&](const uint8_t *src, uint64_t bytes) { // device memory, through a 64 MiB staging buffer
         stage.resize(size_t(64) << 20);
         for (uint64_t at = 0; ok && at < bytes; at += stage.size()) {
             const size_t len = static_cast<size_t>(std::min<uint64_t>(stage.size(), bytes - at));
-            ok = hipMemcpy(stage.data(), base + off + at, len, hipMemcpyDeviceToHost) == hipSuccess;
+            ok = hipMemcpy(stage.data(), src + at, len, hipMemcpyDeviceToHost) == hipSuccess;
             if (ok && sig_words) { // the site table of a sorted image carries a copy of the counts above the signatures
                 uint64_t *w = reinterpret_cast<uint64_t *>(stage.data());
                 for (size_t i = 0; i < len / 8; ++i) w[i] &= kSigMask;
@@ -1011,11 +1023,40 @@ int issl_index_write(const issl_index *idx, const char *path)
             ok = ok && std::fwrite(stage.data(), 1, len, fp) == len;
         }
     };
+    auto stream_out = [&](uint64_t off, uint64_t bytes, bool in_host) {
+        if (in_host) { // the section already sits in host memory
+            ok = ok && std::fwrite(cold + off, 1, bytes, fp) == bytes;
+            return;
+        }
+        stream_dev(base + off, bytes);
+    };
     sig_words = idx->hdr.off_sub_start != 0;
     stream_out(idx->hdr.off_sites, 8 * idx->geo.n_sites, (idx->hdr.cold_on_host & 2u) != 0);
     sig_words = false;
     ok = ok && std::fwrite(idx->host->sizes, 8, idx->geo.n_buckets(), fp) == idx->geo.n_buckets();
-    stream_out(idx->hdr.off_entries, 8 * idx->geo.n_sites * idx->geo.n_slices, (idx->hdr.cold_on_host & 1u) != 0);
+    if (idx->hdr.lists_absent) {
+        // The image holds no slice lists: on a sorted layout they are a function of the site table and the counts -- the
+        // stable counting sort of isslCreateIndex.cpp:218-234 --, made again here, one slice at a time.
+        DevTemp list_mem;
+        const uint64_t n = idx->geo.n_sites;
+        if (hipMalloc(&list_mem.p, std::max<uint64_t>(8 * n, 8)) != hipSuccess) {
+            (void)hipGetLastError();
+            list_mem.p = nullptr;
+            std::fclose(fp);
+            set_error("no device memory to rebuild the slice lists of this image (8 B per site)");
+            return ISSL_E_DEVICE;
+        }
+        for (uint64_t sl = 0; ok && sl < idx->geo.n_slices; ++sl) {
+            int brc = launch_build_entries(reinterpret_cast<const uint64_t *>(base + idx->hdr.off_sites),
+                                           reinterpret_cast<const uint32_t *>(base + idx->hdr.off_site_occ), n, static_cast<uint32_t>(sl),
+                                           static_cast<uint32_t>(sl + 1), static_cast<uint32_t>(idx->geo.slice_width),
+                                           static_cast<uint64_t *>(list_mem.p));
+            if (brc) { std::fclose(fp); return brc; }
+            stream_dev(static_cast<const uint8_t *>(list_mem.p), 8 * n);
+        }
+    } else {
+        stream_out(idx->hdr.off_entries, 8 * idx->geo.n_sites * idx->geo.n_slices, (idx->hdr.cold_on_host & 1u) != 0);
+    }
     ok = (std::fclose(fp) == 0) && ok;
     if (!ok) {
         set_error(std::string("could not write '") + path + "' from the device image");
@@ -1107,6 +1148,8 @@ int issl_index_get_option(const issl_index *idx, const char *key, long long *val
     else if (k == "host_cold") *value = t.host_cold;
     else if (k == "sorted_layout") *value = t.sorted_layout;
     else if (k == "compact") *value = t.compact;
+    else if (k == "keep_lists") *value = t.keep_lists;
+    else if (k == "lists_absent") *value = idx->d_image ? static_cast<long long>(idx->hdr.lists_absent) : -1; // read-only
     else if (k == "prune") *value = t.prune;
     else if (k == "lanes") *value = t.lanes;
     else if (k == "tail_shapes") *value = t.tail_shapes;
@@ -1120,6 +1163,8 @@ int issl_index_get_option(const issl_index *idx, const char *key, long long *val
     else { set_error(std::string("unknown option: ") + key); return ISSL_E_ARG; }
     return ISSL_OK;
 }
+
+static int parse_build_options(issl_index *ix, const char *options);
 
 static int upload_common(issl_index *idx, int device, void *buf, size_t bytes, const DeviceBuildInput *dbi = nullptr)
 {
@@ -1155,7 +1200,8 @@ static int upload_common(issl_index *idx, int device, void *buf, size_t bytes, c
         // temporary device memory: while a list-order host-cold image is packed, signatures + one slice list; for the
         // sorted layouts two key arrays of 8 B per site (one slice at a time) and, lists in host memory, one slice list
         const uint64_t ns = idx->geo.n_sites;
-        const uint64_t temp = c.sorted ? 16 * ns + (c.cold ? 8 * ns : 0) + (64ull << 20) : c.cold ? 16 * ns : 0;
+        const uint64_t temp = c.sorted ? 16 * ns + ((c.cold || c.no_lists) ? 8 * ns : 0) + (64ull << 20)
+                              : (c.cold ? 16 * ns : 0) + ns * idx->geo.n_slices / 8 + 8; // (list order: + the `seen` bitmap)
         if (buf) {
             if (bytes < idx->hdr.total_bytes || (reinterpret_cast<uintptr_t>(buf) & 255u)) {
                 why = "device buffer too small or not 256-byte aligned";
@@ -1166,7 +1212,7 @@ static int upload_common(issl_index *idx, int device, void *buf, size_t bytes, c
         } else {
             // leave room for the scoring workspace: the larger of 2 GiB and 3 % of the device
             size_t free_b = 0, total_b = 0;
-            HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+            HIP_TRY(hipMemGetInfo(&free_b, &total_b)); // (nothing allocated yet on this turn of the loop)
             const uint64_t reserve = std::max<uint64_t>(uint64_t(2) << 30, total_b / 32);
             if (idx->hdr.total_bytes + temp + reserve > free_b) {
                 why = "the image (" + std::to_string(idx->hdr.total_bytes >> 20) + " MiB) does not fit the free device memory (" +
@@ -1193,7 +1239,12 @@ static int upload_common(issl_index *idx, int device, void *buf, size_t bytes, c
                 continue;
             }
             idx->owns_cold = true;
-            HIP_TRY(hipHostGetDevicePointer(&idx->d_cold, idx->h_cold, 0));
+            if (hipHostGetDevicePointer(&idx->d_cold, idx->h_cold, 0) != hipSuccess) {
+                (void)hipGetLastError();
+                release_device(idx);
+                set_error("HIP error: the pinned host buffer of the cold sections has no device address");
+                return ISSL_E_DEVICE;
+            }
         }
         upload_note(idx, c.cold ? "layout + allocation (cold sections in pinned host memory)" : "layout + allocation", t0);
         rc = finish_upload(idx, dbi);
@@ -1230,6 +1281,20 @@ int issl_index_build_on_device_opt(const uint64_t *sigs, const uint32_t *occ, si
     issl_index *ix = nullptr;
     rc = new_index_from_host(std::move(h), &ix);
     if (rc) return rc;
+    rc = parse_build_options(ix, options);
+    if (rc) { issl_index_close(ix); return rc; }
+    const DeviceBuildInput dbi{sigs, occ, false};
+    rc = upload_common(ix, device, nullptr, 0, &dbi);
+    if (rc) {
+        issl_index_close(ix);
+        return rc;
+    }
+    *out = ix;
+    return ISSL_OK;
+}
+
+static int parse_build_options(issl_index *ix, const char *options)
+{
     for (std::string rest = options ? options : ""; !rest.empty();) { // "key=value,key=value"
         const size_t comma = rest.find(',');
         const std::string item = rest.substr(0, comma);
@@ -1237,11 +1302,37 @@ int issl_index_build_on_device_opt(const uint64_t *sigs, const uint32_t *occ, si
         const size_t eq = item.find('=');
         if (eq == std::string::npos || !ix->tuning.set(item.substr(0, eq).c_str(), item.substr(eq + 1).c_str())) {
             set_error("unknown option or value out of range: " + item);
-            issl_index_close(ix);
             return ISSL_E_ARG;
         }
     }
-    const DeviceBuildInput dbi{sigs, occ};
+    return ISSL_OK;
+}
+
+int issl_index_build_from_device_sites(const uint64_t *d_sigs, const uint32_t *d_occ, size_t n_sites, size_t n_lines,
+                                       size_t seq_len, size_t slice_width, int device, const char *options, issl_index **out)
+{
+    if (!d_sigs || !d_occ || !out) { set_error("null argument"); return ISSL_E_ARG; }
+    if (seq_len == 0 || seq_len > 32 || slice_width < 2 || slice_width > 8 || (seq_len * 2) / slice_width == 0 ||
+        (seq_len * 2) / slice_width > kMaxSlices) {
+        set_error("bad sequence length or slice width");
+        return ISSL_E_ARG;
+    }
+    int rc = select_device(device);
+    if (rc) return rc;
+    const uint32_t n_slices = static_cast<uint32_t>((seq_len * 2) / slice_width);
+    std::vector<uint64_t> sizes(size_t(n_slices) << slice_width);
+    rc = launch_bucket_sizes(d_sigs, n_sites, static_cast<uint32_t>(slice_width), n_slices, sizes.data());
+    if (rc) return rc;
+    std::unique_ptr<HostIndex> h(new (std::nothrow) HostIndex());
+    if (!h) { set_error("out of memory"); return ISSL_E_NOMEM; }
+    rc = h->init_from_bucket_sizes(sizes.data(), n_sites, n_lines, seq_len, slice_width);
+    if (rc) return rc;
+    issl_index *ix = nullptr;
+    rc = new_index_from_host(std::move(h), &ix);
+    if (rc) return rc;
+    rc = parse_build_options(ix, options);
+    if (rc) { issl_index_close(ix); return rc; }
+    const DeviceBuildInput dbi{d_sigs, d_occ, true};
     rc = upload_common(ix, device, nullptr, 0, &dbi);
     if (rc) {
         issl_index_close(ix);

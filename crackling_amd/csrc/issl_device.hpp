@@ -43,7 +43,7 @@ namespace issl {
 // from its 32 bit planes in the scan stream, the count comes from `occ8`, and host memory is read only for counts >= 255
 // and for issl_dump_hits).  Their offsets are then relative to that second buffer and `total_bytes` covers the HBM part.
 constexpr uint64_t kImageMagic = 0x314C535349444D41ull; // "AMDISSL1"
-constexpr uint32_t kImageVersion = 8;
+constexpr uint32_t kImageVersion = 9;
 constexpr uint32_t kTileCands = 2048; // candidates per scan tile: one wave, 64 lanes x 32 registers
 constexpr uint32_t kHeaderBytes = 4096;
 
@@ -77,6 +77,12 @@ struct ImageHeader {
     uint64_t off_sid;       // u32[n_tiles * 2048]: ... -> its site id alone (the COMPACT sorted layout: 4 B instead of 16 B per
                             // list entry; signature and count come from `sites` / `site_occ` by id)
     uint64_t off_site_occ;  // u32[N]: occurrence count of every site (sorted layouts)
+    uint64_t lists_absent;  // 1: the image holds no slice lists (`entries`), anywhere.  A sorted layout does not need them to
+                            // score, and its premises (every list ascending by site id, one count per site, every site in
+                            // the bucket its signature selects) make them a function of `sites` and `site_occ`: the stable
+                            // counting sort of isslCreateIndex.cpp:218-234, which issl_index_write and issl_dump_hits redo
+                            // on the device when asked.  52 B per site in HBM and nothing in host memory: BASELINE
+                            // configs[4]'s 3 G lines are 152 GB on one GPU, and the image moves as ONE broadcast.
 };
 static_assert(sizeof(ImageHeader) <= kHeaderBytes, "header must fit its block");
 
@@ -120,6 +126,7 @@ struct LayoutSpec {
     bool inline_sigs = false; // `esig` (list-order layouts only)
     uint32_t cold = 0;        // ImageHeader::cold_on_host: 0, 1 (slice lists in host memory) or 3 (site table too)
     uint32_t sorted = 0;      // 0: stream in list order; 1: sorted, 16-byte stream records; 2: sorted, compact
+    bool no_lists = false;    // ImageHeader::lists_absent (sorted layouts only; cold == 0)
 };
 void layout_image(ImageHeader &h, const Geometry &g, uint64_t n_scores_unique, uint64_t n_tiles, bool dense_mit,
                   const LayoutSpec &spec);
@@ -152,6 +159,8 @@ struct Tuning {
                             //                    between (2: the short kernels of one batch fill the wave slots the scan of
                             //                    the next leaves)
     int host_cold;          // ISSL_FORCE_HOST_COLD  -1 automatic (image larger than the free HBM), 0 never, 1 always
+    int keep_lists;         // ISSL_KEEP_LISTS    the slice lists of a compact sorted image: -1 dropped when the image with them
+                            //                    does not fit the free HBM (ImageHeader::lists_absent), 0 always dropped, 1 always kept
     std::string stamps_path; // ISSL_SCAN_STAMPS  dump per-wave clocks of the scan here (diagnostics)
     static Tuning from_env();
     // Returns false when the key is unknown or the value out of range.
@@ -163,6 +172,9 @@ struct Tuning {
 // Synchronous.
 int launch_build_entries(const uint64_t *d_sites, const uint32_t *d_occ, uint64_t n_sites, uint32_t slice_begin,
                          uint32_t slice_end, uint32_t slice_width, uint64_t *d_entries);
+// Bucket lengths (isslScoreOfftargets.cpp:221-226: slice-major, n_slices << slice_width of them) of a site table that is
+// already in device memory.  Synchronous.
+int launch_bucket_sizes(const uint64_t *d_sites, uint64_t n_sites, uint32_t slice_width, uint32_t n_slices, uint64_t *h_sizes);
 
 // Sorted layouts (issl_build.hip): order every bucket's list by the successor slice's byte (two stable radix passes per
 // slice over keys built from the signatures) and write the maps of the image.  One slice at a time, 16 B per site of

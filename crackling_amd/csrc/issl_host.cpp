@@ -291,8 +291,7 @@ int HostIndex::build_from_sites(const uint64_t *sigs, const uint32_t *occ, size_
     return finish_build(slice_width);
 }
 
-int HostIndex::init_without_arrays(const uint64_t *sigs, size_t n_sites, size_t n_lines, size_t seq_len,
-                                   size_t slice_width)
+static int check_geometry_args(size_t n_sites, size_t seq_len, size_t slice_width)
 {
     if (seq_len == 0 || seq_len > 32) {
         set_error("sequence length must be 1..32");
@@ -306,28 +305,51 @@ int HostIndex::init_without_arrays(const uint64_t *sigs, size_t n_sites, size_t 
         set_error("site count must be 1..2^32-1");
         return ISSL_E_ARG;
     }
-    geo.n_sites = n_sites;
-    geo.seq_len = seq_len;
-    geo.n_lines = n_lines;
-    geo.slice_width = slice_width;
-    geo.n_slices = (seq_len * 2) / slice_width;
-    const uint64_t per_slice = geo.buckets_per_slice();
-    const uint64_t nb = geo.n_buckets();
+    return ISSL_OK;
+}
+
+int HostIndex::init_without_arrays(const uint64_t *sigs, size_t n_sites, size_t n_lines, size_t seq_len,
+                                   size_t slice_width)
+{
+    if (int rc = check_geometry_args(n_sites, seq_len, slice_width)) return rc;
+    const uint64_t n_slices = (seq_len * 2) / slice_width, per_slice = 1ull << slice_width, nb = n_slices << slice_width;
     const unsigned n_threads = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
     std::vector<std::vector<uint64_t>> part(n_threads, std::vector<uint64_t>(nb, 0));
     auto count = [&](unsigned t) {
         const size_t lo = n_sites * t / n_threads, hi = n_sites * (t + 1) / n_threads;
         uint64_t *cnt = part[t].data();
         for (size_t id = lo; id < hi; ++id)
-            for (uint64_t s = 0; s < geo.n_slices; ++s) ++cnt[s * per_slice + ((sigs[id] >> (slice_width * s)) & (per_slice - 1))];
+            for (uint64_t s = 0; s < n_slices; ++s) ++cnt[s * per_slice + ((sigs[id] >> (slice_width * s)) & (per_slice - 1))];
     };
     std::vector<std::thread> pool;
     for (unsigned t = 1; t < n_threads; ++t) pool.emplace_back(count, t);
     count(0);
     for (auto &t : pool) t.join();
-    own_sizes_.assign(nb, 0);
+    std::vector<uint64_t> total(nb, 0);
     for (const auto &p : part)
-        for (uint64_t b = 0; b < nb; ++b) own_sizes_[b] += p[b];
+        for (uint64_t b = 0; b < nb; ++b) total[b] += p[b];
+    return init_from_bucket_sizes(total.data(), n_sites, n_lines, seq_len, slice_width);
+}
+
+int HostIndex::init_from_bucket_sizes(const uint64_t *bucket_sizes, size_t n_sites, size_t n_lines, size_t seq_len,
+                                      size_t slice_width)
+{
+    if (int rc = check_geometry_args(n_sites, seq_len, slice_width)) return rc;
+    geo.n_sites = n_sites;
+    geo.seq_len = seq_len;
+    geo.n_lines = n_lines;
+    geo.slice_width = slice_width;
+    geo.n_slices = (seq_len * 2) / slice_width;
+    const uint64_t nb = geo.n_buckets();
+    own_sizes_.assign(bucket_sizes, bucket_sizes + nb);
+    for (uint64_t s = 0; s < geo.n_slices; ++s) { // every slice lists every site once
+        uint64_t sum = 0;
+        for (uint64_t b = 0; b < geo.buckets_per_slice(); ++b) sum += own_sizes_[s * geo.buckets_per_slice() + b];
+        if (sum != n_sites) {
+            set_error("bucket sizes do not add up to the site count");
+            return ISSL_E_ARG;
+        }
+    }
     sizes = own_sizes_.data();
     sites = nullptr;
     entries = nullptr;

@@ -48,6 +48,8 @@ class HostIndex {
     // Geometry, MIT table and bucket sizes only (threaded histogram of the slice values); `sites` and `entries` stay
     // null: the arrays of such an index exist only in the HBM image (issl_index_build_on_device).
     int init_without_arrays(const uint64_t *sigs, size_t n_sites, size_t n_lines, size_t seq_len, size_t slice_width);
+    // The same from bucket lengths somebody else counted (a site table that lives in device memory).
+    int init_from_bucket_sizes(const uint64_t *bucket_sizes, size_t n_sites, size_t n_lines, size_t seq_len, size_t slice_width);
     bool has_arrays() const { return sites != nullptr && entries != nullptr; }
     // Header, score table (and, with `with_sites`, nothing more): the leading sections of write_file() for callers
     // that stream the big arrays themselves.

@@ -1951,7 +1951,7 @@ __device__ inline HitTerms hit_terms(const ImageView &v, uint64_t gsig, uint32_t
         occ = static_cast<uint32_t>(site >> 40);
         if (occ == kOccSaturated) occ = v.site_occ[id];
         pos = 0;
-        if (want_id) {
+        if (want_id && v.entries) {
             const uint64_t *list = v.entries + v.bucket_start[bucket];
             uint64_t lo = 0, hi = v.bucket_start[bucket + 1] - v.bucket_start[bucket];
             while (lo < hi) {
@@ -1959,6 +1959,22 @@ __device__ inline HitTerms hit_terms(const ImageView &v, uint64_t gsig, uint32_t
                 if (static_cast<uint32_t>(list[mid]) < id) lo = mid + 1; else hi = mid;
             }
             pos = static_cast<uint32_t>(lo);
+        } else if (want_id) {
+            // An image without slice lists (ImageHeader::lists_absent): the position in the bucket's list is the number of
+            // the bucket's sites with a smaller id.  The stream holds the bucket's ids, ascending inside each of its 256
+            // successor-byte groups: one binary search per group.
+            const uint32_t *ss = v.sub_start + static_cast<uint64_t>(bucket) * 257u;
+            const uint64_t first = static_cast<uint64_t>(v.tile_first[bucket]) * kTileCands;
+            for (uint32_t w = 0; w < 256u; ++w) {
+                uint32_t lo = ss[w], hi = ss[w + 1];
+                const uint32_t s0 = lo;
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    const uint32_t there = v.srec ? v.srec[first + mid].id : v.sid[first + mid];
+                    if (there < id) lo = mid + 1; else hi = mid;
+                }
+                pos += lo - s0;
+            }
         }
     } else if (v.occ8) {
         // cold sections in host memory: signature from the scan planes, occurrences from the byte copy in HBM; the list

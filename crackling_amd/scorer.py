@@ -114,6 +114,19 @@ class IsslIndex:
         return cls(h)
 
     @classmethod
+    def build_from_device_sites(cls, d_sigs, d_occ, n_lines, device=0, seq_len=20, slice_width=8, options=None):
+        """The same for a site table that already sits in the memory of `device`: d_sigs (int64/uint64 view of the packed
+        signatures, text order, distinct) and d_occ (int32/uint32 counts) are torch CUDA tensors; nothing of the size of the
+        index touches host memory.  The tensors may be freed afterwards."""
+        assert d_sigs.is_cuda and d_occ.is_cuda and d_sigs.element_size() == 8 and d_occ.element_size() == 4
+        assert d_sigs.is_contiguous() and d_occ.is_contiguous() and d_sigs.numel() == d_occ.numel()
+        h = C.c_void_p()
+        opts = ",".join(f"{k}={v}" for k, v in (options or {}).items()).encode() or None
+        check(lib.issl_index_build_from_device_sites(d_sigs.data_ptr(), d_occ.data_ptr(), d_sigs.numel(), int(n_lines), seq_len,
+                                                     slice_width, device, opts, C.byref(h)))
+        return cls(h)
+
+    @classmethod
     def attach_tensor(cls, tensor):
         """Adopt an HBM image that arrived in a torch uint8 CUDA tensor (e.g. by RCCL broadcast)."""
         h = C.c_void_p()

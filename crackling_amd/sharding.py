@@ -66,9 +66,15 @@ def broadcast_image(dist, torch, index, device, src=0, index_cls=None, piece_byt
     staged = _staged(dist, torch, device)
     nbytes = torch.zeros(1, dtype=torch.int64, device="cpu" if staged else device)
     if rank == src:
-        nbytes[0] = index.device_bytes()
+        # an image with sections in pinned host memory cannot be adopted by another process (issl_index_attach_image):
+        # say so BEFORE the source index is consumed (-1 = every rank raises, nobody hangs in the broadcast)
+        cold = index.cold()[1] if index.has_device_image() and hasattr(index, "cold") else 0
+        nbytes[0] = -1 if cold else index.device_bytes()
     dist.broadcast(nbytes, src)
     n = int(nbytes.item())
+    if n < 0:
+        raise RuntimeError("broadcast_image: the image on the source rank keeps its slice lists in pinned host memory "
+                           "(host_cold=1); upload it with keep_lists=0 / without host_cold so that it is self-contained")
     raw = torch.empty(n + 256, dtype=torch.uint8, device=device)
     off = (-raw.data_ptr()) % 256
     image = raw[off:off + n]

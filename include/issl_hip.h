@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define ISSL_ABI_VERSION 4
+#define ISSL_ABI_VERSION 5
 
 enum {
     ISSL_OK = 0,
@@ -143,6 +143,14 @@ int issl_index_build_on_device_opt(const uint64_t *sigs, const uint32_t *occ, si
                                    size_t n_lines, size_t seq_len, size_t slice_width, int device,
                                    const char *options, issl_index **out);
 
+/* The same for a site table that is ALREADY in the memory of `device` (d_sigs, d_occ: device pointers; e.g. the sorted,
+ * de-duplicated keys issl_extract_* leaves there, or sites generated on the GPU): bucket lengths are counted on the
+ * device, nothing of the size of the index ever exists in host memory.  The inputs are copied into the image and may be
+ * freed when the call returns.  isslCreateIndex.cpp:199-234 from its state after the counting loop on.  (ABI 5) */
+int issl_index_build_from_device_sites(const uint64_t *d_sigs, const uint32_t *d_occ, size_t n_sites,
+                                       size_t n_lines, size_t seq_len, size_t slice_width, int device,
+                                       const char *options, issl_index **out);
+
 /* Write the .issl bytes (isslCreateIndex.cpp:256-289). */
 int issl_index_write(const issl_index *idx, const char *path);
 
@@ -185,9 +193,13 @@ int issl_index_copy_image_to(const issl_index *idx, void *dev_dst, size_t bytes)
  * try, in this order, until one fits the free HBM:
  *   sorted        every bucket ordered by the byte of the next slice (what the pruned scan needs) + 16-byte stream records,
  *                 site table, counts, slice lists: 152 B/site
- *   compact       the same order with 4-byte site ids per stream position: 92 B/site, or -- slice lists in pinned, mapped
- *                 HOST memory, where only issl_dump_hits and issl_index_write read them -- 52 B/site: an index at the
- *                 format's limit of 4.29 G sites takes 223 GB of a 288 GB GPU (3 G lines: 152 GB, measured)
+ *   compact       the same order with 4-byte site ids per stream position: 92 B/site, or 52 B/site WITHOUT the slice lists
+ *                 (ABI 5; the automatic fallback): scoring never reads them, and on a sorted layout they are a function of
+ *                 site table and counts (every list ascends by site id, isslCreateIndex.cpp:218-234), which
+ *                 issl_index_write and issl_dump_hits redo on the device when asked.  An index at the format's limit of
+ *                 4.29 G sites takes 223 GB of a 288 GB GPU (3 G lines: 152 GB, measured), nothing in host memory, and
+ *                 the image still moves as one broadcast.  On request (host_cold=1) the lists are kept in pinned,
+ *                 mapped HOST memory instead (40 B/site there)
  *   list order    (indexes whose lists do not ascend by site id, or whose five lists disagree about a site's count: no
  *                 builder writes such, the reference does not care; no pruned scan then) with / without in-list
  *                 signatures 108 / 68 B/site, or with site table and lists in host memory 25 B/site (the kernels rebuild
@@ -207,9 +219,10 @@ int issl_index_attach_image_cold(int device, void *dev_buf, size_t bytes, void *
  *   scan_generic (ISSL_SCAN_GENERIC) 0|1 runtime-threshold scan       stage_timing (ISSL_STAGE_TIMING) 0|1 events at every stage
  *   raw_chunks (ISSL_RAW_CHUNKS) initial raw-record buffer
  *   sorted_layout (ISSL_SORTED_LAYOUT), compact (ISSL_COMPACT), inline_sigs (ISSL_INLINE_SIGS), host_cold
- *     (ISSL_FORCE_HOST_COLD), each -1|0|1: image layout, read at upload (see above; -1 = automatic).  compact=1 with
- *     host_cold=1: the compact sorted image with its slice lists in host memory; host_cold=1 alone: the list-order image
- *     with site table and lists in host memory
+ *     (ISSL_FORCE_HOST_COLD), keep_lists (ISSL_KEEP_LISTS), each -1|0|1: image layout, read at upload (see above; -1 =
+ *     automatic).  compact=1 with host_cold=1: the compact sorted image with its slice lists in host memory; host_cold=1
+ *     alone: the list-order image with site table and lists in host memory; keep_lists=0: the compact sorted image
+ *     without slice lists (52 B/site), keep_lists=1: never drop them
  *   tail_shapes (ISSL_TAIL_SHAPES) 0|1 (default 1): the short last unit of a successor-byte group runs 2 / 4 guides per
  *     pass on 16 / 8 candidates per lane
  *   hit_slots (ISSL_HIT_SLOTS) 0|1 (default 1): the first 512 hits of every guide go straight from the exact test to a
@@ -226,7 +239,7 @@ int issl_index_attach_image_cold(int device, void *dev_buf, size_t bytes, void *
  *   scan_stamps (ISSL_SCAN_STAMPS) file for per-wave clocks (diagnostics) */
 int issl_index_set_option(issl_index *idx, const char *key, const char *value);
 /* Current value of an integer knob; also the read-only keys is_sorted, is_compact, cold_on_host, cold_sections (0, 1 =
- * slice lists, 3 = lists + site table in host memory), has_inline_sigs and dense_mit (layout of the uploaded image, -1
+ * slice lists, 3 = lists + site table in host memory), lists_absent, has_inline_sigs and dense_mit (layout of the uploaded image, -1
  * before an upload). */
 int issl_index_get_option(const issl_index *idx, const char *key, long long *value);
 

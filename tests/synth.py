@@ -52,6 +52,79 @@ def random_sites_fast(n_lines, seed, threads=16, dup_frac=0.025):
     return np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts])
 
 
+class DeviceSites:
+    """A site table that lives in device memory (torch tensors), for tests at sizes whose host arrays would not fit the
+    box: len() and fancy indexing (-> numpy, a gather on the device) are all the checkers need of it."""
+
+    def __init__(self, tensor, dtype=np.uint64):
+        self.d, self.dtype = tensor, dtype
+
+    def __len__(self):
+        return int(self.d.numel())
+
+    def __getitem__(self, idx):
+        import torch
+        idx = torch.as_tensor(np.asarray(idx, dtype=np.int64), device=self.d.device)
+        return self.d[idx].cpu().numpy().view(self.dtype)
+
+
+def random_sites_device(n_lines, seed, device="cuda:0", threads=16, dup_frac=0.025):
+    """random_sites_fast() -- the SAME sites for the same arguments -- delivered as device tensors: the 256 chunks are
+    drawn on the host thread pool and copied into place one by one, so the host never holds more than the chunks in
+    flight (12 B/site x 3 G lines is what kept BASELINE configs[4] out of the default suite).
+    -> (d_sigs int64 view of the packed signatures, d_occ int32), text order, distinct."""
+    import torch
+    from concurrent.futures import ThreadPoolExecutor
+    per = int(n_lines / (1 + dup_frac)) // 256
+    d_sigs = torch.empty(per * 256, dtype=torch.int64, device=device)
+    d_occ = torch.empty(per * 256, dtype=torch.int32, device=device)
+
+    def chunk(c):  # (identical to random_sites_fast's)
+        rng = np.random.default_rng([seed, c])
+        low = rng.integers(0, 1 << 32, size=per, dtype=np.uint64)
+        low.sort()
+        keep = np.ones(per, dtype=bool)
+        keep[1:] = low[1:] != low[:-1]
+        low = low[keep]
+        occ = np.ones(len(low), dtype=np.uint32)
+        occ[rng.random(len(low)) < dup_frac] = 2
+        return text_order_key((np.uint64(c) << np.uint64(32)) | low), occ
+
+    at = 0
+    with ThreadPoolExecutor(max_workers=threads) as pool:
+        pending = []
+        for c in range(256):  # at most threads + 4 chunks exist on the host at any time
+            pending.append(pool.submit(chunk, c))
+            if len(pending) >= threads + 4 or c == 255:
+                for f in (pending if c == 255 else pending[:1]):
+                    sig, occ = f.result()
+                    d_sigs[at:at + len(sig)] = torch.from_numpy(sig.view(np.int64))
+                    d_occ[at:at + len(sig)] = torch.from_numpy(occ.view(np.int32))
+                    at += len(sig)
+                pending = [] if c == 255 else pending[1:]
+    return d_sigs[:at], d_occ[:at]
+
+
+def neighbours_device(d_sigs, guide, max_dist, chunk=1 << 27):
+    """Indices of the sites within max_dist mismatches of `guide`: brute force over the whole device-resident table with
+    plain torch arithmetic (a checker: nothing of the product is involved)."""
+    import torch
+    g = int(guide)
+    g = g - (1 << 64) if g >= (1 << 63) else g
+    even, m2, m4, ones = 0x5555555555555555, 0x3333333333333333, 0x0F0F0F0F0F0F0F0F, 0x0101010101010101
+    found = []
+    for lo in range(0, d_sigs.numel(), chunk):
+        x = d_sigs[lo:lo + chunk] ^ g
+        x = (x | (x >> 1)) & even                      # one flag per mismatching position, on the even bits (bits 0..39)
+        x = (x & m2) + ((x >> 2) & m2)
+        x = (x + (x >> 4)) & m4
+        cnt = (x * ones) >> 56                         # 40-bit inputs: the byte sums stay far below 256
+        hit = torch.nonzero(cnt <= max_dist).flatten()
+        if hit.numel():
+            found.append((hit + lo).cpu().numpy())
+    return np.concatenate(found) if found else np.empty(0, dtype=np.int64)
+
+
 def random_guides(sigs, n_guides, seed, seq_len=20):
     rng = np.random.default_rng(seed)
     g = np.empty(n_guides, dtype=np.uint64)

@@ -914,7 +914,7 @@ def test_random_small_indexes_differential():
             ix = ca.IsslIndex.build_from_sites(sig, occ)
             path = os.path.join(tmp, f"t{trial}.issl")
             ix.write(path)
-            name = names[int(rng.integers(0, len(names)))] if trial % 3 else SORTED[(trial // 3) % 3]
+            name = names[int(rng.integers(0, len(names)))] if trial % 3 else SORTED[(trial // 3) % len(SORTED)]
             layout = dict(LAYOUTS[name])
             if name in SORTED:
                 layout["prune"] = int(rng.integers(-1, 2)) if trial % 2 else 1

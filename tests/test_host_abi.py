@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/issl_hip.h but not exported"
     assert declared == set(_lib.EXPORTS)
-    assert lib.issl_abi_version() == 4
+    assert lib.issl_abi_version() == 5
 
 
 def test_builder_bytes_match_reference_golden(golden, tmp_path):

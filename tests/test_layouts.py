@@ -3,7 +3,8 @@
 Layouts:
   sorted        stream ordered by the successor slice's byte, 16-byte stream records          (pruned scan)
   compact       the same order, 4-byte site ids per stream position                           (pruned scan)
-  compact_cold  ... with the slice lists in pinned host memory (what a 3 G-site index gets)   (pruned scan)
+  compact_cold  ... with the slice lists in pinned host memory                                (pruned scan)
+  compact_bare  ... without slice lists at all: 52 B/site, what a 3 G-site index gets         (pruned scan)
   list_esig     stream in list order, in-list signatures
   list          stream in list order
   host_cold     stream in list order, site table and lists in pinned host memory (occ8 + plane rebuild)
@@ -22,13 +23,14 @@ pytestmark = pytest.mark.gpu
 
 LAYOUTS = {
     "sorted": {"sorted_layout": 1, "compact": 0, "host_cold": 0},
-    "compact": {"compact": 1, "host_cold": 0},
+    "compact": {"compact": 1, "host_cold": 0, "keep_lists": 1},
     "compact_cold": {"compact": 1, "host_cold": 1},
+    "compact_bare": {"compact": 1, "keep_lists": 0},
     "list_esig": {"sorted_layout": 0, "inline_sigs": 1, "host_cold": 0},
     "list": {"sorted_layout": 0, "inline_sigs": 0, "host_cold": 0},
     "host_cold": {"sorted_layout": 0, "host_cold": 1},
 }
-SORTED = ("sorted", "compact", "compact_cold")
+SORTED = ("sorted", "compact", "compact_cold", "compact_bare")
 SETS = ["uniform", "clustered", "edge", "oddtable", "bigocc", "signedtable"]
 
 
@@ -41,7 +43,8 @@ def _open(path_or_bytes, layout):
 
 def _check_layout(ix, layout):
     assert ix.get_option("is_sorted") == (1 if layout in SORTED else 0)
-    assert ix.get_option("is_compact") == (1 if layout in ("compact", "compact_cold") else 0)
+    assert ix.get_option("is_compact") == (1 if layout in ("compact", "compact_cold", "compact_bare") else 0)
+    assert ix.get_option("lists_absent") == (1 if layout == "compact_bare" else 0)
     assert ix.get_option("cold_sections") == {"compact_cold": 1, "host_cold": 3}.get(layout, 0)
     assert ix.get_option("has_inline_sigs") == (1 if layout == "list_esig" else 0)
 
@@ -146,6 +149,52 @@ def test_compact_image_with_host_lists_built_on_the_device_and_shared_by_a_node(
         ix.close()
 
 
+def test_bare_compact_image_from_a_site_table_on_the_device(golden_uniform, tmp_path):
+    """issl_index_build_from_device_sites + the image without slice lists: signatures and counts handed over as device
+    tensors, bucket sizes counted on the device, nothing pinned; written back out (the lists are made again on the device,
+    isslCreateIndex.cpp:218-234) byte-identical to the reference-built .issl; scores and hit lists -- whose list positions
+    are recomputed from the stream (hit_terms) -- equal to the reference's; the image travels in a tensor like any other."""
+    import torch
+    g = golden_uniform
+    host = ca.IsslIndex.open(g.issl)
+    n = host.header["n_sites"]
+    data = g.issl.read_bytes()
+    off_sites = 48 + 16 * host.header["n_scores"]
+    sigs = np.frombuffer(data, dtype=np.uint64, count=n, offset=off_sites).copy()
+    entries0 = np.frombuffer(data, dtype=np.uint64, count=n, offset=off_sites + 8 * n + 8 * 5 * 256)   # slice 0's lists
+    occ = np.zeros(n, dtype=np.uint32)
+    occ[(entries0 & np.uint64(0xFFFFFFFF)).astype(np.int64)] = (entries0 >> np.uint64(32)).astype(np.uint32)
+    assert np.array_equal(host.bucket_sizes(), ca.IsslIndex.build_from_sites(sigs, occ).bucket_sizes())
+    sizes = host.bucket_sizes()
+    host.close()
+    d_sigs = torch.from_numpy(sigs.view(np.int64)).cuda()
+    d_occ = torch.from_numpy(occ.view(np.int32)).cuda()
+    guides = ca.encode_guides([s.encode() for s in g.guides])
+    for options, bare in (({"keep_lists": 0}, 1), (None, 0)):
+        ix = ca.IsslIndex.build_from_device_sites(d_sigs, d_occ, int(occ.sum()), device=0, options=options)
+        try:
+            assert ix.get_option("lists_absent") == bare and ix.get_option("is_sorted") == 1 and ix.cold() == (None, 0)
+            assert np.array_equal(ix.bucket_sizes(), sizes)
+            out = tmp_path / "roundtrip.issl"
+            ix.write(out)
+            assert out.read_bytes() == data
+            for prune in (0, 1):
+                ix.set_option("prune", prune)
+                mit, cfd = ix.score(guides, 4, 75.0, "and")
+                assert ca.format_scores(guides, mit, cfd, "and") == g.expected["and|75|4"]
+                assert np.array_equal(ix.dump_hits(guides, 4, 0.0, "and"), g.hits(0))
+            p, nbytes = ix.image()
+            raw = torch.empty(nbytes + 256, dtype=torch.uint8, device="cuda:0")
+            off = (-raw.data_ptr()) % 256
+            twin = ca.IsslIndex.attach_tensor(ix.copy_image_to_tensor(raw[off:off + nbytes]))   # what a broadcast delivers
+            mit, cfd = twin.score(guides, 4, 75.0, "and")
+            assert ca.format_scores(guides, mit, cfd, "and") == g.expected["and|75|4"]
+            assert np.array_equal(twin.dump_hits(guides, 4, 0.0, "and"), g.hits(0))
+            twin.close()
+        finally:
+            ix.close()
+
+
 def test_layout_sizes(golden_uniform):
     """HBM bytes per layout, in the order an upload tries them (issl_index_device_bytes needs no device)."""
     size = {}
@@ -158,6 +207,7 @@ def test_layout_sizes(golden_uniform):
     auto.close()
     n = 8200  # about the sites of the set: the sections differ by whole multiples of it
     assert size["sorted"] > size["compact"] + 50 * n > size["compact_cold"] + 80 * n
+    assert size["compact_bare"] == size["compact_cold"]
     assert size["list_esig"] > size["list"] + 30 * n > size["host_cold"] + 60 * n
 
 

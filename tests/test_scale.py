@@ -4,9 +4,9 @@ guides over three replicas of that index) and hit lists at that size, checked ag
 The device-built tests run at configs[2]'s full size or not at all (they fail on an MI355X that cannot hold it and are
 skipped on a smaller GPU; the size is part of the test id and is printed behind the test summary); the host-built test
 keeps 20 M lines (it writes the .issl for the oracle).  The bigger points of profiles/ are the same tests with
-ISSL_SCALE_SITES / ISSL_SCALE_GUIDES / ISSL_SCALE_JSON set; test_layout_for_indexes_beyond_the_hbm_at_scale is
-BASELINE configs[4]'s layout at the largest size the box's host memory holds (ISSL_BEYOND_HBM_LINES=3000000000 is
-configs[4] itself on ONE MI355X).  The .issl for the
+ISSL_SCALE_SITES / ISSL_SCALE_GUIDES / ISSL_SCALE_JSON set; test_index_beyond_the_hbm_at_scale is BASELINE configs[4]
+itself -- 3 G lines on ONE MI355X, the site table drawn straight into device memory (ISSL_BEYOND_HBM_LINES overrides the
+size for smaller boxes).  The .issl for the
 oracle goes to ISSL_SCALE_TMP (default: pytest's tmp dir; use /dev/shm for files larger than the disk)."""
 import json
 import os
@@ -18,7 +18,8 @@ import pytest
 
 import crackling_amd as ca
 import oracle_util as ou
-from synth import random_sites_fast, markov_sites_fast, random_guides, random_guides_fast, text_order_key, check_comparisons
+from synth import (random_sites_fast, markov_sites_fast, random_guides, random_guides_fast, text_order_key, check_comparisons,
+                   random_sites_device, neighbours_device, DeviceSites)
 
 
 def test_fast_generator_is_sorted_and_distinct():
@@ -126,17 +127,22 @@ class ScalePoint:
     is the one asked for or the point does not run: it FAILS when the box is an MI355X-class GPU (>= 40 GB of free HBM)
     that cannot hold it -- a green suite means the full size ran -- and is skipped, with the reason, on a smaller GPU."""
 
-    def __init__(self, n_lines, n_guides, options=None, n_check=None, what="configs[2]", dist="uniform"):
+    def __init__(self, n_lines, n_guides, options=None, n_check=None, what="configs[2]", dist="uniform", device_synth=False):
+        """device_synth: the site table never exists on the host -- drawn chunk by chunk into device tensors (the same
+        sites random_sites_fast makes), the index built from them (issl_index_build_from_device_sites), the checker's
+        brute force run over them with torch arithmetic."""
         from concurrent.futures import ThreadPoolExecutor
         import conftest
         self.threads = min(32, os.cpu_count() or 8)
         options = dict(options or {})
         lists_cold = options.get("host_cold") == 1
+        bare = options.get("keep_lists") == 0
         # HBM per site: sorted layout 152 B (+ 16 B of temporaries while it is built); compact with the lists in host
-        # memory 52 B (+ 24 B of temporaries).  Host: 12 B/site generated (twice while the chunks are concatenated) +
-        # brute-force temporaries, + 40 B/site pinned for host-resident lists
-        per_site_hbm = 76 if lists_cold else 168
-        host_need = n_lines * (24 + (40 if lists_cold else 0)) + 16e9
+        # memory or without lists 52 B (+ 24 B of temporaries; + 12 B of input tensors with device_synth).  Host: 12 B/site
+        # generated (twice while the chunks are concatenated) + brute-force temporaries, + 40 B/site pinned for
+        # host-resident lists -- or, with device_synth, the chunks in flight
+        per_site_hbm = (76 if (lists_cold or bare) else 168) + (12 if device_synth else 0)
+        host_need = (0 if device_synth else n_lines * (24 + (40 if lists_cold else 0))) + 16e9
         free_hbm, limit = _free_hbm_bytes(), _memory_limit_bytes()
         if free_hbm < 40e9:
             pytest.skip(f"{what}: {free_hbm / 1e9:.0f} GB of free HBM -- not the MI355X this point is sized for")
@@ -145,13 +151,21 @@ class ScalePoint:
                         f"~{n_lines * per_site_hbm / 1e9:.0f} GB of HBM (free {free_hbm / 1e9:.0f}); the point does not shrink")
         self.n_lines, self.n_guides = n_lines, n_guides
         t = time.time()
-        if dist == "markov":  # AT-rich order-3 Markov chain: a skewed index (bench.py --dist markov)
+        if device_synth:
+            d_sigs, d_occ = random_sites_device(self.n_lines, seed=11, threads=self.threads)
+            self.sigs, self.occ = DeviceSites(d_sigs), DeviceSites(d_occ, np.uint32)
+        elif dist == "markov":  # AT-rich order-3 Markov chain: a skewed index (bench.py --dist markov)
             self.sigs, self.occ = markov_sites_fast(self.n_lines, seed=20261003)
         else:
             self.sigs, self.occ = random_sites_fast(self.n_lines, seed=11, threads=self.threads)
         self.t_synth = time.time() - t
         self.guides = random_guides_fast(self.sigs, self.n_guides, seed=12)
-        t = time.time(); self.ix = ca.IsslIndex.build_on_device(self.sigs, self.occ, device=0, options=options); self.t_build = time.time() - t
+        t = time.time()
+        if device_synth:
+            self.ix = ca.IsslIndex.build_from_device_sites(d_sigs, d_occ, int(d_occ.sum(dtype=__import__("torch").int64)), device=0, options=options)
+        else:
+            self.ix = ca.IsslIndex.build_on_device(self.sigs, self.occ, device=0, options=options)
+        self.t_build = time.time() - t
         note = (f"{what}: {self.n_lines} lines ({len(self.sigs)} distinct sites) x {self.n_guides} guides, image "
                 f"{self.ix.device_bytes() / 1e9:.1f} GB in HBM + {self.ix.cold()[1] / 1e9:.1f} GB pinned, sorted={self.ix.get_option('is_sorted')} "
                 f"compact={self.ix.get_option('is_compact')}")
@@ -162,8 +176,11 @@ class ScalePoint:
         self.n_check = n_check or int(os.environ.get("ISSL_SCALE_CHECK", 64))
         self.pick = np.linspace(0, self.n_guides - 1, self.n_check).astype(np.int64)
         t = time.time()
-        with ThreadPoolExecutor(max_workers=min(self.threads, 16)) as pool:
-            near = list(pool.map(lambda g: _neighbours(self.sigs, g, 4), self.guides[self.pick]))
+        if device_synth:
+            near = [neighbours_device(self.sigs.d, g, 4) for g in self.guides[self.pick]]
+        else:
+            with ThreadPoolExecutor(max_workers=min(self.threads, 16)) as pool:
+                near = list(pool.map(lambda g: _neighbours(self.sigs, g, 4), self.guides[self.pick]))
         self.t_brute = time.time() - t
         self.keep = np.unique(np.concatenate(near + [np.arange(0, len(self.sigs), max(1, len(self.sigs) // 5000))]))
         print(f"brute force for {self.n_check} guides: {self.t_brute:.1f}s, {sum(len(x) for x in near)} sites within 4 mismatches", flush=True)
@@ -350,9 +367,9 @@ def test_cold_sections_in_host_memory_at_scale(monkeypatch, tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("options", [None, {"compact": 1}, {"compact": 1, "host_cold": 1}, {"sorted_layout": 0},
+@pytest.mark.parametrize("options", [None, {"compact": 1}, {"compact": 1, "host_cold": 1}, {"keep_lists": 0}, {"sorted_layout": 0},
                                      {"sorted_layout": 0, "inline_sigs": 0}, {"sorted_layout": 0, "host_cold": 1}],
-                         ids=["sorted", "compact", "compact-lists-cold", "list-order", "list-order-no-inline", "list-order-cold"])
+                         ids=["sorted", "compact", "compact-lists-cold", "compact-no-lists", "list-order", "list-order-no-inline", "list-order-cold"])
 def test_many_hit_guides_several_per_replay_workgroup(tmp_path, options):
     """More guides of every many-hit class than the replay kernel of that class has workgroups: 2300 guides with 2049 ..
     16384 hits (k_replay_big<256>: 2048 workgroups) and 560 with more (k_replay_big<1024>: 512), besides 2300 of
@@ -382,7 +399,7 @@ def test_many_hit_guides_several_per_replay_workgroup(tmp_path, options):
     ix = ca.IsslIndex.build_on_device(sig, occ, device=0, options=options)
     try:
         assert ix.get_option("is_sorted") == (0 if options and options.get("sorted_layout") == 0 else 1)
-        assert ix.get_option("is_compact") == (1 if options and options.get("compact") == 1 else 0)
+        assert ix.get_option("is_compact") == (1 if options and (options.get("compact") == 1 or options.get("keep_lists") == 0) else 0)
         assert (ix.get_option("cold_on_host") == 1) == bool(options and options.get("host_cold") == 1)
         mit, cfd = ix.score(guides, 4, 0.0, "and")
         hits = ix.stats()["hits"]
@@ -499,35 +516,58 @@ def test_skewed_index_at_scale(tmp_path):
         ix.close()
 
 
-def _beyond_hbm_lines():
-    """BASELINE configs[4]'s index does not fit the default layouts; its layout (compact sorted image, slice lists in
-    pinned host memory) is exercised here at the largest of these line counts whose host arrays fit this box's memory
-    limit (ISSL_BEYOND_HBM_LINES overrides; 3 000 000 000 = configs[4] itself: profiles/r03_scale_3g_*)."""
-    if "ISSL_BEYOND_HBM_LINES" in os.environ:
-        return int(os.environ["ISSL_BEYOND_HBM_LINES"])
-    for n in (1_000_000_000, 600_000_000, 300_000_000, 100_000_000):
-        if n * 64 + 16e9 <= 0.8 * _memory_limit_bytes():
-            return n
-    return 0
+def test_device_side_site_generator_makes_the_host_generators_sites():
+    """random_sites_device (what the 3 G-line point is built from) against random_sites_fast (the generator of every other
+    scale point) -- the same sites and counts -- and the torch brute force against the numpy one.  CPU tensors: no GPU."""
+    sigs, occ = random_sites_fast(400_000, seed=11, threads=4)
+    d_sigs, d_occ = random_sites_device(400_000, seed=11, device="cpu", threads=4)
+    assert np.array_equal(d_sigs.numpy().view(np.uint64), sigs) and np.array_equal(d_occ.numpy().view(np.uint32), occ)
+    proxy = DeviceSites(d_sigs)
+    assert len(proxy) == len(sigs) and np.array_equal(proxy[[5, 0, 399]], sigs[[5, 0, 399]])
+    g = int(sigs[1234]) ^ (3 << 10) ^ (1 << 30)
+    for max_dist in (0, 2, 4, 9):
+        assert np.array_equal(neighbours_device(d_sigs, g, max_dist, chunk=70_000), _neighbours(sigs, np.uint64(g), max_dist, chunk=90_000))
+
+
+BEYOND_HBM_LINES = int(os.environ.get("ISSL_BEYOND_HBM_LINES", 3_000_000_000))
 
 
 @pytest.mark.gpu
-def test_layout_for_indexes_beyond_the_hbm_at_scale(tmp_path):
-    """configs[4]-shaped point: the layout an index larger than the HBM gets (compact sorted image: scan stream, site ids
-    per stream position, site table and counts in HBM = 52 B/site; slice lists in pinned host memory), forced, at the
-    largest size the box's host memory allows (the size is printed behind the test summary).  Pruned scan against the
-    scan of whole buckets on all guides, a sample and its hit lists against the oracle."""
-    n_lines = _beyond_hbm_lines()
-    if not n_lines:
-        pytest.skip(f"host memory limit {_memory_limit_bytes() / 1e9:.0f} GB: no room for the pinned slice lists of even 100 M lines")
-    sp = ScalePoint(n_lines, int(os.environ.get("ISSL_SCALE_GUIDES", 100_000)), options={"compact": 1, "host_cold": 1},
-                    n_check=int(os.environ.get("ISSL_SCALE_CHECK", 32)), what="configs[4]-shaped (compact image, lists in host memory)")
+def test_index_beyond_the_hbm_at_scale(tmp_path):
+    """BASELINE configs[4] itself: a 3 G-line index (2.92 G distinct sites; 144 GB as an .issl, 444 GB in the default
+    layout) on ONE MI355X.  The layout such an index gets -- compact sorted image without slice lists: scan stream, site
+    ids per stream position, site table and counts = 52 B/site, 152 GB, nothing in host memory -- forced; the site table
+    is drawn straight into device memory (the host never holds anything of the index's size) and the index built from
+    there.  Pruned scan against the scan of whole buckets on all 100 000 guides, a sample and its hit lists against the
+    oracle (the sample's neighbourhoods by brute force over the device-resident table).  Like every scale point it runs
+    at its size or fails (skipped on a GPU that is no MI355X); the size is printed behind the test summary."""
+    sp = ScalePoint(BEYOND_HBM_LINES, int(os.environ.get("ISSL_SCALE_GUIDES", 100_000)), options={"keep_lists": 0},
+                    n_check=int(os.environ.get("ISSL_SCALE_CHECK", 32)), what="configs[4] (compact image without slice lists)",
+                    device_synth=True)
     try:
-        assert sp.ix.get_option("is_compact") == 1 and sp.ix.get_option("cold_sections") == 1
-        assert sp.ix.cold()[1] >= 40 * len(sp.sigs) and sp.ix.device_bytes() < 60 * len(sp.sigs) + (64 << 20)
-        summary = _score_and_check(sp, tmp_path, "tests/test_scale.py::test_layout_for_indexes_beyond_the_hbm_at_scale")
+        assert sp.ix.get_option("is_compact") == 1 and sp.ix.get_option("lists_absent") == 1
+        assert sp.ix.cold() == (None, 0) and sp.ix.device_bytes() < 60 * len(sp.sigs) + (64 << 20)
+        summary = _score_and_check(sp, tmp_path, "tests/test_scale.py::test_index_beyond_the_hbm_at_scale")
         _hit_lists_match(sp, tmp_path)
         if os.environ.get("ISSL_BEYOND_HBM_JSON"):
             json.dump(summary, open(os.environ["ISSL_BEYOND_HBM_JSON"], "w"), indent=1)
+    finally:
+        sp.ix.close()
+
+
+@pytest.mark.gpu
+def test_compact_image_with_lists_in_host_memory_at_scale(tmp_path):
+    """The other way to keep a large index's lists out of the HBM (host_cold=1: pinned, mapped host memory, shared by
+    the GPUs of a node), at 300 M lines: same checks."""
+    n_lines = 300_000_000
+    if n_lines * 64 + 16e9 > 0.8 * _memory_limit_bytes():
+        pytest.skip(f"host memory limit {_memory_limit_bytes() / 1e9:.0f} GB: no room for the pinned slice lists of {n_lines} lines")
+    sp = ScalePoint(n_lines, int(os.environ.get("ISSL_SCALE_GUIDES", 100_000)), options={"compact": 1, "host_cold": 1},
+                    n_check=int(os.environ.get("ISSL_SCALE_CHECK", 32)), what="compact image, lists in host memory")
+    try:
+        assert sp.ix.get_option("is_compact") == 1 and sp.ix.get_option("cold_sections") == 1
+        assert sp.ix.cold()[1] >= 40 * len(sp.sigs) and sp.ix.device_bytes() < 60 * len(sp.sigs) + (64 << 20)
+        _score_and_check(sp, tmp_path, "tests/test_scale.py::test_compact_image_with_lists_in_host_memory_at_scale")
+        _hit_lists_match(sp, tmp_path)
     finally:
         sp.ix.close()
