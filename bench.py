@@ -45,9 +45,22 @@ import numpy as np  # noqa: E402
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s HBM3E spec peak
 PEAK_CLOCK_HZ = 2.4e9       # peak engine clock; under the scan's load the chip holds less (profiles/: GRBM_GUI_ACTIVE)
 N_SIMD = 256 * 4
-VALU_PER_2048_CMP = 62      # wave64 VALU instructions per guide and 2048 candidates in k_scan<4>
 VALU_CYCLES_PER_INSTR = 2   # SIMD-32: a wave64 VALU instruction holds the issue port for two cycles
-TILE_BYTES = 8192           # one scan tile: 2048 candidates x 4 B
+BROADCAST_LIMIT_S = 600.0   # N > 1: a rank whose image broadcast has not finished by then exits non-zero (watchdog below)
+
+
+def valu_per_2048_cmp(pruned, max_dist):
+    """Useful wave64 VALU instructions per guide and 2048 candidates in the scan's loop, counted in the compiled kernel
+    (tools/isa_stats.py): whole buckets compare 16 positions -- 32 for the mismatch planes, 29 for
+    the count, 1 hit test = 62.  The pruned scan compares 12 (the successor slice's four are known from the group a
+    guide was placed in): 24 + 17 + 1 = 42 for the twelve of thirteen placements with one mismatch there (budget 3),
+    24 + 22 + 1 = 47 for the thirteenth (budget 4); max_dist <= 2 places every guide once per bucket (budget = max_dist:
+    24 + 19..20 + 1)."""
+    if not pruned:
+        return 62.0
+    if pruned == 1:
+        return 45.0
+    return (12 * 42 + 47) / 13.0
 
 
 def log(*a):
@@ -74,6 +87,14 @@ def traffic_point(sites, guides, dist, pruned):
     except Exception as e:  # noqa: BLE001
         return None, f"{type(e).__name__}: {e}"
     return None, "no PMC point for this workload in profiles/scan_traffic.json"
+
+
+def rccl_version(torch):
+    try:
+        v = torch.cuda.nccl.version()
+        return ".".join(str(x) for x in v) if isinstance(v, (tuple, list)) else str(v)
+    except Exception as e:  # noqa: BLE001
+        return f"unknown ({type(e).__name__})"
 
 
 def host_description():
@@ -148,7 +169,10 @@ def cpu_baseline(issl_path, guides, gpu_scores, max_dist, thr, method, budget_s)
         "single_thread_seconds_per_guide_thr0": per_guide_s,
         "sweep": sweep, "host": host, "index_load_s": load_s, "parity_on_sample": parity,
         "note": "thr0 = no early exit (isslScoreOfftargets.cpp:326: maximum_sum = +inf), the full five-bucket scan the "
-                "GPU always does; the product threshold lets the CPU stop early on promiscuous guides",
+                "GPU always does; the product threshold lets the CPU stop early on promiscuous guides.  kind 'port': the "
+                "oracle's restatement of the reference scorer; timed beside the compiled reference in the build container it "
+                "took 1.54x (threshold 0) / 0.78x (threshold 75) the reference's scoring time (profiles/r03_port_vs_reference_cpu.json, "
+                "noisy VM): read the value as the reference's to within that factor",
     }
 
 
@@ -234,7 +258,21 @@ def main():
         timings["device_build_s"] = time.perf_counter() - t0
         del occ
     if use_dist:
+        # Watchdog: a broadcast that hangs (a rank that never joined, a dead link) must end the job with a message and a
+        # non-zero status instead of running into the launcher's limit.  A timer thread, never an exec.
+        import threading
+
+        def _stuck():
+            log(f"[bench] rank {rank}: image broadcast not finished after {BROADCAST_LIMIT_S:.0f} s -- giving up "
+                f"(world {world}, backend {backend}, device {dev_id})")
+            os._exit(3)
+        watchdog = threading.Timer(BROADCAST_LIMIT_S, _stuck)
+        watchdog.daemon = True
+        watchdog.start()
+        log(f"[bench] rank {rank}/{world}: device {dev_id}, backend {backend}, entering the image broadcast")
         index, timings["broadcast_s"] = sharding.broadcast_image(dist, torch, index, dev)
+        watchdog.cancel()
+        log(f"[bench] rank {rank}: image attached after {timings['broadcast_s']:.2f} s of broadcast")
     hdr = index.header
     image_bytes = index.device_bytes()
     if rank == 0:
@@ -329,12 +367,14 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-        mine_t = torch.tensor([scan_ms, stages["ms_total"], float(n_mine), float(st["candidates"])], dtype=torch.float64, device=cdev)
+        mine_t = torch.tensor([scan_ms, stages["ms_total"], float(n_mine), float(st["candidates"]), timings.get("broadcast_s", 0.0),
+                               float(image_bytes), float(dev_id)], dtype=torch.float64, device=cdev)
         allr = [torch.empty_like(mine_t) for _ in range(world)] if rank == 0 else None
         dist.gather(mine_t, allr, dst=0)
         if rank == 0:
             per_rank = [{"rank": r, "scan_ms": float(x[0]), "pipeline_ms": float(x[1]), "guides": int(x[2]),
-                         "comparisons": int(x[3])} for r, x in enumerate(allr)]
+                         "comparisons": int(x[3]), "broadcast_s": float(x[4]), "image_bytes": int(x[5]), "device": int(x[6])}
+                        for r, x in enumerate(allr)]
 
     extras = {}
     if world > 1 and not a.no_extras:
@@ -382,7 +422,6 @@ def main():
                     continue
                 dt = time.perf_counter() - t1
                 s2 = index.stats()
-                phys = s2["scan_tiles"] * TILE_BYTES
                 pmc, _src = traffic_point(a.sites, n_small, a.dist, s2["pruned"])
                 extras[label] = {
                     "hbm_pmc_bytes_per_launch": pmc, "hbm_pmc_frac": (pmc / s2["ms_scan"] / 1e6 / HBM_PEAK_GBS) if pmc else None,
@@ -390,8 +429,7 @@ def main():
                     "guides_per_step": n_small, "steps": reps, "ms_per_step": dt * 1e3 / reps, "guides_per_s": n_small * reps / dt,
                     "scan_ms": s2["ms_scan"], "comparisons_per_launch": s2["candidates"],
                     "scan_Tcmp_per_s": s2["candidates"] / s2["ms_scan"] / 1e9,
-                    "scan_tile_bytes_per_launch": phys, "hbm_physical_GBps": phys / s2["ms_scan"] / 1e6,
-                    "hbm_physical_frac": phys / s2["ms_scan"] / 1e6 / HBM_PEAK_GBS,
+                    "scan_units_per_launch": s2["scan_tiles"],
                     "algorithmic_GBps": 8.0 * s2["candidates"] / s2["ms_scan"] / 1e6,
                 }
             # two lanes: consecutive batches on two workspaces / streams (option lanes=2), the short kernels of one batch
@@ -446,8 +484,8 @@ def main():
                     "guides_per_step": n_mine, "steps": reps, "ms_per_step": dt * 1e3 / reps, "guides_per_s": n_mine * reps / dt,
                     "scan_ms": s2["ms_scan"], "comparisons_per_launch": s2["candidates"],
                     "scan_Tcmp_per_s": s2["candidates"] / s2["ms_scan"] / 1e9,
-                    "valu_frac": s2["candidates"] / 2048.0 * VALU_PER_2048_CMP * VALU_CYCLES_PER_INSTR / (N_SIMD * PEAK_CLOCK_HZ * s2["ms_scan"] * 1e-3),
-                    "scan_tile_bytes_per_launch": s2["scan_tiles"] * TILE_BYTES,
+                    "valu_frac": s2["candidates"] / 2048.0 * valu_per_2048_cmp(0, a.max_dist) * VALU_CYCLES_PER_INSTR / (N_SIMD * PEAK_CLOCK_HZ * s2["ms_scan"] * 1e-3),
+                    "scan_units_per_launch": s2["scan_tiles"],
                     "note": "option prune=0: the scan kernel works through whole buckets (13.5 x the comparisons on this workload)",
                 }
             finally:
@@ -514,9 +552,9 @@ def main():
         ref_cmp = st["reference_comparisons"]        # comparisons the reference makes for the same batch (SURVEY 8d's unit)
         algo_bytes = 8.0 * ref_cmp + 8.0 * st["hits"] + 24.0 * n_mine
         t_scan = scan_ms * 1e-3
-        useful_valu_cycles = cmp_per_launch / 2048.0 * VALU_PER_2048_CMP * VALU_CYCLES_PER_INSTR
-        lane_ops = cmp_per_launch * VALU_PER_2048_CMP / 32.0     # 64 lanes x instructions
-        tile_bytes = st["scan_tiles"] * TILE_BYTES
+        valu_per = valu_per_2048_cmp(st["pruned"], a.max_dist)
+        useful_valu_cycles = cmp_per_launch / 2048.0 * valu_per * VALU_CYCLES_PER_INSTR
+        lane_ops = cmp_per_launch * valu_per / 32.0     # 64 lanes x instructions
         traffic, traffic_src = traffic_point(a.sites, n_mine, a.dist, st["pruned"])
         regime = extras.get("north_star_10k_guides") or {}
         out = {
@@ -549,11 +587,12 @@ def main():
                 "kernel": f"k_scan<{min(a.max_dist, 4) if a.max_dist <= 4 else -1}>",
                 "achieved": lane_ops / t_scan / 1e12,
                 "peak": N_SIMD * 32 * PEAK_CLOCK_HZ / 1e12,
-                "unit": "TOP/s (32-bit VALU lane-ops; 62 wave64 instructions per guide and 2048 candidates)",
+                "unit": f"TOP/s (32-bit VALU lane-ops; {valu_per:.1f} wave64 instructions per guide and 2048 candidates)",
+                "valu_per_2048_comparisons": valu_per,
                 "frac": useful_valu_cycles / (N_SIMD * PEAK_CLOCK_HZ * t_scan),
                 "traffic": traffic,
                 "traffic_source": traffic_src,
-                "traffic_computed": tile_bytes + 8.0 * st["raw_records"],
+                "scan_units_per_launch": st["scan_tiles"],
                 "avg_launch_ms": scan_ms,
                 "avg_launch_ms_events": st["ms_scan_events"],
                 "avg_launch_ms_alone": stages["ms_scan"],
@@ -569,15 +608,12 @@ def main():
                 "algorithmic_bytes_per_launch": algo_bytes,
                 "algorithmic_GBps": algo_bytes / t_scan / 1e9,
                 "algorithmic_over_hbm_peak": algo_bytes / t_scan / 1e9 / HBM_PEAK_GBS,
-                "hbm_physical_GBps": tile_bytes / t_scan / 1e9,
-                "hbm_physical_frac": tile_bytes / t_scan / 1e9 / HBM_PEAK_GBS,
                 # north_star's own point (10 000 guides per step, same index), where the scan is HBM-bound: flat copies of
                 # extras.north_star_10k_guides so that a reader of `roofline` alone has them
                 "hbm_regime_guides_per_step": regime.get("guides_per_step"),
                 "hbm_regime_scan_ms": regime.get("scan_ms"),
                 "hbm_regime_pmc_bytes_per_launch": regime.get("hbm_pmc_bytes_per_launch"),
                 "hbm_regime_frac": regime.get("hbm_pmc_frac"),
-                "hbm_regime_physical_frac": regime.get("hbm_physical_frac"),
                 "kernels_sha16": kernels_sha16(),
                 "hbm_regime": extras.get("north_star_10k_guides"),
                 "note": "avg_launch_ms is the launch's own span (first workgroup in to last workgroup out, stamped by the kernel "
@@ -585,10 +621,11 @@ def main():
                         "stream; they differ only when a second lane shares the chip (extras.two_lanes).  pruned != 0: every bucket is stored ordered by the byte of the next slice and a guide is compared only "
                         "with the 13 of 256 groups of its five buckets that can hold a site within 4 mismatches (pigeonhole over "
                         "the cyclic successor slice; same hits, bit-identical scores), so the kernel makes "
-                        "comparisons_per_launch, not reference_comparisons_per_launch.  frac = (comparisons made / 2048 x 62 "
-                        "VALU instructions x 2 cycles) / (1024 SIMDs x 2.4 GHz x launch time), comparisons counted by the kernel "
-                        "itself; a tile now serves ~20 guides instead of ~400, so tile fetches (hbm_frac, hbm_physical_*) and "
-                        "the per-tile set-up share the time with the VALU work.  algorithmic_* is SURVEY 8(d)'s figure (8 B per "
+                        "comparisons_per_launch, not reference_comparisons_per_launch, and compares 12 of the 16 positions (a group's "
+                        "successor-slice bases are known when a guide is placed in it).  frac = (comparisons made / 2048 x "
+                        "valu_per_2048_comparisons VALU instructions x 2 cycles) / (1024 SIMDs x 2.4 GHz x launch time), comparisons "
+                        "counted by the kernel itself; a unit now serves ~20 guides instead of ~400, so unit fetches (hbm_frac) and "
+                        "the per-unit set-up share the time with the VALU work.  algorithmic_* is SURVEY 8(d)'s figure (8 B per "
                         "comparison OF THE REFERENCE, no credit for reuse or pruning) and is not a fraction of anything "
                         "physical; extras.whole_bucket_scan is the same kernel working through whole buckets (frac ~0.75); hbm_regime is the "
                         "same kernel at north_star's 10 000 guides per step, where it is HBM-bound (hbm_pmc_frac)",
@@ -599,6 +636,11 @@ def main():
             "setup_s": timings,
             "gather_s": gather_s if use_dist else None,
             "per_rank": per_rank,
+            "collectives": ({"backend": backend, "world": world,
+                             "rccl_version": rccl_version(torch) if backend == "nccl" else None,
+                             "image_bytes": image_bytes, "broadcast_piece_bytes": 1 << 30,
+                             "broadcast_GBps": image_bytes / timings["broadcast_s"] / 1e9 if timings.get("broadcast_s") else None,
+                             "broadcast_limit_s": BROADCAST_LIMIT_S} if use_dist else None),
             "extras": extras or None,
         }
         if world == 1 and not a.no_cpu_baseline:

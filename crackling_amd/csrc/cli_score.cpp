@@ -339,17 +339,28 @@ int serve(const char *sock_path)
     unsigned long long tick = 0, evictions = 0;
     size_t budget = 0;
     if (const char *b = std::getenv("ISSL_SERVER_HBM_BUDGET")) budget = static_cast<size_t>(std::strtoull(b, nullptr, 10));
-    const int mem_device = dc.list.empty() ? dc.single : dc.list[0];
+    std::vector<int> mem_devices = dc.list; // every device an index of this server is uploaded to
+    if (mem_devices.empty()) mem_devices.push_back(dc.single);
     auto make_room = [&](issl_index *incoming) {
-        size_t want = 0;
+        size_t preferred = 0;
         issl_header h{};
-        if (issl_index_device_bytes(incoming, &want) || issl_index_header(incoming, &h)) return;
-        want += 24 * h.n_sites + (size_t(10) << 30); // temporaries of the sorted layout + scoring workspace (hit slots: up to 8 GiB)
+        if (issl_index_device_bytes(incoming, &preferred) || issl_index_header(incoming, &h)) return;
+        // Room asked for: the image of the fastest layout + the temporaries of its construction + the scoring workspace (hit
+        // slots: up to 8 GiB).  An upload settles for the smallest layout (52 B/site, 24 B/site of temporaries) when the
+        // device cannot hold the fastest even when it is empty -- evicting beyond what THAT one needs buys nothing.
+        const size_t reserve = size_t(10) << 30;
+        const size_t want_fast = preferred + 24 * h.n_sites + reserve, want_small = (52 + 24) * h.n_sites + reserve;
         while (!cache.empty()) {
-            size_t free_b = 0, total_b = 0, held = 0;
-            if (issl_device_memory(mem_device, &free_b, &total_b)) return;
+            size_t free_b = ~size_t(0), total_b = ~size_t(0), held = 0;
+            for (int d : mem_devices) { // the tightest device decides
+                size_t f = 0, t = 0;
+                if (issl_device_memory(d, &f, &t)) return;
+                free_b = std::min(free_b, f);
+                total_b = std::min(total_b, t);
+            }
             for (const auto &kv : cache) held += kv.second.image_bytes;
             if (budget) free_b = std::min(free_b, budget > held ? budget - held : size_t(0));
+            const size_t want = want_fast <= total_b ? want_fast : std::min(want_fast, want_small);
             if (free_b >= want) return;
             auto lru = cache.begin();
             for (auto it = cache.begin(); it != cache.end(); ++it)
@@ -360,6 +371,15 @@ int serve(const char *sock_path)
             cache.erase(lru);
             ++evictions;
         }
+    };
+    auto json_string = [](const std::string &in) { // a path may hold quotes, backslashes, control characters
+        std::string out = "\"";
+        for (unsigned char ch : in) {
+            if (ch == '"' || ch == '\\') { out += '\\'; out += static_cast<char>(ch); }
+            else if (ch < 0x20) { char buf[8]; std::snprintf(buf, sizeof buf, "\\u%04x", ch); out += buf; }
+            else out += static_cast<char>(ch);
+        }
+        return out + "\"";
     };
     bool quit = false;
     while (!quit) {
@@ -384,7 +404,7 @@ int serve(const char *sock_path)
                 std::sort(order.begin(), order.end(), [](auto a, auto b) { return a->second.last_used < b->second.last_used; });
                 std::string body = "{\"evictions\": " + std::to_string(evictions) + ", \"resident\": [";
                 for (size_t i = 0; i < order.size(); ++i)
-                    body += std::string(i ? ", " : "") + "{\"issl\": \"" + order[i]->first + "\", \"image_bytes\": " +
+                    body += std::string(i ? ", " : "") + "{\"issl\": " + json_string(order[i]->first) + ", \"image_bytes\": " +
                             std::to_string(order[i]->second.image_bytes) + "}";
                 body += "]}\n";
                 const std::string head = "OK " + std::to_string(body.size()) + " {}\n";

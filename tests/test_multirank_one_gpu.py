@@ -42,3 +42,35 @@ def test_two_ranks_on_one_gpu_through_bench(tmp_path):
     assert np.array_equal(a["mit"].view(np.uint64), b["mit"].view(np.uint64))
     assert np.array_equal(a["cfd"].view(np.uint64), b["cfd"].view(np.uint64))
     assert (a["mit"] < 100).any()
+
+
+def test_one_rank_over_rccl_equals_the_plain_run(tmp_path):
+    """Every RCCL call site of bench.py's N > 1 path -- init_process_group with a device id, the image broadcast of device
+    tensors in pieces, attach, the guide broadcast, the gather of device tensors, barrier, max-reduce -- executed with the
+    `nccl` backend itself and world size 1 (what the one GPU of the box allows), no ISSL_BENCH_BACKEND: the line must carry
+    the collectives' diagnostics (per-rank broadcast time, image bytes, RCCL version) and the scores must equal the plain
+    single-process run bit for bit."""
+    args = ["--steps", "2", "--warmup", "1", "--sites", "3000000", "--guides", "30000", "--chunk", "1024",
+            "--no-cpu-baseline", "--no-extras", "--spinup-ms", "0"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("ISSL_BENCH_BACKEND", None); env.pop("ISSL_BENCH_DEVICE", None)
+    one = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "1", *args, "--dump-scores", str(tmp_path / "plain.npz")],
+                         capture_output=True, text=True, env=env, timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    plain = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
+    assert plain["collectives"] is None and plain["per_rank"] is None
+    rccl = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                           "--master-port", str(_free_port()), str(ROOT / "bench.py"), "--gpus", "1", *args,
+                           "--dump-scores", str(tmp_path / "rccl.npz")], capture_output=True, text=True, env=dict(env, MASTER_ADDR="127.0.0.1"), timeout=600)
+    assert rccl.returncode == 0, rccl.stderr[-3000:]
+    line = json.loads([l for l in rccl.stdout.splitlines() if l.startswith("{")][-1])
+    col = line["collectives"]
+    assert col["backend"] == "nccl" and col["world"] == 1 and col["rccl_version"] and col["image_bytes"] == line["config"]["image_bytes"]
+    assert line["setup_s"]["broadcast_s"] > 0 and col["broadcast_GBps"] > 0
+    assert len(line["per_rank"]) == 1 and line["per_rank"][0]["guides"] == 30000 and line["per_rank"][0]["image_bytes"] == col["image_bytes"]
+    assert line["per_rank"][0]["broadcast_s"] == pytest.approx(line["setup_s"]["broadcast_s"])
+    assert "entering the image broadcast" in rccl.stderr and "image attached" in rccl.stderr
+    a, b = np.load(tmp_path / "plain.npz"), np.load(tmp_path / "rccl.npz")
+    assert np.array_equal(a["guides"], b["guides"])
+    assert np.array_equal(a["mit"].view(np.uint64), b["mit"].view(np.uint64))
+    assert np.array_equal(a["cfd"].view(np.uint64), b["cfd"].view(np.uint64))

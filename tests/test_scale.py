@@ -4,9 +4,8 @@ guides over three replicas of that index) and hit lists at that size, checked ag
 The device-built tests run at configs[2]'s full size or not at all (they fail on an MI355X that cannot hold it and are
 skipped on a smaller GPU; the size is part of the test id and is printed behind the test summary); the host-built test
 keeps 20 M lines (it writes the .issl for the oracle).  The bigger points of profiles/ are the same tests with
-ISSL_SCALE_SITES / ISSL_SCALE_GUIDES / ISSL_SCALE_JSON set; test_index_beyond_the_hbm_at_scale is BASELINE configs[4]
-itself -- 3 G lines on ONE MI355X, the site table drawn straight into device memory (ISSL_BEYOND_HBM_LINES overrides the
-size for smaller boxes).  The .issl for the
+ISSL_SCALE_SITES / ISSL_SCALE_GUIDES / ISSL_SCALE_JSON set; BASELINE configs[4] itself -- 3 G lines on ONE MI355X -- is
+tests/test_scale_beyond_hbm.py (a module of its own: it wants the whole HBM).  The .issl for the
 oracle goes to ISSL_SCALE_TMP (default: pytest's tmp dir; use /dev/shm for files larger than the disk)."""
 import json
 import os
@@ -143,6 +142,8 @@ class ScalePoint:
         # host-resident lists -- or, with device_synth, the chunks in flight
         per_site_hbm = (76 if (lists_cold or bare) else 168) + (12 if device_synth else 0)
         host_need = (0 if device_synth else n_lines * (24 + (40 if lists_cold else 0))) + 16e9
+        import torch
+        torch.cuda.empty_cache()
         free_hbm, limit = _free_hbm_bytes(), _memory_limit_bytes()
         if free_hbm < 40e9:
             pytest.skip(f"{what}: {free_hbm / 1e9:.0f} GB of free HBM -- not the MI355X this point is sized for")
@@ -277,6 +278,44 @@ def test_device_built_scale_point(scale, tmp_path):
     summary = _score_and_check(scale, tmp_path, "tests/test_scale.py::test_device_built_scale_point")
     if os.environ.get("ISSL_SCALE_JSON"):
         json.dump(summary, open(os.environ["ISSL_SCALE_JSON"], "w"), indent=1)
+
+
+@pytest.mark.gpu
+def test_wide_sample_against_the_full_oracle_at_scale(scale, tmp_path):
+    """configs[2] once more with the checker that needs no neighbourhood trick: the whole index written out as an .issl
+    (14 GB, byte-compatible with the reference's), loaded by the CPU oracle, and ISSL_SCALE_WIDE (2000) guides spread
+    over the batch scored by it in full -- every bucket, every candidate, the seen-bitmap, the early exit -- scores at the
+    product threshold and hit lists without early exit, against the GPU's.  ~50 ms per guide and thread on the oracle."""
+    import shutil
+    n_wide = int(os.environ.get("ISSL_SCALE_WIDE", 2000))
+    need = 48 * len(scale.sigs) + (1 << 20)
+    tmp = next((d for d in (os.environ.get("ISSL_SCALE_TMP"), "/dev/shm", str(tmp_path))
+                if d and os.path.isdir(d) and os.access(d, os.W_OK) and shutil.disk_usage(d).free > 1.2 * need), None)
+    if tmp is None or 2.2 * need > 0.8 * _memory_limit_bytes():
+        pytest.fail(f"no room for the oracle's copy of the index ({need / 1e9:.0f} GB as a file + as much in memory)")
+    ix, guides = scale.ix, scale.guides
+    pick = np.unique(np.linspace(0, len(guides) - 1, n_wide).astype(np.int64))
+    ix.set_option("prune", -1)
+    mit, cfd = ix.score(guides, 4, 75.0, "and")
+    assert ix.stats()["pruned"] == 2
+    hits = ix.dump_hits(guides[pick[::20]], 4, 0.0, "and")
+    path = pathlib.Path(tmp) / f"scale_wide_{os.getpid()}.issl"
+    try:
+        t = time.time(); ix.write(path); t_write = time.time() - t
+        t = time.time(); oracle = ou.OracleIndex(path); t_load = time.time() - t
+        threads = min(64, max(8, 2 * (os.cpu_count() or 8)))
+        t = time.time(); omit, ocfd = oracle.score(guides[pick], 4, 75.0, "and", threads=threads); t_score = time.time() - t
+        t = time.time(); _, _, ohits = oracle.score(guides[pick[::20]], 4, 0.0, "and", want_hits=True, threads=threads); t_hits = time.time() - t
+        oracle.close()
+    finally:
+        path.unlink(missing_ok=True)
+    import conftest
+    conftest.SCALE_NOTES.append(f"configs[2] wide sample: {len(pick)} guides (+ hit lists of {len(pick[::20])}) scored in full by the CPU oracle "
+                                f"on the written {need / 1e9:.1f} GB .issl: write {t_write:.1f}s, load {t_load:.1f}s, oracle {t_score:.1f}s + {t_hits:.1f}s")
+    assert np.array_equal(mit[pick].view(np.uint64), omit.view(np.uint64))
+    assert np.array_equal(cfd[pick].view(np.uint64), ocfd.view(np.uint64))
+    assert hits.shape == ohits.shape and np.array_equal(hits, ohits)   # same index on both sides: ids and list positions too
+    assert (omit < 100).sum() > len(pick) // 2
 
 
 @pytest.mark.gpu
@@ -527,32 +566,6 @@ def test_device_side_site_generator_makes_the_host_generators_sites():
     g = int(sigs[1234]) ^ (3 << 10) ^ (1 << 30)
     for max_dist in (0, 2, 4, 9):
         assert np.array_equal(neighbours_device(d_sigs, g, max_dist, chunk=70_000), _neighbours(sigs, np.uint64(g), max_dist, chunk=90_000))
-
-
-BEYOND_HBM_LINES = int(os.environ.get("ISSL_BEYOND_HBM_LINES", 3_000_000_000))
-
-
-@pytest.mark.gpu
-def test_index_beyond_the_hbm_at_scale(tmp_path):
-    """BASELINE configs[4] itself: a 3 G-line index (2.92 G distinct sites; 144 GB as an .issl, 444 GB in the default
-    layout) on ONE MI355X.  The layout such an index gets -- compact sorted image without slice lists: scan stream, site
-    ids per stream position, site table and counts = 52 B/site, 152 GB, nothing in host memory -- forced; the site table
-    is drawn straight into device memory (the host never holds anything of the index's size) and the index built from
-    there.  Pruned scan against the scan of whole buckets on all 100 000 guides, a sample and its hit lists against the
-    oracle (the sample's neighbourhoods by brute force over the device-resident table).  Like every scale point it runs
-    at its size or fails (skipped on a GPU that is no MI355X); the size is printed behind the test summary."""
-    sp = ScalePoint(BEYOND_HBM_LINES, int(os.environ.get("ISSL_SCALE_GUIDES", 100_000)), options={"keep_lists": 0},
-                    n_check=int(os.environ.get("ISSL_SCALE_CHECK", 32)), what="configs[4] (compact image without slice lists)",
-                    device_synth=True)
-    try:
-        assert sp.ix.get_option("is_compact") == 1 and sp.ix.get_option("lists_absent") == 1
-        assert sp.ix.cold() == (None, 0) and sp.ix.device_bytes() < 60 * len(sp.sigs) + (64 << 20)
-        summary = _score_and_check(sp, tmp_path, "tests/test_scale.py::test_index_beyond_the_hbm_at_scale")
-        _hit_lists_match(sp, tmp_path)
-        if os.environ.get("ISSL_BEYOND_HBM_JSON"):
-            json.dump(summary, open(os.environ["ISSL_BEYOND_HBM_JSON"], "w"), indent=1)
-    finally:
-        sp.ix.close()
 
 
 @pytest.mark.gpu

@@ -13,6 +13,18 @@ OUT = ROOT / "build" / "ablate"
 
 VARIANTS = {
     "base": [],
+    # k_scan, full units of the pruned plan (near_plane12): what limits the loop -- the scalar pipe (24 s_bfe_i32 per pass),
+    # scalar operands of vector instructions, or the hit path?
+    "scan_half_bfe": [("        const uint32_t g1 = 0u - ((gw >> (12 + p)) & 1u);\n        m[p] = (c[p] ^ g0) | (c[12 + p] ^ g1);",
+                       "        m[p] = (c[p] ^ g0) | (c[12 + p] ^ g0);")],
+    "scan_no_bfe": [("        const uint32_t g0 = 0u - ((gw >> p) & 1u);\n        const uint32_t g1 = 0u - ((gw >> (12 + p)) & 1u);\n        m[p] = (c[p] ^ g0) | (c[12 + p] ^ g1);",
+                     "        m[p] = (c[p] ^ gw) | (c[12 + p] ^ __builtin_rotateleft32(gw, 7));")],
+    "scan_vgpr_masks": [("    uint32_t m[12];\n#pragma unroll\n    for (int p = 0; p < 12; ++p) {\n        const uint32_t g0",
+                         "    uint32_t m[12];\n    uint32_t vg = c[3], vg2 = c[17];\n#pragma unroll\n    for (int p = 0; p < 12; ++p) {\n        const uint32_t g0"),
+                        ("        const uint32_t g0 = 0u - ((gw >> p) & 1u);\n        const uint32_t g1 = 0u - ((gw >> (12 + p)) & 1u);\n        m[p] = (c[p] ^ g0) | (c[12 + p] ^ g1);",
+                         "        if (p == 0) { asm volatile(\"v_xor_b32 %0, %2, %0\\n v_xor_b32 %1, %2, %1\" : \"+v\"(vg), \"+v\"(vg2) : \"s\"(gw)); }\n        m[p] = (c[p] ^ vg) | (c[12 + p] ^ vg2);")],
+    "scan_no_hit_path": [("                            const uint32_t ok = near_plane12<(THR < 0 ? -1 : THR - 1)>(c, gg.w[uu], thr - 1u, keep);\n                            if (__ballot(ok != 0u) != 0ull) {",
+                          "                            const uint32_t ok = near_plane12<(THR < 0 ? -1 : THR - 1)>(c, gg.w[uu], thr - 1u, keep);\n                            if (__ballot(ok == 0x9E3779B9u) != 0ull) {")],
     # k_verify
     "verify_no_atomic": [("            if (live) rank = atomicAdd(&ws.gcount[guide], 1u);", "            if (live) rank = lane;"),
                          ("if (live && !continues) base = atomicAdd(&ws.gcount[guide], next - lane);", "if (live && !continues) base = next - lane;")],

@@ -8,8 +8,8 @@
 set -u
 OUT=gpurun_out/${1:-prof}; shift || true
 ARGS="bench.py --no-cpu-baseline --no-extras $*"
-mkdir -p "$OUT"
 cd "$(dirname "$0")/.."
+mkdir -p "$OUT"
 export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -o kt -- python3 $ARGS > "$OUT/kt.log" 2>&1
 echo "kt rc=$?" >> "$OUT/kt.log"

@@ -6,8 +6,8 @@
 set -u
 OUT=gpurun_out/${1:-prof_tail}; shift || true
 ARGS="bench.py --no-cpu-baseline --no-extras --steps 10 --warmup 2 $*"
-mkdir -p "$OUT"
 cd "$(dirname "$0")/.."
+mkdir -p "$OUT"
 export TMPDIR=/tmp
 pass() { # name, counters...
   local name=$1; shift
