@@ -512,12 +512,32 @@ __device__ __forceinline__ uint32_t fine_way(uint32_t gj, uint32_t way)
 // class bit as a thirteenth plane.
 constexpr uint32_t kFineFlag = 1u << 24;
 __host__ __device__ __forceinline__ uint32_t fine_quad(uint32_t slice) { return slice < 4u ? slice : 0u; }
+// The order of the 12 positions (three quads of the scan word's four): the quad of the PREVIOUS slice (slice - 1) first --
+// its four mismatch planes tell, for nothing, whether the slice before the bucket's own matches the guide exactly too, and
+// a candidate for which it does is reported from that slice's bucket already (fine_dup) -- then the other two, ascending.
+// Slice 0 has no previous slice: its quads in ascending order.  (Quad q of slice s's scan word holds slice q < s ? q : q + 1.)
+__host__ __device__ __forceinline__ uint32_t fine_order(uint32_t slice, uint32_t j)
+{
+    const uint32_t sq = fine_quad(slice);
+    if (slice == 0u) return j + 1u;                                // quads 1, 2, 3
+    const uint32_t prev = slice - 1u;                              // slice - 1 sits in quad slice - 1 (it is below the own slice)
+    if (j == 0u) return prev;
+    uint32_t q = 0, seen = 0;                                      // the j-th of the quads that are neither sq nor prev
+    for (; q < 4u; ++q) {
+        if (q == sq || q == prev) continue;
+        if (++seen == j) break;
+    }
+    return q;
+}
 __host__ __device__ __forceinline__ uint32_t fine_word(uint32_t word, uint32_t slice)
 {
-    const uint32_t sh = 4u * fine_quad(slice);
     const uint32_t lo = word & 0xFFFFu, hi = word >> 16;
-    const uint32_t lo12 = (lo & ((1u << sh) - 1u)) | ((lo >> (sh + 4u)) << sh);
-    const uint32_t hi12 = (hi & ((1u << sh) - 1u)) | ((hi >> (sh + 4u)) << sh);
+    uint32_t lo12 = 0, hi12 = 0;
+    for (uint32_t j = 0; j < 3u; ++j) {
+        const uint32_t q = fine_order(slice, j);
+        lo12 |= ((lo >> (4u * q)) & 0xFu) << (4u * j);
+        hi12 |= ((hi >> (4u * q)) & 0xFu) << (4u * j);
+    }
     return lo12 | (hi12 << 12);
 }
 
@@ -974,11 +994,17 @@ __device__ __forceinline__ uint32_t count_near(const uint32_t (&m)[16], uint32_t
 // three of weight 4 (k4[0], k4[1], a2 & b2), so the compiled budgets need the weight-2 sums a2, b2 only through a handful
 // of three-input functions: 41 vector operations per pass for B = 3 (the class-1 guides of max_dist 4: twelve of
 // thirteen), 46 for B = 4, against 62 for the 16-position test.
+// `prev` (out): three planes whose OR is "some position of the previous slice mismatches" -- m[0..3] are that slice's
+// (fine_order), and m[0] | m[1] | m[2] = sum | carry of the first adder.  Only the cold block looks at them (fine_dup).
+struct PrevSlice {
+    uint32_t a, b, c;
+};
 template <int B, bool EXTRA>
-__device__ __forceinline__ uint32_t count_near12(const uint32_t (&m)[12], uint32_t f, uint32_t thr, uint32_t keep)
+__device__ __forceinline__ uint32_t count_near12(const uint32_t (&m)[12], uint32_t f, uint32_t thr, uint32_t keep, PrevSlice &prev)
 {
     uint32_t s0, s1, s2, s3, t, n0, a2, b2, k2[6], k40, k41;
     full_add(m[0], m[1], m[2], s0, k2[0]);
+    prev.a = s0; prev.b = k2[0]; prev.c = m[3];
     full_add(m[3], m[4], m[5], s1, k2[1]);
     full_add(m[6], m[7], m[8], s2, k2[2]);
     full_add(m[9], m[10], m[11], s3, k2[3]);
@@ -1024,7 +1050,7 @@ __device__ __forceinline__ uint32_t count_near12(const uint32_t (&m)[12], uint32
 // Full unit of the pruned scan: the lane's 32 candidates (c[0..11] low, c[12..23] high code bits of the 12 positions)
 // against one guide word of the pruned plan (fine_word), budget B.
 template <int B>
-__device__ __forceinline__ uint32_t near_plane12(const uint32_t (&c)[24], uint32_t gw, uint32_t thr, uint32_t keep)
+__device__ __forceinline__ uint32_t near_plane12(const uint32_t (&c)[24], uint32_t gw, uint32_t thr, uint32_t keep, PrevSlice &prev)
 {
     uint32_t m[12];
 #pragma unroll
@@ -1033,14 +1059,14 @@ __device__ __forceinline__ uint32_t near_plane12(const uint32_t (&c)[24], uint32
         const uint32_t g1 = 0u - ((gw >> (12 + p)) & 1u);
         m[p] = (c[p] ^ g0) | (c[12 + p] ^ g1);
     }
-    return count_near12<B, false>(m, 0u, thr, keep);
+    return count_near12<B, false>(m, 0u, thr, keep, prev);
 }
 
 // Short unit of the pruned scan: two / four guides per pass, the masks from the wave's LDS (short_unit_masks: word p of a
 // pass = bit p of its guides' words, spread over their fields; word 24 = the class bits: a plane of weight one).
 template <int B>
 __device__ __forceinline__ uint32_t near_plane12_masks(const uint32_t (&c)[24], const uint4 *gm /*LDS, 8 x uint4*/,
-                                                       uint32_t thr, uint32_t keep)
+                                                       uint32_t thr, uint32_t keep, PrevSlice &prev)
 {
     uint32_t m[12];
 #pragma unroll
@@ -1053,10 +1079,21 @@ __device__ __forceinline__ uint32_t near_plane12_masks(const uint32_t (&c)[24], 
         m[4 * q + 3] = (c[4 * q + 3] ^ lo.w) | (c[12 + 4 * q + 3] ^ hi.w);
     }
     const uint32_t f = reinterpret_cast<const uint32_t *>(gm)[24];
-    return count_near12<B, true>(m, f, thr, keep);
+    return count_near12<B, true>(m, f, thr, keep, prev);
 }
 
 // Guide words that start at any slot (a class boundary is no multiple of 8): a scalar load needs its address dword-aligned only.
+// A candidate that also matches the guide exactly in the slice BEFORE the bucket's own is met in that slice's bucket too --
+// in the group of the guide's own successor byte, which every guide is placed in -- and the smaller slice reports it
+// (k_verify's reporter rule): the record this unit would note is one k_verify reads 16 random bytes for and
+// throws away.  58 % of the duplicate records of a hit at distance 4 are of this kind (enumerated in
+// tests/test_oracle_golden.py); dropping them here costs two operations in the cold block.
+__device__ __forceinline__ uint32_t fine_dup(uint32_t ok, const PrevSlice &prev, uint32_t dup_filter)
+{
+    const uint32_t prev_mismatch = __builtin_amdgcn_bitop3_b32(prev.a, prev.b, prev.c, 0xFE); // a | b | c
+    return ok & (prev_mismatch | ~dup_filter);
+}
+
 struct alignas(4) GuideGroupAny {
     uint32_t w[kGuideGroup];
 };
@@ -1160,8 +1197,9 @@ __device__ __forceinline__ void scan_range(const uint32_t *__restrict__ scan_str
         if constexpr (FINE) {
             // The planes the unit needs: 12 of the 16 positions (fine_word) -- the successor slice's four sit in plane quads
             // sq and 4 + sq of the tile and stay in memory.
-            const uint32_t sq = fine_quad(cur.bucket >> 16); // bucket << 8 | successor byte, 8-bit slices: slice = bucket >> 8
-            const uint32_t q0 = sq == 0u ? 1u : 0u, q1 = sq <= 1u ? 2u : 1u, q2 = sq <= 2u ? 3u : 2u;
+            const uint32_t slice_of = cur.bucket >> 16; // bucket << 8 | successor byte, 8-bit slices: slice = bucket >> 8
+            const uint32_t q0 = fine_order(slice_of, 0u), q1 = fine_order(slice_of, 1u), q2 = fine_order(slice_of, 2u);
+            const uint32_t dup_filter = slice_of != 0u ? ~0u : 0u; // (fine_dup: positions 0..3 are the previous slice's)
             if (cur.shape != 32u) {
                 // ---- a SHORT unit: the last 64 * shape candidates of a successor-byte group, 32 / shape guides per pass ----
                 // Lane l takes candidates [l * shape, (l + 1) * shape) of the window, i.e. field l % per of lane group
@@ -1202,9 +1240,10 @@ __device__ __forceinline__ void scan_range(const uint32_t *__restrict__ scan_str
                     __builtin_amdgcn_wave_barrier();
                     const uint32_t passes = (g_end - gb + per - 1u) / per;
                     for (uint32_t i = 0; i < (passes < 8u ? passes : 8u); ++i) {
-                        const uint32_t ok = near_plane12_masks<THR>(c, wave_masks + i * 8u, thr, keep);
+                        PrevSlice prev;
+                        const uint32_t ok = near_plane12_masks<THR>(c, wave_masks + i * 8u, thr, keep, prev);
                         if (__ballot(ok != 0u) != 0ull) {
-                            note_candidates(ok, gb + i * per, w_log, tile, off0, lane, w, raw, raw_used, max_chunks, counters);
+                            note_candidates(fine_dup(ok, prev, dup_filter), gb + i * per, w_log, tile, off0, lane, w, raw, raw_used, max_chunks, counters);
                             own_chunk = true;
                         }
                     }
@@ -1250,9 +1289,10 @@ __device__ __forceinline__ void scan_range(const uint32_t *__restrict__ scan_str
 #pragma unroll
                         for (uint32_t uu = 0; uu < kGuideGroup; ++uu) {
                             if (g + uu >= gmid) break;
-                            const uint32_t ok = near_plane12<(THR < 0 ? -1 : THR - 1)>(c, gg.w[uu], thr - 1u, keep);
+                            PrevSlice prev;
+                            const uint32_t ok = near_plane12<(THR < 0 ? -1 : THR - 1)>(c, gg.w[uu], thr - 1u, keep, prev);
                             if (__ballot(ok != 0u) != 0ull) {
-                                note_candidates(ok, g + uu, 5u, tile, grp * 32u, lane, w, raw, raw_used, max_chunks, counters);
+                                note_candidates(fine_dup(ok, prev, dup_filter), g + uu, 5u, tile, grp * 32u, lane, w, raw, raw_used, max_chunks, counters);
                                 own_chunk = true;
                             }
                         }
@@ -1264,9 +1304,10 @@ __device__ __forceinline__ void scan_range(const uint32_t *__restrict__ scan_str
 #pragma unroll
                 for (uint32_t uu = 0; uu < kGuideGroup; ++uu) {
                     if (g + uu >= g_end) break;
-                    const uint32_t ok = near_plane12<THR>(c, gg.w[uu], thr, keep);
+                    PrevSlice prev;
+                    const uint32_t ok = near_plane12<THR>(c, gg.w[uu], thr, keep, prev);
                     if (__ballot(ok != 0u) != 0ull) {
-                        note_candidates(ok, g + uu, 5u, tile, grp * 32u, lane, w, raw, raw_used, max_chunks, counters);
+                        note_candidates(fine_dup(ok, prev, dup_filter), g + uu, 5u, tile, grp * 32u, lane, w, raw, raw_used, max_chunks, counters);
                         own_chunk = true;
                     }
                 }
