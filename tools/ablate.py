@@ -23,8 +23,24 @@ VARIANTS = {
                          "    uint32_t m[12];\n    uint32_t vg = c[3], vg2 = c[17];\n#pragma unroll\n    for (int p = 0; p < 12; ++p) {\n        const uint32_t g0"),
                         ("        const uint32_t g0 = 0u - ((gw >> p) & 1u);\n        const uint32_t g1 = 0u - ((gw >> (12 + p)) & 1u);\n        m[p] = (c[p] ^ g0) | (c[12 + p] ^ g1);",
                          "        if (p == 0) { asm volatile(\"v_xor_b32 %0, %2, %0\\n v_xor_b32 %1, %2, %1\" : \"+v\"(vg), \"+v\"(vg2) : \"s\"(gw)); }\n        m[p] = (c[p] ^ vg) | (c[12 + p] ^ vg2);")],
-    "scan_no_hit_path": [("                            const uint32_t ok = near_plane12<(THR < 0 ? -1 : THR - 1)>(c, gg.w[uu], thr - 1u, keep);\n                            if (__ballot(ok != 0u) != 0ull) {",
-                          "                            const uint32_t ok = near_plane12<(THR < 0 ? -1 : THR - 1)>(c, gg.w[uu], thr - 1u, keep);\n                            if (__ballot(ok == 0x9E3779B9u) != 0ull) {")],
+    "scan_no_hit_path_all": [("                            if (__ballot(ok != 0u) != 0ull) {\n                                note_candidates(fine_dup(ok, prev, dup_filter), g + uu,",
+                              "                            if (__ballot(ok == 0x9E3779B9u) != 0ull) {\n                                note_candidates(fine_dup(ok, prev, dup_filter), g + uu,"),
+                             ("                    if (__ballot(ok != 0u) != 0ull) {\n                        note_candidates(fine_dup(ok, prev, dup_filter), g + uu,",
+                              "                    if (__ballot(ok == 0x9E3779B9u) != 0ull) {\n                        note_candidates(fine_dup(ok, prev, dup_filter), g + uu,"),
+                             ("                        if (__ballot(ok != 0u) != 0ull) {\n                            note_candidates(fine_dup(ok, prev, dup_filter), gb + i * per,",
+                              "                        if (__ballot(ok == 0x9E3779B9u) != 0ull) {\n                            note_candidates(fine_dup(ok, prev, dup_filter), gb + i * per,")],
+    "scan_no_hits_no_fetch": [("                            if (__ballot(ok != 0u) != 0ull) {\n                                note_candidates(fine_dup(ok, prev, dup_filter), g + uu,",
+                              "                            if (__ballot(ok == 0x9E3779B9u) != 0ull) {\n                                note_candidates(fine_dup(ok, prev, dup_filter), g + uu,"),
+                             ("                    if (__ballot(ok != 0u) != 0ull) {\n                        note_candidates(fine_dup(ok, prev, dup_filter), g + uu,",
+                              "                    if (__ballot(ok == 0x9E3779B9u) != 0ull) {\n                        note_candidates(fine_dup(ok, prev, dup_filter), g + uu,"),
+                             ("                        if (__ballot(ok != 0u) != 0ull) {\n                            note_candidates(fine_dup(ok, prev, dup_filter), gb + i * per,",
+                              "                        if (__ballot(ok == 0x9E3779B9u) != 0ull) {\n                            note_candidates(fine_dup(ok, prev, dup_filter), gb + i * per,"),
+                              ("                    const uint4 a0 = src[q0 * 64u], a1 = src[q1 * 64u], a2 = src[q2 * 64u];\n                    const uint4 b0 = src[(4u + q0) * 64u], b1 = src[(4u + q1) * 64u], b2 = src[(4u + q2) * 64u];",
+                               "                    const uint4 a0 = make_uint4(lane * 2654435761u + q0, lane * 40503u + q1, (lane << 7) ^ q2 ^ 0x5bd1e995u, lane * 97u + 13u), a1 = make_uint4(lane * 2654435761u + q0, lane * 40503u + q1, (lane << 7) ^ q2 ^ 0x5bd1e995u, lane * 97u + 13u), a2 = make_uint4(lane * 2654435761u + q0, lane * 40503u + q1, (lane << 7) ^ q2 ^ 0x5bd1e995u, lane * 97u + 13u), b0 = make_uint4(lane * 2654435761u + q0, lane * 40503u + q1, (lane << 7) ^ q2 ^ 0x5bd1e995u, lane * 97u + 13u), b1 = make_uint4(lane * 2654435761u + q0, lane * 40503u + q1, (lane << 7) ^ q2 ^ 0x5bd1e995u, lane * 97u + 13u), b2 = make_uint4(lane * 2654435761u + q0, lane * 40503u + q1, (lane << 7) ^ q2 ^ 0x5bd1e995u, lane * 97u + 13u); (void)src;"),
+                              ("                const uint4 a0 = src[q0 * 64u], a1 = src[q1 * 64u], a2 = src[q2 * 64u];\n                const uint4 b0 = src[(4u + q0) * 64u], b1 = src[(4u + q1) * 64u], b2 = src[(4u + q2) * 64u];",
+                               "                const uint4 a0 = make_uint4(lane * 2654435761u + q0, lane * 40503u + q1, (lane << 7) ^ q2 ^ 0x5bd1e995u, lane * 97u + 13u), a1 = make_uint4(lane * 2654435761u + q0, lane * 40503u + q1, (lane << 7) ^ q2 ^ 0x5bd1e995u, lane * 97u + 13u), a2 = make_uint4(lane * 2654435761u + q0, lane * 40503u + q1, (lane << 7) ^ q2 ^ 0x5bd1e995u, lane * 97u + 13u), b0 = make_uint4(lane * 2654435761u + q0, lane * 40503u + q1, (lane << 7) ^ q2 ^ 0x5bd1e995u, lane * 97u + 13u), b1 = make_uint4(lane * 2654435761u + q0, lane * 40503u + q1, (lane << 7) ^ q2 ^ 0x5bd1e995u, lane * 97u + 13u), b2 = make_uint4(lane * 2654435761u + q0, lane * 40503u + q1, (lane << 7) ^ q2 ^ 0x5bd1e995u, lane * 97u + 13u); (void)src;")],
+    "scan_no_hit_path": [("                            if (__ballot(ok != 0u) != 0ull) {\n                                note_candidates(fine_dup(ok, prev, dup_filter), g + uu,",
+                          "                            if (__ballot(ok == 0x9E3779B9u) != 0ull) {\n                                note_candidates(fine_dup(ok, prev, dup_filter), g + uu,")],
     # k_verify
     "verify_no_atomic": [("            if (live) rank = atomicAdd(&ws.gcount[guide], 1u);", "            if (live) rank = lane;"),
                          ("if (live && !continues) base = atomicAdd(&ws.gcount[guide], next - lane);", "if (live && !continues) base = next - lane;")],
