@@ -288,7 +288,7 @@ static int ensure_raw_capacity(Workspace &w, size_t chunks)
 
 static uint32_t scan_waves(const Tuning &tn) { return tn.scan_blocks * 16u; }
 
-static int ensure_workspace(issl_index *ix, size_t n, Lane &lane)
+static int ensure_workspace(issl_index *ix, size_t n, Lane &lane, uint32_t fine_ways = kFineWays)
 {
     Workspace &w = lane.ws;
     const Tuning &tn = ix->tuning;
@@ -309,8 +309,8 @@ static int ensure_workspace(issl_index *ix, size_t n, Lane &lane)
         HIP_TRY(hipMemset(w.scan_count, 0, 8 * kScanMaxBlocks));
         w.n_buckets = static_cast<uint32_t>(nb);
     }
-    if (n > w.cap_guides) {
-        const size_t cap = std::max<size_t>(n, 1024);
+    if (n > w.cap_guides || (ix->hdr.off_sub_start && fine_ways > w.fine_ways && w.fine_ways != 0)) {
+        const size_t cap = std::max<size_t>(std::max(n, w.cap_guides), 1024);
         const size_t slots = cap * ix->hdr.n_slices + kGuideGroup * nb;
         const size_t items = nb + cap * ix->hdr.n_slices / 8 + 2; // item sizes down to 8 guides (item_guides knob)
         if ((rc = dev_alloc(w.gword, slots))) return rc;
@@ -338,8 +338,9 @@ static int ensure_workspace(issl_index *ix, size_t n, Lane &lane)
         w.cap_gslots = slots;
         w.cap_items = items;
         if (ix->hdr.off_sub_start) { // pruned scan: every guide sits in up to 13 successor-byte groups of each of its 5 buckets
-            const size_t m = std::min<size_t>(cap, kPruneMaxGuides);
-            const size_t places = m * ix->hdr.n_slices * kFineWays;
+            const uint32_t ways = std::max(fine_ways, w.fine_ways); // (max_dist 5 places a guide in 67 groups per bucket, not 13)
+            const size_t m = std::min<size_t>(cap, ways > kFineWays ? kPruneMaxGuides2 : kPruneMaxGuides);
+            const size_t places = m * ix->hdr.n_slices * ways;
             const size_t groups = std::min<size_t>(nb * 256, places);
             const size_t fslots = places + kGuideGroup * groups;
             // one item per tile of a group (and per 512 guides of it): sized from the mean group length (uniform data has
@@ -355,6 +356,7 @@ static int ensure_workspace(issl_index *ix, size_t n, Lane &lane)
             if ((rc = dev_alloc(w.fsum, nb))) return rc;
             w.cap_fslots = fslots;
             w.cap_fitems = fitems;
+            w.fine_ways = ways;
         }
     }
     if (w.cap_chunks == 0) {
@@ -753,7 +755,8 @@ static int enqueue_batch(issl_index *ix, Lane &lane, hipStream_t stream, const u
     }
     HIP_TRY(hipSetDevice(ix->device));
     if (n == 0) return ISSL_OK;
-    int rc = ensure_workspace(ix, n, lane);
+    const uint32_t prune_mode = prune_mode_for(ix->view, ix->tuning, static_cast<uint32_t>(n), max_dist);
+    int rc = ensure_workspace(ix, n, lane, fine_ways_of(prune_mode ? prune_mode : 2u));
     if (rc) return rc;
     Workspace &ws = lane.ws;
     const Tuning &tn = ix->tuning;
@@ -778,7 +781,6 @@ static int enqueue_batch(issl_index *ix, Lane &lane, hipStream_t stream, const u
     if (pipelined && lane.pending) HIP_TRY(hipStreamWaitEvent(stream, lane.done, 0)); // the workspace's previous batch (tail stream)
     if (staged) HIP_TRY(hipEventRecord(lane.ev[0], stream));
     ws.span_slot = lane.pending % kSpanRing;
-    const uint32_t prune_mode = prune_mode_for(ix->view, tn, n32, max_dist);
     launch_bin_guides(ix->view, ws, tn, d_guides, n32, prune_mode, stream);
     if (staged) HIP_TRY(hipEventRecord(lane.ev[1], stream));
     if (pipelined && ix->prev_scan_end) HIP_TRY(hipStreamWaitEvent(stream, ix->prev_scan_end, 0)); // one scan at a time
@@ -1580,7 +1582,8 @@ int issl_score(issl_index *idx, const uint64_t *guides, size_t n, int max_dist, 
     // that up front, which saves the first large batch on an index its grow-and-rerun round, and a piece ends
     // early when its estimate would not fit a quarter of the free HBM.  Denser data still grows the buffers.
     // (the pruned scan places every guide in up to 65 groups: pieces of at most 2^20 guides while it may be chosen)
-    const size_t piece = prune_mode_for(idx->view, idx->tuning, 1, max_dist) ? size_t(kPruneMaxGuides) : size_t(1) << 22;
+    const uint32_t piece_mode = prune_mode_for(idx->view, idx->tuning, 1, max_dist);
+    const size_t piece = piece_mode == 3 ? size_t(kPruneMaxGuides2) : piece_mode ? size_t(kPruneMaxGuides) : size_t(1) << 22;
     const bool presize = !idx->tuning.raw_chunks && n >= (size_t(1) << 15); // small pages: the default buffers do
     const double records_per_comparison = 8e-5;
     size_t free_b = 0, total_b = 0;

@@ -296,9 +296,11 @@ struct alignas(32) SlotRec {
     uint64_t key, pad;
 };
 constexpr uint32_t kFineWays = 13;      // successor bytes within one mismatch of a guide's: itself + 4 positions x 3 bases
+constexpr uint32_t kFineWays2 = 67;     // ... within two (max_dist 5): + 6 pairs of positions x 9 base pairs
 constexpr uint32_t kFetchPairs = 8;     // time of fetching one 8 KiB tile, in (guide, tile) comparisons of the chip: measured 7
                                         // (50 M sites, neighbouring groups share tiles in L2) to 12 (300 M sites)
 constexpr uint32_t kPruneMaxGuides = 1u << 20; // guides per pruned launch: 65 slots per guide + padding must fit the 27-bit slot field
+constexpr uint32_t kPruneMaxGuides2 = 1u << 18; // ... 335 slots per guide (max_dist 5)
 
 // What k_verify needs to know about a guide slot of the pruned plan, in one 16-byte load.
 struct alignas(16) FineMeta {
@@ -323,6 +325,7 @@ struct Workspace {
     uint32_t *fcount0 = nullptr; // [nb * 256] ... of them the ones whose own successor byte it is (class 0)
     FineSum *fsum = nullptr;     // [nb] per-bucket totals, then their exclusive prefix
     size_t cap_fslots = 0, cap_fitems = 0;
+    uint32_t fine_ways = 0;      // placements per guide and bucket the pruned plan's arrays are sized for (kFineWays / kFineWays2)
     PlanInfo *plan = nullptr;
     RangeStart *range_start = nullptr; // [kMaxRanges + 1]
     uint64_t *raw = nullptr;     // [(cap_chunks+1) * kChunkRecs] raw records of the scan, chunked
@@ -378,8 +381,10 @@ void launch_pack_scan_stream(const ImageView &v, uint32_t *scan_out, uint64_t *e
                              uint32_t *error_flag, uint32_t *seen, void *stream);
 void launch_pack_scan_range(const ImageView &v, uint32_t *scan_out, uint64_t *esig_out, uint8_t *occ8_out,
                             uint32_t *error_flag, uint32_t *seen, uint32_t tile_begin, uint32_t tile_end, void *stream);
-// prune_mode: 0 = full scan of the five buckets of every guide; 1 / 2 = pruned scan over the successor-byte groups equal
-// to / within one mismatch of the guide's own successor byte (enough for max_dist <= 2 / <= 4, see k_fine_count).
+// prune_mode: 0 = full scan of the five buckets of every guide; 1 / 2 / 3 = pruned scan over the successor-byte groups equal
+// to / within one / within two mismatches of the guide's own successor byte (enough for max_dist <= 2 / <= 4 / = 5, see
+// k_fine_count).
+inline uint32_t fine_ways_of(uint32_t prune_mode) { return prune_mode == 1 ? 1u : prune_mode == 3 ? kFineWays2 : kFineWays; }
 uint32_t prune_mode_for(const ImageView &v, const Tuning &tn, uint32_t n_guides, int max_dist);
 void launch_bin_guides(const ImageView &v, const Workspace &ws, const Tuning &tn, const uint64_t *d_guides, uint32_t n,
                        uint32_t prune_mode, void *stream);

@@ -496,9 +496,18 @@ __device__ __forceinline__ uint64_t group_cost(const GroupUnits &u, uint32_t len
 __device__ __forceinline__ uint32_t fine_way(uint32_t gj, uint32_t way)
 {
     if (way == 0) return gj;
-    const uint32_t q = (way - 1u) / 3u, d = (way - 1u) % 3u + 1u;
-    return gj ^ (d << (2u * q));
+    if (way < kFineWays) {
+        const uint32_t q = (way - 1u) / 3u, d = (way - 1u) % 3u + 1u;
+        return gj ^ (d << (2u * q));
+    }
+    // ways 13..66 (max_dist 5): two of the four positions changed -- pair (a, b) of 6, bases (d1, d2) of 9
+    const uint32_t w2 = way - kFineWays, pair = w2 / 9u, d1 = (w2 % 9u) / 3u + 1u, d2 = w2 % 3u + 1u;
+    const uint32_t a = pair < 3u ? 0u : pair < 5u ? 1u : 2u;
+    const uint32_t b = pair < 3u ? pair + 1u : pair < 5u ? pair - 1u : 3u;
+    return gj ^ (d1 << (2u * a)) ^ (d2 << (2u * b));
 }
+// mismatches in the successor slice of a guide placed by `way`: 0, 1 or 2 -- the guide's class (fine_word)
+__device__ __forceinline__ uint32_t fine_class(uint32_t way) { return way == 0u ? 0u : way < kFineWays ? 1u : 2u; }
 
 // The pruned scan compares 12 positions, not 16.  An item of its plan is ONE (bucket, successor byte) group: inside the
 // item's window every candidate carries the same four bases in the successor slice, and how far a guide is from them is
@@ -506,11 +515,10 @@ __device__ __forceinline__ uint32_t fine_way(uint32_t gj, uint32_t way)
 // "class 1").  The scan therefore leaves the successor slice's planes in memory (two of the eight 16-byte loads per lane,
 // scan_word: positions 4 s' .. 4 s' + 3 of the 16, s' = fine_quad(slice)) and counts the other 12 positions against
 // max_dist - class; the reference's test :376-382 on the full signatures is k_verify's.  Guide word of the pruned plan:
-// bits 0..11 the low code bits of the 12 positions in scan-word order, bits 12..23 the high ones, bit 24 the class.
+// bits 0..11 the low code bits of the 12 positions (fine_order), bits 12..23 the high ones, bits 24..25 the class.
 // A group's slots hold its class-1 guides first (from a multiple of 8 on), its class-0 guides behind them from
 // ScanItem::gmid on: full units run the two classes as two loops with their own compiled tests, short units take the
 // class bit as a thirteenth plane.
-constexpr uint32_t kFineFlag = 1u << 24;
 __host__ __device__ __forceinline__ uint32_t fine_quad(uint32_t slice) { return slice < 4u ? slice : 0u; }
 // The order of the 12 positions (three quads of the scan word's four): the quad of the PREVIOUS slice (slice - 1) first --
 // its four mismatch planes tell, for nothing, whether the slice before the bucket's own matches the guide exactly too, and
@@ -737,7 +745,7 @@ __global__ __launch_bounds__(256) void k_fine_scatter(ImageView v, const uint64_
             const uint32_t ww = fine_way(gj, way);
             if (!has_cands[ww]) continue; // no candidates there: the group has no slots
             const uint32_t slot = way ? slot_of[ww] + atomicAdd(&cursor[ww], 1u) : slot0_of[ww] + atomicAdd(&cursor0[ww], 1u);
-            fword[slot] = word12 | (way ? kFineFlag : 0u);
+            fword[slot] = word12 | (fine_class(way) << 24);
             fmeta[slot] = FineMeta{guide, (b << 8) | ww, gsig};
         }
     }
@@ -756,9 +764,12 @@ __global__ __launch_bounds__(256) void k_fine_ranges(const PlanInfo *__restrict_
 
 uint32_t prune_mode_for(const ImageView &v, const Tuning &tn, uint32_t n_guides, int max_dist)
 {
-    if ((!v.srec && !v.sid) || tn.prune == 0 || max_dist < 0 || max_dist > 4 || n_guides > kPruneMaxGuides || v.n_slices != 5 || v.slice_width != 8)
-        return 0;
-    return max_dist <= 2 ? 1u : 2u;
+    if ((!v.srec && !v.sid) || tn.prune == 0 || max_dist < 0 || max_dist > 5 || v.n_slices != 5 || v.slice_width != 8) return 0;
+    if (n_guides > (max_dist == 5 ? kPruneMaxGuides2 : kPruneMaxGuides)) return 0;
+    // max_dist 5: a hit the reference can find matches some slice exactly (:330-344 walks the buckets of the guide's own
+    // slice values), and then some exact slice is followed by one with at most TWO mismatches (the cycle lemma of the
+    // comment above with 3 |E| + (5 - 2 |E|) > 5): 67 of a bucket's 256 groups instead of all of them.
+    return max_dist <= 2 ? 1u : max_dist <= 4 ? 2u : 3u;
 }
 
 void launch_bin_guides(const ImageView &v, const Workspace &ws, const Tuning &tn, const uint64_t *d_guides, uint32_t n,
@@ -781,15 +792,17 @@ void launch_bin_guides(const ImageView &v, const Workspace &ws, const Tuning &tn
                        v.n_slices, nb, ws.gstart, ws.gfill, ws.gword, ws.gidx, ws.gbucket, blocks, ws.plan, ws.items,
                        ws.range_start);
     if (prune_mode) { // regroup by (bucket, successor byte); k_fine_plan decides which of the two plans the scan follows
-        const uint32_t ways = prune_mode == 1 ? 1u : kFineWays;
+        const uint32_t ways = fine_ways_of(prune_mode);
+        // (max_dist 5: three classes of guides in a pass -- the class plane of the short units has weight one only)
+        const uint32_t tail_shapes = prune_mode == 3 ? 0u : static_cast<uint32_t>(tn.tail_shapes);
         hipLaunchKernelGGL(k_fine_count, dim3(nb), dim3(256), 0, stream, v, d_guides, ws.gstart, ws.gfill, ws.gidx, ws.fcount,
-                           ws.fcount0, ws.fsum, tn.item_guides, ways, static_cast<uint32_t>(tn.tail_shapes));
+                           ws.fcount0, ws.fsum, tn.item_guides, ways, tail_shapes);
         hipLaunchKernelGGL(k_fine_plan, dim3(1), dim3(256), 0, stream, ws.fsum, nb, ws.fitems,
                            static_cast<uint32_t>(ws.cap_fitems), static_cast<uint32_t>(ws.cap_fslots), ws.plan, tn.scan_blocks,
                            prune_mode, tn.prune == 1 ? 1u : 0u, ws.sticky);
         hipLaunchKernelGGL(k_fine_scatter, dim3(nb), dim3(256), 0, stream, v, d_guides, ws.gstart, ws.gfill, ws.gword, ws.gidx,
                            ws.fcount, ws.fcount0, ws.fsum, ws.plan, ws.fword, ws.fmeta, ws.fitems, tn.item_guides, ways,
-                           static_cast<uint32_t>(tn.tail_shapes));
+                           tail_shapes);
         hipLaunchKernelGGL(k_fine_ranges, dim3(range_blocks), dim3(256), 0, stream, ws.plan, ws.fitems, ws.range_start);
     }
 }
@@ -1280,17 +1293,37 @@ __device__ __forceinline__ void scan_range(const uint32_t *__restrict__ scan_str
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 plane_wait += __builtin_amdgcn_s_memrealtime() - t1;
             }
+            if constexpr (THR < 0) {
+                // The runtime-threshold build (max_dist 5, the scan_generic knob): one loop, every guide's budget from the class
+                // bits of its word -- thr minus the 0, 1 or 2 mismatches it has in the successor slice.
+                for (uint32_t g = g_begin; g < g_end; g += kGuideGroup) {
+                    const GuideGroup gg = *reinterpret_cast<const GuideGroup *>(gword_stream + g);
+#pragma unroll
+                    for (uint32_t uu = 0; uu < kGuideGroup; ++uu) {
+                        if (g + uu >= g_end) break;
+                        const uint32_t cls = (gg.w[uu] >> 24) & 3u;
+                        if (cls > thr) continue;
+                        PrevSlice prev;
+                        const uint32_t ok = near_plane12<-1>(c, gg.w[uu], thr - cls, keep, prev);
+                        if (__ballot(ok != 0u) != 0ull) {
+                            note_candidates(fine_dup(ok, prev, dup_filter), g + uu, 5u, tile, grp * 32u, lane, w, raw, raw_used, max_chunks, counters);
+                            own_chunk = true;
+                        }
+                    }
+                }
+                continue;
+            }
             // class 1 (one mismatch in the successor slice): budget THR - 1 over the 12 positions; then class 0: budget THR
             const uint32_t gmid = cur.gmid < g_begin ? g_begin : cur.gmid > g_end ? g_end : cur.gmid;
-            if constexpr (THR < 0 || THR >= 1) {
-                if (THR >= 0 || thr >= 1u) {
+            if constexpr (THR >= 1) {
+                {
                     for (uint32_t g = g_begin; g < gmid; g += kGuideGroup) {
                         const GuideGroupAny gg = *reinterpret_cast<const GuideGroupAny *>(gword_stream + g);
 #pragma unroll
                         for (uint32_t uu = 0; uu < kGuideGroup; ++uu) {
                             if (g + uu >= gmid) break;
                             PrevSlice prev;
-                            const uint32_t ok = near_plane12<(THR < 0 ? -1 : THR - 1)>(c, gg.w[uu], thr - 1u, keep, prev);
+                            const uint32_t ok = near_plane12<(THR < 1 ? 0 : THR - 1)>(c, gg.w[uu], thr - 1u, keep, prev);
                             if (__ballot(ok != 0u) != 0ull) {
                                 note_candidates(fine_dup(ok, prev, dup_filter), g + uu, 5u, tile, grp * 32u, lane, w, raw, raw_used, max_chunks, counters);
                                 own_chunk = true;
@@ -1568,7 +1601,7 @@ __global__ __launch_bounds__(kChunkRecs, 8) void k_verify(ImageView v, Workspace
                         // Pruned scan: the guide meets this site once in every exactly matching slice whose successor
                         // slice has at most `tol` mismatches (k_fine_count); the smallest such slice reports it, under
                         // the slice the reference would meet it in first.
-                        const uint32_t tol = prune_mode == 1 ? 0u : 1u;
+                        const uint32_t tol = prune_mode - 1u; // 0, 1, 2 mismatches allowed in the successor slice
                         const uint64_t mm = mismatch_mask(gsig, ot);
                         uint32_t first = slice, reporter = slice;
                         for (uint32_t j = slice; j-- > 0;) {

@@ -96,8 +96,8 @@ typedef struct {
                                      buckets (full scan) or successor-byte groups (pruned scan) they visit */
     uint64_t reference_comparisons; /* sum over guides of their five bucket lengths = iterations of the reference's
                                        loop :344 without early exit (host equivalent: issl_count_candidates) */
-    uint64_t pruned;              /* 0: full scan; 1 / 2: pruned scan over the successor-byte groups equal to / within
-                                     one mismatch of the guide's own (max_dist <= 2 / <= 4, sorted image) */
+    uint64_t pruned;              /* 0: full scan; 1 / 2 / 3: pruned scan over the successor-byte groups equal to / within
+                                     one / within two mismatches of the guide's own (max_dist <= 2 / <= 4 / = 5, sorted image) */
     double ms_scan_events;        /* the scan launches by the HIP event pair recorded around them on their stream; equals
                                      ms_scan for batches on one lane, includes the wait for wave slots when a second
                                      lane shares the device (lanes option) */
@@ -229,9 +229,9 @@ int issl_index_attach_image_cold(int device, void *dev_buf, size_t bytes, void *
  *     32-byte record of their own (1.6 GB of scratch per 100 000 guides of a batch; batches beyond 512 k guides, a
  *     device short of memory and issl_dump_hits go without); 0: every hit passes through the grouping pass
  *   prune (ISSL_PRUNE) -1|0|1: scan only the successor-byte groups of a bucket that can hold a site within max_dist (13
- *     of 256 for max_dist <= 4, 1 of 256 for <= 2; same hits and scores as the reference's scan of the whole bucket,
- *     isslScoreOfftargets.cpp:344): -1 = a planning kernel decides per batch from the two plans' estimated times,
- *     0 = never, 1 = whenever the image is sorted and max_dist <= 4
+ *     of 256 for max_dist <= 4, 1 of 256 for <= 2, 67 of 256 for max_dist 5; same hits and scores as the reference's scan
+ *     of the whole bucket, isslScoreOfftargets.cpp:344): -1 = a planning kernel decides per batch from the two plans'
+ *     estimated times, 0 = never, 1 = whenever the image is sorted and max_dist <= 5
  *   lanes (ISSL_LANES) 1|2: workspaces that the batches of issl_score_device_async alternate between (default 1).  With
  *     2 the batches form a software pipeline: scans one after the other, verify / group / replay of a batch on a
  *     high-priority stream beside the next batch's scan (a few per cent more guides/s for back-to-back batches);

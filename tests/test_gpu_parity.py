@@ -313,6 +313,39 @@ def test_large_max_dist_and_single_guide(config0):
     assert mit[0] == omit[0] and cfd[0] == ocfd[0]
 
 
+def test_max_dist_5_takes_the_pruned_scan_too(config0):
+    """max_dist 5 (the reference takes any, isslScoreOfftargets.cpp:109,382): a hit the reference can find has an exactly
+    matching slice, and one of those is followed by a slice with at most two mismatches -- 67 of a bucket's 256
+    successor-byte groups, three classes of guides with budgets 5, 4, 3 on the other 12 positions (pruned == 3).  Scores and
+    hit lists against the oracle, pruned = whole buckets = planner's choice; the local MIT table has no masks of five
+    mismatches: such hits add 0.0 (operator[], :394)."""
+    ix, oracle, sigs, guides = config0
+    try:
+        got = {}
+        for prune in (1, 0, -1):
+            ix.set_option("prune", prune)
+            for thr in (0.0, 75.0):
+                mit, cfd = ix.score(guides, 5, thr, "and")
+                st = check_comparisons(ix, guides, prune)
+                if prune == 1:
+                    assert st["pruned"] == 3   # (forced: on a 1 M-site index the planner would not prune)
+                omit, ocfd = oracle.score(guides, 5, thr, "and")
+                assert np.array_equal(mit.view(np.uint64), omit.view(np.uint64)), (prune, thr)
+                assert np.array_equal(cfd.view(np.uint64), ocfd.view(np.uint64)), (prune, thr)
+            hits = ix.dump_hits(guides[:300], 5, 0.0, "and")
+            _, _, ohits = oracle.score(guides[:300], 5, 0.0, "and", want_hits=True)
+            assert np.array_equal(hits, ohits), prune
+            got[prune] = hits
+        assert (got[1][:, 4] == 5).sum() > 100   # hits at distance five are there
+        ix.set_option("prune", 1)
+        for method, thr in (("mit", 50.0), ("cfd", 90.0), ("or", 75.0), ("avg", 60.0)):
+            mit, cfd = ix.score(guides, 5, thr, method)
+            omit, ocfd = oracle.score(guides, 5, thr, method)
+            assert np.array_equal(mit.view(np.uint64), omit.view(np.uint64)) and np.array_equal(cfd.view(np.uint64), ocfd.view(np.uint64)), method
+    finally:
+        ix.set_option("prune", -1)
+
+
 def test_runtime_threshold_build_of_the_scan_kernel(config0):
     """The scan kernel is compiled with max_dist 0..4 as constants and once with a runtime threshold (used for
     max_dist > 4).  Force the runtime-threshold build for small distances too and compare."""
@@ -929,7 +962,7 @@ def test_random_small_indexes_differential():
             for _ in range(4):
                 method = methods[int(rng.integers(0, 5))]
                 thr = float(rng.choice([0.0, 30.0, 75.0, 95.0, 100.0]))
-                dist = int(rng.integers(0, 5))
+                dist = int(rng.integers(0, 6))
                 hits = ix.dump_hits(guides, dist, thr, method)
                 omit, ocfd, ohits = oracle.score(guides, dist, thr, method, want_hits=True)
                 assert np.array_equal(hits, ohits), (trial, layout, method, thr, dist)

@@ -140,6 +140,21 @@ def test_successor_slice_pigeonhole_behind_the_pruned_scan():
     assert not any(counts[i] == 0 and counts[(i + 1) % 5] == 0 for i in range(5))
 
 
+def test_successor_slice_pigeonhole_for_five_mismatches():
+    """max_dist 5 (the pruned scan's third mode): the reference only ever meets a site in the bucket of a slice that
+    matches the guide exactly (isslScoreOfftargets.cpp:330-344), so a hit has one; among the exact slices one is followed
+    by a slice with at most TWO mismatches -- otherwise 3 |E| + (5 - 2 |E|) > 5.  One mismatch does not do (tight)."""
+    import itertools
+    tight = False
+    for counts in itertools.product(range(6), repeat=5):
+        if sum(counts) > 5 or 0 not in counts:
+            continue
+        assert any(counts[i] == 0 and counts[(i + 1) % 5] <= 2 for i in range(5)), counts
+        tight = tight or not any(counts[i] == 0 and counts[(i + 1) % 5] <= 1 for i in range(5))
+    assert tight
+    assert 1 + 4 * 3 + 6 * 9 == 67   # successor bytes within two mismatches of a guide's own
+
+
 def test_previous_slice_filter_of_the_pruned_scan_never_drops_the_reporter():
     """The scan's duplicate filter (csrc/issl_kernels.hip, fine_dup): a guide meets a hit once per exactly matching slice
     whose successor is within tolerance, and the SMALLEST such slice reports it (k_verify).  The scan drops the encounter in
@@ -147,7 +162,7 @@ def test_previous_slice_filter_of_the_pruned_scan_never_drops_the_reporter():
     never the reporter.  Every placement of <= 4 mismatches on the 20 positions, both tolerances: the reporter's encounter
     survives; and the filter takes what the kernel comment says it takes (58 % of the duplicates at distance 4)."""
     import itertools
-    for tol, dists in ((1, (0, 1, 2, 3, 4)), (0, (0, 1, 2))):
+    for tol, dists in ((1, (0, 1, 2, 3, 4)), (0, (0, 1, 2)), (2, (5,))):
         for d in dists:
             hits = records = dups = dropped = 0
             for pos in itertools.combinations(range(20), d):
@@ -155,7 +170,9 @@ def test_previous_slice_filter_of_the_pruned_scan_never_drops_the_reporter():
                 for p in pos:
                     cnt[p // 4] += 1
                 met = [j for j in range(5) if cnt[j] == 0 and cnt[(j + 1) % 5] <= tol]
-                assert met, pos                                            # (the pigeonhole above)
+                if tol == 2 and 0 not in cnt:
+                    continue                                               # (no exact slice: the reference does not find it either)
+                assert met, pos                                            # (the pigeonholes above)
                 reporter = min(met)
                 kept = [j for j in met if not (j >= 1 and cnt[j - 1] == 0)]   # what the scan still notes
                 assert reporter in kept, (pos, met, kept)

@@ -299,6 +299,11 @@ def test_wide_sample_against_the_full_oracle_at_scale(scale, tmp_path):
     mit, cfd = ix.score(guides, 4, 75.0, "and")
     assert ix.stats()["pruned"] == 2
     hits = ix.dump_hits(guides[pick[::20]], 4, 0.0, "and")
+    ix.set_option("prune", 1)
+    mit5, cfd5 = ix.score(guides, 5, 75.0, "and")
+    st5 = ix.stats()
+    assert st5["pruned"] == 3 and st5["candidates"] < 0.40 * st5["reference_comparisons"]   # 67 of 256 groups, in whole units of 2048
+    ix.set_option("prune", -1)
     path = pathlib.Path(tmp) / f"scale_wide_{os.getpid()}.issl"
     try:
         t = time.time(); ix.write(path); t_write = time.time() - t
@@ -306,6 +311,7 @@ def test_wide_sample_against_the_full_oracle_at_scale(scale, tmp_path):
         threads = min(64, max(8, 2 * (os.cpu_count() or 8)))
         t = time.time(); omit, ocfd = oracle.score(guides[pick], 4, 75.0, "and", threads=threads); t_score = time.time() - t
         t = time.time(); _, _, ohits = oracle.score(guides[pick[::20]], 4, 0.0, "and", want_hits=True, threads=threads); t_hits = time.time() - t
+        omit5, ocfd5 = oracle.score(guides[pick[::8]], 5, 75.0, "and", threads=threads)
         oracle.close()
     finally:
         path.unlink(missing_ok=True)
@@ -316,6 +322,8 @@ def test_wide_sample_against_the_full_oracle_at_scale(scale, tmp_path):
     assert np.array_equal(cfd[pick].view(np.uint64), ocfd.view(np.uint64))
     assert hits.shape == ohits.shape and np.array_equal(hits, ohits)   # same index on both sides: ids and list positions too
     assert (omit < 100).sum() > len(pick) // 2
+    assert np.array_equal(mit5[pick[::8]].view(np.uint64), omit5.view(np.uint64))   # max_dist 5: the pruned scan's third mode
+    assert np.array_equal(cfd5[pick[::8]].view(np.uint64), ocfd5.view(np.uint64))
 
 
 @pytest.mark.gpu
