@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <type_traits>
 #include <cstdio>
 
 #include "issl_device.hpp"
@@ -550,13 +551,14 @@ __host__ __device__ __forceinline__ uint32_t fine_word(uint32_t word, uint32_t s
 }
 
 // Per bucket: guides per successor byte, and what the bucket's groups add to the plan.
+template <uint32_t WAYS>
 __global__ __launch_bounds__(256) void k_fine_count(ImageView v, const uint64_t *__restrict__ guides,
                                                     const uint32_t *__restrict__ gstart, const uint32_t *__restrict__ gfill,
                                                     const uint32_t *__restrict__ gidx, uint32_t *__restrict__ fcount,
                                                     uint32_t *__restrict__ fcount0,
-                                                    FineSum *__restrict__ fsum, uint32_t item_guides, uint32_t ways,
-                                                    uint32_t tail_shapes)
+                                                    FineSum *__restrict__ fsum, uint32_t item_guides, uint32_t tail_shapes)
 {
+    constexpr uint32_t ways = WAYS; // compiled in: the 13 (or 67) LDS atomics of a guide are in flight together
     short_kernel_priority();
     __shared__ uint32_t cnt[256], cnt0[256];
     __shared__ uint64_t lds[256];
@@ -569,6 +571,7 @@ __global__ __launch_bounds__(256) void k_fine_count(ImageView v, const uint64_t 
     for (uint32_t i = threadIdx.x; i < n; i += 256) { // one guide per thread and step: its loads once, its ways from registers
         const uint32_t gj = static_cast<uint32_t>(guides[gidx[g0 + i]] >> succ_shift) & 0xFFu;
         atomicAdd(&cnt0[gj], 1u); // class 0: the guide's successor byte is the group's own (fine_class)
+#pragma unroll
         for (uint32_t way = 0; way < ways; ++way) atomicAdd(&cnt[fine_way(gj, way)], 1u);
     }
     __syncthreads();
@@ -664,6 +667,7 @@ __global__ __launch_bounds__(256) void k_fine_plan(FineSum *__restrict__ fsum, u
 }
 
 // Per bucket: the items of its successor-byte groups and the guides of every group in its slots.
+template <uint32_t WAYS>
 __global__ __launch_bounds__(256) void k_fine_scatter(ImageView v, const uint64_t *__restrict__ guides,
                                                       const uint32_t *__restrict__ gstart, const uint32_t *__restrict__ gfill,
                                                       const uint32_t *__restrict__ gword, const uint32_t *__restrict__ gidx,
@@ -671,9 +675,9 @@ __global__ __launch_bounds__(256) void k_fine_scatter(ImageView v, const uint64_
                                                       const FineSum *__restrict__ fbase,
                                                       const PlanInfo *__restrict__ plan, uint32_t *__restrict__ fword,
                                                       FineMeta *__restrict__ fmeta,
-                                                      ScanItem *__restrict__ fitems, uint32_t item_guides, uint32_t ways,
-                                                      uint32_t tail_shapes)
+                                                      ScanItem *__restrict__ fitems, uint32_t item_guides, uint32_t tail_shapes)
 {
+    constexpr uint32_t ways = WAYS;
     short_kernel_priority();
     if (!plan->fine) return; // the bucket-level plan stays
     __shared__ uint64_t lds[256];
@@ -741,6 +745,7 @@ __global__ __launch_bounds__(256) void k_fine_scatter(ImageView v, const uint64_
         const uint64_t gsig = guides[guide];
         const uint32_t gj = static_cast<uint32_t>(gsig >> succ_shift) & 0xFFu;
         const uint32_t word12 = fine_word(word, slice);
+#pragma unroll
         for (uint32_t way = 0; way < ways; ++way) {
             const uint32_t ww = fine_way(gj, way);
             if (!has_cands[ww]) continue; // no candidates there: the group has no slots
@@ -795,14 +800,19 @@ void launch_bin_guides(const ImageView &v, const Workspace &ws, const Tuning &tn
         const uint32_t ways = fine_ways_of(prune_mode);
         // (max_dist 5: three classes of guides in a pass -- the class plane of the short units has weight one only)
         const uint32_t tail_shapes = prune_mode == 3 ? 0u : static_cast<uint32_t>(tn.tail_shapes);
-        hipLaunchKernelGGL(k_fine_count, dim3(nb), dim3(256), 0, stream, v, d_guides, ws.gstart, ws.gfill, ws.gidx, ws.fcount,
-                           ws.fcount0, ws.fsum, tn.item_guides, ways, tail_shapes);
-        hipLaunchKernelGGL(k_fine_plan, dim3(1), dim3(256), 0, stream, ws.fsum, nb, ws.fitems,
-                           static_cast<uint32_t>(ws.cap_fitems), static_cast<uint32_t>(ws.cap_fslots), ws.plan, tn.scan_blocks,
-                           prune_mode, tn.prune == 1 ? 1u : 0u, ws.sticky);
-        hipLaunchKernelGGL(k_fine_scatter, dim3(nb), dim3(256), 0, stream, v, d_guides, ws.gstart, ws.gfill, ws.gword, ws.gidx,
-                           ws.fcount, ws.fcount0, ws.fsum, ws.plan, ws.fword, ws.fmeta, ws.fitems, tn.item_guides, ways,
-                           tail_shapes);
+        auto launch_fine = [&](auto ways_tag) {
+            constexpr uint32_t W = decltype(ways_tag)::value;
+            hipLaunchKernelGGL(k_fine_count<W>, dim3(nb), dim3(256), 0, stream, v, d_guides, ws.gstart, ws.gfill, ws.gidx, ws.fcount,
+                               ws.fcount0, ws.fsum, tn.item_guides, tail_shapes);
+            hipLaunchKernelGGL(k_fine_plan, dim3(1), dim3(256), 0, stream, ws.fsum, nb, ws.fitems,
+                               static_cast<uint32_t>(ws.cap_fitems), static_cast<uint32_t>(ws.cap_fslots), ws.plan, tn.scan_blocks,
+                               prune_mode, tn.prune == 1 ? 1u : 0u, ws.sticky);
+            hipLaunchKernelGGL(k_fine_scatter<W>, dim3(nb), dim3(256), 0, stream, v, d_guides, ws.gstart, ws.gfill, ws.gword, ws.gidx,
+                               ws.fcount, ws.fcount0, ws.fsum, ws.plan, ws.fword, ws.fmeta, ws.fitems, tn.item_guides, tail_shapes);
+        };
+        if (ways == 1u) launch_fine(std::integral_constant<uint32_t, 1u>{});
+        else if (ways == kFineWays) launch_fine(std::integral_constant<uint32_t, kFineWays>{});
+        else launch_fine(std::integral_constant<uint32_t, kFineWays2>{});
         hipLaunchKernelGGL(k_fine_ranges, dim3(range_blocks), dim3(256), 0, stream, ws.plan, ws.fitems, ws.range_start);
     }
 }
