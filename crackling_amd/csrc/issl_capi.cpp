@@ -309,8 +309,10 @@ static int ensure_workspace(issl_index *ix, size_t n, Lane &lane, uint32_t fine_
         HIP_TRY(hipMemset(w.scan_count, 0, 8 * kScanMaxBlocks));
         w.n_buckets = static_cast<uint32_t>(nb);
     }
-    if (n > w.cap_guides || (ix->hdr.off_sub_start && fine_ways > w.fine_ways && w.fine_ways != 0)) {
-        const size_t cap = std::max<size_t>(std::max(n, w.cap_guides), 1024);
+    bool grew = false;
+    if (n > w.cap_guides) {
+        grew = true;
+        const size_t cap = std::max<size_t>(n, 1024);
         const size_t slots = cap * ix->hdr.n_slices + kGuideGroup * nb;
         const size_t items = nb + cap * ix->hdr.n_slices / 8 + 2; // item sizes down to 8 guides (item_guides knob)
         if ((rc = dev_alloc(w.gword, slots))) return rc;
@@ -337,28 +339,33 @@ static int ensure_workspace(issl_index *ix, size_t n, Lane &lane, uint32_t fine_
         w.cap_guides = cap;
         w.cap_gslots = slots;
         w.cap_items = items;
-        if (ix->hdr.off_sub_start) { // pruned scan: every guide sits in up to 13 successor-byte groups of each of its 5 buckets
-            const uint32_t ways = std::max(fine_ways, w.fine_ways); // (max_dist 5 places a guide in 67 groups per bucket, not 13)
-            const size_t m = std::min<size_t>(cap, ways > kFineWays ? kPruneMaxGuides2 : kPruneMaxGuides);
-            const size_t places = m * ix->hdr.n_slices * ways;
-            const size_t groups = std::min<size_t>(nb * 256, places);
-            const size_t fslots = places + kGuideGroup * groups;
-            // one item per tile of a group (and per 512 guides of it): sized from the mean group length (uniform data has
-            // sites / 65536 candidates per group, +1.2 tiles for the ends); a batch that needs more scans whole buckets
-            // and reports it (sticky[3]), finish_batches() then enlarges the list for the next one
-            const size_t tiles_per_group = static_cast<size_t>(ix->hdr.n_sites / (65536ull * kTileCands)) + 4;
-            const size_t fitems = std::max<size_t>(tiles_per_group * (groups + places / 64) + 2, w.cap_fitems);
-            if ((rc = dev_alloc(w.fword, fslots + 64))) return rc; // (+ slack: short_unit_masks reads whole groups of 32 slots)
-            if ((rc = dev_alloc(w.fmeta, fslots))) return rc;
-            if ((rc = dev_alloc(w.fitems, fitems + 1))) return rc;
-            if ((rc = dev_alloc(w.fcount, nb * 256))) return rc;
-            if ((rc = dev_alloc(w.fcount0, nb * 256))) return rc;
-            if ((rc = dev_alloc(w.fsum, nb))) return rc;
-            w.cap_fslots = fslots;
-            w.cap_fitems = fitems;
-            w.fine_ways = ways;
-        }
     }
+    // pruned scan: every guide sits in up to 13 (max_dist 5: 67) successor-byte groups of each of its 5 buckets.  These arrays
+    // grow with the batch AND with the number of groups per bucket -- by themselves: the staging buffers above are in use by
+    // the caller when a batch's max_dist asks for more groups.
+    if (ix->hdr.off_sub_start && (grew || fine_ways > w.fine_ways)) {
+        const size_t cap = w.cap_guides;
+        const uint32_t ways = std::max(fine_ways, w.fine_ways);
+        const size_t m = std::min<size_t>(cap, ways > kFineWays ? kPruneMaxGuides2 : kPruneMaxGuides);
+        const size_t places = m * ix->hdr.n_slices * ways;
+        const size_t groups = std::min<size_t>(nb * 256, places);
+        const size_t fslots = places + kGuideGroup * groups;
+        // one item per tile of a group (and per 512 guides of it): sized from the mean group length (uniform data has
+        // sites / 65536 candidates per group, +1.2 tiles for the ends); a batch that needs more scans whole buckets
+        // and reports it (sticky[3]), finish_batches() then enlarges the list for the next one
+        const size_t tiles_per_group = static_cast<size_t>(ix->hdr.n_sites / (65536ull * kTileCands)) + 4;
+        const size_t fitems = std::max<size_t>(tiles_per_group * (groups + places / 64) + 2, w.cap_fitems);
+        if ((rc = dev_alloc(w.fword, fslots + 64))) return rc; // (+ slack: short_unit_masks reads whole groups of 32 slots)
+        if ((rc = dev_alloc(w.fmeta, fslots))) return rc;
+        if ((rc = dev_alloc(w.fitems, fitems + 1))) return rc;
+        if ((rc = dev_alloc(w.fcount, nb * 256))) return rc;
+        if ((rc = dev_alloc(w.fcount0, nb * 256))) return rc;
+        if ((rc = dev_alloc(w.fsum, nb))) return rc;
+        w.cap_fslots = fslots;
+        w.cap_fitems = fitems;
+        w.fine_ways = ways;
+    }
+
     if (w.cap_chunks == 0) {
         // every scan wave may hold one partly filled chunk; beyond that ~1 record per 50k comparisons.
         // raw_chunks knob: start with a small raw buffer (tests of the grow-and-rerun path)

@@ -2083,7 +2083,7 @@ __device__ inline HitTerms hit_terms(const ImageView &v, uint64_t gsig, uint32_t
     return t;
 }
 
-__global__ __launch_bounds__(64) void k_replay(ImageView v, Workspace ws, const uint64_t *__restrict__ guides,
+__global__ __launch_bounds__(64, 8) void k_replay(ImageView v, Workspace ws, const uint64_t *__restrict__ guides,
                                                uint32_t n, ScoreParams p, double *__restrict__ out_mit,
                                                double *__restrict__ out_cfd, uint32_t *__restrict__ out_kept,
                                                issl_hit *__restrict__ out_hits)
