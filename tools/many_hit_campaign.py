@@ -21,7 +21,7 @@ ap.add_argument("--trials", type=int, default=10)
 ap.add_argument("--seed", type=int, default=1)
 a = ap.parse_args()
 rng = np.random.default_rng(a.seed)
-LAYOUTS = [None, {"compact": 1}, {"compact": 1, "host_cold": 1}, {"sorted_layout": 0}, {"sorted_layout": 0, "inline_sigs": 0},
+LAYOUTS = [None, {"compact": 1}, {"compact": 1, "host_cold": 1}, {"keep_lists": 0}, {"sorted_layout": 0}, {"sorted_layout": 0, "inline_sigs": 0},
            {"sorted_layout": 0, "host_cold": 1}]
 METHODS = ["and", "or", "avg", "mit", "cfd"]
 
