@@ -332,8 +332,9 @@ static int ensure_workspace(issl_index *ix, size_t n, Lane &lane, uint32_t fine_
         // device short of memory) go without, every hit then passes through the grouping pass
         if (w.slots) { (void)hipFree(w.slots); w.slots = nullptr; }
         w.cap_slot_guides = 0;
-        if (cap * kSlotHits * sizeof(SlotRec) <= kSlotBytesMax) {
-            if (hipMalloc(reinterpret_cast<void **>(&w.slots), cap * kSlotHits * sizeof(SlotRec)) == hipSuccess) w.cap_slot_guides = cap;
+        if (cap * w.slot_width * sizeof(SlotRec) > kSlotBytesMax) w.slot_width = kSlotHits; // (a larger batch: back to narrow slots)
+        if (cap * w.slot_width * sizeof(SlotRec) <= kSlotBytesMax) {
+            if (hipMalloc(reinterpret_cast<void **>(&w.slots), cap * w.slot_width * sizeof(SlotRec)) == hipSuccess) w.cap_slot_guides = cap;
             else { (void)hipGetLastError(); w.slots = nullptr; }
         }
         w.cap_guides = cap;
@@ -777,7 +778,7 @@ static int enqueue_batch(issl_index *ix, Lane &lane, hipStream_t stream, const u
         ws.cap_hitrec = ws.cap_hits;
     }
     // issl_dump_hits wants every hit of the batch in one array in guide order: no hit slots there
-    ws.slot_hits = (!dump && tn.hit_slots && ws.cap_slot_guides >= n) ? kSlotHits : 0u;
+    ws.slot_hits = (!dump && tn.hit_slots && ws.cap_slot_guides >= n) ? ws.slot_width : 0u;
     ScoreParams p;
     p.max_dist = max_dist;
     p.method = method;
@@ -865,6 +866,26 @@ static int finish_batches(issl_index *ix, hipStream_t stream)
             int rc = dev_alloc(lp->ws.fitems, want + 1);
             if (rc) return rc;
             lp->ws.cap_fitems = want;
+        }
+        // Hit slots: when a good part of the last batch's guides had more than kSlotHits hits -- an index of billions of sites, a
+        // skewed genome -- the next batches get slots for kSlotHitsWide of them (6.5 GB per 100 k guides), so that only what
+        // lies beyond THAT passes through the grouping pass.  A matter of speed only: the results do not depend on the width.
+        if (lp->ws.slots && lp->ws.slot_width == kSlotHits && ix->tuning.hit_slots && lp->last_n) {
+            Counters c{};
+            HIP_TRY(hipMemcpy(&c, lp->ws.counters, sizeof c, hipMemcpyDeviceToHost));
+            const size_t want = lp->ws.cap_slot_guides * size_t(kSlotHitsWide) * sizeof(SlotRec);
+            size_t free_b = 0, total_b = 0;
+            if (c.overflowed > lp->last_n / 8 && want <= kSlotBytesMax && hipMemGetInfo(&free_b, &total_b) == hipSuccess &&
+                free_b > want + (size_t(4) << 30)) {
+                SlotRec *wide = nullptr;
+                if (hipMalloc(reinterpret_cast<void **>(&wide), want) == hipSuccess) {
+                    (void)hipFree(lp->ws.slots);
+                    lp->ws.slots = wide;
+                    lp->ws.slot_width = kSlotHitsWide;
+                } else {
+                    (void)hipGetLastError();
+                }
+            }
         }
         if (sticky[0]) {
             // sticky[1] = largest number of chunks any batch asked for

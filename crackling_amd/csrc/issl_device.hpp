@@ -278,7 +278,7 @@ struct Counters {
     uint32_t n_big2;      // guides k_replay_mid hands on to k_replay_big (a slice too long for its buffers)
     uint32_t raw_chunks;  // chunks of the raw record buffer handed out
     uint32_t raw_overflow; // set when the raw buffer was too small
-    uint32_t overflowed;  // hit slots: guides whose hits outgrew their slots (k_verify); 0 = nothing to group
+    uint32_t overflowed;  // hit slots: guides with more than kReplayLds hits (k_verify); 0 = nothing to group, no many-hit replay
 };
 
 // Per bucket, pruned scan: what its successor-byte groups add to the plan (k_fine_count -> k_fine_plan -> k_fine_scatter).
@@ -289,6 +289,9 @@ struct FineSum {
 };
 
 constexpr uint32_t kSlotHits = 512;     // = kReplayLds: what k_replay takes
+constexpr uint32_t kSlotHitsWide = 2048; // = kMidHits: what a workspace grows its slots to when many guides of its batches have more
+                                        // than kSlotHits hits (indexes of billions of sites, skewed genomes): the grouping pass then moves
+                                        // only what lies beyond 2048 hits of a guide, and k_replay_mid's guides take no part in it
 // One hit in a guide's slots: terms and key in ONE aligned 32-byte record -- k_verify scatters them, and a write that
 // fills a whole 32-byte sector goes out as it is, where an 8- and a 16-byte piece of two arrays cost two partial ones.
 struct alignas(32) SlotRec {
@@ -351,8 +354,9 @@ struct Workspace {
     // slots[guide * slot_hits + rank]; only guides with more hits than that take part in the grouping pass
     // (on an even index: none -- the pass and its buffers drop out of the step).  0: every hit is grouped (issl_dump_hits,
     // batches too large for the slot arrays, the hit_slots knob).
-    SlotRec *slots = nullptr;       // [cap_slot_guides * kSlotHits]
-    uint32_t slot_hits = 0;
+    SlotRec *slots = nullptr;       // [cap_slot_guides * slot_width]
+    uint32_t slot_hits = 0;         // of the batch being enqueued: 0 or slot_width
+    uint32_t slot_width = kSlotHits; // slots per guide the array was allocated with (kSlotHits / kSlotHitsWide)
     size_t cap_slot_guides = 0;
     uint32_t *blocksum = nullptr;
     uint64_t *d_guides = nullptr; // staging for the host API

@@ -1661,6 +1661,7 @@ __global__ __launch_bounds__(kChunkRecs, 8) void k_verify(ImageView v, Workspace
             if (live && !continues) base = atomicAdd(&ws.gcount[guide], next - lane); // the run is [lane, next)
             rank = static_cast<uint32_t>(__shfl(static_cast<int>(base), static_cast<int>(head), 64)) + (lane - head);
         }
+        if (live && rank == kReplayLds) atomicAdd(&ws.counters->overflowed, 1u); // the guide's first hit beyond what k_replay takes
         if (live && rank < ws.slot_hits) {
             // hit slots (Workspace): the hit goes to its final place at once and takes no part in the grouping pass
             int dist;
@@ -1671,7 +1672,6 @@ __global__ __launch_bounds__(kChunkRecs, 8) void k_verify(ImageView v, Workspace
             ws.slots[at] = r;
             key = kDeadKey;
         } else if (live) {
-            if (rank == ws.slot_hits && rank != 0u) atomicAdd(&ws.counters->overflowed, 1u); // the guide's first hit beyond its slots
             const uint64_t slot = static_cast<uint64_t>(chunk) * (kChunkRecs - 1u) + (t - 1u); // < cap_chunks * 127 <= cap_hits
             ws.rank[slot] = rank;
             // The terms (:392-460) -- unless the guide already has more hits than the replays that read them take
@@ -1733,7 +1733,12 @@ constexpr uint32_t kScanChunk = 2048; // elements per block in the device-wide p
 constexpr uint32_t kBigLds = 7680;    // hits per slice k_replay_big sorts in LDS (2 x 30 KiB); longer slices are sorted in HBM
 
 // What a guide's hits take in the grouped arrays: nothing when they all sit in its hit slots (Workspace::slot_hits).
-__device__ __forceinline__ uint32_t grouped_hits(uint32_t count, uint32_t slot_hits) { return count <= slot_hits ? 0u : count; }
+// (with slots of any width every guide of the many-hit replays keeps a segment for ALL its hits: k_replay_big copies the keys in
+// the slots in front of the rest, and k_replay_mid may hand a guide on to it)
+__device__ __forceinline__ uint32_t grouped_hits(uint32_t count, uint32_t slot_hits)
+{
+    return count <= (slot_hits ? kSlotHits : 0u) ? 0u : count;
+}
 
 __global__ __launch_bounds__(256) void k_prefix_block_sums(const uint32_t *__restrict__ in, uint32_t n,
                                                            uint32_t *__restrict__ sums, uint32_t slot_hits)
@@ -2454,7 +2459,7 @@ __global__ __launch_bounds__(THREADS) void k_replay_big(ImageView v, Workspace w
         // slices behind the exit.
         if (threadIdx.x < kMaxSlices) { slice_cnt[threadIdx.x] = 0; slice_cur[threadIdx.x] = 0; }
         // hit slots: the guide's first slot_hits keys join the rest in its segment (h > slot_hits here: all of them are there)
-        for (uint32_t i = threadIdx.x; i < ws.slot_hits; i += blockDim.x) seg[i] = ws.slots[static_cast<uint64_t>(g) * ws.slot_hits + i].key;
+        for (uint32_t i = threadIdx.x; i < (ws.slot_hits < h ? ws.slot_hits : h); i += blockDim.x) seg[i] = ws.slots[static_cast<uint64_t>(g) * ws.slot_hits + i].key;
         __syncthreads();
         for (uint32_t base = 0; base < h; base += blockDim.x) {
             const uint32_t i = base + threadIdx.x;

@@ -257,6 +257,10 @@ def _score_and_check(scale, tmp_path, what):
                       "guides_per_s_kernels": scale.n_guides / full_st["ms_total"] * 1e3},
     }
     print(json.dumps(summary), flush=True)
+    import conftest
+    conftest.SCALE_NOTES.append(f"{what.split('::')[-1]}: {scale.n_lines} lines x {scale.n_guides} guides: {st['ms_total']:.2f} ms per batch pruned "
+                                f"(bin {st['ms_bin']:.2f}, scan {st['ms_scan']:.2f}, verify {st['ms_verify']:.2f}, group {st['ms_group']:.2f}, replay "
+                                f"{st['ms_replay']:.2f}; {st['hits']} hits), {full_st['ms_total']:.1f} ms with whole buckets; all {scale.n_guides} scores equal")
     return summary
 
 
