@@ -208,7 +208,8 @@ constexpr uint32_t kItemGuides = 512;  // guides per scan item (bounds one tile'
 constexpr uint32_t kGuideCost = 4;      // cost of one guide against one full unit of 2048 candidates (32 per lane); against a
                                         // short unit of 16 / 8 candidates per lane it is 2 / 1: two / four guides then share
                                         // every instruction (ScanItem::shape)
-constexpr uint32_t kTileFixedCost = 4 * kGuideCost; // cost of fetching a unit = four guide comparisons of a full one
+constexpr uint32_t kTileFixedCost = 8 * kGuideCost; // cost of a unit beside its passes (ticket, item, fetch, set-up) = eight guide comparisons of a full one (4 until round 4: the
+                                                    // 12-position pass is a third cheaper and the unit is not; same-box A/B of 4 / 8 / 14: k_scan 1.40 / 1.37 / 1.38 ms)
 constexpr uint32_t kNoGuide = 0xFFFFFFFFu;
 constexpr uint32_t kPadGuideWord = 0xFFFFFFFFu; // scan word of padding guide slots: 16 x T, distance 16 from tile padding
 constexpr uint32_t kScanGridBlocks = 256u * 4u; // scan launch: 256 CUs x 2 resident workgroups of 16 waves, two rounds
