@@ -280,6 +280,8 @@ struct Counters {
     uint32_t raw_chunks;  // chunks of the raw record buffer handed out
     uint32_t raw_overflow; // set when the raw buffer was too small
     uint32_t overflowed;  // hit slots: guides with more than kReplayLds hits (k_verify); 0 = nothing to group, no many-hit replay
+    uint32_t replay_next[3]; // tickets of the many-hit replays (k_replay_mid, k_replay_big<256>, k_replay_big<1024>): the next entry
+                             // of the shared guide list a workgroup of that kernel takes
 };
 
 // Per bucket, pruned scan: what its successor-byte groups add to the plan (k_fine_count -> k_fine_plan -> k_fine_scatter).

@@ -2186,13 +2186,40 @@ __global__ __launch_bounds__(64, 8) void k_replay(ImageView v, Workspace ws, con
 
 // Guides with kReplayLds < hits <= kMidHits (on skewed data four guides in ten): one 256-thread workgroup each, the terms
 // k_verify left fetched by the hit's index.  One slice at a time, as the reference walks them (:330): the slice's keys are
-// gathered into LDS, every thread ranks up to four of them by counting (no barrier inside: a bitonic network over 2048
-// keys costs 66 barrier-separated stages, 170 us per guide), fetches their terms -- all of the slice's at once -- and
-// drops them at their ranks; wave 0 then walks the terms in LDS.  Such a guide usually leaves through the early exit
-// (:467-496) inside its first slice (median: 295 hits walked of 1024 found), and the slices behind the exit are never
-// touched.  A guide with a slice of more than kMidSlice hits is handed on to k_replay_big (second list).
+// gathered into LDS, ranked by counting (no barrier inside: a bitonic network over 2048 keys costs 66 barrier-separated
+// stages, 170 us per guide), their terms fetched -- all of the slice's at once -- and dropped at their ranks; wave 0 then
+// walks the terms in LDS.  Such a guide usually leaves through the early exit (:467-496) inside its first slice (median:
+// 295 hits walked of 1024 found), and the slices behind the exit are never touched.  A guide with a slice of more than
+// kMidSlice hits is handed on to k_replay_big (second list).
+// Round 4, later: (a) a slice of more than kMidDirect hits is ranked INSIDE 256 groups of the range its ids span (one
+// counting pass in LDS puts the ids in group order first): len * len / 256 comparisons on evenly spread ids instead of
+// len * len -- the kernel was bound by the vector instructions of the all-against-all count (0.67 G of them per 100 k guides
+// of the skewed index); (b) the workgroups take the entries of the guide list one at a time from a device-wide ticket
+// (asked for one guide ahead), not every gridDim-th entry: the 2048 workgroups are not all resident (7 per CU), and the
+// stragglers of a static split ran alone on an empty chip for a quarter of the launch.
 constexpr uint32_t kMidSlice = 1024;
-__global__ __launch_bounds__(256) void k_replay_mid(ImageView v, Workspace ws, const uint64_t *__restrict__ guides,
+constexpr uint32_t kMidDirect = 256;  // up to this many hits in a slice: ranked against all of them, one per thread
+// The next entry of the many-hit guide list for this workgroup (`which`: Counters::replay_next), handed to all its threads
+// through LDS; the ticket after it is asked for at once, so that its round trip runs beside the guide's work.  (Two LDS
+// words, used in turn: a wave that is late reading this guide's entry must not find the next one's there.)
+struct ReplayTicket {
+    uint32_t next = 0, turn = 0;
+};
+__device__ __forceinline__ uint32_t replay_take(ReplayTicket &t, uint32_t *cur /*LDS[2]*/, Counters *counters, uint32_t which,
+                                                bool first)
+{
+    if (threadIdx.x == 0) {
+        if (first) t.next = atomicAdd(&counters->replay_next[which], 1u);
+        cur[t.turn] = t.next;
+    }
+    __syncthreads();
+    const uint32_t b = cur[t.turn];
+    t.turn ^= 1u;
+    if (threadIdx.x == 0) t.next = atomicAdd(&counters->replay_next[which], 1u);
+    return b;
+}
+
+__global__ __launch_bounds__(256, 6) void k_replay_mid(ImageView v, Workspace ws, const uint64_t *__restrict__ guides,
                                                     ScoreParams p, double *__restrict__ out_mit,
                                                     double *__restrict__ out_cfd, uint32_t *__restrict__ out_kept,
                                                     issl_hit *__restrict__ out_hits)
@@ -2200,9 +2227,11 @@ __global__ __launch_bounds__(256) void k_replay_mid(ImageView v, Workspace ws, c
     short_kernel_priority();
     __shared__ __attribute__((aligned(16))) uint32_t head[kMidSlice]; // the slice's keys: site ids or positions (distinct) ...
     __shared__ uint16_t head_idx[kMidSlice];                           // ... and the index of the hit each belongs to
-    __shared__ __attribute__((aligned(16))) double2 tmc[kMidSlice];    // its terms {mit, cfd} in key order
+    __shared__ __attribute__((aligned(16))) double2 tmc[kMidSlice];    // its terms {mit, cfd} in key order (before that: the
+                                                                       // slice's ids and hit indexes in group order)
     __shared__ uint32_t slice_cnt[kMaxSlices];
-    __shared__ uint32_t head_fill, stopped_s, carry_kept;
+    __shared__ uint32_t group_at[257], group_cur[256], id_min, id_max;
+    __shared__ uint32_t head_fill, stopped_s, carry_kept, cur_entry[2];
     __shared__ double carry_mit, carry_cfd;
     const bool calc_mit = p.method == ISSL_METHOD_MIT || p.method == ISSL_METHOD_AND || p.method == ISSL_METHOD_OR ||
                           p.method == ISSL_METHOD_AVG;
@@ -2211,7 +2240,10 @@ __global__ __launch_bounds__(256) void k_replay_mid(ImageView v, Workspace ws, c
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n_big = ws.counters->n_big;
     const double2 *__restrict__ terms2 = reinterpret_cast<const double2 *>(ws.terms);
-    for (uint32_t b = blockIdx.x; b < n_big; b += gridDim.x) {
+    ReplayTicket ticket;
+    for (bool first = true;; first = false) {
+        const uint32_t b = replay_take(ticket, cur_entry, ws.counters, 0u, first);
+        if (b >= n_big) break;
         const uint32_t g = ws.gcur_big[b];
         const uint32_t h = ws.gcount[g];
         if (h > kMidHits) continue; // k_replay_big's (uniform over the workgroup)
@@ -2257,8 +2289,11 @@ __global__ __launch_bounds__(256) void k_replay_mid(ImageView v, Workspace ws, c
         for (uint32_t s2 = 0; s2 < v.n_slices; ++s2) {
             const uint32_t len = slice_cnt[s2];
             if (len == 0) continue;
-            if (threadIdx.x == 0) head_fill = 0;
+            const bool grouped_rank = len > kMidDirect; // (uniform)
+            if (threadIdx.x == 0) { head_fill = 0; id_min = 0xFFFFFFFFu; id_max = 0u; }
+            group_cur[threadIdx.x] = 0;
             __syncthreads();
+            uint32_t mn = 0xFFFFFFFFu, mx = 0u;
 #pragma unroll
             for (uint32_t k = 0; k < kMidHits / 256; ++k) { // gather the slice's keys (one cursor bump per wave)
                 if (k * 256u >= h) break;
@@ -2271,38 +2306,101 @@ __global__ __launch_bounds__(256) void k_replay_mid(ImageView v, Workspace ws, c
                 at = __builtin_amdgcn_readfirstlane(at);
                 if (mine) {
                     const uint32_t to = at + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mm >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mm), 0u));
-                    head[to] = static_cast<uint32_t>(key);
+                    const uint32_t id = static_cast<uint32_t>(key);
+                    head[to] = id;
                     head_idx[to] = static_cast<uint16_t>(k * 256u + threadIdx.x);
+                    mn = id < mn ? id : mn;
+                    mx = id > mx ? id : mx;
                 }
             }
+            if (grouped_rank && mn <= mx) { atomicMin(&id_min, mn); atomicMax(&id_max, mx); } // the range the slice's ids span
             __syncthreads();
-            if (threadIdx.x < 4u && len + threadIdx.x < ((len + 3u) & ~3u)) head[len + threadIdx.x] = 0xFFFFFFFFu; // (read four at a time)
-            __syncthreads();
-            {   // rank by counting (the keys are distinct: ids / positions are), then the terms to their ranks
-                uint32_t mine[4], rk[4] = {0, 0, 0, 0};
-#pragma unroll
-                for (uint32_t k = 0; k < 4; ++k) mine[k] = threadIdx.x + k * 256u < len ? head[threadIdx.x + k * 256u] : 0xFFFFFFFFu;
+            if (!grouped_rank) {
+                if (threadIdx.x < 4u && len + threadIdx.x < ((len + 3u) & ~3u)) head[len + threadIdx.x] = 0xFFFFFFFFu; // (read four at a time)
+                __syncthreads();
+                // rank by counting against the whole slice (the keys are distinct: ids / positions are), then the terms to
+                // their ranks; len <= kMidDirect <= 256: one key per thread
+                const uint32_t mine = threadIdx.x < len ? head[threadIdx.x] : 0xFFFFFFFFu;
+                uint32_t rk = 0;
                 const uint4 *quads = reinterpret_cast<const uint4 *>(head);
 #pragma unroll 4
                 for (uint32_t j = 0; j < (len + 3u) / 4u; ++j) {
                     const uint4 q = quads[j];
-#pragma unroll
-                    for (uint32_t k = 0; k < 4; ++k)
-                        rk[k] += (q.x < mine[k] ? 1u : 0u) + (q.y < mine[k] ? 1u : 0u) + (q.z < mine[k] ? 1u : 0u) + (q.w < mine[k] ? 1u : 0u);
+                    rk += (q.x < mine ? 1u : 0u) + (q.y < mine ? 1u : 0u) + (q.z < mine ? 1u : 0u) + (q.w < mine ? 1u : 0u);
                 }
-#pragma unroll
-                for (uint32_t k = 0; k < 4; ++k) {
-                    if (threadIdx.x + k * 256u >= len) continue;
-                    const uint32_t idx = head_idx[threadIdx.x + k * 256u];
+                if (threadIdx.x < len) {
+                    const uint32_t idx = head_idx[threadIdx.x];
                     const double2 t2 = idx < in_slots ? *reinterpret_cast<const double2 *>(&srec[idx].mit) : terms2[h0 + idx];
-                    tmc[rk[k]] = t2;
+                    tmc[rk] = t2;
                     if (out_hits)
-                        out_hits[h0 + walked + rk[k]] = hit_terms(v, gsig, g, (static_cast<uint64_t>(g) << kKeyGuideShift) |
-                                                                      (static_cast<uint64_t>(s2) << kKeySliceShift) | mine[k],
-                                                                  calc_mit, calc_cfd, true).rec;
+                        out_hits[h0 + walked + rk] = hit_terms(v, gsig, g, (static_cast<uint64_t>(g) << kKeyGuideShift) |
+                                                                   (static_cast<uint64_t>(s2) << kKeySliceShift) | mine,
+                                                               calc_mit, calc_cfd, true).rec;
                 }
-                if (threadIdx.x < 8u && len + threadIdx.x < ((len + 7u) & ~7u)) tmc[len + threadIdx.x] = make_double2(0.0, 0.0); // (walked eight at a time)
+            } else {
+                // Ranked inside 256 groups of the range the ids span (the hits of a guide in one slice share the slice's bases:
+                // on a text-sorted index their ids lie in a narrow range far from zero): group sizes, their prefix, the ids and
+                // hit indexes in group order (in the memory the terms will take), then every id against its own group only.
+                const uint32_t low = id_min, top = id_max - low;
+                const uint32_t shift = top < 256u ? 0u : 24u - static_cast<uint32_t>(__builtin_clz(top)); // (id - low) >> shift < 256
+#pragma unroll
+                for (uint32_t k = 0; k < kMidSlice / 256; ++k)
+                    if (threadIdx.x + k * 256u < len) atomicAdd(&group_cur[(head[threadIdx.x + k * 256u] - low) >> shift], 1u);
+                __syncthreads();
+                if (threadIdx.x < 64) { // exclusive scan of the 256 group sizes by one wave, 4 per lane; the cursors start there
+                    uint32_t v4[4], sum = 0;
+                    for (uint32_t k = 0; k < 4; ++k) { v4[k] = group_cur[threadIdx.x * 4 + k]; sum += v4[k]; }
+                    uint32_t x = sum;
+                    for (uint32_t d = 1; d < 64; d <<= 1) {
+                        const uint32_t y = __shfl_up(x, d, 64);
+                        if (threadIdx.x >= d) x += y;
+                    }
+                    uint32_t run = x - sum;
+                    for (uint32_t k = 0; k < 4; ++k) { group_at[threadIdx.x * 4 + k] = run; group_cur[threadIdx.x * 4 + k] = run; run += v4[k]; }
+                    if (threadIdx.x == 63) group_at[256] = run;
+                }
+                __syncthreads();
+                uint32_t *ids2 = reinterpret_cast<uint32_t *>(tmc);                 // [kMidSlice]
+                uint16_t *idx2 = reinterpret_cast<uint16_t *>(ids2 + kMidSlice);    // [kMidSlice]
+#pragma unroll
+                for (uint32_t k = 0; k < kMidSlice / 256; ++k) {
+                    const uint32_t i = threadIdx.x + k * 256u;
+                    if (i >= len) continue;
+                    const uint32_t id = head[i];
+                    const uint32_t to = atomicAdd(&group_cur[(id - low) >> shift], 1u);
+                    ids2[to] = id;
+                    idx2[to] = head_idx[i];
+                }
+                __syncthreads();
+                // every id against its own group; id and hit index go to the id's rank (`head`, `head_idx`: their first contents
+                // are in group order now), so that nothing is carried across the barrier but the arrays
+#pragma unroll
+                for (uint32_t k = 0; k < kMidSlice / 256; ++k) {
+                    const uint32_t i = threadIdx.x + k * 256u;
+                    if (i < len) {
+                        const uint32_t id = ids2[i];
+                        const uint32_t g0 = group_at[(id - low) >> shift], g1 = group_at[((id - low) >> shift) + 1u];
+                        uint32_t r = g0;
+                        for (uint32_t j = g0; j < g1; ++j) r += ids2[j] < id ? 1u : 0u;
+                        head[r] = id;
+                        head_idx[r] = idx2[i];
+                    }
+                }
+                __syncthreads(); // (everybody has read the ids in group order: the terms may land on them)
+#pragma unroll
+                for (uint32_t k = 0; k < kMidSlice / 256; ++k) {
+                    const uint32_t i = threadIdx.x + k * 256u;
+                    if (i < len) {
+                        const uint32_t idx = head_idx[i];
+                        tmc[i] = idx < in_slots ? *reinterpret_cast<const double2 *>(&srec[idx].mit) : terms2[h0 + idx];
+                        if (out_hits)
+                            out_hits[h0 + walked + i] = hit_terms(v, gsig, g, (static_cast<uint64_t>(g) << kKeyGuideShift) |
+                                                                      (static_cast<uint64_t>(s2) << kKeySliceShift) | head[i],
+                                                                  calc_mit, calc_cfd, true).rec;
+                    }
+                }
             }
+            if (threadIdx.x < 8u && len + threadIdx.x < ((len + 7u) & ~7u)) tmc[len + threadIdx.x] = make_double2(0.0, 0.0); // (walked eight at a time)
             __syncthreads();
             if (st && threadIdx.x == 0 && walked == 0) { st[3] = __builtin_amdgcn_s_memrealtime(); st[4] = len; }
             if (threadIdx.x < 64) { // wave 0 walks the slice
@@ -2418,7 +2516,7 @@ __device__ __forceinline__ void rank_sort_slice_grouped(const uint32_t *pos_lds,
 // hits in parallel, let wave 0 add them up in key order with the reference's running totals and early exit.
 constexpr uint32_t kBigSmall = 16384;
 template <uint32_t THREADS, uint32_t LDS_HITS>
-__global__ __launch_bounds__(THREADS) void k_replay_big(ImageView v, Workspace ws, const uint64_t *__restrict__ guides,
+__global__ __launch_bounds__(THREADS, THREADS < 1024u ? 6 : 4) void k_replay_big(ImageView v, Workspace ws, const uint64_t *__restrict__ guides,
                                                      ScoreParams p, double *__restrict__ out_mit,
                                                      double *__restrict__ out_cfd, uint32_t *__restrict__ out_kept,
                                                      issl_hit *__restrict__ out_hits)
@@ -2436,7 +2534,11 @@ __global__ __launch_bounds__(THREADS) void k_replay_big(ImageView v, Workspace w
                           p.method == ISSL_METHOD_AVG;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n_big = ws.counters->n_big, n_big2 = ws.counters->n_big2;
-    for (uint32_t b = blockIdx.x; b < n_big + n_big2; b += gridDim.x) {
+    __shared__ uint32_t cur_entry[2];
+    ReplayTicket ticket;
+    for (bool first = true;; first = false) { // (entries by ticket, as in k_replay_mid)
+        const uint32_t b = replay_take(ticket, cur_entry, ws.counters, THREADS < 1024u ? 1u : 2u, first);
+        if (b >= n_big + n_big2) break;
         // first the list of all guides with more than kReplayLds hits, then the ones k_replay_mid handed on
         const bool handed_on = b >= n_big;
         const uint32_t g = handed_on ? ws.gcur_big2[b - n_big] : ws.gcur_big[b];
