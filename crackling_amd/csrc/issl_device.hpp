@@ -276,7 +276,8 @@ struct PlanInfo {
 struct Counters {
     uint32_t next_range;  // ticket counter of the scan's dynamic tail
     uint32_t n_big;       // guides with more than kReplayLds hits (the list k_replay_mid and k_replay_big share)
-    uint32_t n_big2;      // guides k_replay_mid hands on to k_replay_big (a slice too long for its buffers)
+    uint32_t n_big2;      // guides k_replay_mid passes on to the 256-thread k_replay_big: more than kMidHits hits, or a slice too long for its buffers
+    uint32_t n_big3;      // ... to the 1024-thread build (more than kBigSmall hits): listed from the far end of the same array
     uint32_t raw_chunks;  // chunks of the raw record buffer handed out
     uint32_t raw_overflow; // set when the raw buffer was too small
     uint32_t overflowed;  // hit slots: guides with more than kReplayLds hits (k_verify); 0 = nothing to group, no many-hit replay
@@ -349,7 +350,7 @@ struct Workspace {
     uint32_t *gcount = nullptr;  // [G+1] hits per guide
     uint32_t *goff = nullptr;    // [G+1] exclusive prefix
     uint32_t *gcur_big = nullptr; // [G] guides with more than kReplayLds hits
-    uint32_t *gcur_big2 = nullptr; // [G] ... that k_replay_mid hands on to k_replay_big
+    uint32_t *gcur_big2 = nullptr; // [G + 1] ... that k_replay_mid passes on to k_replay_big (Counters::n_big2 from the front, n_big3 from the back)
     double *terms = nullptr;     // [2 * hit_cap] MIT/CFD terms of the hits, grouped by guide like `sorted`
     double *pay = nullptr;       // [2 * hit_cap] the same terms as k_verify computed them, by raw-record slot
     uint32_t *rank = nullptr;    // [hit_cap] place of a surviving raw record inside its guide's segment, by raw-record slot

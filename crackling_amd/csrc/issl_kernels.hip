@@ -2198,6 +2198,7 @@ __global__ __launch_bounds__(64, 8) void k_replay(ImageView v, Workspace ws, con
 // (asked for one guide ahead), not every gridDim-th entry: the 2048 workgroups are not all resident (7 per CU), and the
 // stragglers of a static split ran alone on an empty chip for a quarter of the launch.
 constexpr uint32_t kMidSlice = 1024;
+constexpr uint32_t kBigSmall = 16384; // up to this many hits of a guide: the 256-thread build of k_replay_big
 constexpr uint32_t kMidDirect = 256;  // up to this many hits in a slice: ranked against all of them, one per thread
 // The next entry of the many-hit guide list for this workgroup (`which`: Counters::replay_next), handed to all its threads
 // through LDS; the ticket after it is asked for at once, so that its round trip runs beside the guide's work.  (Two LDS
@@ -2246,7 +2247,13 @@ __global__ __launch_bounds__(256, 6) void k_replay_mid(ImageView v, Workspace ws
         if (b >= n_big) break;
         const uint32_t g = ws.gcur_big[b];
         const uint32_t h = ws.gcount[g];
-        if (h > kMidHits) continue; // k_replay_big's (uniform over the workgroup)
+        if (h > kMidHits) { // (uniform) k_replay_big's: onto the list of its 256-thread build, or -- from the far end of the same array -- of the other
+            if (threadIdx.x == 0) {
+                if (h <= kBigSmall) ws.gcur_big2[atomicAdd(&ws.counters->n_big2, 1u)] = g;
+                else ws.gcur_big2[static_cast<uint32_t>(ws.cap_guides) - atomicAdd(&ws.counters->n_big3, 1u)] = g;
+            }
+            continue;
+        }
         const uint32_t h0 = ws.goff[g];
         const uint64_t gsig = guides[g];
         // hit i of the guide: in its hit slots below slot_hits, in its segment of the grouped arrays from there on
@@ -2514,7 +2521,6 @@ __device__ __forceinline__ void rank_sort_slice_grouped(const uint32_t *pos_lds,
 // Guides with many hits (dense neighbourhoods, repeats): one 1024-thread workgroup each, one slice at a time: sort
 // the slice's keys (by counting in LDS up to 8192 per slice, else a bitonic network in HBM), compute the terms of its
 // hits in parallel, let wave 0 add them up in key order with the reference's running totals and early exit.
-constexpr uint32_t kBigSmall = 16384;
 template <uint32_t THREADS, uint32_t LDS_HITS>
 __global__ __launch_bounds__(THREADS, THREADS < 1024u ? 6 : 4) void k_replay_big(ImageView v, Workspace ws, const uint64_t *__restrict__ guides,
                                                      ScoreParams p, double *__restrict__ out_mit,
@@ -2525,6 +2531,7 @@ __global__ __launch_bounds__(THREADS, THREADS < 1024u ? 6 : 4) void k_replay_big
     __shared__ __attribute__((aligned(16))) uint32_t pos_lds[LDS_HITS];
     __shared__ uint32_t grouped[LDS_HITS];
     __shared__ uint32_t group_at[257], group_cur[256], max_pos, min_pos;
+    __shared__ uint32_t outer_at[257]; // a slice beyond the LDS: where its 256 id groups start once it is in group order
     __shared__ uint32_t slice_cnt[kMaxSlices], slice_off[kMaxSlices + 1], slice_cur[kMaxSlices];
     __shared__ uint32_t walk_stopped, head_groups, head_count, head_fill;
     __shared__ __attribute__((aligned(16))) double2 walk_terms[64]; // wave 0: the terms of the 64 hits it is adding up
@@ -2533,26 +2540,26 @@ __global__ __launch_bounds__(THREADS, THREADS < 1024u ? 6 : 4) void k_replay_big
     const bool calc_cfd = p.method == ISSL_METHOD_CFD || p.method == ISSL_METHOD_AND || p.method == ISSL_METHOD_OR ||
                           p.method == ISSL_METHOD_AVG;
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t n_big = ws.counters->n_big, n_big2 = ws.counters->n_big2;
+    // The guides of this build: a list k_replay_mid has made while it went through the shared one (more than kMidHits hits, or
+    // handed on; the 1024-thread build's from the far end of the array).  (Each build used to walk the whole shared list and skip
+    // what was not its own: 40 k entries of three dependent loads each, for the few dozen guides of the 1024-thread build.)
+    const uint32_t n_mine = THREADS < 1024u ? ws.counters->n_big2 : ws.counters->n_big3;
     __shared__ uint32_t cur_entry[2];
     ReplayTicket ticket;
     for (bool first = true;; first = false) { // (entries by ticket, as in k_replay_mid)
         const uint32_t b = replay_take(ticket, cur_entry, ws.counters, THREADS < 1024u ? 1u : 2u, first);
-        if (b >= n_big + n_big2) break;
-        // first the list of all guides with more than kReplayLds hits, then the ones k_replay_mid handed on
-        const bool handed_on = b >= n_big;
-        const uint32_t g = handed_on ? ws.gcur_big2[b - n_big] : ws.gcur_big[b];
+        if (b >= n_mine) break;
+        const uint32_t g = THREADS < 1024u ? ws.gcur_big2[b] : ws.gcur_big2[static_cast<uint32_t>(ws.cap_guides) - b];
         const uint32_t h = ws.gcount[g];
         const uint32_t h0 = ws.goff[g];
         // k_replay_mid's, or the other build's: up to kBigSmall hits a 256-thread workgroup with 2048 hits per slice in
         // LDS (eight per CU: what such a guide costs is a chain of barriers and memory round trips, and what counts is
         // how many are in flight), beyond that 1024 threads with 7680 (two per CU).  (uniform over the workgroup)
-        if ((h <= kMidHits && !handed_on) || (h <= kBigSmall) != (THREADS < 1024u)) continue;
         const uint64_t gsig = guides[g];
         uint64_t *seg = ws.sorted + h0;
         uint64_t *tmp = ws.raw + h0; // the raw records are dead once they are grouped; the buffer holds >= all hits
         // diagnostics (ISSL_SCAN_STAMPS, tools/replay_stamps.py): phase clocks of the first 4096 big guides
-        unsigned long long *st = (ws.stamps && b < 4096u) ? ws.stamps + 65536u + 16u * b : nullptr;
+        unsigned long long *st = (ws.stamps && b < 4096u) ? ws.stamps + (THREADS < 1024u ? 131072u : 196608u) + 16u * b : nullptr; // (behind k_replay_mid's)
         if (st && threadIdx.x == 0) { st[0] = __builtin_amdgcn_s_memrealtime(); st[1] = h; st[15] = blockIdx.x; }
 
         // The scoring order is (slice, position in bucket) and the walk usually ends inside the first slice (the
@@ -2640,12 +2647,13 @@ __global__ __launch_bounds__(THREADS, THREADS < 1024u ? 6 : 4) void k_replay_big
                     if (walk_stopped != 0u) break; // uniform
                 }
             };
-            auto sort_in_lds = [&](uint32_t n) { // pos_lds[0 .. n) -> dst[0 .. n) in key order
-                if (n <= THREADS) rank_sort_slice<1, THREADS>(pos_lds, n, high_bits, dst);
-                else rank_sort_slice_grouped(pos_lds, grouped, group_at, group_cur, &max_pos, &min_pos, n, high_bits, dst);
+            auto sort_in_lds = [&](uint32_t n, uint64_t *out) { // pos_lds[0 .. n) -> out[0 .. n) in key order
+                if (n <= THREADS) rank_sort_slice<1, THREADS>(pos_lds, n, high_bits, out);
+                else rank_sort_slice_grouped(pos_lds, grouped, group_at, group_cur, &max_pos, &min_pos, n, high_bits, out);
                 __syncthreads();
             };
             uint32_t walked = 0;
+            uint32_t g_low = 0, g_shift = 0, g_done = 0; // the id groups of the head pass: (id - g_low) >> g_shift; the first g_done are walked
             if (threadIdx.x == 0) walk_stopped = 0;
             __syncthreads();
             if (len > THREADS) {
@@ -2675,6 +2683,7 @@ __global__ __launch_bounds__(THREADS, THREADS < 1024u ? 6 : 4) void k_replay_big
                 }
                 __syncthreads();
                 const uint32_t nb = head_groups, cnt = head_count;
+                g_low = low; g_shift = shift;
                 constexpr uint32_t kHeadMax = 4u * THREADS < LDS_HITS ? 4u * THREADS : LDS_HITS; // what rank_sort_slice<4> takes
                 if (cnt <= kHeadMax && cnt < len) {
                     for (uint32_t i = threadIdx.x; i < len; i += blockDim.x) {
@@ -2689,6 +2698,7 @@ __global__ __launch_bounds__(THREADS, THREADS < 1024u ? 6 : 4) void k_replay_big
                     __syncthreads();
                     walk(0u, cnt);
                     walked = cnt;
+                    g_done = nb;
                 }
             }
             if (walk_stopped == 0u && walked < len) { // (uniform) the whole slice in key order
@@ -2696,12 +2706,53 @@ __global__ __launch_bounds__(THREADS, THREADS < 1024u ? 6 : 4) void k_replay_big
                     for (uint32_t i = threadIdx.x; i < ((len + 3u) & ~3u); i += blockDim.x)
                         pos_lds[i] = i < len ? static_cast<uint32_t>(tmp[off + i]) : 0xFFFFFFFFu;
                     __syncthreads();
-                    sort_in_lds(len);
+                    sort_in_lds(len, dst);
                 } else {
-                    for (uint32_t i = threadIdx.x; i < len; i += blockDim.x) dst[i] = tmp[off + i];
+                    // A slice beyond the LDS.  Its keys go into group order first -- the 256 groups of the range its ids span
+                    // that the head pass counted (group_cur), one pass with the cursors in LDS --, then run after run of
+                    // consecutive groups that fit the LDS is sorted there and walked: the exit (:467-496) usually comes before
+                    // the second run, and no run costs more than a slice that fits.  (A bitonic network over the whole slice in
+                    // HBM, ~140 stages of memory round trips, set the duration of this kernel before: 0.5 ms per batch on the
+                    // skewed index for a few dozen guides.)  Only a single group beyond the LDS -- ids piled up in 1/256 of the
+                    // range -- still takes the network, alone.
+                    if (threadIdx.x < 64) { // exclusive scan of the 256 group sizes by one wave, 4 per lane; the cursors start there
+                        uint32_t v4[4], sum = 0;
+                        for (uint32_t k = 0; k < 4; ++k) { v4[k] = group_cur[threadIdx.x * 4 + k]; sum += v4[k]; }
+                        uint32_t x = sum;
+                        for (uint32_t d = 1; d < 64; d <<= 1) {
+                            const uint32_t y = __shfl_up(x, d, 64);
+                            if (threadIdx.x >= d) x += y;
+                        }
+                        uint32_t run = x - sum;
+                        for (uint32_t k = 0; k < 4; ++k) { outer_at[threadIdx.x * 4 + k] = run; group_cur[threadIdx.x * 4 + k] = run; run += v4[k]; }
+                        if (threadIdx.x == 63) outer_at[256] = run;
+                    }
                     __syncthreads();
-                    wave_sort(dst, len);
+                    for (uint32_t i = threadIdx.x; i < len; i += blockDim.x) {
+                        const uint64_t key = tmp[off + i];
+                        dst[atomicAdd(&group_cur[(static_cast<uint32_t>(key) - g_low) >> g_shift], 1u)] = key;
+                    }
                     __syncthreads();
+                    for (uint32_t g_lo = g_done; g_lo < 256u;) { // (uniform: every thread reads the same LDS words)
+                        const uint32_t start = outer_at[g_lo];
+                        uint32_t g_hi = g_lo + 1u;
+                        while (g_hi < 256u && outer_at[g_hi + 1u] - start <= LDS_HITS) ++g_hi;
+                        const uint32_t n = outer_at[g_hi] - start;
+                        g_lo = g_hi;
+                        if (n == 0u) continue;
+                        if (n <= LDS_HITS) {
+                            for (uint32_t i = threadIdx.x; i < ((n + 3u) & ~3u); i += blockDim.x)
+                                pos_lds[i] = i < n ? static_cast<uint32_t>(dst[start + i]) : 0xFFFFFFFFu;
+                            __syncthreads();
+                            sort_in_lds(n, dst + start);
+                        } else {
+                            wave_sort(dst + start, n);
+                            __syncthreads();
+                        }
+                        walk(start, start + n);
+                        if (walk_stopped != 0u) break;
+                    }
+                    walked = len; // (nothing is left for the walk below)
                 }
             }
             if (st && threadIdx.x == 0 && s2 == 0) st[5] = __builtin_amdgcn_s_memrealtime();

@@ -574,6 +574,16 @@ def test_guides_with_thousands_of_hits(tmp_path):
             s ^= int(rng.integers(1, 4)) << (2 * (4 + int(p)))
         wide.add(s)
     sites |= wide
+    # ... and one with more than 16384 hits, 20 000 of them in slice 0: the 1024-thread build of k_replay_big, whose LDS
+    # takes 7680 hits of a slice -- the slice is walked in runs of id groups that fit (without early exit: all of them)
+    centres = np.append(centres, rng.integers(0, 1 << 40, dtype=np.uint64))
+    wider = set()
+    while len(wider) < 20000:
+        s = int(centres[5])
+        for p in rng.choice(16, size=int(rng.integers(1, 5)), replace=False):
+            s ^= int(rng.integers(1, 4)) << (2 * (4 + int(p)))
+        wider.add(s)
+    sites |= wider
     sites |= set(int(x) for x in rng.integers(0, 1 << 40, size=20000, dtype=np.uint64))
     sig = np.array(sorted(sites), dtype=np.uint64)
     sig = sig[np.argsort(text_order_key(sig), kind="stable")]
@@ -595,7 +605,8 @@ def test_guides_with_thousands_of_hits(tmp_path):
     assert np.array_equal(hits, ohits)
     per_guide = np.bincount(hits[:, 0], minlength=len(guides))
     assert per_guide.max() > 2048 and per_guide[1] > 512 and 64 < per_guide[3] <= 512 and per_guide[2] <= 64
-    assert np.count_nonzero((hits[:, 0] == 4) & (hits[:, 1] == 0)) > 7680  # the HBM sort of one slice
+    assert np.count_nonzero((hits[:, 0] == 4) & (hits[:, 1] == 0)) > 7680  # a slice beyond the LDS of either build
+    assert per_guide[5] > 16384 and np.count_nonzero((hits[:, 0] == 5) & (hits[:, 1] == 0)) > 2 * 7680
     for thr in (50.0, 75.0, 99.0):   # ... and the hits scored before the early exit (the head of such a slice is tried first)
         _, _, ohits = oracle.score(guides, 4, thr, "and", want_hits=True)
         assert np.array_equal(ix.dump_hits(guides, 4, thr, "and"), ohits), thr

@@ -14,3 +14,16 @@ for name, x in (("keys + slice counts", us(a[:, 2] - a[:, 0])), ("first slice ga
     print(f"{name:44s} p50 {np.median(x):7.1f} p90 {np.percentile(x, 90):7.1f} max {x.max():7.1f} us")
 wg = a[:, 15]
 print("guides per workgroup among the stamped:", np.bincount(np.bincount(wg)).tolist()[:6])
+# where the slow first phases are: by start time inside the launch, by hits, by position in the workgroup's sequence
+t0 = a[:, 0].min()
+start = us(a[:, 0] - t0)
+ph1 = us(a[:, 2] - a[:, 0])
+print("launch span of the stamped guides: %.0f us" % us(a[:, 7].max() - t0))
+for lo, hi in ((0, 50), (50, 200), (200, 400), (400, 800), (800, 1e9)):
+    m = (start >= lo) & (start < hi)
+    if m.any():
+        print(f"  started at {lo:>4.0f}..{hi:<6.0f} us: {m.sum():5d} guides, first phase p50 {np.median(ph1[m]):6.1f} p90 {np.percentile(ph1[m], 90):6.1f}, total p50 {np.median(us(a[m, 7] - a[m, 0])):6.1f}")
+for lo, hi in ((512, 768), (768, 1024), (1024, 1536), (1536, 2049)):
+    m = (a[:, 1] >= lo) & (a[:, 1] < hi)
+    if m.any():
+        print(f"  hits {lo:>4d}..{hi:<4d}: {m.sum():5d} guides, first phase p50 {np.median(ph1[m]):6.1f} p90 {np.percentile(ph1[m], 90):6.1f}, total p50 {np.median(us(a[m, 7] - a[m, 0])):6.1f} p90 {np.percentile(us(a[m, 7] - a[m, 0]), 90):6.1f}")

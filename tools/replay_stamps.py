@@ -3,10 +3,11 @@
 scan's records: start, hits, after partition, slice-0 start, its length, after its sort, after its terms, end, kept).
 
     ISSL_SCAN_STAMPS=/tmp/st.bin python bench.py --dist markov --steps 5 --warmup 3 --no-cpu-baseline
-    python tools/replay_stamps.py /tmp/st.bin
+    python tools/replay_stamps.py /tmp/st.bin [1024]      (the 256-thread build's guides, or the 1024-thread build's)
 """
 import numpy as np, sys
-a=np.fromfile(sys.argv[1],dtype=np.uint64)[65536:65536+16*4096].reshape(-1,16).astype(np.int64)
+base = 196608 if len(sys.argv) > 2 and sys.argv[2] == '1024' else 131072
+a=np.fromfile(sys.argv[1],dtype=np.uint64)[base:base+16*4096].reshape(-1,16).astype(np.int64)
 a=a[a[:,0]>0]
 t0=a[:,0].min()
 print("guides",len(a))
