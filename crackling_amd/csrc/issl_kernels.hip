@@ -2241,6 +2241,7 @@ __global__ __launch_bounds__(256, 6) void k_replay_mid(ImageView v, Workspace ws
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n_big = ws.counters->n_big;
     const double2 *__restrict__ terms2 = reinterpret_cast<const double2 *>(ws.terms);
+    if (blockIdx.x >= n_big) return; // (more workgroups than entries -- on an even index there are none: no ticket is taken)
     ReplayTicket ticket;
     for (bool first = true;; first = false) {
         const uint32_t b = replay_take(ticket, cur_entry, ws.counters, 0u, first);
@@ -2545,6 +2546,7 @@ __global__ __launch_bounds__(THREADS, THREADS < 1024u ? 6 : 4) void k_replay_big
     // what was not its own: 40 k entries of three dependent loads each, for the few dozen guides of the 1024-thread build.)
     const uint32_t n_mine = THREADS < 1024u ? ws.counters->n_big2 : ws.counters->n_big3;
     __shared__ uint32_t cur_entry[2];
+    if (blockIdx.x >= n_mine) return; // (more workgroups than entries: no ticket is taken)
     ReplayTicket ticket;
     for (bool first = true;; first = false) { // (entries by ticket, as in k_replay_mid)
         const uint32_t b = replay_take(ticket, cur_entry, ws.counters, THREADS < 1024u ? 1u : 2u, first);
