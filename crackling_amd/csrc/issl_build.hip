@@ -27,14 +27,14 @@ struct SliceEntry {
 };
 
 // ---- sorted layouts: every bucket's candidates ordered by the byte of the successor slice ------------------------
-// One slice at a time (16 B per site of temporary memory): key = (slice << 16 | own byte << 8 | successor byte) << 40 |
-// index of the list entry.  A slice's lists are already grouped by own byte; two stable 8-bit passes (successor byte,
+// One slice at a time (16 B per site of temporary memory): key = (slice << 16 | own value << 8 | successor byte) << 40 |
+// index of the list entry (the successor byte: succ_byte -- the next slice of five 8-bit ones, the next two of ten 4-bit ones).  A slice's lists are already grouped by own byte; two stable 8-bit passes (successor byte,
 // own byte) leave them grouped and order every bucket by successor byte, ties in list order.
 constexpr uint32_t kKeyShift = 40;
 
 __global__ __launch_bounds__(256) void k_sort_keys(const uint64_t *__restrict__ sites, const uint64_t *__restrict__ list,
                                                    const uint64_t *__restrict__ bucket_start, uint64_t n_sites,
-                                                   uint32_t n_slices, uint32_t slice, uint64_t *__restrict__ keys,
+                                                   uint32_t slice_width, uint32_t slice, uint64_t *__restrict__ keys,
                                                    uint32_t *__restrict__ flag)
 {
     const uint64_t e0 = static_cast<uint64_t>(slice) * n_sites; // every slice lists every site once
@@ -43,12 +43,12 @@ __global__ __launch_bounds__(256) void k_sort_keys(const uint64_t *__restrict__ 
         const uint64_t id = list[i] & 0xFFFFFFFFull;
         if (id >= n_sites) atomicOr(flag, 1u); // reported as a format error, like the pack kernel does
         const uint64_t sig = id < n_sites ? sites[id] : 0ull;
-        const uint32_t own = static_cast<uint32_t>(sig >> (8u * slice)) & 0xFFu;
-        const uint32_t succ = static_cast<uint32_t>(sig >> (8u * ((slice + 1u) % n_slices))) & 0xFFu;
+        const uint32_t own = static_cast<uint32_t>(sig >> (slice_width * slice)) & ((1u << slice_width) - 1u);
+        const uint32_t succ = succ_byte(sig, slice, slice_width);
         keys[i] = (static_cast<uint64_t>((slice << 16) | (own << 8) | succ) << kKeyShift) | e;
         // The scoring order of the sorted layouts is (slice, site id): every list must be ascending by id, as the builder
         // writes it (isslCreateIndex.cpp:218-234).  (An entry in the wrong bucket is k_fill_maps' to flag.)
-        if (i > 0 && e > bucket_start[(slice << 8) | own]) {
+        if (i > 0 && e > bucket_start[(slice << slice_width) | own]) {
             const uint64_t before = list[i - 1] & 0xFFFFFFFFull;
             if (before == id) atomicOr(flag, 4u);     // the same site twice: not an index
             else if (before > id) atomicOr(flag, 2u); // valid, but only in list order
@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void k_sort_keys(const uint64_t *__restrict__ 
 
 __global__ __launch_bounds__(256) void k_fill_maps(const uint64_t *__restrict__ keys, const uint64_t *__restrict__ bucket_start,
                                                    const uint32_t *__restrict__ tile_first, const uint64_t *__restrict__ list, uint64_t n_sites, uint32_t slice,
-                                                   const uint64_t *__restrict__ sites, StreamRec *__restrict__ srec,
+                                                   uint32_t slice_width, const uint64_t *__restrict__ sites, StreamRec *__restrict__ srec,
                                                    uint32_t *__restrict__ sid, uint32_t *__restrict__ site_occ,
                                                    uint32_t *__restrict__ flag)
 {
@@ -66,7 +66,8 @@ __global__ __launch_bounds__(256) void k_fill_maps(const uint64_t *__restrict__ 
     for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x; i < n_sites; i += static_cast<uint64_t>(gridDim.x) * 256) {
         const uint64_t key = keys[i];
         const uint64_t e = key & ((1ull << kKeyShift) - 1ull);
-        const uint32_t bucket = static_cast<uint32_t>(key >> (kKeyShift + 8)); // slice << 8 | own byte
+        const uint32_t so = static_cast<uint32_t>(key >> (kKeyShift + 8)); // slice << 8 | own value
+        const uint32_t bucket = ((so >> 8) << slice_width) | (so & 0xFFu);
         // An entry listed in a bucket its signature does not belong to: not an index (see k_pack_scan_stream).
         if (e < bucket_start[bucket] || e >= bucket_start[bucket + 1]) { atomicOr(flag, 4u); continue; }
         const uint32_t p = static_cast<uint32_t>(e - bucket_start[bucket]);
@@ -156,11 +157,12 @@ void SortTemp::release()
 }
 
 int launch_sort_slice(SortTemp &t, const uint64_t *d_sites, const uint64_t *d_list, const uint64_t *d_bucket_start,
-                      const uint32_t *d_tile_first, uint64_t n_sites, uint32_t n_slices, uint32_t n_buckets, uint32_t slice, uint32_t *d_sub_start,
+                      const uint32_t *d_tile_first, uint64_t n_sites, uint32_t n_slices, uint32_t n_buckets, uint32_t slice_width, uint32_t slice, uint32_t *d_sub_start,
                       StreamRec *d_srec, uint32_t *d_sid, uint32_t *d_site_occ, uint32_t *d_flag)
 {
-    if (n_slices == 0 || n_slices > 8 || n_buckets != n_slices * 256u || n_sites >= (1ull << 32) || slice >= n_slices) {
-        set_error("the sorted layout handles up to 8 slices of 8 bits and up to 2^32 - 1 sites");
+    if (!((slice_width == 8 && n_slices == 5) || (slice_width == 4 && n_slices == 10)) || n_buckets != (n_slices << slice_width) ||
+        n_sites >= (1ull << 32) || slice >= n_slices) {
+        set_error("the sorted layout handles 20 positions in five 8-bit or ten 4-bit slices and up to 2^32 - 1 sites");
         return ISSL_E_UNSUPPORTED;
     }
     const uint32_t per_slice = n_buckets / n_slices;
@@ -170,7 +172,7 @@ int launch_sort_slice(SortTemp &t, const uint64_t *d_sites, const uint64_t *d_li
     }
     const uint32_t n_blocks = static_cast<uint32_t>((n_sites + 256ull * kSortItems - 1) / (256ull * kSortItems));
     const uint32_t grid = static_cast<uint32_t>(std::min<uint64_t>((n_sites + 255) / 256, 1u << 20));
-    hipLaunchKernelGGL(k_sort_keys, dim3(grid), dim3(256), 0, nullptr, d_sites, d_list, d_bucket_start, n_sites, n_slices, slice,
+    hipLaunchKernelGGL(k_sort_keys, dim3(grid), dim3(256), 0, nullptr, d_sites, d_list, d_bucket_start, n_sites, slice_width, slice,
                        t.keys, d_flag);
     uint64_t *src = t.keys, *dst = t.tmp;
     for (uint32_t pass = 0; pass < 2; ++pass) { // successor byte, then own byte
@@ -181,8 +183,8 @@ int launch_sort_slice(SortTemp &t, const uint64_t *d_sites, const uint64_t *d_li
                            n_blocks, KeyItself{});
         std::swap(src, dst);
     }
-    hipLaunchKernelGGL(k_fill_maps, dim3(grid), dim3(256), 0, nullptr, src, d_bucket_start, d_tile_first, d_list, n_sites, slice, d_sites,
-                       d_srec, d_sid, d_site_occ, d_flag);
+    hipLaunchKernelGGL(k_fill_maps, dim3(grid), dim3(256), 0, nullptr, src, d_bucket_start, d_tile_first, d_list, n_sites, slice, slice_width,
+                       d_sites, d_srec, d_sid, d_site_occ, d_flag);
     hipLaunchKernelGGL(k_sub_start, dim3((per_slice * 257u + 255u) / 256u), dim3(256), 0, nullptr, src, d_bucket_start,
                        n_sites, slice, per_slice, d_sub_start);
     if (hipGetLastError() != hipSuccess) {

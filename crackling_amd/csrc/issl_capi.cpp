@@ -347,14 +347,14 @@ static int ensure_workspace(issl_index *ix, size_t n, Lane &lane, uint32_t fine_
     if (ix->hdr.off_sub_start && (grew || fine_ways > w.fine_ways)) {
         const size_t cap = w.cap_guides;
         const uint32_t ways = std::max(fine_ways, w.fine_ways);
-        const size_t m = std::min<size_t>(cap, ways > kFineWays ? kPruneMaxGuides2 : kPruneMaxGuides);
+        const size_t m = std::min<size_t>(cap, prune_max_guides(ways > kFineWays ? 3u : 2u, ix->hdr.n_slices));
         const size_t places = m * ix->hdr.n_slices * ways;
         const size_t groups = std::min<size_t>(nb * 256, places);
         const size_t fslots = places + kGuideGroup * groups;
         // one item per tile of a group (and per 512 guides of it): sized from the mean group length (uniform data has
-        // sites / 65536 candidates per group, +1.2 tiles for the ends); a batch that needs more scans whole buckets
+        // sites / 65536 candidates per group -- sites / 4096 with 4-bit slices --, +1.2 tiles for the ends); a batch that needs more scans whole buckets
         // and reports it (sticky[3]), finish_batches() then enlarges the list for the next one
-        const size_t tiles_per_group = static_cast<size_t>(ix->hdr.n_sites / (65536ull * kTileCands)) + 4;
+        const size_t tiles_per_group = static_cast<size_t>(ix->hdr.n_sites * ix->hdr.n_slices / (static_cast<uint64_t>(nb) * 256ull * kTileCands)) + 4;
         const size_t fitems = std::max<size_t>(tiles_per_group * (groups + places / 64) + 2, w.cap_fitems);
         if ((rc = dev_alloc(w.fword, fslots + 64))) return rc; // (+ slack: short_unit_masks reads whole groups of 32 slots)
         if ((rc = dev_alloc(w.fmeta, fslots))) return rc;
@@ -539,7 +539,7 @@ static int finish_upload(issl_index *ix, const DeviceBuildInput *dbi = nullptr)
             }
             src = launch_sort_slice(st, d_sites, d_list, reinterpret_cast<const uint64_t *>(base + ix->hdr.off_bucket_start),
                                     reinterpret_cast<const uint32_t *>(base + ix->hdr.off_tile_first), n,
-                                    static_cast<uint32_t>(g.n_slices), static_cast<uint32_t>(nb),
+                                    static_cast<uint32_t>(g.n_slices), static_cast<uint32_t>(nb), static_cast<uint32_t>(g.slice_width),
                                     static_cast<uint32_t>(sl), reinterpret_cast<uint32_t *>(base + ix->hdr.off_sub_start),
                                     ix->hdr.off_srec ? reinterpret_cast<StreamRec *>(base + ix->hdr.off_srec) : nullptr,
                                     ix->hdr.off_sid ? reinterpret_cast<uint32_t *>(base + ix->hdr.off_sid) : nullptr, d_site_occ, flag);
@@ -646,10 +646,18 @@ static std::vector<LayoutSpec> layout_choices(const Tuning &tn, const Geometry &
 {
     std::vector<LayoutSpec> c;
     auto spec = [](bool esig, uint32_t cold, uint32_t sorted, bool no_lists = false) { LayoutSpec s; s.inline_sigs = esig; s.cold = cold; s.sorted = sorted; s.no_lists = no_lists; return s; };
-    const bool narrow = g.slice_width != 8; // list order in HBM only: the sorted layouts order by a successor BYTE, and the
-                                            // host-cold layout rebuilds signatures from 16 stream positions + the bucket's byte
+    const bool narrow = g.slice_width != 8; // no host-cold layouts (they rebuild signatures from 16 stream positions + the bucket's
+                                            // byte) and no image without its lists (the device-side list builder takes 8-bit slices)
     if (narrow) {
-        if (tn.sorted_layout == 1 || tn.compact == 1 || tn.host_cold == 1 || tn.keep_lists == 0) return c;
+        // 4-bit slices (round 4): the sorted layouts order a bucket by the byte of the NEXT TWO slices (succ_byte), so the pruned
+        // scan applies; 2-bit slices keep to list order (their buckets hold a quarter of the index each)
+        const bool can_sort = g.slice_width == 4 && g.n_slices == 10 && !list_order_only && tn.sorted_layout != 0 && tn.inline_sigs != 1;
+        if (tn.host_cold == 1 || tn.keep_lists == 0) return c;
+        if (can_sort) {
+            if (tn.compact != 1) c.push_back(spec(false, 0, 1));
+            if (tn.compact != 0) c.push_back(spec(false, 0, 2));
+        }
+        if (tn.sorted_layout == 1 || tn.compact == 1) return c;
         if (want_inline_sigs(tn, g)) c.push_back(spec(true, 0, 0));
         if (tn.inline_sigs != 1) c.push_back(spec(false, 0, 0));
         return c;
@@ -1611,7 +1619,7 @@ int issl_score(issl_index *idx, const uint64_t *guides, size_t n, int max_dist, 
     // early when its estimate would not fit a quarter of the free HBM.  Denser data still grows the buffers.
     // (the pruned scan places every guide in up to 65 groups: pieces of at most 2^20 guides while it may be chosen)
     const uint32_t piece_mode = prune_mode_for(idx->view, idx->tuning, 1, max_dist);
-    const size_t piece = piece_mode == 3 ? size_t(kPruneMaxGuides2) : piece_mode ? size_t(kPruneMaxGuides) : size_t(1) << 22;
+    const size_t piece = piece_mode ? size_t(prune_max_guides(piece_mode, idx->view.n_slices)) : size_t(1) << 22;
     const bool presize = !idx->tuning.raw_chunks && n >= (size_t(1) << 15); // small pages: the default buffers do
     const double records_per_comparison = 8e-5;
     size_t free_b = 0, total_b = 0;

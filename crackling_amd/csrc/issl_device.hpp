@@ -90,6 +90,20 @@ static_assert(sizeof(ImageHeader) <= kHeaderBytes, "header must fit its block");
 // Sorted layout: what k_verify needs to know about the candidate at a stream position, in one 16-byte load.
 constexpr uint32_t kOccSaturated = 0xFFFFFFu; // StreamRec (and the site table of the sorted layouts): occurrence counts from here on are looked up
 constexpr uint64_t kSigMask = (1ull << 40) - 1ull; // the 20-mer's bits of a signature word
+
+// The successor unit of slice `s`: the four positions (one byte of 2-bit codes) that follow the slice cyclically -- slice
+// s + 1 of five 8-bit slices, slices s + 1 and s + 2 of ten 4-bit ones.  The sorted layouts order every bucket by it and
+// the pruned scan visits the 13 (1, 67) values within one (no, two) mismatches of a guide's own.  Applied to
+// a word of mismatch flags (one flag per position at bit 2p) it yields the flags of those four positions.
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline uint32_t succ_byte(uint64_t sig, uint32_t s, uint32_t slice_width)
+{
+    const uint32_t sh = (slice_width * (s + 1u)) % 40u;
+    const uint64_t x = sig & kSigMask;
+    return static_cast<uint32_t>(sh ? (x >> sh) | (x << (40u - sh)) : x) & 0xFFu;
+}
 struct alignas(16) StreamRec {
     uint64_t sig;  // packed signature of the site (bits 0..39) | min(occurrences, kOccSaturated) << 40
     uint32_t id;   // site id (low half of the list entry)
@@ -196,7 +210,7 @@ struct SortTemp {
 // slice's part of sub_start, of srec OR sid (the other one null) and -- slice 0 -- site_occ (later slices check their
 // counts against it).  Asynchronous on the null stream; d_flag: a device word zeroed before the first slice.
 int launch_sort_slice(SortTemp &t, const uint64_t *d_sites, const uint64_t *d_list, const uint64_t *d_bucket_start,
-                      const uint32_t *d_tile_first, uint64_t n_sites, uint32_t n_slices, uint32_t n_buckets, uint32_t slice, uint32_t *d_sub_start,
+                      const uint32_t *d_tile_first, uint64_t n_sites, uint32_t n_slices, uint32_t n_buckets, uint32_t slice_width, uint32_t slice, uint32_t *d_sub_start,
                       StreamRec *d_srec, uint32_t *d_sid, uint32_t *d_site_occ, uint32_t *d_flag);
 // Synchronises and reads the flag word: ISSL_OK, ISSL_E_FORMAT (an id beyond the site table), kSortNeedsListOrder.
 int finish_sort(uint32_t *d_flag);
@@ -308,6 +322,12 @@ constexpr uint32_t kFetchPairs = 8;     // time of fetching one 8 KiB tile, in (
                                         // (50 M sites, neighbouring groups share tiles in L2) to 12 (300 M sites)
 constexpr uint32_t kPruneMaxGuides = 1u << 20; // guides per pruned launch: 65 slots per guide + padding must fit the 27-bit slot field
 constexpr uint32_t kPruneMaxGuides2 = 1u << 18; // ... 335 slots per guide (max_dist 5)
+// (ten 4-bit slices: twice the buckets per guide, half the guides)
+inline uint32_t prune_max_guides(uint32_t prune_mode, uint32_t n_slices)
+{
+    const uint32_t m = prune_mode == 3 ? kPruneMaxGuides2 : kPruneMaxGuides;
+    return n_slices > 5 ? m >> 1 : m;
+}
 
 // What k_verify needs to know about a guide slot of the pruned plan, in one 16-byte load.
 struct alignas(16) FineMeta {

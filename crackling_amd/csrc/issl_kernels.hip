@@ -67,6 +67,24 @@ __host__ __device__ inline uint32_t scan_word(uint64_t sig, uint32_t s, uint32_t
     return gather_even16(rem) | (gather_even16(rem >> 1) << 16);
 }
 
+// 4-bit slices on a SORTED layout (round 4): the word's first quad holds the four positions of the successor unit (slices
+// s + 1 and s + 2: one byte, the same for every candidate of a successor-byte group, so the pruned scan leaves that quad in
+// memory as it does with 8-bit slices), then the two positions of the previous slice (fine_dup), then slices s + 3 .. s + 7;
+// the two positions of slice s + 8 are left out -- the count is a lower bound, k_verify decides.
+__host__ __device__ inline uint32_t scan_word_sorted4(uint64_t sig, uint32_t s)
+{
+    const uint32_t sh = (4u * (s + 1u)) % 40u;
+    const uint64_t x = sig & kSigMask;
+    const uint64_t a = (sh ? (x >> sh) | (x << (40u - sh)) : x) & kSigMask; // slices s + 1, s + 2, ... s + 9, s from bit 0 on
+    const uint32_t rem = static_cast<uint32_t>((a & 0xFFull) | (((a >> 32) & 0xFull) << 8) | (((a >> 8) & 0xFFFFFull) << 12));
+    return gather_even16(rem) | (gather_even16(rem >> 1) << 16);
+}
+// The word of a signature in slice s as the image's stream holds it (guides are packed the same way).
+__host__ __device__ inline uint32_t image_word(uint64_t sig, uint32_t s, uint32_t width, bool sorted_layout)
+{
+    return (sorted_layout && width == 4u) ? scan_word_sorted4(sig, s) : scan_word(sig, s, width);
+}
+
 // Mismatch flags of two packed signatures, one flag at bit 2p (isslScoreOfftargets.cpp:376-379).
 __host__ __device__ inline uint64_t mismatch_mask(uint64_t a, uint64_t b)
 {
@@ -120,7 +138,7 @@ __global__ __launch_bounds__(256) void k_pack_scan_stream(ImageView v, uint32_t 
             if (pos < len && (v.srec || v.sid)) {
                 // sorted layouts: the stream holds the candidates v.srec / v.sid list (built and checked by launch_sort_slice)
                 const uint64_t at = static_cast<uint64_t>(t) * kTileCands + k0 + lane; // the maps are indexed like the stream
-                w = scan_word(v.srec ? v.srec[at].sig & kSigMask : v.sites[v.sid[at]] & kSigMask, slice, v.slice_width);
+                w = image_word(v.srec ? v.srec[at].sig & kSigMask : v.sites[v.sid[at]] & kSigMask, slice, v.slice_width, true);
             } else if (pos < len) {
                 const uint64_t e = v.entries[start + pos];
                 const uint64_t id = e & 0xFFFFFFFFull;
@@ -399,7 +417,7 @@ __global__ __launch_bounds__(256) void k_plan(ImageView v, uint32_t *__restrict_
 
 // Scatter every guide into its bucket's range of (gword, gidx), once per slice.
 __global__ __launch_bounds__(256) void k_guide_scatter(const uint64_t *__restrict__ guides, uint32_t n,
-                                                       uint32_t slice_width, uint32_t n_slices,
+                                                       uint32_t slice_width, uint32_t n_slices, uint32_t sorted_layout,
                                                        uint32_t n_buckets, const uint32_t *__restrict__ gstart,
                                                        uint32_t *__restrict__ gfill, uint32_t *__restrict__ gword,
                                                        uint32_t *__restrict__ gidx, uint32_t *__restrict__ gbucket,
@@ -446,7 +464,7 @@ __global__ __launch_bounds__(256) void k_guide_scatter(const uint64_t *__restric
                 const uint32_t key = static_cast<uint32_t>(sig >> (slice_width * s)) & low;
                 const uint32_t b = (s << slice_width) + key;
                 const uint32_t slot = gstart[b] + base[b] + rank[s];
-                gword[slot] = scan_word(sig, s, slice_width);
+                gword[slot] = image_word(sig, s, slice_width, sorted_layout != 0u);
                 gidx[slot] = g;
                 gbucket[slot] = b;
             }
@@ -525,8 +543,10 @@ __host__ __device__ __forceinline__ uint32_t fine_quad(uint32_t slice) { return 
 // its four mismatch planes tell, for nothing, whether the slice before the bucket's own matches the guide exactly too, and
 // a candidate for which it does is reported from that slice's bucket already (fine_dup) -- then the other two, ascending.
 // Slice 0 has no previous slice: its quads in ascending order.  (Quad q of slice s's scan word holds slice q < s ? q : q + 1.)
-__host__ __device__ __forceinline__ uint32_t fine_order(uint32_t slice, uint32_t j)
+// 4-bit slices (scan_word_sorted4): the successor unit is quad 0 for every slice, the previous slice opens quad 1: quads 1, 2, 3.
+__host__ __device__ __forceinline__ uint32_t fine_order(uint32_t slice, uint32_t j, uint32_t slice_width = 8u)
 {
+    if (slice_width == 4u) return j + 1u;
     const uint32_t sq = fine_quad(slice);
     if (slice == 0u) return j + 1u;                                // quads 1, 2, 3
     const uint32_t prev = slice - 1u;                              // slice - 1 sits in quad slice - 1 (it is below the own slice)
@@ -538,12 +558,12 @@ __host__ __device__ __forceinline__ uint32_t fine_order(uint32_t slice, uint32_t
     }
     return q;
 }
-__host__ __device__ __forceinline__ uint32_t fine_word(uint32_t word, uint32_t slice)
+__host__ __device__ __forceinline__ uint32_t fine_word(uint32_t word, uint32_t slice, uint32_t slice_width = 8u)
 {
     const uint32_t lo = word & 0xFFFFu, hi = word >> 16;
     uint32_t lo12 = 0, hi12 = 0;
     for (uint32_t j = 0; j < 3u; ++j) {
-        const uint32_t q = fine_order(slice, j);
+        const uint32_t q = fine_order(slice, j, slice_width);
         lo12 |= ((lo >> (4u * q)) & 0xFu) << (4u * j);
         hi12 |= ((hi >> (4u * q)) & 0xFu) << (4u * j);
     }
@@ -563,13 +583,12 @@ __global__ __launch_bounds__(256) void k_fine_count(ImageView v, const uint64_t 
     __shared__ uint32_t cnt[256], cnt0[256];
     __shared__ uint64_t lds[256];
     const uint32_t b = blockIdx.x, slice = b >> v.slice_width;
-    const uint32_t succ_shift = v.slice_width * ((slice + 1u) % v.n_slices);
     cnt[threadIdx.x] = 0;
     cnt0[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t g0 = gstart[b], n = gfill[b];
     for (uint32_t i = threadIdx.x; i < n; i += 256) { // one guide per thread and step: its loads once, its ways from registers
-        const uint32_t gj = static_cast<uint32_t>(guides[gidx[g0 + i]] >> succ_shift) & 0xFFu;
+        const uint32_t gj = succ_byte(guides[gidx[g0 + i]], slice, v.slice_width);
         atomicAdd(&cnt0[gj], 1u); // class 0: the guide's successor byte is the group's own (fine_class)
 #pragma unroll
         for (uint32_t way = 0; way < ways; ++way) atomicAdd(&cnt[fine_way(gj, way)], 1u);
@@ -683,7 +702,6 @@ __global__ __launch_bounds__(256) void k_fine_scatter(ImageView v, const uint64_
     __shared__ uint64_t lds[256];
     __shared__ uint32_t slot_of[256], slot0_of[256], cursor[256], cursor0[256], has_cands[256];
     const uint32_t b = blockIdx.x, slice = b >> v.slice_width;
-    const uint32_t succ_shift = v.slice_width * ((slice + 1u) % v.n_slices);
     const uint32_t w = threadIdx.x;
     const uint32_t c = fcount[static_cast<uint64_t>(b) * 256u + w];
     const uint32_t c1 = c - fcount0[static_cast<uint64_t>(b) * 256u + w]; // class 1 first, class 0 behind it (fine_class)
@@ -743,8 +761,8 @@ __global__ __launch_bounds__(256) void k_fine_scatter(ImageView v, const uint64_
     for (uint32_t i = threadIdx.x; i < n; i += 256) {
         const uint32_t guide = gidx[g0 + i], word = gword[g0 + i];
         const uint64_t gsig = guides[guide];
-        const uint32_t gj = static_cast<uint32_t>(gsig >> succ_shift) & 0xFFu;
-        const uint32_t word12 = fine_word(word, slice);
+        const uint32_t gj = succ_byte(gsig, slice, v.slice_width);
+        const uint32_t word12 = fine_word(word, slice, v.slice_width);
 #pragma unroll
         for (uint32_t way = 0; way < ways; ++way) {
             const uint32_t ww = fine_way(gj, way);
@@ -769,8 +787,9 @@ __global__ __launch_bounds__(256) void k_fine_ranges(const PlanInfo *__restrict_
 
 uint32_t prune_mode_for(const ImageView &v, const Tuning &tn, uint32_t n_guides, int max_dist)
 {
-    if ((!v.srec && !v.sid) || tn.prune == 0 || max_dist < 0 || max_dist > 5 || v.n_slices != 5 || v.slice_width != 8) return 0;
-    if (n_guides > (max_dist == 5 ? kPruneMaxGuides2 : kPruneMaxGuides)) return 0;
+    const bool geometry = (v.n_slices == 5 && v.slice_width == 8) || (v.n_slices == 10 && v.slice_width == 4); // succ_byte
+    if ((!v.srec && !v.sid) || tn.prune == 0 || max_dist < 0 || max_dist > 5 || !geometry) return 0;
+    if (n_guides > prune_max_guides(max_dist == 5 ? 3u : 2u, v.n_slices)) return 0;
     // max_dist 5: a hit the reference can find matches some slice exactly (:330-344 walks the buckets of the guide's own
     // slice values), and then some exact slice is followed by one with at most TWO mismatches (the cycle lemma of the
     // comment above with 3 |E| + (5 - 2 |E|) > 5): 67 of a bucket's 256 groups instead of all of them.
@@ -794,7 +813,7 @@ void launch_bin_guides(const ImageView &v, const Workspace &ws, const Tuning &tn
                        static_cast<uint32_t>(ws.cap_items), ws.plan, tn.item_guides, tn.scan_blocks);
     const uint32_t range_blocks = (tn.scan_blocks + 1u + 255u) / 256u;
     hipLaunchKernelGGL(k_guide_scatter, dim3(blocks + range_blocks), dim3(256), 0, stream, d_guides, n, v.slice_width,
-                       v.n_slices, nb, ws.gstart, ws.gfill, ws.gword, ws.gidx, ws.gbucket, blocks, ws.plan, ws.items,
+                       v.n_slices, (v.srec || v.sid) ? 1u : 0u, nb, ws.gstart, ws.gfill, ws.gword, ws.gidx, ws.gbucket, blocks, ws.plan, ws.items,
                        ws.range_start);
     if (prune_mode) { // regroup by (bucket, successor byte); k_fine_plan decides which of the two plans the scan follows
         const uint32_t ways = fine_ways_of(prune_mode);
@@ -1173,7 +1192,7 @@ __device__ __forceinline__ void scan_range(const uint32_t *__restrict__ scan_str
                                            Counters *counters, uint32_t thr, unsigned long long *stamps,
                                            uint64_t *__restrict__ scan_count, uint32_t *next_unit_p, uint32_t *waves_done_p,
                                            unsigned long long *wg_compared_p, unsigned long long t_start,
-                                           unsigned long long *span, uint32_t n_tiles)
+                                           unsigned long long *span, uint32_t n_tiles, uint32_t slice_bits)
 {
     uint32_t &next_unit = *next_unit_p;
     uint32_t &waves_done = *waves_done_p;
@@ -1220,8 +1239,8 @@ __device__ __forceinline__ void scan_range(const uint32_t *__restrict__ scan_str
         if constexpr (FINE) {
             // The planes the unit needs: 12 of the 16 positions (fine_word) -- the successor slice's four sit in plane quads
             // sq and 4 + sq of the tile and stay in memory.
-            const uint32_t slice_of = cur.bucket >> 16; // bucket << 8 | successor byte, 8-bit slices: slice = bucket >> 8
-            const uint32_t q0 = fine_order(slice_of, 0u), q1 = fine_order(slice_of, 1u), q2 = fine_order(slice_of, 2u);
+            const uint32_t slice_of = cur.bucket >> (8u + slice_bits); // bucket << 8 | successor byte; slice = bucket >> slice width
+            const uint32_t q0 = fine_order(slice_of, 0u, slice_bits), q1 = fine_order(slice_of, 1u, slice_bits), q2 = fine_order(slice_of, 2u, slice_bits);
             const uint32_t dup_filter = slice_of != 0u ? ~0u : 0u; // (fine_dup: positions 0..3 are the previous slice's)
             if (cur.shape != 32u) {
                 // ---- a SHORT unit: the last 64 * shape candidates of a successor-byte group, 32 / shape guides per pass ----
@@ -1432,7 +1451,7 @@ __global__ __launch_bounds__(1024, 8) void k_scan(const uint32_t *__restrict__ s
                                                   const uint32_t *__restrict__ gword_fine, uint64_t *raw,
                                                   uint32_t *raw_used, uint32_t max_chunks, Counters *counters, uint32_t thr,
                                                   unsigned long long *stamps, uint64_t *__restrict__ scan_count,
-                                                  unsigned long long *span, uint32_t n_tiles)
+                                                  unsigned long long *span, uint32_t n_tiles, uint32_t slice_bits)
 {
     __shared__ uint32_t next_unit;
     __shared__ uint32_t waves_done;
@@ -1451,10 +1470,10 @@ __global__ __launch_bounds__(1024, 8) void k_scan(const uint32_t *__restrict__ s
     // the plan of this batch: bucket-level items, or the successor-byte groups of the pruned scan (k_fine_plan)
     if (plan->fine != 0u)
         scan_range<THR, true>(scan_stream, items_fine, plan, range_start, gword_fine, tail_masks[threadIdx.x >> 6], raw, raw_used, max_chunks, counters, thr, stamps,
-                              scan_count, &next_unit, &waves_done, &wg_compared, t_start, span, n_tiles);
+                              scan_count, &next_unit, &waves_done, &wg_compared, t_start, span, n_tiles, slice_bits);
     else
         scan_range<THR, false>(scan_stream, items_full, plan, range_start, gword_full, tail_masks[threadIdx.x >> 6], raw, raw_used, max_chunks, counters, thr, stamps,
-                               scan_count, &next_unit, &waves_done, &wg_compared, t_start, span, n_tiles);
+                               scan_count, &next_unit, &waves_done, &wg_compared, t_start, span, n_tiles, slice_bits);
 }
 
 // precalculatedScores[mask] with operator[] semantics: a missing mask contributes 0.0 (:394).
@@ -1617,8 +1636,7 @@ __global__ __launch_bounds__(kChunkRecs, 8) void k_verify(ImageView v, Workspace
                         for (uint32_t j = slice; j-- > 0;) {
                             if (((x >> (v.slice_width * j)) & low) != 0) continue;
                             first = j;
-                            const uint32_t nx = (j + 1u) % v.n_slices;
-                            if (static_cast<uint32_t>(__builtin_popcountll((mm >> (v.slice_width * nx)) & low)) <= tol) reporter = j;
+                            if (static_cast<uint32_t>(__builtin_popcount(succ_byte(mm, j, v.slice_width))) <= tol) reporter = j; // (the successor unit's flags)
                         }
                         if (reporter == slice)
                             key = (static_cast<uint64_t>(guide) << kKeyGuideShift) | (static_cast<uint64_t>(first) << kKeySliceShift) | sr.id;
@@ -1696,7 +1714,7 @@ static void launch_scan_thr(const ImageView &v, const Workspace &ws, const Tunin
     hipLaunchKernelGGL(k_scan<THR>, dim3(tn.scan_blocks), dim3(1024), 0, stream, v.scan, ws.items,
                        prune_mode ? ws.fitems : ws.items, ws.plan, ws.range_start, ws.gword, prune_mode ? ws.fword : ws.gword,
                        ws.raw, ws.raw_used, static_cast<uint32_t>(ws.cap_chunks), ws.counters, thr, ws.stamps, ws.scan_count,
-                       ws.scan_span + 2u * ws.span_slot, v.n_tiles);
+                       ws.scan_span + 2u * ws.span_slot, v.n_tiles, v.slice_width);
 }
 
 void launch_scan(const ImageView &v, const Workspace &ws, const Tuning &tn, const uint64_t *d_guides, uint32_t n,

@@ -955,10 +955,13 @@ def test_random_small_indexes_differential():
             sig = np.array(sorted(sites), dtype=np.uint64)
             sig = sig[np.argsort(text_order_key(sig), kind="stable")]
             occ = rng.integers(1, 7, size=len(sig)).astype(np.uint32)
-            ix = ca.IsslIndex.build_from_sites(sig, occ)
+            width = 4 if trial % 4 == 3 else 8   # ten 4-bit slices: sorted layouts by the byte of the next two slices
+            ix = ca.IsslIndex.build_from_sites(sig, occ, slice_width=width)
             path = os.path.join(tmp, f"t{trial}.issl")
             ix.write(path)
             name = names[int(rng.integers(0, len(names)))] if trial % 3 else SORTED[(trial // 3) % len(SORTED)]
+            if width == 4 and name not in ("sorted", "compact", "list", "list_esig"):
+                name = ("sorted", "compact")[trial // 4 % 2]
             layout = dict(LAYOUTS[name])
             if name in SORTED:
                 layout["prune"] = int(rng.integers(-1, 2)) if trial % 2 else 1
@@ -982,6 +985,68 @@ def test_random_small_indexes_differential():
                 assert np.array_equal(cfd.view(np.uint64), ocfd.view(np.uint64)), (trial, layout, method, thr, dist)
             oracle.close()
             ix.close()
+
+
+def test_four_bit_slices_on_the_sorted_layouts_against_the_oracle(tmp_path):
+    """Ten 4-bit slices (isslScoreOfftargets.cpp:261-270,330-341 take any width): the sorted layouts order every bucket by
+    the byte of the NEXT TWO slices and the pruned scan visits 13 (1, 67) of its 256 groups.  An index of 120 k sites -- dense
+    neighbourhoods, so that guides have hits at every distance and in every slice, and groups of several scan windows -- on
+    the sorted and the compact layout, pruned scan forced, whole buckets, planner's choice: hit lists and scores for max_dist
+    0..6 against the oracle (5: 67 groups; 6: whole buckets), early exit on and off."""
+    rng = np.random.default_rng(4040)
+    centres = rng.integers(0, 1 << 40, size=150, dtype=np.uint64)
+    sites = set(int(c) for c in centres)
+    for c in centres:
+        for _ in range(int(rng.integers(20, 400))):
+            s = int(c)
+            for pos in rng.choice(20, size=int(rng.integers(1, 7)), replace=False):
+                s ^= int(rng.integers(1, 4)) << (2 * int(pos))
+            sites.add(s)
+    # one bucket (slice 0 = 0x5) with a few long successor-byte groups: several scan windows per group
+    for _ in range(30000):
+        sites.add(0x5 | (int(rng.integers(0, 3)) << 4) | (0x2 << 8) | (int(rng.integers(0, 1 << 28)) << 12))
+    sites |= set(int(x) for x in rng.integers(0, 1 << 40, size=60000, dtype=np.uint64))
+    sig = np.array(sorted(sites), dtype=np.uint64)
+    sig = sig[np.argsort(text_order_key(sig), kind="stable")]
+    occ = rng.integers(1, 5, size=len(sig)).astype(np.uint32)
+    path = tmp_path / "w4.issl"
+    ca.IsslIndex.build_from_sites(sig, occ, slice_width=4).write(path)
+    oracle = ou.OracleIndex(path)
+    extra = np.array([0x5 | (1 << 4) | (0x2 << 8) | (int(x) << 12) for x in rng.integers(0, 1 << 28, size=40)], dtype=np.uint64)
+    guides = np.concatenate([centres, centres ^ np.uint64(3 << 10), extra, rng.integers(0, 1 << 40, size=30, dtype=np.uint64)])
+    want = {}
+    for dist in range(0, 7):
+        for thr in (0.0, 75.0):
+            want[dist, thr] = oracle.score(guides, dist, thr, "and", want_hits=True)
+    assert len(want[4, 0.0][2]) > 20000 and len(want[4, 75.0][2]) < len(want[4, 0.0][2])
+    for layout in ({"sorted_layout": 1, "compact": 0}, {"compact": 1}):
+        ix = ca.IsslIndex.open(path)
+        for key, value in layout.items():
+            ix.set_option(key, value)
+        ix.upload(0)
+        assert ix.get_option("is_sorted") == 1 and ix.header["n_slices"] == 10
+        try:
+            for prune in (1, 0, -1):
+                ix.set_option("prune", prune)
+                for (dist, thr), (omit, ocfd, ohits) in want.items():
+                    hits = ix.dump_hits(guides, dist, thr, "and")
+                    assert np.array_equal(hits, ohits), (layout, prune, dist, thr)
+                    mit, cfd = ix.score(guides, dist, thr, "and")
+                    st = ix.stats()
+                    assert np.array_equal(mit.view(np.uint64), omit.view(np.uint64)), (layout, prune, dist, thr)
+                    assert np.array_equal(cfd.view(np.uint64), ocfd.view(np.uint64)), (layout, prune, dist, thr)
+                    if prune == 1:
+                        assert st["pruned"] == (1 if dist <= 2 else 2 if dist <= 4 else 3 if dist == 5 else 0), (dist, st["pruned"])
+                    if prune == 0:
+                        assert st["pruned"] == 0 and st["candidates"] == st["reference_comparisons"]
+            for method, thr, dist in (("mit", 50.0, 4), ("cfd", 90.0, 3), ("or", 75.0, 4), ("avg", 30.0, 2)):
+                ix.set_option("prune", 1)
+                mit, cfd = ix.score(guides, dist, thr, method)
+                omit, ocfd = oracle.score(guides, dist, thr, method)
+                assert np.array_equal(mit.view(np.uint64), omit.view(np.uint64)) and np.array_equal(cfd.view(np.uint64), ocfd.view(np.uint64)), (method, thr, dist)
+        finally:
+            ix.close()
+    oracle.close()
 
 
 def test_runtime_threshold_kernel_with_the_pruned_scan(config0):

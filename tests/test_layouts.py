@@ -74,32 +74,51 @@ def test_every_layout_reproduces_the_reference(name, layout):
         ix.close()
 
 
-@pytest.mark.parametrize("layout", [None, "list_esig", "list"])
+@pytest.mark.parametrize("layout", [None, "sorted", "compact", "list_esig", "list"])
 @pytest.mark.parametrize("name", ["width4", "width2"])
 def test_narrow_slices_reproduce_the_reference(name, layout):
     """Indexes with 4- and 2-bit slices (10 / 20 slices per site; isslScoreOfftargets.cpp:261-270,330-341 is generic in
-    both): list-order image in HBM, scan of whole buckets -- the scan word keeps 16 of the 18 / 19 positions outside the
-    slice, the exact test decides.  Stdout and hit lists of the compiled reference, max distances 2, 4 and 6; the layouts
-    that need 8-bit slices are refused."""
+    both).  List-order images scan whole buckets -- the scan word keeps 16 of the 18 / 19 positions outside the slice, the
+    exact test decides.  4-bit slices also take the sorted layouts (round 4; the default): every bucket ordered by the byte
+    of the NEXT TWO slices, and the pruned scan visits 13 (1, 67) of a bucket's 256 groups -- with <= 4 mismatches over ten
+    slices some exact slice is followed by two slices with at most one mismatch between them (enumerated in
+    tests/test_oracle_golden.py).  Stdout and hit lists of the compiled reference, max distances 2, 4 and 6 (6: whole buckets
+    on every layout); the layouts a width cannot take are refused."""
     g = Golden(name)
+    width = int(name[5:])
+    sortable = width == 4
+    if layout in ("sorted", "compact") and not sortable:
+        bad = _open(g.issl, layout)
+        with pytest.raises(ca.IsslError):
+            bad.upload(0)
+        bad.close()
+        return
     ix = ca.IsslIndex.open(g.issl) if layout is None else _open(g.issl, layout)
     ix.upload(0)
-    assert ix.get_option("is_sorted") == 0 and ix.get_option("cold_on_host") == 0
-    assert ix.header["slice_width"] == int(name[5:]) and ix.header["n_slices"] == 40 // int(name[5:])
+    is_sorted = sortable and layout in (None, "sorted", "compact")
+    assert ix.get_option("is_sorted") == (1 if is_sorted else 0) and ix.get_option("cold_on_host") == 0
+    assert ix.get_option("is_compact") == (1 if layout == "compact" else 0) and ix.get_option("lists_absent") == 0
+    assert ix.header["slice_width"] == width and ix.header["n_slices"] == 40 // width
     sigs = ca.encode_guides([s.encode() for s in g.guides])
     try:
-        for key, want in g.expected.items():
-            method, thr, dist = key.split("|")
-            mit, cfd = ix.score(sigs, int(dist), float(thr), method)
-            assert ca.format_scores(sigs, mit, cfd, method) == want, key
-            st = ix.stats()
-            assert st["pruned"] == 0 and st["candidates"] == st["reference_comparisons"] == ix.count_candidates(sigs)
-        for thr in g.hit_thresholds():
-            assert np.array_equal(ix.dump_hits(sigs, 4, float(thr), "and"), g.hits(thr)), thr
+        for prune in ((0, 1, -1) if is_sorted else (-1,)):
+            ix.set_option("prune", prune)
+            for key, want in g.expected.items():
+                method, thr, dist = key.split("|")
+                mit, cfd = ix.score(sigs, int(dist), float(thr), method)
+                assert ca.format_scores(sigs, mit, cfd, method) == want, (key, prune)
+                st = ix.stats()
+                assert st["reference_comparisons"] == ix.count_candidates(sigs)
+                if prune == 1 and 0 <= int(dist) <= 5:
+                    assert st["pruned"] == (1 if int(dist) <= 2 else 2 if int(dist) <= 4 else 3), (key, st["pruned"])
+                if prune == 0 or not is_sorted or int(dist) > 5:
+                    assert st["pruned"] == 0 and st["candidates"] == st["reference_comparisons"]
+            for thr in g.hit_thresholds():
+                assert np.array_equal(ix.dump_hits(sigs, 4, float(thr), "and"), g.hits(thr)), (thr, prune)
     finally:
         ix.close()
     if layout is None:
-        for forced in ("sorted", "compact", "host_cold"):
+        for forced in ("host_cold", "compact_cold", "compact_bare"):
             bad = _open(g.issl, forced)
             with pytest.raises(ca.IsslError):
                 bad.upload(0)

@@ -18,6 +18,7 @@ ap.add_argument("--fast-synth", action="store_true", help="random_sites_fast + i
 ap.add_argument("--dist", default="uniform", choices=["uniform", "markov"])
 ap.add_argument("--subsets", default="", help="comma list of batch sizes: score the first k guides for every k (default: all)")
 ap.add_argument("--max-dist", type=int, default=4)
+ap.add_argument("--slice-width", type=int, default=8, help="4: ten 4-bit slices (host-built index)")
 ap.add_argument("--json", default=None, help="write the best repetition (by scan time) of the last variant here")
 ap.add_argument("--write-issl", default=None)
 ap.add_argument("--write-guides", default=None)
@@ -26,14 +27,15 @@ gen = (markov_sites_fast if a.fast_synth else markov_sites) if a.dist == "markov
 t = time.time(); sigs, occ = gen(a.sites, seed=1); guides = random_guides(sigs, a.guides, seed=2)
 print(f"synth {time.time()-t:.1f}s  distinct={len(sigs)}", flush=True)
 t = time.time()
-ix = ca.IsslIndex.build_on_device(sigs, occ, device=0) if (a.fast_synth or a.dist == "markov") else ca.IsslIndex.build_from_sites(sigs, occ)
+on_device = (a.fast_synth or a.dist == "markov") and a.slice_width == 8
+ix = ca.IsslIndex.build_on_device(sigs, occ, device=0) if on_device else ca.IsslIndex.build_from_sites(sigs, occ, slice_width=a.slice_width)
 t_build = time.time() - t; print(f"build {t_build:.1f}s", flush=True)
 if a.write_issl:
     t = time.time(); ix.write(a.write_issl); print(f"write issl {time.time()-t:.1f}s", flush=True)
 if a.write_guides:
     open(a.write_guides, "w").write("".join(s + "\n" for s in ca.decode_guides(guides)))
 t = time.time()
-if not (a.fast_synth or a.dist == "markov"):
+if not on_device:
     ix.upload(0)
 t_upload = time.time() - t
 print(f"upload {t_upload:.1f}s  image={ix.device_bytes()/1e9:.2f} GB", flush=True)
