@@ -28,7 +28,7 @@ struct SliceEntry {
 
 // ---- sorted layouts: every bucket's candidates ordered by the byte of the successor slice ------------------------
 // One slice at a time (16 B per site of temporary memory): key = (slice << 16 | own value << 8 | successor byte) << 40 |
-// index of the list entry (the successor byte: succ_byte -- the next slice of five 8-bit ones, the next two of ten 4-bit ones).  A slice's lists are already grouped by own byte; two stable 8-bit passes (successor byte,
+// index of the list entry (the successor byte: succ_byte -- the next slice of five 8-bit ones, the next two / four of ten 4-bit / twenty 2-bit ones).  A slice's lists are already grouped by own byte; two stable 8-bit passes (successor byte,
 // own byte) leave them grouped and order every bucket by successor byte, ties in list order.
 constexpr uint32_t kKeyShift = 40;
 
@@ -160,9 +160,9 @@ int launch_sort_slice(SortTemp &t, const uint64_t *d_sites, const uint64_t *d_li
                       const uint32_t *d_tile_first, uint64_t n_sites, uint32_t n_slices, uint32_t n_buckets, uint32_t slice_width, uint32_t slice, uint32_t *d_sub_start,
                       StreamRec *d_srec, uint32_t *d_sid, uint32_t *d_site_occ, uint32_t *d_flag)
 {
-    if (!((slice_width == 8 && n_slices == 5) || (slice_width == 4 && n_slices == 10)) || n_buckets != (n_slices << slice_width) ||
+    if (!((slice_width == 8 && n_slices == 5) || (slice_width == 4 && n_slices == 10) || (slice_width == 2 && n_slices == 20)) || n_buckets != (n_slices << slice_width) ||
         n_sites >= (1ull << 32) || slice >= n_slices) {
-        set_error("the sorted layout handles 20 positions in five 8-bit or ten 4-bit slices and up to 2^32 - 1 sites");
+        set_error("the sorted layout handles 20 positions in 8-, 4- or 2-bit slices and up to 2^32 - 1 sites");
         return ISSL_E_UNSUPPORTED;
     }
     const uint32_t per_slice = n_buckets / n_slices;

@@ -649,9 +649,9 @@ static std::vector<LayoutSpec> layout_choices(const Tuning &tn, const Geometry &
     const bool narrow = g.slice_width != 8; // no host-cold layouts (they rebuild signatures from 16 stream positions + the bucket's
                                             // byte) and no image without its lists (the device-side list builder takes 8-bit slices)
     if (narrow) {
-        // 4-bit slices (round 4): the sorted layouts order a bucket by the byte of the NEXT TWO slices (succ_byte), so the pruned
-        // scan applies; 2-bit slices keep to list order (their buckets hold a quarter of the index each)
-        const bool can_sort = g.slice_width == 4 && g.n_slices == 10 && !list_order_only && tn.sorted_layout != 0 && tn.inline_sigs != 1;
+        // narrow slices (round 4): the sorted layouts order a bucket by the byte of the next two (4-bit) / four (2-bit) slices
+        // (succ_byte), so the pruned scan applies
+        const bool can_sort = g.n_slices * g.slice_width == 40 && !list_order_only && tn.sorted_layout != 0 && tn.inline_sigs != 1;
         if (tn.host_cold == 1 || tn.keep_lists == 0) return c;
         if (can_sort) {
             if (tn.compact != 1) c.push_back(spec(false, 0, 1));

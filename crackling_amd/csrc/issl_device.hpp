@@ -92,7 +92,7 @@ constexpr uint32_t kOccSaturated = 0xFFFFFFu; // StreamRec (and the site table o
 constexpr uint64_t kSigMask = (1ull << 40) - 1ull; // the 20-mer's bits of a signature word
 
 // The successor unit of slice `s`: the four positions (one byte of 2-bit codes) that follow the slice cyclically -- slice
-// s + 1 of five 8-bit slices, slices s + 1 and s + 2 of ten 4-bit ones.  The sorted layouts order every bucket by it and
+// s + 1 of five 8-bit slices, slices s + 1 and s + 2 of ten 4-bit ones, s + 1 .. s + 4 of twenty 2-bit ones.  The sorted layouts order every bucket by it and
 // the pruned scan visits the 13 (1, 67) values within one (no, two) mismatches of a guide's own.  Applied to
 // a word of mismatch flags (one flag per position at bit 2p) it yields the flags of those four positions.
 #if defined(__HIPCC__)
@@ -322,11 +322,11 @@ constexpr uint32_t kFetchPairs = 8;     // time of fetching one 8 KiB tile, in (
                                         // (50 M sites, neighbouring groups share tiles in L2) to 12 (300 M sites)
 constexpr uint32_t kPruneMaxGuides = 1u << 20; // guides per pruned launch: 65 slots per guide + padding must fit the 27-bit slot field
 constexpr uint32_t kPruneMaxGuides2 = 1u << 18; // ... 335 slots per guide (max_dist 5)
-// (ten 4-bit slices: twice the buckets per guide, half the guides)
+// (ten 4-bit / twenty 2-bit slices: two / four times the buckets per guide, a half / a quarter of the guides)
 inline uint32_t prune_max_guides(uint32_t prune_mode, uint32_t n_slices)
 {
     const uint32_t m = prune_mode == 3 ? kPruneMaxGuides2 : kPruneMaxGuides;
-    return n_slices > 5 ? m >> 1 : m;
+    return n_slices > 10 ? m >> 2 : n_slices > 5 ? m >> 1 : m;
 }
 
 // What k_verify needs to know about a guide slot of the pruned plan, in one 16-byte load.

@@ -67,22 +67,25 @@ __host__ __device__ inline uint32_t scan_word(uint64_t sig, uint32_t s, uint32_t
     return gather_even16(rem) | (gather_even16(rem >> 1) << 16);
 }
 
-// 4-bit slices on a SORTED layout (round 4): the word's first quad holds the four positions of the successor unit (slices
-// s + 1 and s + 2: one byte, the same for every candidate of a successor-byte group, so the pruned scan leaves that quad in
-// memory as it does with 8-bit slices), then the two positions of the previous slice (fine_dup), then slices s + 3 .. s + 7;
-// the two positions of slice s + 8 are left out -- the count is a lower bound, k_verify decides.
-__host__ __device__ inline uint32_t scan_word_sorted4(uint64_t sig, uint32_t s)
+// Narrow slices on a SORTED layout (round 4; ten 4-bit or twenty 2-bit slices): the word's first quad holds the four
+// positions of the successor unit (the next two / four slices: one byte, the same for every candidate of a successor-byte
+// group, so the pruned scan leaves that quad in memory as it does with 8-bit slices), then the previous slice's two / one
+// (fine_dup), then the ten / eleven positions that follow the successor unit; the last two / three before the previous slice
+// are left out -- the count is a lower bound, k_verify decides.
+__host__ __device__ inline uint32_t scan_word_sorted_narrow(uint64_t sig, uint32_t s, uint32_t width)
 {
-    const uint32_t sh = (4u * (s + 1u)) % 40u;
+    const uint32_t sh = (width * (s + 1u)) % 40u;
     const uint64_t x = sig & kSigMask;
-    const uint64_t a = (sh ? (x >> sh) | (x << (40u - sh)) : x) & kSigMask; // slices s + 1, s + 2, ... s + 9, s from bit 0 on
-    const uint32_t rem = static_cast<uint32_t>((a & 0xFFull) | (((a >> 32) & 0xFull) << 8) | (((a >> 8) & 0xFFFFFull) << 12));
+    const uint64_t a = (sh ? (x >> sh) | (x << (40u - sh)) : x) & kSigMask; // slices s + 1, s + 2, ... , s - 1, s from bit 0 on
+    const uint64_t prev = (a >> (40u - 2u * width)) & ((1ull << width) - 1ull);
+    const uint64_t mid = (a >> 8) & ((1ull << (24u - width)) - 1ull);
+    const uint32_t rem = static_cast<uint32_t>((a & 0xFFull) | (prev << 8) | (mid << (8u + width)));
     return gather_even16(rem) | (gather_even16(rem >> 1) << 16);
 }
 // The word of a signature in slice s as the image's stream holds it (guides are packed the same way).
 __host__ __device__ inline uint32_t image_word(uint64_t sig, uint32_t s, uint32_t width, bool sorted_layout)
 {
-    return (sorted_layout && width == 4u) ? scan_word_sorted4(sig, s) : scan_word(sig, s, width);
+    return (sorted_layout && width < 8u) ? scan_word_sorted_narrow(sig, s, width) : scan_word(sig, s, width);
 }
 
 // Mismatch flags of two packed signatures, one flag at bit 2p (isslScoreOfftargets.cpp:376-379).
@@ -543,10 +546,10 @@ __host__ __device__ __forceinline__ uint32_t fine_quad(uint32_t slice) { return 
 // its four mismatch planes tell, for nothing, whether the slice before the bucket's own matches the guide exactly too, and
 // a candidate for which it does is reported from that slice's bucket already (fine_dup) -- then the other two, ascending.
 // Slice 0 has no previous slice: its quads in ascending order.  (Quad q of slice s's scan word holds slice q < s ? q : q + 1.)
-// 4-bit slices (scan_word_sorted4): the successor unit is quad 0 for every slice, the previous slice opens quad 1: quads 1, 2, 3.
+// Narrow slices (scan_word_sorted_narrow): the successor unit is quad 0 for every slice, the previous slice opens quad 1: quads 1, 2, 3.
 __host__ __device__ __forceinline__ uint32_t fine_order(uint32_t slice, uint32_t j, uint32_t slice_width = 8u)
 {
-    if (slice_width == 4u) return j + 1u;
+    if (slice_width != 8u) return j + 1u;
     const uint32_t sq = fine_quad(slice);
     if (slice == 0u) return j + 1u;                                // quads 1, 2, 3
     const uint32_t prev = slice - 1u;                              // slice - 1 sits in quad slice - 1 (it is below the own slice)
@@ -787,7 +790,7 @@ __global__ __launch_bounds__(256) void k_fine_ranges(const PlanInfo *__restrict_
 
 uint32_t prune_mode_for(const ImageView &v, const Tuning &tn, uint32_t n_guides, int max_dist)
 {
-    const bool geometry = (v.n_slices == 5 && v.slice_width == 8) || (v.n_slices == 10 && v.slice_width == 4); // succ_byte
+    const bool geometry = v.n_slices * v.slice_width == 40u && (v.slice_width == 8 || v.slice_width == 4 || v.slice_width == 2); // succ_byte
     if ((!v.srec && !v.sid) || tn.prune == 0 || max_dist < 0 || max_dist > 5 || !geometry) return 0;
     if (n_guides > prune_max_guides(max_dist == 5 ? 3u : 2u, v.n_slices)) return 0;
     // max_dist 5: a hit the reference can find matches some slice exactly (:330-344 walks the buckets of the guide's own

@@ -955,13 +955,13 @@ def test_random_small_indexes_differential():
             sig = np.array(sorted(sites), dtype=np.uint64)
             sig = sig[np.argsort(text_order_key(sig), kind="stable")]
             occ = rng.integers(1, 7, size=len(sig)).astype(np.uint32)
-            width = 4 if trial % 4 == 3 else 8   # ten 4-bit slices: sorted layouts by the byte of the next two slices
+            width = (4, 2)[trial // 4 % 2] if trial % 4 == 3 else 8   # narrow slices: sorted layouts by the byte of the next two / four slices
             ix = ca.IsslIndex.build_from_sites(sig, occ, slice_width=width)
             path = os.path.join(tmp, f"t{trial}.issl")
             ix.write(path)
             name = names[int(rng.integers(0, len(names)))] if trial % 3 else SORTED[(trial // 3) % len(SORTED)]
-            if width == 4 and name not in ("sorted", "compact", "list", "list_esig"):
-                name = ("sorted", "compact")[trial // 4 % 2]
+            if width != 8 and name not in ("sorted", "compact", "list", "list_esig"):
+                name = ("sorted", "compact")[trial // 8 % 2]
             layout = dict(LAYOUTS[name])
             if name in SORTED:
                 layout["prune"] = int(rng.integers(-1, 2)) if trial % 2 else 1
@@ -987,9 +987,10 @@ def test_random_small_indexes_differential():
             ix.close()
 
 
-def test_four_bit_slices_on_the_sorted_layouts_against_the_oracle(tmp_path):
-    """Ten 4-bit slices (isslScoreOfftargets.cpp:261-270,330-341 take any width): the sorted layouts order every bucket by
-    the byte of the NEXT TWO slices and the pruned scan visits 13 (1, 67) of its 256 groups.  An index of 120 k sites -- dense
+@pytest.mark.parametrize("width", [4, 2])
+def test_narrow_slices_on_the_sorted_layouts_against_the_oracle(tmp_path, width):
+    """Ten 4-bit / twenty 2-bit slices (isslScoreOfftargets.cpp:261-270,330-341 take any width): the sorted layouts order every
+    bucket by the byte of the next two / four slices and the pruned scan visits 13 (1, 67) of its 256 groups.  An index of 120 k sites -- dense
     neighbourhoods, so that guides have hits at every distance and in every slice, and groups of several scan windows -- on
     the sorted and the compact layout, pruned scan forced, whole buckets, planner's choice: hit lists and scores for max_dist
     0..6 against the oracle (5: 67 groups; 6: whole buckets), early exit on and off."""
@@ -1010,7 +1011,7 @@ def test_four_bit_slices_on_the_sorted_layouts_against_the_oracle(tmp_path):
     sig = sig[np.argsort(text_order_key(sig), kind="stable")]
     occ = rng.integers(1, 5, size=len(sig)).astype(np.uint32)
     path = tmp_path / "w4.issl"
-    ca.IsslIndex.build_from_sites(sig, occ, slice_width=4).write(path)
+    ca.IsslIndex.build_from_sites(sig, occ, slice_width=width).write(path)
     oracle = ou.OracleIndex(path)
     extra = np.array([0x5 | (1 << 4) | (0x2 << 8) | (int(x) << 12) for x in rng.integers(0, 1 << 28, size=40)], dtype=np.uint64)
     guides = np.concatenate([centres, centres ^ np.uint64(3 << 10), extra, rng.integers(0, 1 << 40, size=30, dtype=np.uint64)])
@@ -1024,7 +1025,7 @@ def test_four_bit_slices_on_the_sorted_layouts_against_the_oracle(tmp_path):
         for key, value in layout.items():
             ix.set_option(key, value)
         ix.upload(0)
-        assert ix.get_option("is_sorted") == 1 and ix.header["n_slices"] == 10
+        assert ix.get_option("is_sorted") == 1 and ix.header["n_slices"] == 40 // width
         try:
             for prune in (1, 0, -1):
                 ix.set_option("prune", prune)

@@ -79,14 +79,14 @@ def test_every_layout_reproduces_the_reference(name, layout):
 def test_narrow_slices_reproduce_the_reference(name, layout):
     """Indexes with 4- and 2-bit slices (10 / 20 slices per site; isslScoreOfftargets.cpp:261-270,330-341 is generic in
     both).  List-order images scan whole buckets -- the scan word keeps 16 of the 18 / 19 positions outside the slice, the
-    exact test decides.  4-bit slices also take the sorted layouts (round 4; the default): every bucket ordered by the byte
-    of the NEXT TWO slices, and the pruned scan visits 13 (1, 67) of a bucket's 256 groups -- with <= 4 mismatches over ten
-    slices some exact slice is followed by two slices with at most one mismatch between them (enumerated in
+    exact test decides.  Both widths also take the sorted layouts (round 4; the default): every bucket ordered by the byte
+    of the next two / four slices, and the pruned scan visits 13 (1, 67) of a bucket's 256 groups -- with <= 4 mismatches
+    some exact slice is followed by four positions with at most one mismatch between them (enumerated in
     tests/test_oracle_golden.py).  Stdout and hit lists of the compiled reference, max distances 2, 4 and 6 (6: whole buckets
-    on every layout); the layouts a width cannot take are refused."""
+    on every layout); the layouts a narrow width cannot take are refused."""
     g = Golden(name)
     width = int(name[5:])
-    sortable = width == 4
+    sortable = True
     if layout in ("sorted", "compact") and not sortable:
         bad = _open(g.issl, layout)
         with pytest.raises(ca.IsslError):

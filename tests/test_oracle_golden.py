@@ -155,24 +155,33 @@ def test_successor_slice_pigeonhole_for_five_mismatches():
     assert 1 + 4 * 3 + 6 * 9 == 67   # successor bytes within two mismatches of a guide's own
 
 
-def test_successor_unit_pigeonhole_for_ten_four_bit_slices():
-    """4-bit slices (ten per site, two positions each): the sorted layouts order a bucket by the byte of the NEXT TWO slices
-    (succ_byte, csrc/issl_device.hpp), and a hit within max_dist of a guide -- which matches it exactly in some slice, or the
-    reference never meets it (isslScoreOfftargets.cpp:330-344) -- has an exact slice whose two successors hold no mismatch
-    (max_dist <= 2), at most one (<= 4), at most two (5): every distribution of mismatches over the slices.  And the filter of
-    the scan's cold block (fine_dup: the encounter in slice s is dropped when slice s - 1 AND slice s + 3 match exactly --
-    the first four of the twelve positions compared, scan_word_sorted4) never drops the reporter's encounter."""
+def test_successor_unit_pigeonhole_for_narrow_slices():
+    """4- and 2-bit slices (ten / twenty per site, two / one positions each): the sorted layouts order a bucket by the byte of
+    the next two / four slices (succ_byte, csrc/issl_device.hpp), and a hit within max_dist of a guide -- which matches it
+    exactly in some slice, or the reference never meets it (isslScoreOfftargets.cpp:330-344) -- has an exact slice whose
+    successor unit holds no mismatch (max_dist <= 2), at most one (<= 4), at most two (5): every distribution of mismatches
+    over the slices.  And the filter of the scan's cold block (fine_dup: the encounter in slice s is dropped when the first
+    four of the twelve positions compared match exactly -- the previous slice and the two / three positions behind the
+    successor unit, scan_word_sorted_narrow) never drops the reporter's encounter."""
     import itertools
-    for max_dist, tol in ((2, 0), (4, 1), (5, 2)):
-        for counts in itertools.product(range(3), repeat=10):
-            if sum(counts) > max_dist or 0 not in counts:
-                continue
-            ok = [i for i in range(10) if counts[i] == 0 and counts[(i + 1) % 10] + counts[(i + 2) % 10] <= tol]
-            assert ok, (max_dist, counts)
-            reporter = ok[0]
-            # the scan meets the hit in every slice of `ok`; it drops the encounter in s > 0 when s - 1 and s + 3 are exact
-            kept = [s for s in ok if not (s > 0 and counts[s - 1] == 0 and counts[(s + 3) % 10] == 0)]
-            assert reporter in kept, (max_dist, counts)
+    for n_slices, per in ((10, 2), (20, 1)):
+        unit = 4 // per            # slices of the successor unit
+        behind = (4 - per) // per  # slices behind it that share the first quad with the previous slice
+        for max_dist, tol in ((2, 0), (4, 1), (5, 2)):
+            for k in range(max_dist + 1):
+                for pos in itertools.combinations(range(20), k):
+                    counts = [0] * n_slices
+                    for q in pos:
+                        counts[q // per] += 1
+                    if 0 not in counts:
+                        continue
+                    ok = [i for i in range(n_slices)
+                          if counts[i] == 0 and sum(counts[(i + j) % n_slices] for j in range(1, unit + 1)) <= tol]
+                    assert ok, (n_slices, max_dist, counts)
+                    # the scan meets the hit in every slice of `ok`; it drops the encounter in s > 0 when its first quad is exact
+                    kept = [s for s in ok if not (s > 0 and counts[s - 1] == 0 and
+                                                  all(counts[(s + unit + j) % n_slices] == 0 for j in range(1, behind + 1)))]
+                    assert ok[0] in kept, (n_slices, max_dist, counts)
 
 
 def test_previous_slice_filter_of_the_pruned_scan_never_drops_the_reporter():
