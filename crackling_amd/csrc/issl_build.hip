@@ -177,10 +177,10 @@ int launch_sort_slice(SortTemp &t, const uint64_t *d_sites, const uint64_t *d_li
     uint64_t *src = t.keys, *dst = t.tmp;
     for (uint32_t pass = 0; pass < 2; ++pass) { // successor byte, then own byte
         const uint32_t shift = kKeyShift + 8 * pass;
-        hipLaunchKernelGGL(k_radix_hist, dim3(n_blocks), dim3(256), 0, nullptr, src, n_sites, shift, t.hist, n_blocks);
+        hipLaunchKernelGGL(k_radix_hist, dim3(n_blocks), dim3(256), 0, nullptr, src, n_sites, shift, t.hist, n_blocks, 0xFFu);
         launch_radix_scan(t.hist, n_blocks, nullptr);
         hipLaunchKernelGGL(k_radix_scatter<KeyItself>, dim3(n_blocks), dim3(256), 0, nullptr, src, dst, n_sites, shift, t.hist,
-                           n_blocks, KeyItself{});
+                           n_blocks, KeyItself{}, 0xFFu);
         std::swap(src, dst);
     }
     hipLaunchKernelGGL(k_fill_maps, dim3(grid), dim3(256), 0, nullptr, src, d_bucket_start, d_tile_first, d_list, n_sites, slice, slice_width,
@@ -263,10 +263,11 @@ int launch_bucket_sizes(const uint64_t *d_sites, uint64_t n_sites, uint32_t slic
 int launch_build_entries(const uint64_t *d_sites, const uint32_t *d_occ, uint64_t n_sites, uint32_t slice_begin,
                          uint32_t slice_end, uint32_t slice_width, uint64_t *d_entries)
 {
-    if (slice_width != 8) { // one pass = one byte of the signature
-        set_error("the device-side builder handles 8-bit slices only");
+    if (slice_width == 0 || slice_width > 8) { // one pass = one slice value of up to 8 bits
+        set_error("the device-side builder handles slices of up to 8 bits");
         return ISSL_E_UNSUPPORTED;
     }
+    const uint32_t mask = (1u << slice_width) - 1u;
     const uint32_t n_blocks = static_cast<uint32_t>((n_sites + 256ull * kSortItems - 1) / (256ull * kSortItems));
     uint32_t *d_hist = nullptr;
     hipError_t e = hipMalloc(reinterpret_cast<void **>(&d_hist), 4ull * radix_hist_words(n_blocks));
@@ -276,11 +277,11 @@ int launch_build_entries(const uint64_t *d_sites, const uint32_t *d_occ, uint64_
     }
     for (uint32_t s = slice_begin; s < slice_end; ++s) {
         const uint32_t shift = slice_width * s;
-        hipLaunchKernelGGL(k_radix_hist, dim3(n_blocks), dim3(256), 0, nullptr, d_sites, n_sites, shift, d_hist, n_blocks);
+        hipLaunchKernelGGL(k_radix_hist, dim3(n_blocks), dim3(256), 0, nullptr, d_sites, n_sites, shift, d_hist, n_blocks, mask);
         launch_radix_scan(d_hist, n_blocks, nullptr);
         hipLaunchKernelGGL(k_radix_scatter<SliceEntry>, dim3(n_blocks), dim3(256), 0, nullptr, d_sites,
                            d_entries + static_cast<uint64_t>(s - slice_begin) * n_sites, n_sites, shift, d_hist, n_blocks,
-                           SliceEntry{d_occ});
+                           SliceEntry{d_occ}, mask);
     }
     e = hipDeviceSynchronize();
     (void)hipFree(d_hist);

@@ -646,22 +646,10 @@ static std::vector<LayoutSpec> layout_choices(const Tuning &tn, const Geometry &
 {
     std::vector<LayoutSpec> c;
     auto spec = [](bool esig, uint32_t cold, uint32_t sorted, bool no_lists = false) { LayoutSpec s; s.inline_sigs = esig; s.cold = cold; s.sorted = sorted; s.no_lists = no_lists; return s; };
-    const bool narrow = g.slice_width != 8; // no host-cold layouts (they rebuild signatures from 16 stream positions + the bucket's
-                                            // byte) and no image without its lists (the device-side list builder takes 8-bit slices)
-    if (narrow) {
-        // narrow slices (round 4): the sorted layouts order a bucket by the byte of the next two (4-bit) / four (2-bit) slices
-        // (succ_byte), so the pruned scan applies
-        const bool can_sort = g.n_slices * g.slice_width == 40 && !list_order_only && tn.sorted_layout != 0 && tn.inline_sigs != 1;
-        if (tn.host_cold == 1 || tn.keep_lists == 0) return c;
-        if (can_sort) {
-            if (tn.compact != 1) c.push_back(spec(false, 0, 1));
-            if (tn.compact != 0) c.push_back(spec(false, 0, 2));
-        }
-        if (tn.sorted_layout == 1 || tn.compact == 1) return c;
-        if (want_inline_sigs(tn, g)) c.push_back(spec(true, 0, 0));
-        if (tn.inline_sigs != 1) c.push_back(spec(false, 0, 0));
-        return c;
-    }
+    // Narrow slices (4 / 2 bits; round 4): the sorted layouts order a bucket by the byte of the next two / four slices (succ_byte),
+    // so everything sorted applies; only the list-order layout with ALL cold sections in host memory does not -- it rebuilds a
+    // candidate's signature from the stream's 16 positions + the bucket's byte, and a narrow slice leaves 18 / 19 outside.
+    const bool narrow = g.slice_width != 8;
     const bool may_sort = !list_order_only && tn.sorted_layout != 0 && tn.inline_sigs != 1;
     const bool must_sort = tn.sorted_layout == 1 || tn.compact == 1 || tn.keep_lists == 0; // (only a sorted image can do without its lists)
     if (may_sort || must_sort) {
@@ -680,11 +668,11 @@ static std::vector<LayoutSpec> layout_choices(const Tuning &tn, const Geometry &
     }
     if (!must_sort) {
         if (tn.host_cold == 1) {
-            c.push_back(spec(false, 3, 0));
+            if (!narrow) c.push_back(spec(false, 3, 0));
         } else {
             if (want_inline_sigs(tn, g)) c.push_back(spec(true, 0, 0));
             if (tn.inline_sigs != 1) c.push_back(spec(false, 0, 0));
-            if (tn.host_cold == -1 && tn.inline_sigs != 1) c.push_back(spec(false, 3, 0));
+            if (tn.host_cold == -1 && tn.inline_sigs != 1 && !narrow) c.push_back(spec(false, 3, 0));
         }
     }
     return c;

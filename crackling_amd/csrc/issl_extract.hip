@@ -150,10 +150,10 @@ int radix_sort(uint64_t *d_keys, uint64_t *d_tmp, uint64_t n, uint32_t bits)
     EX_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_hist), 4ull * radix_hist_words(n_blocks)));
     uint64_t *src = d_keys, *dst = d_tmp;
     for (uint32_t shift = 0; shift < bits; shift += 8) {
-        hipLaunchKernelGGL(k_radix_hist, dim3(n_blocks), dim3(256), 0, nullptr, src, n, shift, d_hist, n_blocks);
+        hipLaunchKernelGGL(k_radix_hist, dim3(n_blocks), dim3(256), 0, nullptr, src, n, shift, d_hist, n_blocks, 0xFFu);
         launch_radix_scan(d_hist, n_blocks, nullptr);
         hipLaunchKernelGGL(k_radix_scatter<KeyItself>, dim3(n_blocks), dim3(256), 0, nullptr, src, dst, n, shift, d_hist,
-                           n_blocks, KeyItself{});
+                           n_blocks, KeyItself{}, 0xFFu);
         std::swap(src, dst);
     }
     hipError_t e = hipDeviceSynchronize();

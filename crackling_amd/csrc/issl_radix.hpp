@@ -1,4 +1,4 @@
-// One stable 8-bit radix pass over 64-bit keys, shared by the off-target extraction (LSD sort of the site keys,
+// One stable radix pass of up to 8 bits (digit = key >> shift & mask) over 64-bit keys, shared by the off-target extraction (LSD sort of the site keys,
 // issl_extract.hip) and the device-side index builder (one pass per slice, issl_build.hip).  Included by both; the
 // kernels live in an anonymous namespace, one copy per translation unit.
 #pragma once
@@ -14,7 +14,7 @@ constexpr uint32_t kSortItems = 16; // keys per thread and radix pass (4096 per 
 // ---- LSD radix sort of 64-bit keys, 8 bits per pass -----------------------------------------------------------
 
 __global__ __launch_bounds__(256) void k_radix_hist(const uint64_t *__restrict__ keys, uint64_t n, uint32_t shift,
-                                                    uint32_t *__restrict__ hist, uint32_t n_blocks)
+                                                    uint32_t *__restrict__ hist, uint32_t n_blocks, uint32_t mask)
 {
     __shared__ uint32_t h[256];
     h[threadIdx.x] = 0;
@@ -22,7 +22,7 @@ __global__ __launch_bounds__(256) void k_radix_hist(const uint64_t *__restrict__
     const uint64_t base = static_cast<uint64_t>(blockIdx.x) * (256 * kSortItems);
     for (uint32_t r = 0; r < kSortItems; ++r) {
         const uint64_t i = base + r * 256 + threadIdx.x;
-        if (i < n) atomicAdd(&h[(keys[i] >> shift) & 0xFFu], 1u);
+        if (i < n) atomicAdd(&h[(keys[i] >> shift) & mask], 1u);
     }
     __syncthreads();
     hist[static_cast<uint64_t>(threadIdx.x) * n_blocks + blockIdx.x] = h[threadIdx.x]; // digit-major for the scan
@@ -125,7 +125,7 @@ struct KeyItself {
 template <typename Payload>
 __global__ __launch_bounds__(256) void k_radix_scatter(const uint64_t *__restrict__ in, uint64_t *__restrict__ out,
                                                        uint64_t n, uint32_t shift, const uint32_t *__restrict__ offsets,
-                                                       uint32_t n_blocks, Payload payload)
+                                                       uint32_t n_blocks, Payload payload, uint32_t mask)
 {
     __shared__ uint32_t next[256];       // next free output slot of every digit for this workgroup
     __shared__ uint32_t wave_cnt[4][256]; // keys of every digit per wave in the current round
@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256) void k_radix_scatter(const uint64_t *__restric
         const uint64_t i = base + r * 256 + threadIdx.x;
         const bool valid = i < n;
         const uint64_t key = valid ? in[i] : 0ull;
-        const uint32_t d = static_cast<uint32_t>(key >> shift) & 0xFFu;
+        const uint32_t d = static_cast<uint32_t>(key >> shift) & mask;
         uint64_t same = __ballot(valid); // lanes of this wave holding the same digit
 #pragma unroll
         for (uint32_t b = 0; b < 8; ++b) {

@@ -879,6 +879,35 @@ def test_index_built_on_device_is_byte_identical(golden, tmp_path):
     ix.close()
 
 
+@pytest.mark.parametrize("options", [None, {"compact": 1, "keep_lists": 0}])
+def test_narrow_index_built_on_device_is_byte_identical(golden_width, tmp_path, options):
+    """The device-side builder with 4- and 2-bit slices (one radix pass per slice over the slice's own bits): written back
+    out it is the reference builder's file (tests/golden/width4, width2) -- also from an image that holds no slice lists,
+    which are made again for the file --, and it scores like the host-built index."""
+    g = golden_width
+    width = int(g.name[5:])
+    lines = g.sites_txt.read_text().splitlines()
+    sigs_all = ca.encode_guides(lines)
+    keep = np.ones(len(sigs_all), dtype=bool)
+    keep[1:] = sigs_all[1:] != sigs_all[:-1]
+    first = np.flatnonzero(keep)
+    sigs = sigs_all[first]
+    occ = np.diff(np.append(first, len(sigs_all))).astype(np.uint32)
+    ix = ca.IsslIndex.build_on_device(sigs, occ, device=0, slice_width=width, options=options)
+    assert ix.get_option("is_sorted") == 1 and ix.get_option("lists_absent") == (1 if options else 0)
+    out = tmp_path / "dev.issl"
+    ix.write(out)
+    assert out.read_bytes() == g.issl.read_bytes()
+    guides = ca.encode_guides(g.guides)
+    for key in ("and|75|4", "and|0|2", "cfd|75|6"):
+        method, thr, dist = key.split("|")
+        mit, cfd = ix.score(guides, int(dist), float(thr), method)
+        assert ca.format_scores(guides, mit, cfd, method) == g.expected[key], key
+    for thr in g.hit_thresholds():
+        assert np.array_equal(ix.dump_hits(guides, 4, float(thr), "and"), g.hits(thr)), thr
+    ix.close()
+
+
 def test_device_builder_matches_host_builder_on_config0(config0, tmp_path):
     """1 M sites (245 workgroups per radix pass): same .issl bytes as the host builder, same scores."""
     ix, oracle, sigs, guides = config0

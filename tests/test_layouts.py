@@ -74,7 +74,7 @@ def test_every_layout_reproduces_the_reference(name, layout):
         ix.close()
 
 
-@pytest.mark.parametrize("layout", [None, "sorted", "compact", "list_esig", "list"])
+@pytest.mark.parametrize("layout", [None] + list(LAYOUTS))
 @pytest.mark.parametrize("name", ["width4", "width2"])
 def test_narrow_slices_reproduce_the_reference(name, layout):
     """Indexes with 4- and 2-bit slices (10 / 20 slices per site; isslScoreOfftargets.cpp:261-270,330-341 is generic in
@@ -83,11 +83,10 @@ def test_narrow_slices_reproduce_the_reference(name, layout):
     of the next two / four slices, and the pruned scan visits 13 (1, 67) of a bucket's 256 groups -- with <= 4 mismatches
     some exact slice is followed by four positions with at most one mismatch between them (enumerated in
     tests/test_oracle_golden.py).  Stdout and hit lists of the compiled reference, max distances 2, 4 and 6 (6: whole buckets
-    on every layout); the layouts a narrow width cannot take are refused."""
+    on every layout); the one layout a narrow width cannot take is refused."""
     g = Golden(name)
     width = int(name[5:])
-    sortable = True
-    if layout in ("sorted", "compact") and not sortable:
+    if layout == "host_cold":   # rebuilds signatures from the stream's 16 positions + the bucket's byte: 8-bit slices only
         bad = _open(g.issl, layout)
         with pytest.raises(ca.IsslError):
             bad.upload(0)
@@ -95,9 +94,11 @@ def test_narrow_slices_reproduce_the_reference(name, layout):
         return
     ix = ca.IsslIndex.open(g.issl) if layout is None else _open(g.issl, layout)
     ix.upload(0)
-    is_sorted = sortable and layout in (None, "sorted", "compact")
-    assert ix.get_option("is_sorted") == (1 if is_sorted else 0) and ix.get_option("cold_on_host") == 0
-    assert ix.get_option("is_compact") == (1 if layout == "compact" else 0) and ix.get_option("lists_absent") == 0
+    is_sorted = layout is None or layout in SORTED
+    if layout is None:
+        assert ix.get_option("is_sorted") == 1 and ix.get_option("is_compact") == 0 and ix.get_option("cold_sections") == 0
+    else:
+        _check_layout(ix, layout)
     assert ix.header["slice_width"] == width and ix.header["n_slices"] == 40 // width
     sigs = ca.encode_guides([s.encode() for s in g.guides])
     try:
@@ -118,11 +119,6 @@ def test_narrow_slices_reproduce_the_reference(name, layout):
     finally:
         ix.close()
     if layout is None:
-        for forced in ("host_cold", "compact_cold", "compact_bare"):
-            bad = _open(g.issl, forced)
-            with pytest.raises(ca.IsslError):
-                bad.upload(0)
-            bad.close()
         odd = ca.IsslIndex.build_from_text(g.sites_txt.read_bytes(), slice_width=5)   # 5-bit slices cut positions in two
         with pytest.raises(ca.IsslError) as e:
             odd.upload(0)
