@@ -2228,8 +2228,11 @@ struct ReplayTicket {
     uint32_t next = 0, turn = 0;
 };
 __device__ __forceinline__ uint32_t replay_take(ReplayTicket &t, uint32_t *cur /*LDS[2]*/, Counters *counters, uint32_t which,
-                                                bool first)
+                                                bool first, uint32_t n_entries)
 {
+    // no more entries than workgroups (a small batch, a few many-hit guides): one each, no ticket, no barrier -- the kernel then
+    // lasts as long as its slowest guide, and the round trip of the atomic is part of that
+    if (n_entries <= gridDim.x) return first ? blockIdx.x : n_entries;
     if (threadIdx.x == 0) {
         if (first) t.next = atomicAdd(&counters->replay_next[which], 1u);
         cur[t.turn] = t.next;
@@ -2265,7 +2268,7 @@ __global__ __launch_bounds__(256, 6) void k_replay_mid(ImageView v, Workspace ws
     if (blockIdx.x >= n_big) return; // (more workgroups than entries -- on an even index there are none: no ticket is taken)
     ReplayTicket ticket;
     for (bool first = true;; first = false) {
-        const uint32_t b = replay_take(ticket, cur_entry, ws.counters, 0u, first);
+        const uint32_t b = replay_take(ticket, cur_entry, ws.counters, 0u, first, n_big);
         if (b >= n_big) break;
         const uint32_t g = ws.gcur_big[b];
         const uint32_t h = ws.gcount[g];
@@ -2344,32 +2347,43 @@ __global__ __launch_bounds__(256, 6) void k_replay_mid(ImageView v, Workspace ws
             }
             if (grouped_rank && mn <= mx) { atomicMin(&id_min, mn); atomicMax(&id_max, mx); } // the range the slice's ids span
             __syncthreads();
-            if (!grouped_rank) {
+            // Rank by counting against the WHOLE slice (the keys are distinct: ids / positions are), K keys per thread, the
+            // slice's ids read four at a time by every thread at once; then the terms to their ranks.
+            auto rank_against_all = [&](auto k_tag) {
+                constexpr uint32_t K = decltype(k_tag)::value;
                 if (threadIdx.x < 4u && len + threadIdx.x < ((len + 3u) & ~3u)) head[len + threadIdx.x] = 0xFFFFFFFFu; // (read four at a time)
                 __syncthreads();
-                // rank by counting against the whole slice (the keys are distinct: ids / positions are), then the terms to
-                // their ranks; len <= kMidDirect <= 256: one key per thread
-                const uint32_t mine = threadIdx.x < len ? head[threadIdx.x] : 0xFFFFFFFFu;
-                uint32_t rk = 0;
+                uint32_t mine[K], rk[K];
+#pragma unroll
+                for (uint32_t k = 0; k < K; ++k) { mine[k] = threadIdx.x + k * 256u < len ? head[threadIdx.x + k * 256u] : 0xFFFFFFFFu; rk[k] = 0; }
                 const uint4 *quads = reinterpret_cast<const uint4 *>(head);
 #pragma unroll 4
                 for (uint32_t j = 0; j < (len + 3u) / 4u; ++j) {
                     const uint4 q = quads[j];
-                    rk += (q.x < mine ? 1u : 0u) + (q.y < mine ? 1u : 0u) + (q.z < mine ? 1u : 0u) + (q.w < mine ? 1u : 0u);
+#pragma unroll
+                    for (uint32_t k = 0; k < K; ++k)
+                        rk[k] += (q.x < mine[k] ? 1u : 0u) + (q.y < mine[k] ? 1u : 0u) + (q.z < mine[k] ? 1u : 0u) + (q.w < mine[k] ? 1u : 0u);
                 }
-                if (threadIdx.x < len) {
-                    const uint32_t idx = head_idx[threadIdx.x];
+#pragma unroll
+                for (uint32_t k = 0; k < K; ++k) {
+                    if (threadIdx.x + k * 256u >= len) continue;
+                    const uint32_t idx = head_idx[threadIdx.x + k * 256u];
                     const double2 t2 = idx < in_slots ? *reinterpret_cast<const double2 *>(&srec[idx].mit) : terms2[h0 + idx];
-                    tmc[rk] = t2;
+                    tmc[rk[k]] = t2;
                     if (out_hits)
-                        out_hits[h0 + walked + rk] = hit_terms(v, gsig, g, (static_cast<uint64_t>(g) << kKeyGuideShift) |
-                                                                   (static_cast<uint64_t>(s2) << kKeySliceShift) | mine,
-                                                               calc_mit, calc_cfd, true).rec;
+                        out_hits[h0 + walked + rk[k]] = hit_terms(v, gsig, g, (static_cast<uint64_t>(g) << kKeyGuideShift) |
+                                                                      (static_cast<uint64_t>(s2) << kKeySliceShift) | mine[k],
+                                                                  calc_mit, calc_cfd, true).rec;
                 }
+            };
+            if (!grouped_rank) {
+                rank_against_all(std::integral_constant<uint32_t, 1u>{});
             } else {
                 // Ranked inside 256 groups of the range the ids span (the hits of a guide in one slice share the slice's bases:
                 // on a text-sorted index their ids lie in a narrow range far from zero): group sizes, their prefix, the ids and
                 // hit indexes in group order (in the memory the terms will take), then every id against its own group only.
+                // Ids that pile up in one group -- a repeat family: neighbours in the text-sorted site table -- leave nothing to
+                // gain there: a slice whose largest group holds more than a quarter of it is ranked against all of it.
                 const uint32_t low = id_min, top = id_max - low;
                 const uint32_t shift = top < 256u ? 0u : 24u - static_cast<uint32_t>(__builtin_clz(top)); // (id - low) >> shift < 256
 #pragma unroll
@@ -2377,18 +2391,24 @@ __global__ __launch_bounds__(256, 6) void k_replay_mid(ImageView v, Workspace ws
                     if (threadIdx.x + k * 256u < len) atomicAdd(&group_cur[(head[threadIdx.x + k * 256u] - low) >> shift], 1u);
                 __syncthreads();
                 if (threadIdx.x < 64) { // exclusive scan of the 256 group sizes by one wave, 4 per lane; the cursors start there
-                    uint32_t v4[4], sum = 0;
-                    for (uint32_t k = 0; k < 4; ++k) { v4[k] = group_cur[threadIdx.x * 4 + k]; sum += v4[k]; }
+                    uint32_t v4[4], sum = 0, big = 0;
+                    for (uint32_t k = 0; k < 4; ++k) { v4[k] = group_cur[threadIdx.x * 4 + k]; sum += v4[k]; big = v4[k] > big ? v4[k] : big; }
                     uint32_t x = sum;
                     for (uint32_t d = 1; d < 64; d <<= 1) {
                         const uint32_t y = __shfl_up(x, d, 64);
                         if (threadIdx.x >= d) x += y;
                     }
+                    for (uint32_t d = 32; d > 0; d >>= 1) { const uint32_t y = __shfl_xor(big, d, 64); big = y > big ? y : big; }
                     uint32_t run = x - sum;
                     for (uint32_t k = 0; k < 4; ++k) { group_at[threadIdx.x * 4 + k] = run; group_cur[threadIdx.x * 4 + k] = run; run += v4[k]; }
                     if (threadIdx.x == 63) group_at[256] = run;
+                    if (threadIdx.x == 0) id_max = big; // (the range is in registers: the word now says how large the largest group is)
                 }
                 __syncthreads();
+                if (id_max * 4u > len) { // (uniform)
+                    if (len <= 512u) rank_against_all(std::integral_constant<uint32_t, 2u>{});
+                    else rank_against_all(std::integral_constant<uint32_t, 4u>{});
+                } else {
                 uint32_t *ids2 = reinterpret_cast<uint32_t *>(tmc);                 // [kMidSlice]
                 uint16_t *idx2 = reinterpret_cast<uint16_t *>(ids2 + kMidSlice);    // [kMidSlice]
 #pragma unroll
@@ -2400,17 +2420,24 @@ __global__ __launch_bounds__(256, 6) void k_replay_mid(ImageView v, Workspace ws
                     ids2[to] = id;
                     idx2[to] = head_idx[i];
                 }
+                if (threadIdx.x < 4u && len + threadIdx.x < ((len + 3u) & ~3u)) ids2[len + threadIdx.x] = 0xFFFFFFFFu; // (read four at a time)
                 __syncthreads();
-                // every id against its own group; id and hit index go to the id's rank (`head`, `head_idx`: their first contents
-                // are in group order now), so that nothing is carried across the barrier but the arrays
+                // every id against its own group, four ids per LDS read: the quads that cover the group also hold ids of the
+                // groups around it -- smaller ones below (each counts: the rank starts at the quad, not at the group), larger
+                // ones and the padding above (none counts); id and hit index go to the id's rank (`head`, `head_idx`: their
+                // first contents are in group order now), so that nothing is carried across the barrier but the arrays
+                const uint4 *quads2 = reinterpret_cast<const uint4 *>(ids2);
 #pragma unroll
                 for (uint32_t k = 0; k < kMidSlice / 256; ++k) {
                     const uint32_t i = threadIdx.x + k * 256u;
                     if (i < len) {
                         const uint32_t id = ids2[i];
                         const uint32_t g0 = group_at[(id - low) >> shift], g1 = group_at[((id - low) >> shift) + 1u];
-                        uint32_t r = g0;
-                        for (uint32_t j = g0; j < g1; ++j) r += ids2[j] < id ? 1u : 0u;
+                        uint32_t r = g0 & ~3u;
+                        for (uint32_t j = g0 >> 2; j < (g1 + 3u) >> 2; ++j) {
+                            const uint4 q = quads2[j];
+                            r += (q.x < id ? 1u : 0u) + (q.y < id ? 1u : 0u) + (q.z < id ? 1u : 0u) + (q.w < id ? 1u : 0u);
+                        }
                         head[r] = id;
                         head_idx[r] = idx2[i];
                     }
@@ -2427,6 +2454,7 @@ __global__ __launch_bounds__(256, 6) void k_replay_mid(ImageView v, Workspace ws
                                                                       (static_cast<uint64_t>(s2) << kKeySliceShift) | head[i],
                                                                   calc_mit, calc_cfd, true).rec;
                     }
+                }
                 }
             }
             if (threadIdx.x < 8u && len + threadIdx.x < ((len + 7u) & ~7u)) tmc[len + threadIdx.x] = make_double2(0.0, 0.0); // (walked eight at a time)
@@ -2570,7 +2598,7 @@ __global__ __launch_bounds__(THREADS, THREADS < 1024u ? 6 : 4) void k_replay_big
     if (blockIdx.x >= n_mine) return; // (more workgroups than entries: no ticket is taken)
     ReplayTicket ticket;
     for (bool first = true;; first = false) { // (entries by ticket, as in k_replay_mid)
-        const uint32_t b = replay_take(ticket, cur_entry, ws.counters, THREADS < 1024u ? 1u : 2u, first);
+        const uint32_t b = replay_take(ticket, cur_entry, ws.counters, THREADS < 1024u ? 1u : 2u, first, n_mine);
         if (b >= n_mine) break;
         const uint32_t g = THREADS < 1024u ? ws.gcur_big2[b] : ws.gcur_big2[static_cast<uint32_t>(ws.cap_guides) - b];
         const uint32_t h = ws.gcount[g];
