@@ -133,7 +133,7 @@ int issl_index_build_from_sites(const uint64_t *sigs, const uint32_t *occ, size_
  * input instead of 48 B/site of host arrays), so indexes up to the format's 2^32-1 sites fit a 288 GB GPU.
  * issl_index_write() streams the arrays back out of the image (same bytes as the host builder);
  * issl_index_upload() to another device is refused -- replicate with issl_index_image/attach_image.
- * 20 bp / 8-bit slices only. */
+ * 20 bp; slices of 8, 4 or 2 bits (the scorer's geometries). */
 int issl_index_build_on_device(const uint64_t *sigs, const uint32_t *occ, size_t n_sites,
                                size_t n_lines, size_t seq_len, size_t slice_width, int device,
                                issl_index **out);
@@ -204,6 +204,8 @@ int issl_index_copy_image_to(const issl_index *idx, void *dev_dst, size_t bytes)
  *                 builder writes such, the reference does not care; no pruned scan then) with / without in-list
  *                 signatures 108 / 68 B/site, or with site table and lists in host memory 25 B/site (the kernels rebuild
  *                 signatures from the scan stream and read host memory only for counts >= 255 and for issl_dump_hits)
+ * Indexes with ten 4-bit or twenty 2-bit slices take every layout but the last (the sorted ones order a bucket by the byte
+ * of the next two / four slices; per site the slice lists then cost 80 / 160 B instead of 40).
  * Options sorted_layout / compact / inline_sigs / host_cold force a choice (or the upload fails); results are identical
  * in every layout.  An index with a site in a bucket its signature does not select, or twice in one slice, is refused
  * (ISSL_E_FORMAT).  issl_index_cold() returns the host buffer of an image with host-resident sections (NULL / 0 when
