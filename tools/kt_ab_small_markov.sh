@@ -1,4 +1,7 @@
-cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp; mkdir -p gpurun_out/s12
+#!/bin/bash
+# rocprofv3 kernel tables of two builds (tools/_build/libissl_hip_prev.so against the one in the tree) on the small skewed
+# workload (10 k guides x 50 M sites): which replay kernel a difference in `replay` comes from.   gpurun -- bash tools/kt_ab_small_markov.sh
+cd "$(dirname "$0")/.."; export TMPDIR=/tmp; mkdir -p gpurun_out/s12
 cp crackling_amd/libissl_hip.so tools/_build/libissl_hip_cur.so
 for which in prev cur; do
   cp tools/_build/libissl_hip_$which.so crackling_amd/libissl_hip.so
