@@ -180,6 +180,7 @@ struct Lane {
 
 struct issl_index {
     std::unique_ptr<HostIndex> host; // absent for attached images
+    size_t presized_guides = 0;      // largest batch issl_score has sized this handle's record buffers for
     Geometry geo;
     std::vector<uint64_t> bucket_sizes;
     Tuning tuning = Tuning::from_env(); // the environment is read here, once per handle
@@ -251,7 +252,22 @@ static void free_workspace(Workspace &w)
         if (p) (void)hipFree(p);
     if (w.raw) (void)hipFree(w.raw);
     if (w.raw_used) (void)hipFree(w.raw_used);
+    if (w.h_stage) (void)hipHostFree(w.h_stage);
     w = Workspace{};
+}
+
+// Pinned host memory for the host-pointer entry point: a copy from pageable memory is staged by the runtime piece by piece
+// (three of them cost 0.5 ms per 100 k guides); from here it is one DMA each.  No pinned memory: the plain copies do.
+static bool ensure_stage(Workspace &w, size_t bytes)
+{
+    if (w.h_stage_bytes >= bytes) return true;
+    if (w.h_stage) (void)hipHostFree(w.h_stage);
+    w.h_stage = nullptr;
+    w.h_stage_bytes = 0;
+    const size_t want = bytes + bytes / 4;
+    if (hipHostMalloc(&w.h_stage, want, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); w.h_stage = nullptr; return false; }
+    w.h_stage_bytes = want;
+    return true;
 }
 
 template <typename T> static int dev_alloc(T *&p, size_t count)
@@ -688,6 +704,7 @@ static uint64_t count_tiles(const HostIndex &h)
 static void release_device(issl_index *ix)
 {
     if (ix->device >= 0) (void)hipSetDevice(ix->device);
+    ix->presized_guides = 0; // (the workspaces go with the image)
     for (Lane *lp : {&ix->lane, &ix->lane2}) {
         Lane &lane = *lp;
         if (lane.ready) {
@@ -1608,7 +1625,8 @@ int issl_score(issl_index *idx, const uint64_t *guides, size_t n, int max_dist, 
     // (the pruned scan places every guide in up to 65 groups: pieces of at most 2^20 guides while it may be chosen)
     const uint32_t piece_mode = prune_mode_for(idx->view, idx->tuning, 1, max_dist);
     const size_t piece = piece_mode ? size_t(prune_max_guides(piece_mode, idx->view.n_slices)) : size_t(1) << 22;
-    const bool presize = !idx->tuning.raw_chunks && n >= (size_t(1) << 15); // small pages: the default buffers do
+    // (small pages: the default buffers do; a handle that has scored a batch of this size has grown its buffers for it)
+    const bool presize = !idx->tuning.raw_chunks && n >= (size_t(1) << 15) && n > idx->presized_guides;
     const double records_per_comparison = 8e-5;
     size_t free_b = 0, total_b = 0;
     if (presize) HIP_TRY(hipMemGetInfo(&free_b, &total_b));
@@ -1639,11 +1657,25 @@ int issl_score(issl_index *idx, const uint64_t *guides, size_t n, int max_dist, 
             rc = ensure_raw_capacity(ws, static_cast<size_t>(slots / (kChunkRecs - 1)) + size_t(scan_waves(idx->tuning)) * 10);
             if (rc) return rc;
         }
-        HIP_TRY(hipMemcpy(ws.d_guides, guides + at, 8 * cnt, hipMemcpyHostToDevice));
-        rc = score_core(idx, ws.d_guides, cnt, max_dist, threshold, method, ws.d_mit, ws.d_cfd, nullptr, false);
-        if (rc) return rc;
-        HIP_TRY(hipMemcpy(mit + at, ws.d_mit, 8 * cnt, hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(cfd + at, ws.d_cfd, 8 * cnt, hipMemcpyDeviceToHost));
+        if (ensure_stage(ws, 24 * cnt)) { // guides in, scores out through pinned memory: one DMA each, one synchronisation
+            uint64_t *sg = static_cast<uint64_t *>(ws.h_stage);
+            double *sm = reinterpret_cast<double *>(sg + cnt), *sc = sm + cnt;
+            std::memcpy(sg, guides + at, 8 * cnt);
+            HIP_TRY(hipMemcpyAsync(ws.d_guides, sg, 8 * cnt, hipMemcpyHostToDevice, nullptr));
+            rc = score_core(idx, ws.d_guides, cnt, max_dist, threshold, method, ws.d_mit, ws.d_cfd, nullptr, false);
+            if (rc) return rc;
+            HIP_TRY(hipMemcpyAsync(sm, ws.d_mit, 8 * cnt, hipMemcpyDeviceToHost, nullptr));
+            HIP_TRY(hipMemcpyAsync(sc, ws.d_cfd, 8 * cnt, hipMemcpyDeviceToHost, nullptr));
+            HIP_TRY(hipStreamSynchronize(nullptr));
+            std::memcpy(mit + at, sm, 8 * cnt);
+            std::memcpy(cfd + at, sc, 8 * cnt);
+        } else {
+            HIP_TRY(hipMemcpy(ws.d_guides, guides + at, 8 * cnt, hipMemcpyHostToDevice));
+            rc = score_core(idx, ws.d_guides, cnt, max_dist, threshold, method, ws.d_mit, ws.d_cfd, nullptr, false);
+            if (rc) return rc;
+            HIP_TRY(hipMemcpy(mit + at, ws.d_mit, 8 * cnt, hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(cfd + at, ws.d_cfd, 8 * cnt, hipMemcpyDeviceToHost));
+        }
         const issl_stats &s = idx->stats;
         total.n_guides += s.n_guides; total.candidates += s.candidates; total.hits += s.hits;
         total.planned_comparisons += s.planned_comparisons; total.reference_comparisons += s.reference_comparisons;
@@ -1656,6 +1688,7 @@ int issl_score(issl_index *idx, const uint64_t *guides, size_t n, int max_dist, 
         at += cnt;
     }
     idx->stats = total;
+    idx->presized_guides = std::max(idx->presized_guides, n);
     return ISSL_OK;
 }
 

@@ -384,6 +384,8 @@ struct Workspace {
     size_t cap_slot_guides = 0;
     uint32_t *blocksum = nullptr;
     uint64_t *d_guides = nullptr; // staging for the host API
+    void *h_stage = nullptr;      // ... and its pinned host side: guides in, MIT and CFD scores out (issl_score; 24 B per guide)
+    size_t h_stage_bytes = 0;
     double *d_mit = nullptr, *d_cfd = nullptr;
     uint32_t *d_kept = nullptr;   // [G] hits scored before early exit (dump_hits)
     issl_hit *d_hitrec = nullptr; // [hit_cap] expanded records (dump_hits)
