@@ -511,8 +511,9 @@ def main():
                 settle(step)
                 settle(step)
             # the caller-visible host entry point: guides from host memory, scores back to host memory, one sync per call
+            index.score(guides, a.max_dist, a.threshold, a.method)   # (untimed: the handle's first call pins its staging memory)
             t1 = time.perf_counter()
-            reps = 3
+            reps = 5
             for _ in range(reps):
                 hm, hc = index.score(guides, a.max_dist, a.threshold, a.method)
             dt = (time.perf_counter() - t1) / reps
