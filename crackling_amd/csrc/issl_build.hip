@@ -219,6 +219,8 @@ int finish_sort(uint32_t *d_flag)
 }
 
 namespace {
+// (sizes[nb]: set when a signature carries bits above the n_slices * slice_width the geometry gives it -- the sorted layouts keep
+// a site's count in those bits of the site table, k_tag_sites)
 __global__ __launch_bounds__(256) void k_bucket_sizes(const uint64_t *__restrict__ sites, uint64_t n_sites, uint32_t slice_width,
                                                       uint32_t n_slices, unsigned long long *__restrict__ sizes)
 {
@@ -230,6 +232,7 @@ __global__ __launch_bounds__(256) void k_bucket_sizes(const uint64_t *__restrict
     for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x; i < n_sites; i += static_cast<uint64_t>(gridDim.x) * 256) {
         const uint64_t sig = sites[i];
         for (uint32_t s = 0; s < n_slices; ++s) atomicAdd(&hist[(s << slice_width) + (static_cast<uint32_t>(sig >> (slice_width * s)) & low)], 1u);
+        if (n_slices * slice_width < 64u && (sig >> (n_slices * slice_width)) != 0ull) sizes[nb] = 1ull; // (every writer stores the same value)
     }
     __syncthreads();
     for (uint32_t b = threadIdx.x; b < nb; b += 256)
@@ -245,14 +248,21 @@ int launch_bucket_sizes(const uint64_t *d_sites, uint64_t n_sites, uint32_t slic
     }
     const uint32_t nb = n_slices << slice_width;
     unsigned long long *d_sizes = nullptr;
-    hipError_t e = hipMalloc(reinterpret_cast<void **>(&d_sizes), 8ull * nb);
-    if (e == hipSuccess) e = hipMemset(d_sizes, 0, 8ull * nb);
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&d_sizes), 8ull * (nb + 1u));
+    if (e == hipSuccess) e = hipMemset(d_sizes, 0, 8ull * (nb + 1u));
+    unsigned long long stray = 0ull;
     if (e == hipSuccess) {
         const uint32_t grid = static_cast<uint32_t>(std::min<uint64_t>((n_sites + 255) / 256, 4096));
         hipLaunchKernelGGL(k_bucket_sizes, dim3(std::max(grid, 1u)), dim3(256), 0, nullptr, d_sites, n_sites, slice_width, n_slices, d_sizes);
         e = hipMemcpy(h_sizes, d_sizes, 8ull * nb, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(&stray, d_sizes + nb, 8, hipMemcpyDeviceToHost);
     }
     if (d_sizes) (void)hipFree(d_sizes);
+    if (e == hipSuccess && stray) {
+        set_error("site table on the device: a signature carries bits above the " + std::to_string(n_slices * slice_width) +
+                  " its geometry gives it (2 bits per position, position 0 in the lowest)");
+        return ISSL_E_ARG;
+    }
     if (e != hipSuccess) {
         set_error(std::string("HIP error: ") + hipGetErrorString(e) + " (bucket sizes of a site table on the device)");
         return ISSL_E_DEVICE;

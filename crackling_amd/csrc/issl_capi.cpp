@@ -148,7 +148,7 @@ bool Tuning::set(const char *key, const char *value)
     else if (k == "prune") { if (!is_int || n < -1 || n > 1) return false; prune = static_cast<int>(n); }
     else if (k == "lanes") { if (!is_int || n < 1 || n > 2) return false; lanes = static_cast<int>(n); }
     else if (k == "tail_shapes") { if (!is_int || n < 0 || n > 1) return false; tail_shapes = static_cast<int>(n); }
-    else if (k == "hit_slots") { if (!is_int || n < 0 || n > 1) return false; hit_slots = static_cast<int>(n); }
+    else if (k == "hit_slots") { if (!is_int || n < 0 || n > 2) return false; hit_slots = static_cast<int>(n); }
     else if (k == "scan_stamps") stamps_path = value;
     else return false;
     return true;
@@ -179,8 +179,8 @@ struct Lane {
 };
 
 struct issl_index {
+    uint64_t worst_per_guide = 0;    // sum over the slices of their longest bucket: what one guide can be compared with at most (issl_score)
     std::unique_ptr<HostIndex> host; // absent for attached images
-    size_t presized_guides = 0;      // largest batch issl_score has sized this handle's record buffers for
     Geometry geo;
     std::vector<uint64_t> bucket_sizes;
     Tuning tuning = Tuning::from_env(); // the environment is read here, once per handle
@@ -326,9 +326,13 @@ static int ensure_workspace(issl_index *ix, size_t n, Lane &lane, uint32_t fine_
         w.n_buckets = static_cast<uint32_t>(nb);
     }
     bool grew = false;
-    if (n > w.cap_guides) {
+    // hit_slots = 2 (tests, A/B): wide hit slots from the first batch on, not only once a batch has shown that it needs them
+    const bool force_wide = tn.hit_slots == 2 && w.slot_width != kSlotHitsWide &&
+                            std::max<size_t>(std::max<size_t>(n, w.cap_guides), 1024) * kSlotHitsWide * sizeof(SlotRec) <= kSlotBytesMax;
+    if (force_wide) w.slot_width = kSlotHitsWide;
+    if (n > w.cap_guides || (force_wide && w.slots)) {
         grew = true;
-        const size_t cap = std::max<size_t>(n, 1024);
+        const size_t cap = std::max<size_t>(std::max<size_t>(n, w.cap_guides), 1024);
         const size_t slots = cap * ix->hdr.n_slices + kGuideGroup * nb;
         const size_t items = nb + cap * ix->hdr.n_slices / 8 + 2; // item sizes down to 8 guides (item_guides knob)
         if ((rc = dev_alloc(w.gword, slots))) return rc;
@@ -403,8 +407,8 @@ static int ensure_workspace(issl_index *ix, size_t n, Lane &lane, uint32_t fine_
         lane.ready = true;
     }
     if (!w.stamps && !tn.stamps_path.empty()) { // diagnostics: per-wave start/end times of the scan
-        if ((rc = dev_alloc(w.stamps, 4 * kScanWaves))) return rc;
-        HIP_TRY(hipMemset(w.stamps, 0, 32 * kScanWaves));
+        if ((rc = dev_alloc(w.stamps, kStampsWords))) return rc;
+        HIP_TRY(hipMemset(w.stamps, 0, 8ull * kStampsWords));
     }
     if (!w.sticky) {
         if ((rc = dev_alloc(w.sticky, 4))) return rc;
@@ -704,7 +708,6 @@ static uint64_t count_tiles(const HostIndex &h)
 static void release_device(issl_index *ix)
 {
     if (ix->device >= 0) (void)hipSetDevice(ix->device);
-    ix->presized_guides = 0; // (the workspaces go with the image)
     for (Lane *lp : {&ix->lane, &ix->lane2}) {
         Lane &lane = *lp;
         if (lane.ready) {
@@ -953,8 +956,8 @@ static int finish_batches(issl_index *ix, hipStream_t stream)
     ix->stats.scan_tiles = pl.tiles;
     ix->stats.n_batches = batches;
     if (lane.ws.stamps) { // scan_stamps knob: dump the wave stamps of the last scan (4 u64 per wave)
-        std::vector<unsigned long long> st(4 * kScanWaves);
-        HIP_TRY(hipMemcpy(st.data(), lane.ws.stamps, 32 * kScanWaves, hipMemcpyDeviceToHost));
+        std::vector<unsigned long long> st(kStampsWords);
+        HIP_TRY(hipMemcpy(st.data(), lane.ws.stamps, 8ull * kStampsWords, hipMemcpyDeviceToHost));
         if (FILE *f = std::fopen(ix->tuning.stamps_path.c_str(), "wb")) {
             std::fwrite(st.data(), 8, st.size(), f);
             std::fclose(f);
@@ -1299,7 +1302,9 @@ static int upload_common(issl_index *idx, int device, void *buf, size_t bytes, c
             continue;
         }
         if (rc == kSortNeedsListOrder) {
-            if (tn.sorted_layout == 1 || tn.compact == 1) {
+            // (keep_lists=0 forces a sorted layout like the other two -- only a sorted image can do without its lists --, and an
+            // index that has been here before is not sent round again: the second turn would end where the first did)
+            if (tn.sorted_layout == 1 || tn.compact == 1 || tn.keep_lists == 0 || idx->list_order_only) {
                 set_error("this index cannot take the sorted layout that was asked for: a list is not ascending by site id, "
                           "holds a site in a bucket its signature does not select, or carries different counts for one site");
                 return ISSL_E_UNSUPPORTED;
@@ -1625,24 +1630,41 @@ int issl_score(issl_index *idx, const uint64_t *guides, size_t n, int max_dist, 
     // (the pruned scan places every guide in up to 65 groups: pieces of at most 2^20 guides while it may be chosen)
     const uint32_t piece_mode = prune_mode_for(idx->view, idx->tuning, 1, max_dist);
     const size_t piece = piece_mode ? size_t(prune_max_guides(piece_mode, idx->view.n_slices)) : size_t(1) << 22;
-    // (small pages: the default buffers do; a handle that has scored a batch of this size has grown its buffers for it)
-    const bool presize = !idx->tuning.raw_chunks && n >= (size_t(1) << 15) && n > idx->presized_guides;
+    // Every piece is cut where its estimated records would outgrow the record buffers this handle may have: five table
+    // look-ups per guide.  What is skipped on a handle whose buffers already cover a piece is only the question how much
+    // memory is free (hipMemGetInfo: asked lazily, once per call, when a piece's estimate first exceeds the buffers in
+    // hand) and the call that grows them.  (Small pages: the default buffers do.)
+    const bool estimate = !idx->tuning.raw_chunks && n >= (size_t(1) << 15);
     const double records_per_comparison = 8e-5;
-    size_t free_b = 0, total_b = 0;
-    if (presize) HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-    const double budget_slots = std::max<double>(static_cast<double>(idx->lane.ws.cap_chunks) * (kChunkRecs - 1),
-                                                 static_cast<double>(std::min<size_t>(free_b / 4, size_t(32) << 30)) / 32.0);
+    double budget_slots = -1.0; // records the buffers may grow to: the larger of what they hold and a quarter of the free HBM (<= 32 GiB)
     const uint64_t per = idx->geo.buckets_per_slice();
+    if (estimate && !idx->worst_per_guide) // the most a guide can be compared with: the longest bucket of every slice
+        for (uint64_t sl = 0; sl < idx->geo.n_slices; ++sl)
+            idx->worst_per_guide += *std::max_element(idx->bucket_sizes.begin() + sl * per, idx->bucket_sizes.begin() + (sl + 1) * per);
+    const size_t wave_chunks = size_t(scan_waves(idx->tuning)) * 10; // every scan wave's own first chunk and the unused tail of its last reservation of up to 16
     issl_stats total{};
     for (size_t at = 0; at < n;) {
         uint64_t cand = 0;
         size_t cnt = 0;
-        if (!presize) cnt = std::min(piece, n - at);
-        while (presize && at + cnt < n && cnt < piece) {
+        const size_t most = std::min(piece, n - at);
+        const size_t cap_chunks = idx->lane.ws.cap_chunks;
+        const double have_slots = static_cast<double>(cap_chunks > wave_chunks ? cap_chunks - wave_chunks : 0) * (kChunkRecs - 1);
+        // (an index of even buckets on a handle that has grown its buffers: the bound alone says the piece fits)
+        const bool covered = static_cast<double>(most) * static_cast<double>(idx->worst_per_guide) * records_per_comparison <= have_slots;
+        if (!estimate || covered) cnt = most;
+        while (estimate && !covered && at + cnt < n && cnt < piece) {
             uint64_t c = 0;
             for (uint64_t sl = 0; sl < idx->geo.n_slices; ++sl)
                 c += idx->bucket_sizes[sl * per + ((guides[at + cnt] >> (idx->geo.slice_width * sl)) & (per - 1))];
-            if (presize && cnt > 0 && static_cast<double>(cand + c) * records_per_comparison > budget_slots) break;
+            const double want = static_cast<double>(cand + c) * records_per_comparison;
+            if (want > have_slots) { // beyond the buffers in hand: may they grow that far?
+                if (budget_slots < 0.0) {
+                    size_t free_b = 0, total_b = 0;
+                    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+                    budget_slots = std::max(have_slots, static_cast<double>(std::min<size_t>(free_b / 4, size_t(32) << 30)) / 32.0);
+                }
+                if (cnt > 0 && want > budget_slots) break;
+            }
             cand += c;
             ++cnt;
         }
@@ -1651,10 +1673,10 @@ int issl_score(issl_index *idx, const uint64_t *guides, size_t n, int max_dist, 
         if (rc) return rc;
         rc = ensure_workspace(idx, cnt, idx->lane);
         if (rc) return rc;
-        if (presize) {
-            const double slots = std::min(static_cast<double>(cand) * records_per_comparison, budget_slots);
-            // (+ every scan wave's own first chunk and the unused tail of its last reservation of up to 16)
-            rc = ensure_raw_capacity(ws, static_cast<size_t>(slots / (kChunkRecs - 1)) + size_t(scan_waves(idx->tuning)) * 10);
+        if (estimate && !covered) {
+            double slots = static_cast<double>(cand) * records_per_comparison;
+            if (budget_slots >= 0.0) slots = std::min(slots, budget_slots);
+            rc = ensure_raw_capacity(ws, static_cast<size_t>(slots / (kChunkRecs - 1)) + wave_chunks);
             if (rc) return rc;
         }
         if (ensure_stage(ws, 24 * cnt)) { // guides in, scores out through pinned memory: one DMA each, one synchronisation
@@ -1688,7 +1710,6 @@ int issl_score(issl_index *idx, const uint64_t *guides, size_t n, int max_dist, 
         at += cnt;
     }
     idx->stats = total;
-    idx->presized_guides = std::max(idx->presized_guides, n);
     return ISSL_OK;
 }
 

@@ -168,7 +168,8 @@ struct Tuning {
                             //                    0 never, 1 whenever possible
     int tail_shapes;        // ISSL_TAIL_SHAPES   1 (default): the short last unit of a successor-byte group runs 2 / 4 guides
                             //                    per pass on 16 / 8 candidates per lane; 0: every unit is a full one (A/B)
-    int hit_slots;          // ISSL_HIT_SLOTS     1 (default): Workspace::slot_hits = kSlotHits when the arrays fit; 0: never (A/B, tests)
+    int hit_slots;          // ISSL_HIT_SLOTS     1 (default): Workspace::slot_hits = kSlotHits when the arrays fit (kSlotHitsWide once a batch has shown
+                            //                    many guides beyond that); 0: never; 2: kSlotHitsWide from the first batch on (A/B, tests)
     int lanes;              // ISSL_LANES         1|2 (default 1): workspaces + streams that asynchronous batches alternate
                             //                    between (2: the short kernels of one batch fill the wave slots the scan of
                             //                    the next leaves)
@@ -230,6 +231,11 @@ constexpr uint32_t kScanGridBlocks = 256u * 4u; // scan launch: 256 CUs x 2 resi
 constexpr uint32_t kScanMaxBlocks = 8192u;       // upper bound of the ISSL_SCAN_BLOCKS knob
 constexpr uint32_t kScanWaves = kScanMaxBlocks * 16u;
 constexpr uint32_t kMaxRanges = kScanMaxBlocks;  // one equal-cost range per workgroup
+// ISSL_SCAN_STAMPS diagnostics buffer (u64 words): 4 per scan wave for the largest scan grid, then 16 per guide for the first
+// 4096 guides of k_replay_mid, k_replay_big<256> and k_replay_big<1024> -- regions of their own behind the scan's, whatever the grid
+constexpr uint32_t kStampsScanWords = 4u * kScanWaves, kStampsPerReplay = 16u * 4096u;
+constexpr uint32_t kStampsMid = kStampsScanWords, kStampsBig256 = kStampsMid + kStampsPerReplay, kStampsBig1024 = kStampsBig256 + kStampsPerReplay;
+constexpr uint32_t kStampsWords = kStampsBig1024 + kStampsPerReplay;
 constexpr uint32_t kSpanRing = 64;              // batches per lane whose scan spans are kept until the next finish
 constexpr uint32_t kChunkRecs = 128;            // raw-record chunk: 1 KiB, slot 0 is the fill count
 constexpr uint64_t kDeadKey = ~0ull;            // raw slot that did not survive the exact check
@@ -364,7 +370,7 @@ struct Workspace {
                                     // kernel's own duration also when another stream shares the chip
     uint32_t span_slot = 0;         // slot of the batch being enqueued
     uint64_t *scan_count = nullptr; // [kScanMaxBlocks] comparisons every scan workgroup actually made (real candidates x real guides)
-    unsigned long long *stamps = nullptr; // [4 * kScanWaves] scan wave clocks, then replay phase clocks (ISSL_SCAN_STAMPS diagnostics)
+    unsigned long long *stamps = nullptr; // [kStampsWords] scan wave clocks, then replay phase clocks (ISSL_SCAN_STAMPS diagnostics)
     uint32_t *sticky = nullptr;  // [4] survives the per-batch resets: [0] raw overflow seen, [1] max chunks asked, [2] plan errors, [3] items a pruned plan wanted beyond cap_fitems
     uint64_t *sorted = nullptr;  // [hit_cap] keys guide<<37 | slice<<32 | site id or list position, grouped by guide (with hit slots: of the guides that outgrew them)
     uint32_t *gcount = nullptr;  // [G+1] hits per guide

@@ -2286,7 +2286,7 @@ __global__ __launch_bounds__(256, 6) void k_replay_mid(ImageView v, Workspace ws
         const SlotRec *__restrict__ srec = ws.slots + static_cast<uint64_t>(g) * in_slots;
         const uint64_t *__restrict__ gkeys = ws.sorted + h0;
         // diagnostics (ISSL_SCAN_STAMPS): phase clocks of the first 4096 listed guides, like k_replay_big's
-        unsigned long long *st = (ws.stamps && b < 4096u) ? ws.stamps + 65536u + 16u * b : nullptr;
+        unsigned long long *st = (ws.stamps && b < 4096u) ? ws.stamps + kStampsMid + 16u * b : nullptr;
         if (st && threadIdx.x == 0) { st[0] = __builtin_amdgcn_s_memrealtime(); st[1] = h; st[15] = blockIdx.x; st[14] = 1; }
         if (threadIdx.x < kMaxSlices) slice_cnt[threadIdx.x] = 0;
         if (threadIdx.x == 0) { stopped_s = 0; carry_mit = 0.0; carry_cfd = 0.0; carry_kept = 0; }
@@ -2610,7 +2610,7 @@ __global__ __launch_bounds__(THREADS, THREADS < 1024u ? 6 : 4) void k_replay_big
         uint64_t *seg = ws.sorted + h0;
         uint64_t *tmp = ws.raw + h0; // the raw records are dead once they are grouped; the buffer holds >= all hits
         // diagnostics (ISSL_SCAN_STAMPS, tools/replay_stamps.py): phase clocks of the first 4096 big guides
-        unsigned long long *st = (ws.stamps && b < 4096u) ? ws.stamps + (THREADS < 1024u ? 131072u : 196608u) + 16u * b : nullptr; // (behind k_replay_mid's)
+        unsigned long long *st = (ws.stamps && b < 4096u) ? ws.stamps + (THREADS < 1024u ? kStampsBig256 : kStampsBig1024) + 16u * b : nullptr; // (behind k_replay_mid's)
         if (st && threadIdx.x == 0) { st[0] = __builtin_amdgcn_s_memrealtime(); st[1] = h; st[15] = blockIdx.x; }
 
         // The scoring order is (slice, position in bucket) and the walk usually ends inside the first slice (the

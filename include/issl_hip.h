@@ -146,7 +146,11 @@ int issl_index_build_on_device_opt(const uint64_t *sigs, const uint32_t *occ, si
 /* The same for a site table that is ALREADY in the memory of `device` (d_sigs, d_occ: device pointers; e.g. the sorted,
  * de-duplicated keys issl_extract_* leaves there, or sites generated on the GPU): bucket lengths are counted on the
  * device, nothing of the size of the index ever exists in host memory.  The inputs are copied into the image and may be
- * freed when the call returns.  isslCreateIndex.cpp:199-234 from its state after the counting loop on.  (ABI 5) */
+ * freed when the call returns.  isslCreateIndex.cpp:199-234 from its state after the counting loop on.  (ABI 5)
+ * Checked on the device: no signature carries bits above 2 * seq_len (ISSL_E_ARG).  NOT checked, as in the host-side
+ * builders and in the reference (which collapses only CONSECUTIVE equal lines, isslCreateIndex.cpp:189-193): that the
+ * signatures are distinct -- a signature listed twice is two sites, found and scored twice, exactly as the reference scores
+ * an index built from unsorted text. */
 int issl_index_build_from_device_sites(const uint64_t *d_sigs, const uint32_t *d_occ, size_t n_sites,
                                        size_t n_lines, size_t seq_len, size_t slice_width, int device,
                                        const char *options, issl_index **out);
@@ -227,9 +231,11 @@ int issl_index_attach_image_cold(int device, void *dev_buf, size_t bytes, void *
  *     without slice lists (52 B/site), keep_lists=1: never drop them
  *   tail_shapes (ISSL_TAIL_SHAPES) 0|1 (default 1): the short last unit of a successor-byte group runs 2 / 4 guides per
  *     pass on 16 / 8 candidates per lane
- *   hit_slots (ISSL_HIT_SLOTS) 0|1 (default 1): the first 512 hits of every guide go straight from the exact test to a
+ *   hit_slots (ISSL_HIT_SLOTS) 0|1|2 (default 1): the first 512 hits of every guide go straight from the exact test to a
  *     32-byte record of their own (1.6 GB of scratch per 100 000 guides of a batch; batches beyond 512 k guides, a
- *     device short of memory and issl_dump_hits go without); 0: every hit passes through the grouping pass
+ *     device short of memory and issl_dump_hits go without; a handle whose batches show many guides beyond 512 hits
+ *     widens its slots to 2048 by itself); 0: every hit passes through the grouping pass; 2: slots for 2048 hits per
+ *     guide from the first batch on (tests and A/B: the results do not depend on the width)
  *   prune (ISSL_PRUNE) -1|0|1: scan only the successor-byte groups of a bucket that can hold a site within max_dist (13
  *     of 256 for max_dist <= 4, 1 of 256 for <= 2, 67 of 256 for max_dist 5; same hits and scores as the reference's scan
  *     of the whole bucket, isslScoreOfftargets.cpp:344): -1 = a planning kernel decides per batch from the two plans'

@@ -388,7 +388,7 @@ def test_scheduling_knobs_do_not_change_results(config0):
             st = check_comparisons(ix, batch, prune)
             assert st["reference_comparisons"] == expected and st["pruned"] == 2 * prune, (sched, blocks, prune)
         ix.set_option("item_guides", 512).set_option("scan_blocks", 1024)
-        for slots, prune in ((0, 0), (0, 1), (1, 1)):   # without / with the per-guide hit slots (Workspace::slot_hits)
+        for slots, prune in ((0, 0), (0, 1), (1, 1), (2, 1), (2, 0)):   # without / with the per-guide hit slots (Workspace::slot_hits), 2: the wide ones
             ix.set_option("hit_slots", slots).set_option("prune", prune)
             for thr in (75.0, 0.0):
                 gm, gc = ix.score(batch, 4, thr, "and")
@@ -994,7 +994,7 @@ def test_random_small_indexes_differential():
             layout = dict(LAYOUTS[name])
             if name in SORTED:
                 layout["prune"] = int(rng.integers(-1, 2)) if trial % 2 else 1
-            layout["hit_slots"] = int(rng.integers(0, 2))   # hits straight to per-guide slots, or all through the grouping pass
+            layout["hit_slots"] = int(rng.integers(0, 3))   # hits straight to per-guide slots (2: the wide ones), or all through the grouping pass
             for key, value in layout.items():
                 ix.set_option(key, value)
             ix.upload(0)

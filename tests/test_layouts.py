@@ -208,6 +208,12 @@ def test_bare_compact_image_from_a_site_table_on_the_device(golden_uniform, tmp_
             twin.close()
         finally:
             ix.close()
+    # a signature with bits above the 40 of a 20-mer would spill into the count the sorted layouts keep beside it: refused
+    bad = sigs.copy()
+    bad[n // 2] |= np.uint64(1) << np.uint64(41)
+    with pytest.raises(ca.IsslError) as e:
+        ca.IsslIndex.build_from_device_sites(torch.from_numpy(bad.view(np.int64)).cuda(), d_occ, int(occ.sum()), device=0)
+    assert "bits above" in str(e.value)
 
 
 def test_layout_sizes(golden_uniform):
@@ -249,6 +255,13 @@ def test_counts_that_differ_between_a_sites_lists_keep_the_list_order():
             ix.upload(0)
         assert "sorted layout" in str(e.value)
         ix.close()
+    # keep_lists=0 alone asks for a sorted image too (only such an image can do without its lists): the same refusal,
+    # not an upload that starts over for ever
+    ix = ca.IsslIndex.open(g.issl).set_option("keep_lists", 0)
+    with pytest.raises(ca.IsslError) as e:
+        ix.upload(0)
+    assert "sorted layout" in str(e.value)
+    ix.close()
 
 
 def _sections(data):

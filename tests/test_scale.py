@@ -471,10 +471,11 @@ def test_many_hit_guides_several_per_replay_workgroup(tmp_path, options):
                 pm[lo:lo + piece], pc[lo:lo + piece] = ix.score(guides[lo:lo + piece], 4, thr, method)
             bad = np.flatnonzero((pm.view(np.uint64) != mit.view(np.uint64)) | (pc.view(np.uint64) != cfd.view(np.uint64)))
             assert len(bad) == 0, (thr, method, len(bad), bad[:8].tolist())
-            ix.set_option("hit_slots", 0)   # every hit through the grouping pass (no per-guide slots): the same scores
-            m0, c0 = ix.score(guides, 4, thr, method)
+            for slots in (0, 2):   # every hit through the grouping pass (no per-guide slots) / slots for 2048 hits per guide: the same scores
+                ix.set_option("hit_slots", slots)
+                m0, c0 = ix.score(guides, 4, thr, method)
+                assert np.array_equal(m0.view(np.uint64), mit.view(np.uint64)) and np.array_equal(c0.view(np.uint64), cfd.view(np.uint64)), (thr, method, slots)
             ix.set_option("hit_slots", 1)
-            assert np.array_equal(m0.view(np.uint64), mit.view(np.uint64)) and np.array_equal(c0.view(np.uint64), cfd.view(np.uint64)), (thr, method)
             # the oracle on the neighbourhoods of a sample (brute force over the site table)
             pick = np.linspace(0, len(guides) - 1, 36).astype(np.int64)
             if thr in (0.0, 75.0):
@@ -493,7 +494,7 @@ def test_many_hit_guides_several_per_replay_workgroup(tmp_path, options):
         filler = rng.integers(0, 1 << 40, size=(1 << 18) + 1000, dtype=np.uint64)
         long_batch = np.concatenate([filler, guides])
         want_m, want_c = ix.score(guides, 4, 75.0, "and")
-        for slots in (1, 0):
+        for slots in (1, 0, 2):
             ix.set_option("hit_slots", slots)
             lm, lc = ix.score(long_batch, 4, 75.0, "and")
             assert np.array_equal(lm[len(filler):].view(np.uint64), want_m.view(np.uint64)), slots

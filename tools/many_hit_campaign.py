@@ -85,6 +85,8 @@ for trial in range(a.trials):
         same(pm, pc, "pieces of 64")
         ix.set_option("hit_slots", 0)
         same(*ix.score(guides, dist, thr, method), "no hit slots")
+        ix.set_option("hit_slots", 2)
+        same(*ix.score(guides, dist, thr, method), "wide hit slots")
         ix.set_option("hit_slots", 1)
         if ix.get_option("is_sorted") == 1:
             ix.set_option("prune", 0)

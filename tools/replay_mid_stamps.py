@@ -4,7 +4,7 @@ entries with [14] == 1 are k_replay_mid's):
     ISSL_SCAN_STAMPS=/tmp/st.bin python bench.py --dist markov --no-extras --no-cpu-baseline --steps 3 --warmup 1
     python tools/replay_mid_stamps.py /tmp/st.bin"""
 import numpy as np, sys
-a = np.fromfile(sys.argv[1], dtype=np.uint64)[65536:65536 + 16 * 4096].reshape(-1, 16).astype(np.int64)
+a = np.fromfile(sys.argv[1], dtype=np.uint64)[524288:524288 + 16 * 4096].reshape(-1, 16).astype(np.int64)
 a = a[(a[:, 0] > 0) & (a[:, 14] == 1) & (a[:, 7] > 0)]
 us = lambda x: x / 100.0
 print("mid guides stamped", len(a), "hits p50/p90", np.percentile(a[:, 1], [50, 90]), "first slice p50/p90", np.percentile(a[:, 4], [50, 90]),

@@ -6,7 +6,7 @@ scan's records: start, hits, after partition, slice-0 start, its length, after i
     python tools/replay_stamps.py /tmp/st.bin [1024]      (the 256-thread build's guides, or the 1024-thread build's)
 """
 import numpy as np, sys
-base = 196608 if len(sys.argv) > 2 and sys.argv[2] == '1024' else 131072
+base = 524288 + (131072 if len(sys.argv) > 2 and sys.argv[2] == '1024' else 65536)  # issl_device.hpp: kStampsBig1024 / kStampsBig256
 a=np.fromfile(sys.argv[1],dtype=np.uint64)[base:base+16*4096].reshape(-1,16).astype(np.int64)
 a=a[a[:,0]>0]
 t0=a[:,0].min()
