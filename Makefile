@@ -11,14 +11,16 @@ LIB      = crackling_amd/libissl_hip.so
 
 all: $(LIB) bin/isslScoreOfftargets bin/isslCreateIndex bin/extractOfftargets
 
-$(LIB): $(CSRC)/issl_kernels.hip $(CSRC)/issl_extract.hip $(CSRC)/issl_build.hip $(CSRC)/issl_capi.cpp $(CSRC)/issl_host.cpp \
+$(LIB): $(CSRC)/issl_kernels.hip $(CSRC)/issl_extract.hip $(CSRC)/issl_build.hip $(CSRC)/issl_capi.cpp $(CSRC)/issl_host.cpp $(CSRC)/issl_text.cpp \
         $(CSRC)/issl_node.cpp $(CSRC)/issl_host.hpp $(CSRC)/issl_device.hpp $(CSRC)/issl_radix.hpp $(CSRC)/cfd_tables.inc include/issl_hip.h
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/issl_kernels.hip $(CSRC)/issl_extract.hip $(CSRC)/issl_build.hip $(CSRC)/issl_capi.cpp \
-	    $(CSRC)/issl_host.cpp $(CSRC)/issl_node.cpp -lpthread -ldl
+	    $(CSRC)/issl_host.cpp $(CSRC)/issl_text.cpp $(CSRC)/issl_node.cpp -lpthread -ldl
 
-bin/isslScoreOfftargets: $(CSRC)/cli_score.cpp $(LIB)
+# host-only executable: libissl_hip.so is loaded with dlopen when the process has to score by itself, not when a resident
+# server answers (cli_score.cpp)
+bin/isslScoreOfftargets: $(CSRC)/cli_score.cpp include/issl_hip.h $(LIB)
 	@mkdir -p bin
-	$(HIPCC) $(CXXFLAGS) -o $@ $< -Lcrackling_amd -lissl_hip -lpthread -Wl,-rpath,'$$ORIGIN/../crackling_amd'
+	g++ $(CXXFLAGS) -o $@ $< -lpthread -ldl
 
 bin/extractOfftargets: $(CSRC)/cli_extract.cpp $(LIB)
 	@mkdir -p bin

@@ -201,6 +201,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=24.0, help="CPU seconds for the baseline sweep")
     ap.add_argument("--no-extras", action="store_true", help="skip the 10k-guide, 64-guide and host-pointer points")
+    ap.add_argument("--no-cli", action="store_true", help="skip extras.cli_end_to_end (bin/isslScoreOfftargets as Crackling runs it)")
     ap.add_argument("--dump-scores", default=None,
                     help="rank 0 writes the scores of the last timed step, in input order, to this .npz (tests: the N>1 "
                          "path against the single-process result)")
@@ -662,8 +663,9 @@ def main():
                              "broadcast_limit_s": BROADCAST_LIMIT_S} if use_dist else None),
             "extras": extras or None,
         }
-        if world == 1 and not a.no_cpu_baseline:
-            # the baseline leg must never cost the line itself: on any failure it is reported inside the line
+        want_cli = world == 1 and not a.no_cli and not a.no_extras
+        if world == 1 and (not a.no_cpu_baseline or want_cli):
+            # neither leg must ever cost the line itself: on any failure it is reported inside the line
             t1 = time.perf_counter()
             issl_path = None
             try:
@@ -672,20 +674,54 @@ def main():
                 tmp = next((d for d in ("/dev/shm", "/tmp", str(ROOT / "gpurun_out"))
                             if os.path.isdir(d) and os.access(d, os.W_OK) and shutil.disk_usage(d).free > 1.2 * need), None)
                 if tmp is None:
-                    raise RuntimeError(f"no scratch directory with {need / 1e9:.0f} GB free for the oracle's .issl")
+                    raise RuntimeError(f"no scratch directory with {need / 1e9:.0f} GB free for the .issl")
                 issl_path = f"{tmp}/bench_{os.getpid()}.issl"
                 index.write(issl_path)
                 write_s = time.perf_counter() - t1
-                gpu_scores = (out_mit[-1].cpu().numpy(), out_cfd[-1].cpu().numpy())
-                out["cpu_baseline"] = cpu_baseline(issl_path, guides, gpu_scores, a.max_dist, a.threshold, a.method, a.cpu_budget_s)
-                out["cpu_baseline"]["issl_write_s"] = write_s
+                if not a.no_cpu_baseline:
+                    try:
+                        gpu_scores = (out_mit[-1].cpu().numpy(), out_cfd[-1].cpu().numpy())
+                        out["cpu_baseline"] = cpu_baseline(issl_path, guides, gpu_scores, a.max_dist, a.threshold, a.method, a.cpu_budget_s)
+                        out["cpu_baseline"]["issl_write_s"] = write_s
+                    except Exception as e:  # noqa: BLE001
+                        out["cpu_baseline"] = {"value": None, "unit": "guides/s", "cores": 0, "kind": "port", "sample": "not measured",
+                                               "error": f"{type(e).__name__}: {e}"}
+                    log(f"[bench] cpu baseline leg took {time.perf_counter()-t1:.1f} s")
+                if want_cli:
+                    # The drop-in where Crackling meets it (Crackling.py:767-778, config.ini:106-112): `bin/isslScoreOfftargets
+                    # <issl> <query> 4 75 and > out` as a fresh child process per page, one-shot and through the resident
+                    # server, a 1 M-guide and a 10 k-guide page, stdout compared byte for byte with the in-process result.
+                    t2 = time.perf_counter()
+                    try:
+                        sys.path.insert(0, str(ROOT / "tools"))
+                        import cli_end_to_end as e2e
+                        pages, want = [], {}
+                        for label, n_page, seed in (("page_1m_guides", 1_000_000, 4321), ("page_10k_guides", 10_000, 4322)):
+                            g = random_guides_fast(sigs, n_page, seed=seed)
+                            pm, pc = index.score(g, a.max_dist, a.threshold, a.method)
+                            want[label] = ca.format_scores_native(g, pm, pc, a.method)
+                            pages.append((label, g))
+                        cli = e2e.measure(issl_path, pages, tmp, expected=want.get, server=True, log=log)
+                        cli["what"] = ("bin/isslScoreOfftargets <issl> <query> 4 75 and > out as a fresh child process per page (wall = fork to exit as "
+                                       "the caller sees it), .issl and query in " + tmp + "; one_shot: the process opens, uploads and scores by itself; "
+                                       "resident: ISSL_SERVER points at `--serve` (index already uploaded there); timing = the process's ISSL_TIMING line")
+                        cli["seconds"] = time.perf_counter() - t2
+                        extras["cli_end_to_end"] = cli
+                        out["extras"] = extras
+                    except Exception as e:  # noqa: BLE001
+                        extras["cli_end_to_end"] = {"error": f"{type(e).__name__}: {e}"}
+                        out["extras"] = extras
+                    log(f"[bench] cli leg took {time.perf_counter()-t2:.1f} s")
             except Exception as e:  # noqa: BLE001
-                out["cpu_baseline"] = {"value": None, "unit": "guides/s", "cores": 0, "kind": "port", "sample": "not measured",
-                                       "error": f"{type(e).__name__}: {e}"}
+                if not a.no_cpu_baseline and "cpu_baseline" not in out:
+                    out["cpu_baseline"] = {"value": None, "unit": "guides/s", "cores": 0, "kind": "port", "sample": "not measured",
+                                           "error": f"{type(e).__name__}: {e}"}
+                if want_cli and "cli_end_to_end" not in extras:
+                    extras["cli_end_to_end"] = {"error": f"{type(e).__name__}: {e}"}
+                    out["extras"] = extras
             finally:
                 if issl_path and os.path.exists(issl_path):
                     os.unlink(issl_path)
-            log(f"[bench] cpu baseline leg took {time.perf_counter()-t1:.1f} s")
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if use_dist:
         dist.barrier()

@@ -16,12 +16,13 @@ from .scorer import (  # noqa: F401
     extract_offtargets,
     decode_guides,
     format_scores,
+    format_scores_native,
     run_scorer_binary,
     parse_scorer_output,
     verdicts,
 )
 
 __all__ = [
-    "IsslIndex", "IsslNode", "IsslError", "METHODS", "encode_guides", "extract_offtargets", "decode_guides", "format_scores",
+    "IsslIndex", "IsslNode", "IsslError", "METHODS", "encode_guides", "extract_offtargets", "decode_guides", "format_scores", "format_scores_native",
     "run_scorer_binary", "parse_scorer_output", "verdicts", "lib", "LIB_PATH",
 ]

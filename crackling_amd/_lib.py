@@ -62,6 +62,10 @@ class Stats(C.Structure):
     ]
 
 
+class Span(C.Structure):
+    _fields_ = [("data", C.POINTER(C.c_char)), ("len", C.c_size_t)]
+
+
 class NodeInfo(C.Structure):
     _fields_ = [("n_devices", C.c_int), ("used_rccl", C.c_int), ("ms_upload", C.c_double),
                 ("ms_broadcast", C.c_double), ("ms_last_score", C.c_double)]
@@ -100,6 +104,8 @@ _protos = {
     "issl_decode_guide": (C.c_int, [C.c_uint64, C.c_size_t, C.c_char_p]),
     "issl_read_query_file": (C.c_int, [C.c_char_p, C.c_size_t, C.POINTER(_P), C.POINTER(C.c_size_t)]),
     "issl_free": (None, [_P]),
+    "issl_format_scores": (C.c_int, [_P, _P, _P, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.POINTER(Span)), C.POINTER(C.c_size_t)]),
+    "issl_free_spans": (None, [C.POINTER(Span), C.c_size_t]),
     "issl_method_from_string": (C.c_int, [C.c_char_p]),
     "issl_score": (C.c_int, [_P, _P, C.c_size_t, C.c_int, C.c_double, C.c_int, _P, _P]),
     "issl_score_device": (C.c_int, [_P, _P, C.c_size_t, C.c_int, C.c_double, C.c_int, _P, _P, _P]),

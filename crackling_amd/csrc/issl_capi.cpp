@@ -1527,40 +1527,7 @@ int issl_decode_guide(uint64_t sig, size_t seq_len, char *out)
     return ISSL_OK;
 }
 
-int issl_read_query_file(const char *path, size_t seq_len, uint64_t **out, size_t *n)
-{
-    if (!path || !out || !n || seq_len == 0 || seq_len > 32) { set_error("bad argument"); return ISSL_E_ARG; }
-    FILE *fp = std::fopen(path, "rb");
-    if (!fp) {
-        set_error(std::string("cannot open query file '") + path + "'");
-        return ISSL_E_IO;
-    }
-    std::fseek(fp, 0, SEEK_END);
-    const long sz = std::ftell(fp);
-    std::fseek(fp, 0, SEEK_SET);
-    const size_t line = seq_len + 1;
-    if (sz < 0 || static_cast<size_t>(sz) % line != 0) { // isslScoreOfftargets.cpp:277-282
-        std::fclose(fp);
-        set_error("Error: query file is not a multiple of the expected line length (" + std::to_string(line) +
-                  ")\nThe sequence length may be incorrect; alternatively, the line endings\nmay be something "
-                  "other than LF, or there may be junk at the end of the file.");
-        return ISSL_E_FORMAT;
-    }
-    std::vector<char> buf(static_cast<size_t>(sz));
-    if (sz == 0 || std::fread(buf.data(), static_cast<size_t>(sz), 1, fp) < 1) { // :290-293
-        std::fclose(fp);
-        set_error("Failed to read in query file.");
-        return ISSL_E_FORMAT;
-    }
-    std::fclose(fp);
-    const size_t count = static_cast<size_t>(sz) / line;
-    uint64_t *g = static_cast<uint64_t *>(std::malloc(8 * std::max<size_t>(count, 1)));
-    if (!g) { set_error("out of memory"); return ISSL_E_NOMEM; }
-    for (size_t i = 0; i < count; ++i) g[i] = encode_guide(buf.data() + i * line, seq_len);
-    *out = g;
-    *n = count;
-    return ISSL_OK;
-}
+// (issl_read_query_file, issl_format_scores: issl_text.cpp)
 
 void issl_free(void *p) { std::free(p); }
 

@@ -56,6 +56,22 @@ def format_scores(sigs, mit, cfd, method, seq_len=20):
     return "".join(lines)
 
 
+def format_scores_native(sigs, mit, cfd, method, seq_len=20, threads=0):
+    """The same text from the library's own formatter (issl_format_scores: what bin/isslScoreOfftargets prints), as bytes."""
+    sigs = np.ascontiguousarray(sigs, dtype=np.uint64)
+    mit = np.ascontiguousarray(mit, dtype=np.float64)
+    cfd = np.ascontiguousarray(cfd, dtype=np.float64)
+    assert len(sigs) == len(mit) == len(cfd)
+    from ._lib import Span
+    spans, n_spans = C.POINTER(Span)(), C.c_size_t()
+    check(lib.issl_format_scores(sigs.ctypes.data, mit.ctypes.data, cfd.ctypes.data, len(sigs), seq_len, _method_code(method),
+                                 threads, C.byref(spans), C.byref(n_spans)))
+    try:
+        return b"".join(C.string_at(spans[i].data, spans[i].len) for i in range(n_spans.value))
+    finally:
+        lib.issl_free_spans(spans, n_spans)
+
+
 class IsslIndex:
     """An ISSL index: host arrays (.issl sections) and, after upload(), its HBM image."""
 

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define ISSL_ABI_VERSION 5
+#define ISSL_ABI_VERSION 6
 
 enum {
     ISSL_OK = 0,
@@ -257,8 +257,24 @@ int issl_index_get_option(const issl_index *idx, const char *key, long long *val
 int issl_encode_guides(const char *text, size_t n, size_t seq_len, size_t stride, uint64_t *out);
 /* out must hold seq_len+1 bytes. */
 int issl_decode_guide(uint64_t sig, size_t seq_len, char *out);
-/* Query file rules of :275-294; *out is malloc'd (free with issl_free). */
+/* Query file rules of :275-294; *out is malloc'd (free with issl_free).  Large files are read and packed by several
+ * threads. */
 int issl_read_query_file(const char *path, size_t seq_len, uint64_t **out, size_t *n);
+
+/* ---- output text (A12, isslScoreOfftargets.cpp:514-527) ------------------------------------- */
+/* The scorer's stdout for n guides, in input order: "<seq>\t<MIT>\t<CFD>\n" with both scores as printf("%f") prints
+ * them and "-1" for a score `method` (ISSL_METHOD_*) does not ask for (:517-525; ISSL_METHOD_UNKNOWN: "-1\t-1").  The text
+ * comes in *n_spans consecutive pieces (formatted by up to `threads` threads, 0 = automatic; a million lines are
+ * otherwise as long as their scoring): write them out one after the other, release with issl_free_spans.  The "%f" is
+ * the library's own exact formatter (the binary value rounded to six decimals, ties to even: digit for digit glibc's
+ * output), snprintf for negative, huge and non-finite values.  Host arithmetic only.  (ABI 6) */
+typedef struct issl_span {
+    char *data;
+    size_t len;
+} issl_span;
+int issl_format_scores(const uint64_t *guides, const double *mit, const double *cfd, size_t n, size_t seq_len,
+                       int method, int threads, issl_span **spans, size_t *n_spans);
+void issl_free_spans(issl_span *spans, size_t n_spans);
 void issl_free(void *p);
 
 /* ---- scoring (A3-A11, isslScoreOfftargets.cpp:307-511) ------------------------------------ */

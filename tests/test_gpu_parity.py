@@ -218,6 +218,18 @@ def test_cli_stdout_is_byte_identical(golden):
                            capture_output=True)
         assert r.returncode == 0, r.stderr.decode()
         assert r.stdout.decode() == golden.expected[key], key
+    # the process leaves through _exit once its text is written, with the runtime started on a thread of its own beside the
+    # host-side parsing; the tidy variants (everything released, runtime started in line) print the same
+    key = "and|75|4"
+    for extra in ({"ISSL_TIDY_EXIT": "1"}, {"ISSL_NO_WARMUP": "1"}, {"ISSL_TIMING": "1"}):
+        r = subprocess.run([str(exe), str(golden.issl), str(golden.guides_txt), "4", "75", "and"], capture_output=True,
+                           env=dict(os.environ, **extra))
+        assert r.returncode == 0 and r.stdout.decode() == golden.expected[key], (extra, r.stderr.decode())
+        if "ISSL_TIMING" in extra:
+            import json as _json
+            t = _json.loads(r.stderr.decode().strip().splitlines()[-1])
+            assert {"start_ms", "open_ms", "runtime_ms", "upload_ms", "query_ms", "score_ms", "format_ms", "write_ms", "total_ms"} <= set(t)
+            assert t["guides"] == len(golden.guides) and t["resident"] is False
 
 
 def test_crackling_caller_roundtrip(golden_uniform):
@@ -717,10 +729,26 @@ def test_resident_server_mode(golden, tmp_path):
             assert r.returncode == 0, r.stderr.decode()
             assert r.stdout.decode() == golden.expected[key], key
             assert (b'"resident": true' in r.stderr) == (i > 0), r.stderr
+        # stdout redirected into a file, as Crackling does it (Crackling.py:767): the descriptor travels to the server,
+        # which writes the text itself (head line "OKFD"); appended behind what the file holds; ISSL_SERVER_NO_FD: through
+        # the socket as for a pipe -- the same bytes every way
+        out_file = tmp_path / "redirected.out"
+        for mode, extra in (("wb", {}), ("ab", {}), ("wb", {"ISSL_SERVER_NO_FD": "1"})):
+            before = out_file.read_bytes() if mode == "ab" else b""
+            with open(out_file, mode) as fh:
+                r = subprocess.run([exe, str(golden.issl), str(golden.guides_txt), "4", "75", "and"], stdout=fh, stderr=subprocess.PIPE,
+                                   env=dict(env, **extra), cwd=str(tmp_path))
+            assert r.returncode == 0, r.stderr.decode()
+            assert out_file.read_bytes() == before + golden.expected["and|75|4"].encode(), (mode, extra)
+            assert b'"resident": true' in r.stderr and b'"write_ms"' in r.stderr
         # errors travel back with exit status 1 and nothing on stdout
         r = subprocess.run([exe, str(tmp_path / "missing.issl"), str(golden.guides_txt), "4", "75", "and"],
                            capture_output=True, env=env)
         assert r.returncode == 1 and r.stdout == b"" and b"cannot open index" in r.stderr
+        with open(out_file, "wb") as fh:   # ... also when stdout is a file that went along with the request
+            r = subprocess.run([exe, str(tmp_path / "missing.issl"), str(golden.guides_txt), "4", "75", "and"], stdout=fh,
+                               stderr=subprocess.PIPE, env=env)
+        assert r.returncode == 1 and out_file.read_bytes() == b"" and b"cannot open index" in r.stderr
         bad = tmp_path / "bad.txt"; bad.write_text("ACGT\n")
         r = subprocess.run([exe, str(golden.issl), str(bad), "4", "75", "and"], capture_output=True, env=env)
         assert r.returncode == 1 and r.stdout == b"" and b"multiple of the expected line length" in r.stderr

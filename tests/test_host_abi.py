@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/issl_hip.h but not exported"
     assert declared == set(_lib.EXPORTS)
-    assert lib.issl_abi_version() == 5
+    assert lib.issl_abi_version() == 6
 
 
 def test_builder_bytes_match_reference_golden(golden, tmp_path):
@@ -221,3 +221,68 @@ def test_image_layouts_and_their_sizes(golden_uniform):
     with pytest.raises(ca.IsslError):
         ca.IsslIndex.open(golden_uniform.issl).set_option("compact", 2)
     bad.close()
+
+
+def _libc_f(values):
+    """glibc's own printf("%f") of every value (the reference prints its scores with it, isslScoreOfftargets.cpp:517-525)."""
+    libc = C.CDLL(None)
+    libc.snprintf.restype = C.c_int
+    buf = C.create_string_buffer(512)
+    out = []
+    for v in values:
+        k = libc.snprintf(buf, C.c_size_t(512), b"%f", C.c_double(float(v)))
+        out.append(buf.raw[:k])
+    return out
+
+
+def test_own_percent_f_is_glibcs_digit_for_digit(golden):
+    """issl_format_scores prints "%f" with a formatter of its own (a million lines through printf are as long as their
+    scoring).  It must print what glibc prints: the exact binary value rounded to six decimals, ties to even."""
+    rng = np.random.default_rng(11)
+    ties = np.arange(1, 4001, 2, dtype=np.float64) / 128.0          # k/128 with k odd: x.xxxxxx5 exactly -- the ties
+    near = np.concatenate([ties * (1 + 2.0 ** -52), ties * (1 - 2.0 ** -53), np.nextafter(ties, 0), np.nextafter(ties, 1e9)])
+    scores = 10000.0 / (100.0 + np.concatenate([rng.exponential(30.0, 200000), rng.exponential(1e6, 20000), [0.0]]))  # :505-506
+    special = np.array([0.0, -0.0, 100.0, 99.9999995, 99.99999949999999, 5e-7, 4.9999999999999996e-07, 5.000000000000001e-07,
+                        1.5e-6, 2.5e-6, 2.4999999999999998e-06, 1e-300, 5e-324, 2.0 ** 39, 2.0 ** 40 - 0.5, 2.0 ** 40, 1e22, 1.7976931348623157e308,
+                        np.inf, -np.inf, np.nan, -1.0, -1e-9, 0.1, 0.3, 1 / 3, 123456.7890125, 0.0078125, 0.0234375, 1e15 + 0.3])
+    bits = rng.integers(0, 2 ** 63, size=100000, dtype=np.int64).view(np.float64)   # every exponent, sign bit clear
+    vals = np.concatenate([ties, near, scores, special, bits, -bits[:2000]])
+    sigs = rng.integers(0, 1 << 40, size=len(vals), dtype=np.uint64)
+    want_f = _libc_f(vals)
+    for i in rng.integers(0, len(vals), size=3000):   # Python's % is correctly rounded too: a second witness
+        if np.isfinite(vals[i]):
+            assert want_f[i] == (b"%f" % vals[i]), vals[i]
+    seqs = [s.encode() for s in ca.decode_guides(sigs)]
+    for threads in (1, 0, 5):
+        got = ca.format_scores_native(sigs, vals, vals[::-1].copy(), "and", threads=threads)
+        want = b"".join(s + b"\t" + m + b"\t" + c + b"\n" for s, m, c in zip(seqs, want_f, want_f[::-1]))
+        assert got == want, threads
+    # the method decides which columns are printed (:517-525), as in the reference's golden stdout
+    small = slice(0, 50)
+    for method, cols in (("mit", (1, 0)), ("cfd", (0, 1)), ("or", (1, 1)), ("avg", (1, 1)), ("bogus", (0, 0))):
+        got = ca.format_scores_native(sigs[small], vals[small], vals[small], method)
+        want = b"".join(s + b"\t" + (m if cols[0] else b"-1") + b"\t" + (m if cols[1] else b"-1") + b"\n" for s, m in zip(seqs[small], want_f[small]))
+        assert got == want, method
+    assert ca.format_scores_native(sigs[:0], vals[:0], vals[:0], "and") == b""
+    # and the Python restatement the parity tests compare stdout with says the same
+    assert ca.format_scores_native(sigs[:5000], scores[:5000], scores[5000:10000], "and").decode() == ca.format_scores(sigs[:5000], scores[:5000], scores[5000:10000], "and")
+
+
+def test_query_file_reader_threads_and_rules(tmp_path):
+    """issl_read_query_file (isslScoreOfftargets.cpp:275-305): lines of seq_len + 1 bytes, any other byte packs as 'A'; large
+    files are read by several threads -- same guides, same order."""
+    rng = np.random.default_rng(12)
+    sigs = rng.integers(0, 1 << 40, size=300_001, dtype=np.uint64)
+    text = "".join(s + "\n" for s in ca.decode_guides(sigs))
+    path = tmp_path / "q.txt"
+    path.write_text(text)
+    out, n = C.c_void_p(), C.c_size_t()
+    _lib.check(_lib.lib.issl_read_query_file(os.fsencode(path), 20, C.byref(out), C.byref(n)))
+    got = np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_uint64)), shape=(n.value,)).copy()
+    _lib.lib.issl_free(out)
+    assert np.array_equal(got, sigs)
+    for bad, code in ((text[:-3], "multiple of the expected line length"), ("", "Failed to read in query file")):
+        path.write_text(bad)
+        assert _lib.lib.issl_read_query_file(os.fsencode(path), 20, C.byref(out), C.byref(n)) != 0
+        assert code in _lib.lib.issl_last_error().decode()
+    assert _lib.lib.issl_read_query_file(os.fsencode(tmp_path / "absent"), 20, C.byref(out), C.byref(n)) != 0

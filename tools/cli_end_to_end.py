@@ -1,82 +1,163 @@
 #!/usr/bin/env python3
-"""Wall time of the drop-in executable on a synthetic index, the way Crackling runs it (one process per page):
+"""Wall time of the drop-in executable the way Crackling runs it (src/crackling/Crackling.py:767-778: one process per
+page, `<binary> <issl> <query> 4 75 and > output`), one-shot and through the resident server:
 
-    python tools/cli_end_to_end.py --sites 300000000 --guides 1000000 [--server] [--json out.json]
+    python tools/cli_end_to_end.py --sites 300000000 [--json out.json]
 
-Writes the .issl and the query file to --tmp, runs `bin/isslScoreOfftargets <issl> <query> 4 75 and > out` with
-ISSL_TIMING=1 (twice: the second run has the file in the page cache) and, with --server, twice more through a
-resident scorer."""
-import argparse, json, os, pathlib, subprocess, sys, time
+measure() is what bench.py calls for `extras.cli_end_to_end` (on the .issl its CPU-baseline leg has written)."""
+import json
+import os
+import pathlib
+import subprocess
+import sys
+import time
+
 ROOT = pathlib.Path(__file__).resolve().parent.parent
-sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
-import numpy as np
-import crackling_amd as ca
-from synth import random_sites_fast, random_guides
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+import numpy as np  # noqa: E402
 
-ap = argparse.ArgumentParser()
-ap.add_argument("--sites", type=int, default=50_000_000)
-ap.add_argument("--guides", type=int, default=1_000_000)
-ap.add_argument("--tmp", default="/tmp")
-ap.add_argument("--server", action="store_true")
-ap.add_argument("--json", default=None)
-a = ap.parse_args()
-tmp = pathlib.Path(a.tmp)
-issl, query, out = tmp / "e2e.issl", tmp / "e2e.query", tmp / "e2e.out"
-t = time.time(); sigs, occ = random_sites_fast(a.sites, seed=21, threads=min(32, os.cpu_count() or 8))
-ix = ca.IsslIndex.build_from_sites(sigs, occ); ix.write(issl)
-print(f"index: {len(sigs)} distinct sites, {issl.stat().st_size / 1e9:.2f} GB, made in {time.time() - t:.1f}s", flush=True)
-rng = np.random.default_rng(22)
-guides = sigs[rng.integers(0, len(sigs), size=a.guides)] ^ (np.uint64(3) << (np.uint64(2) * rng.integers(0, 20, size=a.guides).astype(np.uint64)))
-del sigs, occ, ix
-seqs = ca.decode_guides(guides[:1000])
-# query text: 2-bit decode, vectorised
-letters = np.frombuffer(b"ACGT", dtype=np.uint8)
-txt = np.empty((a.guides, 21), dtype=np.uint8)
-for j in range(20):
-    txt[:, j] = letters[((guides >> np.uint64(2 * j)) & np.uint64(3)).astype(np.int64)]
-txt[:, 20] = ord("\n")
-query.write_bytes(txt.tobytes())
-assert query.read_text().splitlines()[:1000] == seqs
-exe = str(ROOT / "bin" / "isslScoreOfftargets")
-res = {"what": f"bin/isslScoreOfftargets on a {a.sites}-line index ({issl.stat().st_size / 1e9:.2f} GB .issl), "
-               f"{a.guides} guides, 4 75 and; one process per call as Crackling does", "runs": []}
+EXE = str(ROOT / "bin" / "isslScoreOfftargets")
 
 
-def run(label, env):
-    t = time.time()
+def write_query(path, guides):
+    """The query file Crackling writes (Crackling.py:747-752): seq[0:20] + LF per guide."""
+    letters = np.frombuffer(b"ACGT", dtype=np.uint8)
+    txt = np.empty((len(guides), 21), dtype=np.uint8)
+    for j in range(20):
+        txt[:, j] = letters[((guides >> np.uint64(2 * j)) & np.uint64(3)).astype(np.int64)]
+    txt[:, 20] = ord("\n")
+    pathlib.Path(path).write_bytes(txt.tobytes())
+
+
+def _run(issl, query, out, env, args=("4", "75", "and"), exe=EXE):
+    t = time.perf_counter()
     with open(out, "wb") as fh:
-        r = subprocess.run([exe, str(issl), str(query), "4", "75", "and"], stdout=fh, stderr=subprocess.PIPE, env=env)
-    wall = time.time() - t
-    assert r.returncode == 0, r.stderr.decode()
-    err_lines = r.stderr.decode().strip().splitlines()
-    timing = json.loads(err_lines[-1])
-    notes = [l for l in err_lines[:-1] if l.startswith("[issl")]
-    if notes:
-        print("   " + " | ".join(notes), flush=True)
-    n_lines = sum(1 for _ in open(out, "rb"))
-    assert n_lines == a.guides
-    res["runs"].append({"label": label, "wall_s": wall, "guides_per_s_wall": a.guides / wall, "timing": timing})
-    print(label, f"wall {wall:.2f}s", json.dumps(timing), flush=True)
+        r = subprocess.run([exe, str(issl), str(query), *args], stdout=fh, stderr=subprocess.PIPE, env=env)
+    wall = time.perf_counter() - t
+    if r.returncode != 0:
+        raise RuntimeError(f"{exe} exited {r.returncode}: {r.stderr.decode(errors='replace')[-400:]}")
+    timing = None
+    for line in reversed(r.stderr.decode(errors="replace").strip().splitlines()):
+        if line.startswith("{"):
+            timing = json.loads(line)
+            break
+    return wall, timing
 
 
-env = dict(os.environ, ISSL_TIMING="1")
-run("process, first run", env)
-run("process, file cached", env)
-if a.server:
-    sock = str(tmp / "e2e.sock")
-    srv = subprocess.Popen([exe, "--serve", sock], stderr=subprocess.DEVNULL)
+def measure(issl, pages, tmp, expected=None, server=True, exe=EXE, log=None, one_shot_runs=2):
+    """pages: [(label, uint64 guide signatures)].  expected(label) -> the stdout bytes the page must produce, or None.
+    Returns {label: {"one_shot": [...], "resident": [...], "stdout_identical": bool}}; every run = wall seconds of the child
+    process as the caller sees it (fork, exec, exit included) + the ISSL_TIMING stage breakdown the process printed."""
+    tmp = pathlib.Path(tmp)
+    say = log or (lambda *a: None)
+    res = {}
+    env = dict(os.environ, ISSL_TIMING="1")
+    env.pop("ISSL_SERVER", None)
+    queries = {}
+    for label, guides in pages:
+        q = tmp / f"cli_{os.getpid()}_{label}.query"
+        write_query(q, guides)
+        queries[label] = q
+        res[label] = {"guides": int(len(guides)), "one_shot": [], "resident": [], "stdout_identical": None}
+    out = tmp / f"cli_{os.getpid()}.out"
+
+    def check(label):
+        if expected is None:
+            return
+        want = expected(label)
+        if want is None:
+            return
+        same = out.read_bytes() == want
+        prev = res[label]["stdout_identical"]
+        res[label]["stdout_identical"] = same if prev is None else (prev and same)
+
     try:
-        for _ in range(200):
-            if os.path.exists(sock):
-                break
-            time.sleep(0.05)
-        env2 = dict(env, ISSL_SERVER=sock)
-        run("resident server, first request (loads the index)", env2)
-        run("resident server, index resident", env2)
+        for label, guides in pages:
+            for i in range(one_shot_runs):
+                wall, timing = _run(issl, queries[label], out, env, exe=exe)
+                check(label)
+                res[label]["one_shot"].append({"wall_s": wall, "guides_per_s_wall": len(guides) / wall, "timing": timing})
+                say(f"[cli] {label} one-shot run {i}: {wall*1e3:.0f} ms wall  {json.dumps(timing)}")
+        if server:
+            sock = str(tmp / f"cli_{os.getpid()}.sock")
+            srv = subprocess.Popen([exe, "--serve", sock], stderr=subprocess.DEVNULL, env=env)
+            try:
+                for _ in range(400):
+                    if os.path.exists(sock):
+                        break
+                    time.sleep(0.025)
+                env2 = dict(env, ISSL_SERVER=sock)
+                first = True
+                for label, guides in pages:
+                    for i in range(3 if not first else 4):
+                        wall, timing = _run(issl, queries[label], out, env2, exe=exe)
+                        check(label)
+                        rec = {"wall_s": wall, "guides_per_s_wall": len(guides) / wall, "timing": timing}
+                        if first:  # this request made the server open and upload the index
+                            res["server_first_request"] = dict(rec, page=label)
+                            first = False
+                        else:
+                            res[label]["resident"].append(rec)
+                        say(f"[cli] {label} through the server, request {i}: {wall*1e3:.1f} ms wall  {json.dumps(timing)}")
+            finally:
+                subprocess.run([exe, "--stop", sock], capture_output=True)
+                try:
+                    srv.wait(timeout=60)
+                except subprocess.TimeoutExpired:
+                    srv.kill()
+        for label, _ in pages:
+            r = res[label]
+            if r["one_shot"]:
+                r["one_shot_best_wall_s"] = min(x["wall_s"] for x in r["one_shot"])
+            if r["resident"]:
+                r["resident_best_wall_s"] = min(x["wall_s"] for x in r["resident"])
+                r["resident_guides_per_s"] = r["guides"] / r["resident_best_wall_s"]
     finally:
-        subprocess.run([exe, "--stop", sock], capture_output=True)
-        srv.wait(timeout=60)
-for p in (issl, query, out):
-    p.unlink(missing_ok=True)
-if a.json:
-    json.dump(res, open(a.json, "w"), indent=1)
+        for p in list(queries.values()) + [out]:
+            pathlib.Path(p).unlink(missing_ok=True)
+    return res
+
+
+def main():
+    import argparse
+    import crackling_amd as ca
+    from synth import random_sites_fast, random_guides_fast
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--sites", type=int, default=50_000_000)
+    ap.add_argument("--pages", default="1000000,10000")
+    ap.add_argument("--tmp", default="/dev/shm" if os.path.isdir("/dev/shm") else "/tmp")
+    ap.add_argument("--no-server", action="store_true")
+    ap.add_argument("--exe", default=EXE, help="another build of the executable (A/B)")
+    ap.add_argument("--json", default=None)
+    a = ap.parse_args()
+    tmp = pathlib.Path(a.tmp)
+    issl = tmp / f"e2e_{os.getpid()}.issl"
+    t = time.time()
+    sigs, occ = random_sites_fast(a.sites, seed=21, threads=min(16, os.cpu_count() or 8))
+    ix = ca.IsslIndex.build_on_device(sigs, occ, device=0)
+    ix.write(issl)
+    print(f"index: {len(sigs)} distinct sites, {issl.stat().st_size / 1e9:.2f} GB, made in {time.time() - t:.1f}s", flush=True)
+    pages = [(f"{n}_guides", random_guides_fast(sigs, n, seed=22 + i)) for i, n in enumerate(int(x) for x in a.pages.split(","))]
+    scores = {}
+    for label, g in pages:
+        mit, cfd = ix.score(g, 4, 75.0, "and")
+        scores[label] = ca.format_scores_native(g, mit, cfd, "and")
+    ix.close()
+    del sigs, occ
+    allres = {}
+    try:
+        for exe in a.exe.split(","):   # (several builds of the executable: same-box A/B)
+            print(f"== {exe}", flush=True)
+            res = measure(issl, pages, tmp, expected=scores.get, server=not a.no_server, exe=exe, log=lambda *x: print(*x, flush=True))
+            res["what"] = f"{exe} on a {a.sites}-line index, `<issl> <query> 4 75 and > out`, one process per page as Crackling runs it"
+            print(json.dumps({k: (v if not isinstance(v, dict) else {kk: vv for kk, vv in v.items() if kk not in ('one_shot', 'resident')}) for k, v in res.items()}, indent=1), flush=True)
+            allres[exe] = res
+    finally:
+        issl.unlink(missing_ok=True)
+    if a.json:
+        json.dump(allres if len(allres) > 1 else next(iter(allres.values())), open(a.json, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
