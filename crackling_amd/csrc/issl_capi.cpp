@@ -3,6 +3,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cctype>
 #include <chrono>
 #include <cmath>
@@ -11,8 +12,11 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <new>
 #include <string>
+#include <thread>
+#include <unistd.h>
 #include <vector>
 
 #include "issl_device.hpp"
@@ -457,6 +461,99 @@ struct DevTemp { // device allocation freed on every path out of a function
     ~DevTemp() { if (p) (void)hipFree(p); }
 };
 
+// A section of a file-mapped index into device memory.  hipMemcpy from a FRESH private file mapping moves 11 GB/s on an
+// MI355X host (every page of the mapping is faulted in on the way; 56 GB/s once they are), so the 14 GB of a human-scale
+// .issl took 0.6 - 0.8 s of a one-shot scorer's second.  Here a few threads pread() the file into a ring of pinned chunks
+// and every chunk goes out with its own asynchronous copy: 48 - 53 GB/s, the link's rate (tools/ubench_h2d.cpp,
+// profiles/r05_ubench_h2d.txt).  Anything that is not file-backed, or small, takes the plain copy.
+class FileUploader {
+  public:
+    ~FileUploader() { release(); }
+    int copy(const HostIndex &h, void *dst, const void *src, size_t bytes)
+    {
+        int fd = -1;
+        uint64_t off = 0;
+        if (bytes < (size_t(64) << 20) || !h.file_range(src, bytes, &fd, &off) || !ensure()) {
+            HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+            return ISSL_OK;
+        }
+        const size_t n_chunks = (bytes + kChunk - 1) / kChunk;
+        std::atomic<size_t> next{0};
+        std::atomic<int> failed{0};
+        int device = 0;
+        (void)hipGetDevice(&device);
+        auto work = [&](uint32_t w) {
+            (void)hipSetDevice(device);
+            for (uint32_t turn = 0;; ++turn) {
+                const size_t c = next.fetch_add(1);
+                if (c >= n_chunks || failed.load()) break;
+                const uint32_t slot = w + (turn & 1u) * kThreads; // every thread alternates between its two slots
+                if (hipEventSynchronize(ev_[slot]) != hipSuccess) { failed = 1; break; } // the slot's previous copy has left it
+                const size_t len = std::min(kChunk, bytes - c * kChunk);
+                size_t got = 0;
+                while (got < len) {
+                    const ssize_t k = ::pread(fd, static_cast<char *>(pin_[slot]) + got, len - got, static_cast<off_t>(off + c * kChunk + got));
+                    if (k < 0 && errno == EINTR) continue;
+                    if (k <= 0) { failed = 2; break; }
+                    got += static_cast<size_t>(k);
+                }
+                if (got < len) break;
+                std::lock_guard<std::mutex> lock(mu_);
+                if (hipMemcpyAsync(static_cast<char *>(dst) + c * kChunk, pin_[slot], len, hipMemcpyHostToDevice, stream_) != hipSuccess ||
+                    hipEventRecord(ev_[slot], stream_) != hipSuccess) { failed = 1; break; }
+            }
+        };
+        {
+            std::vector<std::thread> pool;
+            for (uint32_t w = 1; w < kThreads; ++w) pool.emplace_back(work, w);
+            work(0);
+            for (auto &th : pool) th.join();
+        }
+        HIP_TRY(hipStreamSynchronize(stream_));
+        if (failed.load() == 2) { set_error("Error reading index: the file shrank or could not be read while it was uploaded"); return ISSL_E_IO; }
+        if (failed.load()) { (void)hipGetLastError(); set_error("HIP error while a section of the index was uploaded"); return ISSL_E_DEVICE; }
+        return ISSL_OK;
+    }
+    void release()
+    {
+        if (block_) (void)hipHostFree(block_);
+        block_ = nullptr;
+        for (void *&p : pin_) p = nullptr;
+        for (hipEvent_t &e : ev_) { if (e) (void)hipEventDestroy(e); e = nullptr; }
+        if (stream_) (void)hipStreamDestroy(stream_);
+        stream_ = nullptr;
+        ready_ = false;
+    }
+
+  private:
+    static constexpr uint32_t kThreads = 8;
+    static constexpr size_t kChunk = size_t(16) << 20; // 16 slots: 256 MiB of pinned memory while an upload lasts (pinning costs ~0.2 ms per MiB)
+    bool ensure()
+    {
+        if (ready_) return true;
+        if (tried_) return false;
+        tried_ = true;
+        if (hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); stream_ = nullptr; return false; }
+        if (hipHostMalloc(&block_, 2 * kThreads * kChunk, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); block_ = nullptr; release(); return false; }
+        for (uint32_t i = 0; i < 2 * kThreads; ++i) {
+            pin_[i] = static_cast<char *>(block_) + i * kChunk;
+            if (hipEventCreateWithFlags(&ev_[i], hipEventDisableTiming) != hipSuccess) {
+                (void)hipGetLastError();
+                release();
+                return false;
+            }
+        }
+        ready_ = true;
+        return true;
+    }
+    void *block_ = nullptr; // one pinned allocation, cut into the slots
+    void *pin_[2 * kThreads] = {};
+    hipEvent_t ev_[2 * kThreads] = {};
+    hipStream_t stream_ = nullptr;
+    std::mutex mu_; // one thread at a time talks to the stream
+    bool ready_ = false, tried_ = false;
+};
+
 static int finish_upload(issl_index *ix, const DeviceBuildInput *dbi = nullptr)
 {
     // sections that are plain copies
@@ -508,6 +605,7 @@ static int finish_upload(issl_index *ix, const DeviceBuildInput *dbi = nullptr)
         seen = static_cast<uint32_t *>(seen_mem.p);
     }
     double t0 = wall_ms();
+    FileUploader from_file;
     if (ix->hdr.off_sub_start) {
         // Sorted layouts.  Site table and counts into the image, then one slice at a time: the slice's list (in the
         // image, or -- lists in pinned host memory -- in a temporary 8 B/site device copy), the successor-byte order
@@ -515,7 +613,8 @@ static int finish_upload(issl_index *ix, const DeviceBuildInput *dbi = nullptr)
         const uint64_t n = g.n_sites;
         uint64_t *d_sites = reinterpret_cast<uint64_t *>(base + ix->hdr.off_sites);
         uint32_t *d_site_occ = reinterpret_cast<uint32_t *>(base + ix->hdr.off_site_occ);
-        HIP_TRY(hipMemcpy(d_sites, dbi ? dbi->sigs : h.sites, 8 * n, dbi ? dbi_kind : hipMemcpyHostToDevice));
+        if (dbi) HIP_TRY(hipMemcpy(d_sites, dbi->sigs, 8 * n, dbi_kind));
+        else if (int crc = from_file.copy(h, d_sites, h.sites, 8 * n)) return crc;
         if (dbi) HIP_TRY(hipMemcpy(d_site_occ, dbi->occ, 4 * n, dbi_kind)); // (k_fill_maps writes the same again)
         upload_note(ix, "sites", t0);
         t0 = wall_ms();
@@ -536,13 +635,16 @@ static int finish_upload(issl_index *ix, const DeviceBuildInput *dbi = nullptr)
                                            static_cast<uint32_t>(g.slice_width), d_entries);
             if (brc) return brc;
             upload_note(ix, "slice lists built on the device", t0);
-        } else {
-            HIP_TRY(hipMemcpy(d_entries, h.entries, 8 * n * g.n_slices, hipMemcpyHostToDevice));
-            upload_note(ix, "entries", t0);
         }
+        // Lists from the host: one slice at a time, so that the kernels that order slice s run while slice s + 1 is on
+        // its way (the copy returns when the slice has landed; the kernels are asynchronous on the null stream, the
+        // copies run on a stream of their own).
+        const bool stream_lists = !lists_cold && !dbi;
         t0 = wall_ms();
         for (uint64_t sl = 0; sl < g.n_slices; ++sl) {
             const uint64_t *d_list = lists_cold ? static_cast<uint64_t *>(list_mem.p) : d_entries + sl * n;
+            if (stream_lists)
+                if (int crc = from_file.copy(h, d_entries + sl * n, h.entries + sl * n, 8 * n)) return crc;
             if (lists_cold) {
                 uint64_t *t_list = static_cast<uint64_t *>(list_mem.p);
                 if (dbi) {
@@ -554,7 +656,7 @@ static int finish_upload(issl_index *ix, const DeviceBuildInput *dbi = nullptr)
                     std::memcpy(c_entries + sl * n, h.entries + sl * n, 8 * n);
                     HIP_TRY(hipMemcpy(t_list, c_entries + sl * n, 8 * n, hipMemcpyHostToDevice));
                 } else {
-                    HIP_TRY(hipMemcpy(t_list, h.entries + sl * n, 8 * n, hipMemcpyHostToDevice));
+                    if (int crc = from_file.copy(h, t_list, h.entries + sl * n, 8 * n)) return crc;
                 }
             }
             src = launch_sort_slice(st, d_sites, d_list, reinterpret_cast<const uint64_t *>(base + ix->hdr.off_bucket_start),
@@ -569,16 +671,17 @@ static int finish_upload(issl_index *ix, const DeviceBuildInput *dbi = nullptr)
         src = finish_sort(flag);
         if (src) return src;
         st.release();
-        upload_note(ix, "sorted layout (successor-byte order of every bucket + stream maps)", t0);
+        upload_note(ix, stream_lists ? "entries, slice by slice, beside the sorted layout (successor-byte order of every bucket + stream maps)"
+                                     : "sorted layout (successor-byte order of every bucket + stream maps)", t0);
         t0 = wall_ms();
         launch_pack_scan_stream(ix->view, scan_out, nullptr, nullptr, flag, nullptr, nullptr);
         HIP_TRY(hipGetLastError());
         launch_tag_sites(d_sites, d_site_occ, n); // (last: from here on `sites` carries a 24-bit copy of the counts)
         HIP_TRY(hipGetLastError());
     } else if (!ix->hdr.cold_on_host) {
-        // Plain copies from the (file-mapped) host arrays: measured 48 GB/s on a 14 GB index, where a 12-thread
-        // pipeline through pinned staging buffers reached 24 GB/s.
-        HIP_TRY(hipMemcpy(base + ix->hdr.off_sites, dbi ? dbi->sigs : h.sites, 8 * g.n_sites, dbi ? dbi_kind : hipMemcpyHostToDevice));
+        // (file-mapped host arrays go through FileUploader's pinned ring, everything else through plain copies)
+        if (dbi) HIP_TRY(hipMemcpy(base + ix->hdr.off_sites, dbi->sigs, 8 * g.n_sites, dbi_kind));
+        else if (int crc = from_file.copy(h, base + ix->hdr.off_sites, h.sites, 8 * g.n_sites)) return crc;
         upload_note(ix, "sites", t0);
         t0 = wall_ms();
         if (dbi) { // isslCreateIndex.cpp:218-234 on the device
@@ -587,16 +690,24 @@ static int finish_upload(issl_index *ix, const DeviceBuildInput *dbi = nullptr)
                                            reinterpret_cast<uint64_t *>(base + ix->hdr.off_entries));
             if (brc) return brc;
             upload_note(ix, "slice lists built on the device", t0);
+            t0 = wall_ms();
+            launch_pack_scan_stream(ix->view, scan_out,
+                                    ix->hdr.off_esig ? reinterpret_cast<uint64_t *>(base + ix->hdr.off_esig) : nullptr, nullptr, flag,
+                                    seen, nullptr);
+            HIP_TRY(hipGetLastError());
         } else {
-            HIP_TRY(hipMemcpy(base + ix->hdr.off_entries, h.entries, 8 * g.n_sites * g.n_slices, hipMemcpyHostToDevice));
-            upload_note(ix, "entries", t0);
+            // scan stream: built on the device from sites + entries, one slice at a time: the kernel that packs slice s runs
+            // while the list of slice s + 1 is on its way (a slice's buckets own a contiguous run of tiles)
+            uint64_t *d_entries = reinterpret_cast<uint64_t *>(base + ix->hdr.off_entries);
+            for (uint64_t sl = 0; sl < g.n_slices; ++sl) {
+                if (int crc = from_file.copy(h, d_entries + sl * g.n_sites, h.entries + sl * g.n_sites, 8 * g.n_sites)) return crc;
+                launch_pack_scan_range(ix->view, scan_out, ix->hdr.off_esig ? reinterpret_cast<uint64_t *>(base + ix->hdr.off_esig) : nullptr,
+                                       nullptr, flag, seen, tfirst[sl << g.slice_width], tfirst[(sl + 1) << g.slice_width], nullptr);
+                HIP_TRY(hipGetLastError());
+            }
+            upload_note(ix, "entries, slice by slice, beside the packing of the scan stream", t0);
+            t0 = wall_ms();
         }
-        t0 = wall_ms();
-        // scan stream: built on the device from sites + entries
-        launch_pack_scan_stream(ix->view, scan_out,
-                                ix->hdr.off_esig ? reinterpret_cast<uint64_t *>(base + ix->hdr.off_esig) : nullptr, nullptr, flag,
-                                seen, nullptr);
-        HIP_TRY(hipGetLastError());
     } else {
         // List-order layout with sites and lists in pinned host memory: the scan stream is packed one slice at a time from temporary device
         // copies of the signatures (8 B/site) and of that slice's list (8 B/site); random reads of the site table

@@ -20,6 +20,16 @@ const char *get_error() { return g_error.c_str(); }
 HostIndex::~HostIndex()
 {
     if (map_) munmap(map_, map_len_);
+    if (fd_ >= 0) ::close(fd_);
+}
+
+bool HostIndex::file_range(const void *p, size_t bytes, int *fd, uint64_t *offset) const
+{
+    const uint8_t *b = static_cast<const uint8_t *>(p), *m = static_cast<const uint8_t *>(map_);
+    if (fd_ < 0 || !map_ || b < m || b + bytes > m + map_len_) return false;
+    *fd = fd_;
+    *offset = static_cast<uint64_t>(b - m);
+    return true;
 }
 
 uint64_t encode_guide(const char *p, size_t seq_len)
@@ -173,13 +183,14 @@ int HostIndex::open_file(const char *path)
         return ISSL_E_FORMAT;
     }
     void *m = mmap(nullptr, static_cast<size_t>(st.st_size), PROT_READ, MAP_PRIVATE, fd, 0);
-    ::close(fd);
     if (m == MAP_FAILED) {
+        ::close(fd);
         set_error(std::string("cannot map index file '") + path + "': " + std::strerror(errno));
         return ISSL_E_IO;
     }
     map_ = m;
     map_len_ = static_cast<size_t>(st.st_size);
+    fd_ = fd; // kept: the upload reads the big sections with pread (file_range), which is several times faster than faulting the mapping in
     madvise(m, map_len_, MADV_SEQUENTIAL);
     return parse(static_cast<const uint8_t *>(m), map_len_);
 }

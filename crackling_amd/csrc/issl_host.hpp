@@ -51,6 +51,9 @@ class HostIndex {
     // The same from bucket lengths somebody else counted (a site table that lives in device memory).
     int init_from_bucket_sizes(const uint64_t *bucket_sizes, size_t n_sites, size_t n_lines, size_t seq_len, size_t slice_width);
     bool has_arrays() const { return sites != nullptr && entries != nullptr; }
+    // [p, p + bytes) lies in the file this index is mapped from: its descriptor and the offset of p (for readers that want
+    // the bytes without touching the mapping, e.g. pread into pinned memory).  False for indexes that were built or copied.
+    bool file_range(const void *p, size_t bytes, int *fd, uint64_t *offset) const;
     // Header, score table (and, with `with_sites`, nothing more): the leading sections of write_file() for callers
     // that stream the big arrays themselves.
     int write_leading_sections(FILE *fp) const;
@@ -63,6 +66,7 @@ class HostIndex {
     int finish_build(size_t slice_width);
     void *map_ = nullptr;
     size_t map_len_ = 0;
+    int fd_ = -1;
     std::vector<uint8_t> image_;         // from_memory copy
     std::vector<uint64_t> own_masks_;    // de-interleaved score table
     std::vector<double> own_vals_;

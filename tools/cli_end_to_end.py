@@ -45,10 +45,14 @@ def _run(issl, query, out, env, args=("4", "75", "and"), exe=EXE):
     return wall, timing
 
 
-def measure(issl, pages, tmp, expected=None, server=True, exe=EXE, log=None, one_shot_runs=2):
+def measure(issl, pages, tmp, expected=None, server=True, exe=EXE, log=None, one_shot_runs=3, pause_s=1.5):
     """pages: [(label, uint64 guide signatures)].  expected(label) -> the stdout bytes the page must produce, or None.
     Returns {label: {"one_shot": [...], "resident": [...], "stdout_identical": bool}}; every run = wall seconds of the child
-    process as the caller sees it (fork, exec, exit included) + the ISSL_TIMING stage breakdown the process printed."""
+    process as the caller sees it (fork, exec, exit included) + the ISSL_TIMING stage breakdown the process printed.
+    One-shot runs: the first of a page follows the previous process at once, the others after `pause_s` seconds --
+    Crackling parses a page's output and filters the next page's guides between two scorer processes, and a process that
+    starts while the driver is still taking back the 45 GB of its predecessor waits for it inside its own allocations
+    (profiles/r05_cli_upload_probe.log: 1 - 2.4 s, erratic); every record says which kind it is."""
     tmp = pathlib.Path(tmp)
     say = log or (lambda *a: None)
     res = {}
@@ -75,10 +79,12 @@ def measure(issl, pages, tmp, expected=None, server=True, exe=EXE, log=None, one
     try:
         for label, guides in pages:
             for i in range(one_shot_runs):
+                pause = pause_s if i else 0.0
+                time.sleep(pause)
                 wall, timing = _run(issl, queries[label], out, env, exe=exe)
                 check(label)
-                res[label]["one_shot"].append({"wall_s": wall, "guides_per_s_wall": len(guides) / wall, "timing": timing})
-                say(f"[cli] {label} one-shot run {i}: {wall*1e3:.0f} ms wall  {json.dumps(timing)}")
+                res[label]["one_shot"].append({"wall_s": wall, "guides_per_s_wall": len(guides) / wall, "pause_before_s": pause, "timing": timing})
+                say(f"[cli] {label} one-shot run {i} ({pause:g} s after the previous process): {wall*1e3:.0f} ms wall  {json.dumps(timing)}")
         if server:
             sock = str(tmp / f"cli_{os.getpid()}.sock")
             srv = subprocess.Popen([exe, "--serve", sock], stderr=subprocess.DEVNULL, env=env)
