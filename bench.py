@@ -161,7 +161,7 @@ def cpu_baseline(issl_path, guides, gpu_scores, max_dist, thr, method, budget_s)
     ix.close()
     key = f"thr{thr:g}"
     threads, rate, n, dt = best[key]
-    return {
+    port = {
         "value": rate, "unit": "guides/s", "cores": threads, "kind": "port",
         "sample": f"{n} guides of the batch, same index, OpenMP over guides with {threads} threads (best of the sweep "
                   f"{sweep_threads}), threshold {thr:g}, {dt:.2f} s wall (scan+score only, index already in memory)",
@@ -174,6 +174,64 @@ def cpu_baseline(issl_path, guides, gpu_scores, max_dist, thr, method, budget_s)
                 "took 1.54x (threshold 0) / 0.78x (threshold 75) the reference's scoring time (profiles/r03_port_vs_reference_cpu.json, "
                 "noisy VM): read the value as the reference's to within that factor",
     }
+    ref = reference_baseline(issl_path, guides, gpu_scores, max_dist, thr, method, threads, rate)
+    if ref is None:
+        return port
+    ref["host"] = host
+    ref["port"] = {k: port[k] for k in ("value", "cores", "sample", "value_thr0", "cores_thr0", "single_thread_seconds_per_guide_thr0",
+                                         "sweep", "index_load_s", "parity_on_sample", "note")}
+    ref["parity_on_sample"] = bool(ref["parity_on_sample"] and parity)
+    return ref
+
+
+def reference_baseline(issl_path, guides, gpu_scores, max_dist, thr, method, threads, port_rate, seconds=10.0):
+    """The compiled reference itself (oracle/_ref/isslScoreOfftargets: the reference's own sources, built by oracle/Makefile
+    where they lie, never copied) on a sample of the batch, when the binary is there: `kind: "reference"`.  It loads the
+    index on every call (it has no other mode), so it runs twice -- with the sample and with ONE guide -- and the scoring
+    time is the difference.  None when the binary is absent or anything goes wrong: the port's figure stands then."""
+    import subprocess
+    exe = ROOT / "oracle" / "_ref" / "isslScoreOfftargets"
+    if not exe.exists():
+        return None
+    try:
+        import crackling_amd as ca
+        sys.path.insert(0, str(ROOT / "tools"))
+        from cli_end_to_end import write_query
+        n = int(min(len(guides), max(threads, port_rate * seconds)))
+        tmp = os.path.dirname(issl_path)
+        q, q1 = f"{tmp}/bench_{os.getpid()}_ref.q", f"{tmp}/bench_{os.getpid()}_ref1.q"
+        write_query(q, guides[:n])
+        write_query(q1, guides[:1])
+        env = dict(os.environ, OMP_NUM_THREADS=str(threads))
+        try:
+            def run(query):
+                t0 = time.perf_counter()
+                r = subprocess.run([str(exe), issl_path, query, str(max_dist), f"{thr:g}", method], capture_output=True, env=env, timeout=180)
+                if r.returncode != 0:
+                    raise RuntimeError(f"reference exited {r.returncode}: {r.stderr.decode(errors='replace')[-200:]}")
+                return time.perf_counter() - t0, r.stdout
+            t_load, _ = run(q1)
+            t_full, out = run(q)
+        finally:
+            for f in (q, q1):
+                if os.path.exists(f):
+                    os.unlink(f)
+        scoring = max(t_full - t_load, 1e-6)
+        gm, gc = gpu_scores
+        same = out == ca.format_scores_native(guides[:n], gm[:n], gc[:n], method)
+        return {
+            "value": n / scoring, "unit": "guides/s", "cores": threads, "kind": "reference",
+            "sample": f"the first {n} guides of the batch through oracle/_ref/isslScoreOfftargets (the compiled reference, Makefile flags "
+                      f"-O3 -std=c++11 -fopenmp -mpopcnt), OMP_NUM_THREADS={threads}, `<issl> <query> {max_dist} {thr:g} {method}`: "
+                      f"{t_full:.2f} s wall, minus {t_load:.2f} s for a one-guide query (index load) = {scoring:.2f} s of scoring",
+            "wall_s": t_full, "load_only_s": t_load, "scoring_s": scoring,
+            "parity_on_sample": bool(same),
+            "note": "stdout of the reference on the sample compared byte for byte with the GPU's scores as text (parity_on_sample); "
+                    "`port` = the same sweep with the oracle's restatement (thread sweep, threshold 0 and the product threshold)",
+        }
+    except Exception as e:  # noqa: BLE001
+        log(f"[bench] reference baseline not measured: {type(e).__name__}: {e}")
+        return None
 
 
 def main():
@@ -199,7 +257,7 @@ def main():
                     help="site distribution: iid uniform bases (BASELINE configs) or an AT-rich order-3 Markov chain")
     ap.add_argument("--chunk", type=int, default=4096, help="guides per interleaved shard chunk (N>1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-budget-s", type=float, default=24.0, help="CPU seconds for the baseline sweep")
+    ap.add_argument("--cpu-budget-s", type=float, default=16.0, help="CPU seconds for the port's thread sweep (the compiled reference takes ~10 s of scoring + two index loads on top)")
     ap.add_argument("--no-extras", action="store_true", help="skip the 10k-guide, 64-guide and host-pointer points")
     ap.add_argument("--no-cli", action="store_true", help="skip extras.cli_end_to_end (bin/isslScoreOfftargets as Crackling runs it)")
     ap.add_argument("--dump-scores", default=None,
@@ -271,9 +329,13 @@ def main():
         watchdog.daemon = True
         watchdog.start()
         log(f"[bench] rank {rank}/{world}: device {dev_id}, backend {backend}, entering the image broadcast")
-        index, timings["broadcast_s"] = sharding.broadcast_image(dist, torch, index, dev)
+        bstats = {}
+        index, timings["broadcast_s"] = sharding.broadcast_image(dist, torch, index, dev, stats=bstats)
+        timings["hbm_used_peak_bytes_in_broadcast"] = bstats.get("hbm_used_peak_bytes")
         watchdog.cancel()
-        log(f"[bench] rank {rank}: image attached after {timings['broadcast_s']:.2f} s of broadcast")
+        log(f"[bench] rank {rank}: image attached after {timings['broadcast_s']:.2f} s of broadcast; HBM in use at the high-water mark "
+            f"of the broadcast on this rank: {(bstats.get('hbm_used_peak_bytes') or 0) / 1e9:.1f} GB (image {bstats.get('image_bytes', 0) / 1e9:.1f} GB"
+            f"{'; rank 0 holds the built image and the tensor it is copied into' if rank == 0 else ''})")
     hdr = index.header
     image_bytes = index.device_bytes()
     if rank == 0:
@@ -369,12 +431,14 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
         mine_t = torch.tensor([scan_ms, stages["ms_total"], float(n_mine), float(st["candidates"]), timings.get("broadcast_s", 0.0),
-                               float(image_bytes), float(dev_id)], dtype=torch.float64, device=cdev)
+                               float(image_bytes), float(dev_id), float(timings.get("hbm_used_peak_bytes_in_broadcast") or 0)],
+                              dtype=torch.float64, device=cdev)
         allr = [torch.empty_like(mine_t) for _ in range(world)] if rank == 0 else None
         dist.gather(mine_t, allr, dst=0)
         if rank == 0:
             per_rank = [{"rank": r, "scan_ms": float(x[0]), "pipeline_ms": float(x[1]), "guides": int(x[2]),
-                         "comparisons": int(x[3]), "broadcast_s": float(x[4]), "image_bytes": int(x[5]), "device": int(x[6])}
+                         "comparisons": int(x[3]), "broadcast_s": float(x[4]), "image_bytes": int(x[5]), "device": int(x[6]),
+                         "hbm_used_peak_bytes_in_broadcast": int(x[7])}
                         for r, x in enumerate(allr)]
 
     extras = {}

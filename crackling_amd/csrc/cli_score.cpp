@@ -480,10 +480,10 @@ int serve(const char *sock_path)
         issl_header h{};
         if (api.issl_index_device_bytes(incoming, &preferred) || api.issl_index_header(incoming, &h)) return;
         // Room asked for: the image of the fastest layout + the temporaries of its construction + the scoring workspace (hit
-        // slots: up to 8 GiB).  An upload settles for the smallest layout (52 B/site, 24 B/site of temporaries) when the
+        // slots: up to 8 GiB).  An upload settles for the smallest layout (52 B/site, 8 B/site of temporaries) when the
         // device cannot hold the fastest even when it is empty -- evicting beyond what THAT one needs buys nothing.
         const size_t reserve = size_t(10) << 30;
-        const size_t want_fast = preferred + 24 * h.n_sites + reserve, want_small = (52 + 24) * h.n_sites + reserve;
+        const size_t want_fast = preferred + 8 * h.n_sites + reserve, want_small = (52 + 8) * h.n_sites + reserve;
         while (!cache.empty()) {
             size_t free_b = ~size_t(0), total_b = ~size_t(0), held = 0;
             for (int d : mem_devices) { // the tightest device decides

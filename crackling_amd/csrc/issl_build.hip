@@ -132,11 +132,12 @@ void launch_tag_sites(uint64_t *d_sites, const uint32_t *d_site_occ, uint64_t n_
     hipLaunchKernelGGL(k_tag_sites, dim3(grid), dim3(256), 0, nullptr, d_sites, d_site_occ, n_sites);
 }
 
-int SortTemp::alloc(uint64_t n_sites)
+int SortTemp::alloc(uint64_t n_sites, void *borrowed_keys)
 {
     release();
     const uint32_t n_blocks = static_cast<uint32_t>((n_sites + 256ull * kSortItems - 1) / (256ull * kSortItems));
-    if (hipMalloc(reinterpret_cast<void **>(&keys), 8 * std::max<uint64_t>(n_sites, 1)) != hipSuccess) keys = nullptr;
+    if (borrowed_keys) { keys = static_cast<uint64_t *>(borrowed_keys); keys_borrowed = true; }
+    else if (hipMalloc(reinterpret_cast<void **>(&keys), 8 * std::max<uint64_t>(n_sites, 1)) != hipSuccess) keys = nullptr;
     if (keys && hipMalloc(reinterpret_cast<void **>(&tmp), 8 * std::max<uint64_t>(n_sites, 1)) != hipSuccess) tmp = nullptr;
     if (tmp && hipMalloc(reinterpret_cast<void **>(&hist), 4ull * radix_hist_words(std::max(n_blocks, 1u))) != hipSuccess) hist = nullptr;
     if (!hist) {
@@ -149,7 +150,8 @@ int SortTemp::alloc(uint64_t n_sites)
 
 void SortTemp::release()
 {
-    if (keys) (void)hipFree(keys);
+    if (keys && !keys_borrowed) (void)hipFree(keys);
+    keys_borrowed = false;
     if (tmp) (void)hipFree(tmp);
     if (hist) (void)hipFree(hist);
     keys = tmp = nullptr;

@@ -618,18 +618,24 @@ static int finish_upload(issl_index *ix, const DeviceBuildInput *dbi = nullptr)
         if (dbi) HIP_TRY(hipMemcpy(d_site_occ, dbi->occ, 4 * n, dbi_kind)); // (k_fill_maps writes the same again)
         upload_note(ix, "sites", t0);
         t0 = wall_ms();
-        SortTemp st;
-        int src = st.alloc(n);
-        if (src) return src;
         // lists in pinned host memory, or nowhere (lists_absent): either way a slice's list exists on the device only while
         // the slice is worked on, in one 8 B/site temporary
         const bool lists_kept_cold = (ix->hdr.cold_on_host & 1u) != 0;
         const bool lists_cold = lists_kept_cold || ix->hdr.lists_absent != 0;
+        // The scan stream is packed last (from the maps the slices leave behind): until then its section -- 20 B per site --
+        // holds the sort keys and the one slice list, so that the construction needs 8 B per site beyond the image
+        // (the radix passes' second buffer) and an index of the format's 2^32 - 1 sites (52 + 8 B per site) fits 288 GB.
+        const uint64_t scan_bytes = ix->hdr.n_tiles * static_cast<uint64_t>(kTileCands) * 4ull, key_bytes = align256(8 * n);
+        const bool lend = scan_bytes >= key_bytes + (lists_cold ? 8 * n : 0) && n > 0;
+        SortTemp st;
+        int src = st.alloc(n, lend ? scan_out : nullptr);
+        if (src) return src;
         DevTemp list_mem;
+        uint64_t *lent_list = (lend && lists_cold) ? reinterpret_cast<uint64_t *>(reinterpret_cast<uint8_t *>(scan_out) + key_bytes) : nullptr;
         uint64_t *d_entries = lists_cold ? nullptr : reinterpret_cast<uint64_t *>(base + ix->hdr.off_entries);
         uint64_t *c_entries = lists_kept_cold ? reinterpret_cast<uint64_t *>(static_cast<uint8_t *>(ix->h_cold) + ix->hdr.off_entries) : nullptr;
         if (lists_cold) {
-            if (hipMalloc(&list_mem.p, std::max<uint64_t>(8 * n, 8)) != hipSuccess) { (void)hipGetLastError(); list_mem.p = nullptr; return kSortNoRoom; }
+            if (!lent_list && hipMalloc(&list_mem.p, std::max<uint64_t>(8 * n, 8)) != hipSuccess) { (void)hipGetLastError(); list_mem.p = nullptr; return kSortNoRoom; }
         } else if (dbi) { // isslCreateIndex.cpp:218-234 on the device
             int brc = launch_build_entries(d_sites, d_site_occ, n, 0, static_cast<uint32_t>(g.n_slices),
                                            static_cast<uint32_t>(g.slice_width), d_entries);
@@ -642,11 +648,12 @@ static int finish_upload(issl_index *ix, const DeviceBuildInput *dbi = nullptr)
         const bool stream_lists = !lists_cold && !dbi;
         t0 = wall_ms();
         for (uint64_t sl = 0; sl < g.n_slices; ++sl) {
-            const uint64_t *d_list = lists_cold ? static_cast<uint64_t *>(list_mem.p) : d_entries + sl * n;
+            uint64_t *const t_list_mem = lent_list ? lent_list : static_cast<uint64_t *>(list_mem.p);
+            const uint64_t *d_list = lists_cold ? t_list_mem : d_entries + sl * n;
             if (stream_lists)
                 if (int crc = from_file.copy(h, d_entries + sl * n, h.entries + sl * n, 8 * n)) return crc;
             if (lists_cold) {
-                uint64_t *t_list = static_cast<uint64_t *>(list_mem.p);
+                uint64_t *t_list = t_list_mem;
                 if (dbi) {
                     int brc = launch_build_entries(d_sites, d_site_occ, n, static_cast<uint32_t>(sl), static_cast<uint32_t>(sl + 1),
                                                    static_cast<uint32_t>(g.slice_width), t_list);
@@ -1357,7 +1364,7 @@ static int upload_common(issl_index *idx, int device, void *buf, size_t bytes, c
         // temporary device memory: while a list-order host-cold image is packed, signatures + one slice list; for the
         // sorted layouts two key arrays of 8 B per site (one slice at a time) and, lists in host memory, one slice list
         const uint64_t ns = idx->geo.n_sites;
-        const uint64_t temp = c.sorted ? 16 * ns + ((c.cold || c.no_lists) ? 8 * ns : 0) + (64ull << 20)
+        const uint64_t temp = c.sorted ? 8 * ns + (64ull << 20) // (keys and slice list live in the image's scan section while it is built)
                               : (c.cold ? 16 * ns : 0) + ns * idx->geo.n_slices / 8 + 8; // (list order: + the `seen` bitmap)
         if (buf) {
             if (bytes < idx->hdr.total_bytes || (reinterpret_cast<uintptr_t>(buf) & 255u)) {

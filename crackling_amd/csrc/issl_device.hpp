@@ -193,7 +193,10 @@ int launch_bucket_sizes(const uint64_t *d_sites, uint64_t n_sites, uint32_t slic
 
 // Sorted layouts (issl_build.hip): order every bucket's list by the successor slice's byte (two stable radix passes per
 // slice over keys built from the signatures) and write the maps of the image.  One slice at a time, 16 B per site of
-// temporary device memory (SortTemp, allocated once per upload).
+// temporary device memory (SortTemp, allocated once per upload) -- of which the upload lends the first 8 out of the image
+// itself: the scan stream (20 B per site) is packed last, and until then its section holds the keys (and, where the slice
+// lists are not kept in HBM, the one list being worked on), so that a sorted image needs 8 B per site beyond its own size
+// while it is built.
 constexpr int kSortNeedsListOrder = -1000; // the index cannot take a sorted layout: an entry sits in a bucket its signature
                                            // does not select, a list is not ascending by site id, or a site carries
                                            // different counts in different lists (no builder writes any of these; the
@@ -203,7 +206,8 @@ constexpr int kSortNoRoom = -1001;         // no device memory for the temporari
 struct SortTemp {
     uint64_t *keys = nullptr, *tmp = nullptr;
     uint32_t *hist = nullptr;
-    int alloc(uint64_t n_sites); // ISSL_OK or kSortNoRoom
+    bool keys_borrowed = false;
+    int alloc(uint64_t n_sites, void *borrowed_keys = nullptr); // ISSL_OK or kSortNoRoom; borrowed_keys: 8 B per site somebody else owns
     void release();
     ~SortTemp() { release(); }
 };

@@ -48,7 +48,7 @@ def _staged(dist, torch, device):
     return getattr(device, "type", str(device)) != "cpu" and str(dist.get_backend()).lower() == "gloo"
 
 
-def broadcast_image(dist, torch, index, device, src=0, index_cls=None, piece_bytes=1 << 30):
+def broadcast_image(dist, torch, index, device, src=0, index_cls=None, piece_bytes=1 << 30, stats=None):
     """Rank `src` holds an IsslIndex (host arrays, or an image already on `device`); every rank ends up with an
     IsslIndex attached to its own copy of the image.  Returns (index, seconds spent in the broadcast proper).
     The index passed in on rank `src` is CONSUMED when it already has a device image: that image is copied into the
@@ -58,7 +58,9 @@ def broadcast_image(dist, torch, index, device, src=0, index_cls=None, piece_byt
     device-built image there; the others receive and attach (issl_index_attach_image).  The broadcast itself goes in
     pieces of `piece_bytes` (1 GiB: a 300 M-site image is 61 GB, and no collective has to take a count beyond 2^31).
     `index_cls` (default IsslIndex) provides attach_tensor(); the CPU tests pass a host-memory stand-in with the same
-    methods."""
+    methods.  `stats` (a dict, optional) receives `image_bytes` and, on a GPU, `hbm_used_peak_bytes`: what the device holds
+    at the high-water mark of this function on this rank -- on rank `src` with a device-built index that is the library's
+    image AND the tensor it is copied into (2 x 44.5 GB at 300 M sites), everywhere else the tensor alone."""
     import time
     if index_cls is None:
         from .scorer import IsslIndex as index_cls
@@ -79,9 +81,18 @@ def broadcast_image(dist, torch, index, device, src=0, index_cls=None, piece_byt
     off = (-raw.data_ptr()) % 256
     image = raw[off:off + n]
     attach = True
+
+    def note_peak():
+        if stats is not None:
+            stats["image_bytes"] = n
+            if getattr(device, "type", str(device)) != "cpu" and torch.cuda.is_available():
+                free_b, total_b = torch.cuda.mem_get_info(device)
+                stats["hbm_used_peak_bytes"] = max(stats.get("hbm_used_peak_bytes", 0), int(total_b - free_b))
+    note_peak()
     if rank == src:
         if index.has_device_image():           # built on the device: move the image into the tensor, then attach like
             index.copy_image_to_tensor(image)  # everybody else (the library-owned copy is released)
+            note_peak()
             index.close()
         else:                                  # host arrays: build the image straight into the tensor
             index.upload_into_tensor(image)

@@ -202,7 +202,10 @@ int issl_index_copy_image_to(const issl_index *idx, void *dev_dst, size_t bytes)
  *                 site table and counts (every list ascends by site id, isslCreateIndex.cpp:218-234), which
  *                 issl_index_write and issl_dump_hits redo on the device when asked.  An index at the format's limit of
  *                 4.29 G sites takes 223 GB of a 288 GB GPU (3 G lines: 152 GB, measured), nothing in host memory, and
- *                 the image still moves as one broadcast.  On request (host_cold=1) the lists are kept in pinned,
+ *                 the image still moves as one broadcast.  While a sorted image is built it needs 8 B per site beyond its
+ *                 own size (keys and slice list of the slice being ordered borrow the image's scan section, which is packed
+ *                 last): 60 B/site = 258 GB at the format's limit from a file or host arrays (+ a 2 - 9 GB working reserve);
+ *                 issl_index_build_from_device_sites has the caller's 12 B/site beside it (~3.8 G sites on 288 GB).  On request (host_cold=1) the lists are kept in pinned,
  *                 mapped HOST memory instead (40 B/site there)
  *   list order    (indexes whose lists do not ascend by site id, or whose five lists disagree about a site's count: no
  *                 builder writes such, the reference does not care; no pruned scan then) with / without in-list

@@ -136,11 +136,12 @@ class ScalePoint:
         options = dict(options or {})
         lists_cold = options.get("host_cold") == 1
         bare = options.get("keep_lists") == 0
-        # HBM per site: sorted layout 152 B (+ 16 B of temporaries while it is built); compact with the lists in host
-        # memory or without lists 52 B (+ 24 B of temporaries; + 12 B of input tensors with device_synth).  Host: 12 B/site
-        # generated (twice while the chunks are concatenated) + brute-force temporaries, + 40 B/site pinned for
-        # host-resident lists -- or, with device_synth, the chunks in flight
-        per_site_hbm = (76 if (lists_cold or bare) else 168) + (12 if device_synth else 0)
+        # HBM per site: sorted layout 152 B, compact with the lists in host memory or without lists 52 B; + 8 B of temporaries
+        # while either is built (the sort's keys and the slice list being worked on live in the image's own scan section:
+        # finish_upload); + 12 B of input tensors with device_synth.  Host: 12 B/site generated (twice while the chunks are
+        # concatenated) + brute-force temporaries, + 40 B/site pinned for host-resident lists -- or, with device_synth, the
+        # chunks in flight
+        per_site_hbm = (60 if (lists_cold or bare) else 160) + (12 if device_synth else 0)
         host_need = (0 if device_synth else n_lines * (24 + (40 if lists_cold else 0))) + 16e9
         import torch
         torch.cuda.empty_cache()
@@ -161,17 +162,42 @@ class ScalePoint:
             self.sigs, self.occ = random_sites_fast(self.n_lines, seed=11, threads=self.threads)
         self.t_synth = time.time() - t
         self.guides = random_guides_fast(self.sigs, self.n_guides, seed=12)
+        # HBM low-water mark of the construction: free memory sampled every 20 ms while the build runs (the call releases the GIL)
+        import threading
+        n_lines_sum = int(d_occ.sum(dtype=torch.int64)) if device_synth else None
+        torch.cuda.synchronize()
+        self.free_before_build = _free_hbm_bytes()
+        low = [self.free_before_build]
+        stop = threading.Event()
+
+        def watch():
+            while not stop.is_set():
+                low[0] = min(low[0], _free_hbm_bytes())
+                stop.wait(0.02)
+        watcher = threading.Thread(target=watch, daemon=True)
+        watcher.start()
         t = time.time()
-        if device_synth:
-            self.ix = ca.IsslIndex.build_from_device_sites(d_sigs, d_occ, int(d_occ.sum(dtype=__import__("torch").int64)), device=0, options=options)
-        else:
-            self.ix = ca.IsslIndex.build_on_device(self.sigs, self.occ, device=0, options=options)
+        try:
+            if device_synth:
+                self.ix = ca.IsslIndex.build_from_device_sites(d_sigs, d_occ, n_lines_sum, device=0, options=options)
+            else:
+                self.ix = ca.IsslIndex.build_on_device(self.sigs, self.occ, device=0, options=options)
+        finally:
+            stop.set()
+            watcher.join()
         self.t_build = time.time() - t
+        self.build_peak_bytes = self.free_before_build - low[0]   # image + temporaries at the high-water mark of the build
         note = (f"{what}: {self.n_lines} lines ({len(self.sigs)} distinct sites) x {self.n_guides} guides, image "
                 f"{self.ix.device_bytes() / 1e9:.1f} GB in HBM + {self.ix.cold()[1] / 1e9:.1f} GB pinned, sorted={self.ix.get_option('is_sorted')} "
                 f"compact={self.ix.get_option('is_compact')}")
+        note += f", {self.build_peak_bytes / 1e9:.1f} GB at the high-water mark of its construction"
         conftest.SCALE_NOTES.append(note)
         print(f"scale point {note}; synth {self.t_synth:.1f}s, built on the device in {self.t_build:.1f}s", flush=True)
+        # what the construction may take beyond the image it leaves behind: 8 B per site (the radix passes' second buffer)
+        # + histograms, flags and allocator granularity -- the documented "image + 8 B/site" (README, include/issl_hip.h)
+        if self.ix.get_option("is_sorted") == 1:
+            assert self.build_peak_bytes <= self.ix.device_bytes() + 8 * len(self.sigs) + (1 << 30), \
+                (self.build_peak_bytes, self.ix.device_bytes(), len(self.sigs))
         # the checker: for a sample of guides every site within 4 mismatches, by brute force over the site table; those
         # sites (+ bystanders), with their occurrences and in the same relative order, form a small index for the oracle
         self.n_check = n_check or int(os.environ.get("ISSL_SCALE_CHECK", 64))

@@ -130,3 +130,69 @@ def test_interleaved_shards_partition_the_batch():
                 if chunk is not None and n >= w * chunk * 4:             # a region of the batch is spread over all ranks
                     region = np.arange(n // 2, n // 2 + w * chunk)
                     assert all(np.intersect1d(p, region).size > 0 for p in parts)
+
+
+def _worker_layout(rank, world, port, n, chunk, steps, out_path):
+    """The orchestration alone at full size: a scorer that is a function of the guide (so that a guide returned to the
+    wrong place shows), bench.py's calls -- guide broadcast, interleaved shards, K steps, ONE gather, input order."""
+    sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from crackling_amd import sharding
+    if rank == 0:
+        g_all = torch.from_numpy(np.random.default_rng(31).integers(0, 1 << 40, size=n, dtype=np.int64))
+    else:
+        g_all = torch.empty(n, dtype=torch.int64)
+    dist.broadcast(g_all, 0)                                   # bench.py: the batch goes to every rank
+    layout = sharding.ShardLayout(torch, n, world, chunk, "cpu")
+    mine = g_all[layout.index_tensors[rank]].contiguous()      # ... and every rank takes its interleaved shard
+    assert mine.numel() == layout.sizes[rank] == sharding.shard_size(n, world, rank, chunk)
+    score = lambda g, k: ((g % 1000003).to(torch.float64) + k, (g >> 20).to(torch.float64) * 0.25 - k)   # noqa: E731
+    out_m = torch.stack([score(mine, k)[0] for k in range(steps)]) if mine.numel() else torch.empty(steps, 0, dtype=torch.float64)
+    out_c = torch.stack([score(mine, k)[1] for k in range(steps)]) if mine.numel() else torch.empty(steps, 0, dtype=torch.float64)
+    gm, gc = sharding.gather_scores(dist, torch, layout, out_m, out_c, device="cpu")
+    sizes = torch.tensor([float(mine.numel())], dtype=torch.float64)
+    allsizes = [torch.empty_like(sizes) for _ in range(world)] if rank == 0 else None
+    dist.gather(sizes, allsizes, dst=0)                         # (bench.py's per-rank record goes the same way)
+    if rank == 0:
+        assert gm.shape == (steps, n) and gc.shape == (steps, n)
+        for k in range(steps):
+            wm, wc = score(g_all, k)
+            assert torch.equal(gm[k], wm) and torch.equal(gc[k], wc), k
+        np.save(out_path, np.array([int(s.item()) for s in allsizes]))
+    else:
+        assert gm is None and gc is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n,chunk", [(1_000_000, 4096), (3 * 4096 + 10, 4096), (8 * 4096, 4096), (5, 4096)])
+def test_eight_ranks_with_configs3_layout(tmp_path, n, chunk):
+    """BASELINE configs[3]'s shape on eight ranks (gloo): 1 M guides in interleaved chunks of 4096 -- 244 whole chunks and a
+    tail of 576 that lands on rank 4 --, a batch that leaves ranks 4..7 without a single guide, one that divides evenly
+    and one smaller than a chunk: shard sizes, one gather, input order."""
+    from crackling_amd.sharding import shard_size
+    world, out = 8, tmp_path / "sizes.npy"
+    mp.spawn(_worker_layout, args=(world, _free_port(), n, chunk, 3, str(out)), nprocs=world, join=True)
+    sizes = np.load(out)
+    assert sizes.sum() == n and sizes.tolist() == [shard_size(n, world, r, chunk) for r in range(world)]
+    if n == 1_000_000:
+        assert sizes.tolist() == [31 * 4096] * 4 + [30 * 4096 + 576] + [30 * 4096] * 3
+    if n == 3 * 4096 + 10:
+        assert sizes.tolist() == [4096, 4096, 4096, 10, 0, 0, 0, 0]
+
+
+def test_eight_ranks_oracle_scored_with_empty_shards(golden_uniform, tmp_path):
+    """World 8 through the whole path -- image broadcast in pieces, attach, shards, gather -- with the oracle as scorer: 101
+    guides in chunks of 16 leave rank 7 an empty shard."""
+    import oracle_util as ou
+    world = 8
+    sigs = ou.encode(golden_uniform.guides)[:101]
+    gp = tmp_path / "g.npy"; np.save(gp, sigs)
+    out = tmp_path / "out.npz"
+    mp.spawn(_worker, args=(world, _free_port(), str(golden_uniform.issl), str(gp), str(out), True, 16), nprocs=world, join=True)
+    got = np.load(out)
+    ix = ou.OracleIndex(golden_uniform.issl)
+    mit, cfd = ix.score(sigs, 4, 75.0, "and")
+    assert np.array_equal(got["mit"], mit) and np.array_equal(got["cfd"], cfd)
+    assert np.array_equal(got["gm"], np.stack([mit, mit])) and np.array_equal(got["gc"], np.stack([cfd, cfd]))
