@@ -25,9 +25,9 @@ def test_index_beyond_the_hbm_at_scale(tmp_path):
     try:
         assert sp.ix.get_option("is_compact") == 1 and sp.ix.get_option("lists_absent") == 1
         assert sp.ix.cold() == (None, 0) and sp.ix.device_bytes() < 60 * len(sp.sigs) + (64 << 20)
-        # image + temporaries at the high-water mark of the construction: 52 + 8 B per site (asserted in ScalePoint against the
+        # image + temporaries at the high-water mark of the construction: 52 + 8.5 B per site (asserted in ScalePoint against the
         # image's own size): what makes the format's 2^32 - 1 sites (258 GB) fit the 288 GB of one MI355X
-        assert sp.build_peak_bytes <= 60.5 * len(sp.sigs) + (1 << 30), (sp.build_peak_bytes, len(sp.sigs))
+        assert sp.build_peak_bytes <= 61 * len(sp.sigs) + (1 << 30), (sp.build_peak_bytes, len(sp.sigs))
         print(f"construction of the {len(sp.sigs)}-site image: {sp.build_peak_bytes / 1e9:.1f} GB of HBM at its high-water mark "
               f"= {sp.build_peak_bytes / len(sp.sigs):.1f} B per site (image {sp.ix.device_bytes() / 1e9:.1f} GB)", flush=True)
         summary = _score_and_check(sp, tmp_path, "tests/test_scale_beyond_hbm.py::test_index_beyond_the_hbm_at_scale")
