@@ -515,36 +515,40 @@ def main():
                                                "what the chip sustains once clocks and power have settled"}
             except Exception as e:  # noqa: BLE001
                 extras["sustained"] = {"error": f"{type(e).__name__}: {e}"}
-            # two lanes: consecutive batches on two workspaces / streams (option lanes=2), the short kernels of one batch
-            # beside the scan of the next
-            index.set_option("lanes", 2)
-            try:
-                def step2(i):  # consecutive batches are in flight together: every one its own output buffers
-                    index.score_device_async(d_guides, out_mit[i % a.steps], out_cfd[i % a.steps], a.max_dist, a.threshold, a.method, stream=None)
-                settle(step)
-                settle(step)
-                for i in range(4):
-                    step2(i)
-                index.finish(stream)
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                reps = a.steps
-                for i in range(reps):
-                    step2(i)
-                ok2 = index.finish(stream)
-                dt = time.perf_counter() - t1
-                s2 = index.stats()
-                if ok2:  # (a RETRY would mean batches to re-run: no number then)
-                    extras["two_lanes"] = {
-                        "guides_per_step": n_mine, "steps": reps, "ms_per_step": dt * 1e3 / reps, "guides_per_s": n_mine * reps / dt,
-                        "scan_ms": s2["ms_scan"], "scan_ms_events": s2["ms_scan_events"],
-                        "note": "option lanes=2 (not the default): a software pipeline over two workspaces -- the scans of "
-                                "consecutive batches one after the other, verify / group / replay of a batch on a high-priority "
-                                "stream beside the next batch's scan; every kernel then shares the chip (scan_ms is the launch's "
-                                "own span), the step shrinks by a few per cent only",
-                    }
-            finally:
-                index.set_option("lanes", lanes)
+            # two workspaces, consecutive batches alternating between them (options lanes = 2 / 3): a software pipeline --
+            # 2: the short kernels of one batch beside the scan of the next; 3: only a batch's binning beside the batch before it
+            for label, lanes_opt, note in (
+                    ("two_lanes", 2, "option lanes=2 (not the default): a software pipeline over two workspaces -- the scans of "
+                                     "consecutive batches one after the other, verify / group / replay of a batch on a high-priority "
+                                     "stream beside the next batch's scan; every kernel then shares the chip (scan_ms is the launch's "
+                                     "own span)"),
+                    ("bin_ahead", 3, "option lanes=3 (not the default): two workspaces; only the binning of a batch (seven short launches) "
+                                     "runs beside the batch before it, its scan waits for that batch's replay")):
+                index.set_option("lanes", lanes_opt)
+                try:
+                    def step2(i):  # consecutive batches are in flight together: every one its own output buffers
+                        index.score_device_async(d_guides, out_mit[i % a.steps], out_cfd[i % a.steps], a.max_dist, a.threshold, a.method, stream=None)
+                    settle(step)
+                    settle(step)
+                    for i in range(4):
+                        step2(i)
+                    index.finish(stream)
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    reps = a.steps
+                    for i in range(reps):
+                        step2(i)
+                    ok2 = index.finish(stream)
+                    dt = time.perf_counter() - t1
+                    s2 = index.stats()
+                    if ok2:  # (a RETRY would mean batches to re-run: no number then)
+                        same = bool(torch.equal(out_mit[(reps - 1) % a.steps], out_mit[0]) and torch.equal(out_cfd[(reps - 1) % a.steps], out_cfd[0]))
+                        extras[label] = {
+                            "guides_per_step": n_mine, "steps": reps, "ms_per_step": dt * 1e3 / reps, "guides_per_s": n_mine * reps / dt,
+                            "scan_ms": s2["ms_scan"], "scan_ms_events": s2["ms_scan_events"], "scores_equal_across_steps": same, "note": note,
+                        }
+                finally:
+                    index.set_option("lanes", lanes)
             # the same batch with the pruned scan switched off: every bucket of every guide compared in full, which is
             # what the reference's loop (:344) does and what round 1 and the first half of round 2 measured
             index.set_option("prune", 0)

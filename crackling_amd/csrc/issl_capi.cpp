@@ -150,7 +150,7 @@ bool Tuning::set(const char *key, const char *value)
     else if (k == "sorted_layout") { if (!is_int || n < -1 || n > 1) return false; sorted_layout = static_cast<int>(n); }
     else if (k == "compact") { if (!is_int || n < -1 || n > 1) return false; compact = static_cast<int>(n); }
     else if (k == "prune") { if (!is_int || n < -1 || n > 1) return false; prune = static_cast<int>(n); }
-    else if (k == "lanes") { if (!is_int || n < 1 || n > 2) return false; lanes = static_cast<int>(n); }
+    else if (k == "lanes") { if (!is_int || n < 1 || n > 3) return false; lanes = static_cast<int>(n); }
     else if (k == "tail_shapes") { if (!is_int || n < 0 || n > 1) return false; tail_shapes = static_cast<int>(n); }
     else if (k == "hit_slots") { if (!is_int || n < 0 || n > 2) return false; hit_slots = static_cast<int>(n); }
     else if (k == "scan_stamps") stamps_path = value;
@@ -206,6 +206,7 @@ struct issl_index {
     issl_stats stats{};
     uint32_t n_pending = 0;  // batches enqueued and not yet finished
     hipEvent_t prev_scan_end = nullptr; // lanes = 2: end of the previous batch's scan (scans run one after the other)
+    hipEvent_t prev_batch_end = nullptr; // lanes = 3: end of the previous batch (its scan starts when that batch is through)
     bool list_order_only = false; // the lists of this index cannot be re-ordered (kSortNeedsListOrder)
 };
 
@@ -848,6 +849,7 @@ static void release_device(issl_index *ix)
     }
     ix->n_pending = 0;
     ix->prev_scan_end = nullptr;
+    ix->prev_batch_end = nullptr;
     if (ix->d_image && ix->owns_image) (void)hipFree(ix->d_image);
     ix->d_image = nullptr;
     ix->owns_image = false;
@@ -883,8 +885,13 @@ static int new_index_from_host(std::unique_ptr<HostIndex> h, issl_index **out)
 // bound tail of batch i runs beside the scan of batch i + 1 -- a step then costs max(bin + scan, tail) instead of their sum.
 static int enqueue_batch(issl_index *ix, Lane &lane, hipStream_t stream, const uint64_t *d_guides, size_t n, int max_dist,
                          double threshold, int method, double *d_mit, double *d_cfd, bool dump, bool staged,
-                         bool pipelined = false)
+                         int lanes_mode = 1)
 {
+    // lanes_mode 2: the software pipeline described above.  3 ("binning ahead"): two workspaces as well, but only the BINNING
+    // of a batch -- seven short, latency-bound launches, 0.19 ms at 100 k guides -- runs beside the batch before it; its scan
+    // waits for that batch's replay, so the heavy kernels never share the chip (which is what made mode 2 lose: they share
+    // its power budget).
+    const bool pipelined = lanes_mode == 2, bin_ahead = lanes_mode == 3;
     if (!ix->d_image) {
         set_error("index has no device image: call issl_index_upload first");
         return ISSL_E_STATE;
@@ -921,11 +928,13 @@ static int enqueue_batch(issl_index *ix, Lane &lane, hipStream_t stream, const u
     const uint32_t slot = ix->n_pending % kRing;
     lane.staged = staged;
     if (pipelined && lane.pending) HIP_TRY(hipStreamWaitEvent(stream, lane.done, 0)); // the workspace's previous batch (tail stream)
+    // (bin_ahead: the workspace's previous batch ran on this very stream)
     if (staged) HIP_TRY(hipEventRecord(lane.ev[0], stream));
     ws.span_slot = lane.pending % kSpanRing;
     launch_bin_guides(ix->view, ws, tn, d_guides, n32, prune_mode, stream);
     if (staged) HIP_TRY(hipEventRecord(lane.ev[1], stream));
     if (pipelined && ix->prev_scan_end) HIP_TRY(hipStreamWaitEvent(stream, ix->prev_scan_end, 0)); // one scan at a time
+    if (bin_ahead && ix->prev_batch_end) HIP_TRY(hipStreamWaitEvent(stream, ix->prev_batch_end, 0)); // the batch before is through
     HIP_TRY(hipEventRecord(ix->ring[2 * slot], stream));
     launch_scan(ix->view, ws, tn, d_guides, n32, max_dist, prune_mode, stream);
     HIP_TRY(hipEventRecord(ix->ring[2 * slot + 1], stream));
@@ -944,6 +953,7 @@ static int enqueue_batch(issl_index *ix, Lane &lane, hipStream_t stream, const u
                   dump ? ws.d_hitrec : nullptr, tail);
     if (staged) HIP_TRY(hipEventRecord(lane.ev[5], tail));
     HIP_TRY(hipEventRecord(lane.done, tail));
+    if (bin_ahead) ix->prev_batch_end = lane.done;
     ix->n_pending += 1;
     lane.pending += 1;
     lane.last_n = n32;
@@ -967,6 +977,7 @@ static int finish_batches(issl_index *ix, hipStream_t stream)
             HIP_TRY(hipStreamSynchronize(lp->tail_stream));
         }
     ix->prev_scan_end = nullptr;
+    ix->prev_batch_end = nullptr;
     HIP_TRY(hipGetLastError());
     const uint32_t batches = ix->n_pending;
     ix->n_pending = 0;
@@ -1673,7 +1684,7 @@ int issl_score_device_async(issl_index *idx, const uint64_t *d_guides, size_t n,
     // lanes option = 2: consecutive batches use different workspaces and streams, so that the short, latency-bound
     // kernels behind one batch's scan run in the wave slots the next batch's scan leaves free: +9-11 % guides/s at 100 k
     // guides x 300 M sites; every kernel then shares the chip and takes longer, which is why it is not the default
-    Lane &lane = (idx->tuning.lanes == 2 && (idx->n_async++ & 1u)) ? idx->lane2 : idx->lane;
+    Lane &lane = (idx->tuning.lanes >= 2 && (idx->n_async++ & 1u)) ? idx->lane2 : idx->lane;
     int rc = ensure_workspace(idx, n, lane); // creates the internal stream on first use
     if (rc) return rc;
     if (stream) { // inputs are produced on the caller's stream: the batch starts after what is enqueued there now
@@ -1681,7 +1692,7 @@ int issl_score_device_async(issl_index *idx, const uint64_t *d_guides, size_t n,
         HIP_TRY(hipStreamWaitEvent(lane.stream, lane.ev[0], 0));
     }
     return enqueue_batch(idx, lane, lane.stream, d_guides, n, max_dist, threshold, method, d_mit, d_cfd, false,
-                         idx->tuning.stage_timing, idx->tuning.lanes == 2);
+                         idx->tuning.stage_timing, idx->tuning.lanes);
 }
 
 int issl_score_wait(issl_index *idx, void *stream)

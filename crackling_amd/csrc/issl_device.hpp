@@ -170,7 +170,7 @@ struct Tuning {
                             //                    per pass on 16 / 8 candidates per lane; 0: every unit is a full one (A/B)
     int hit_slots;          // ISSL_HIT_SLOTS     1 (default): Workspace::slot_hits = kSlotHits when the arrays fit (kSlotHitsWide once a batch has shown
                             //                    many guides beyond that); 0: never; 2: kSlotHitsWide from the first batch on (A/B, tests)
-    int lanes;              // ISSL_LANES         1|2 (default 1): workspaces + streams that asynchronous batches alternate
+    int lanes;              // ISSL_LANES         1|2|3 (default 1; 3: only the binning of a batch beside the batch before it): workspaces + streams that asynchronous batches alternate
                             //                    between (2: the short kernels of one batch fill the wave slots the scan of
                             //                    the next leaves)
     int host_cold;          // ISSL_FORCE_HOST_COLD  -1 automatic (image larger than the free HBM), 0 never, 1 always

@@ -1151,16 +1151,18 @@ __device__ __forceinline__ void note_candidates(uint32_t ok, uint32_t gslot, uin
                                                 uint32_t lane, RawWriter &w, uint64_t *raw, uint32_t *raw_used,
                                                 uint32_t max_chunks, Counters *counters)
 {
-    while (true) {
-        const bool has = ok != 0u;
-        const uint64_t who = __ballot(has);
-        if (who == 0ull) break;
+    uint64_t who = __ballot(ok != 0u);
+    if (who == 0ull) return;
+    // One round per candidate of the lane that has most -- almost always ONE: the loop is laid out with its first round as the
+    // straight path (a taken branch drains the wave's instruction buffer, and more than half of the passes come through
+    // here: k_scan<4> -3 % same-box, profiles/r05_ab_scan_peel_lanes3.log).
+    do {
         const uint32_t n = static_cast<uint32_t>(__builtin_popcountll(who));
-        if (w.fill + n > kChunkRecs) {
+        if (__builtin_expect(w.fill + n > kChunkRecs, 0)) {
             raw_retire(w, lane, raw, raw_used);
             raw_acquire(w, raw, max_chunks, counters, lane);
         }
-        if (has) {
+        if (ok != 0u) {
             const uint32_t q = static_cast<uint32_t>(__builtin_ctz(ok));
             ok &= ok - 1u;
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(who >> 32),
@@ -1168,7 +1170,8 @@ __device__ __forceinline__ void note_candidates(uint32_t ok, uint32_t gslot, uin
             w.chunk[w.fill + rank] = raw_record(gslot + (q >> w_log), tile, off0 + (q & ((1u << w_log) - 1u)));
         }
         w.fill += n;
-    }
+        who = __ballot(ok != 0u);
+    } while (__builtin_expect(who != 0ull, 0));
 }
 
 // Scan kernel.  A workgroup of 16 waves (two per CU = 8 waves per SIMD) owns one equal-cost range of the work

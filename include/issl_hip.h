@@ -243,10 +243,11 @@ int issl_index_attach_image_cold(int device, void *dev_buf, size_t bytes, void *
  *     of 256 for max_dist <= 4, 1 of 256 for <= 2, 67 of 256 for max_dist 5; same hits and scores as the reference's scan
  *     of the whole bucket, isslScoreOfftargets.cpp:344): -1 = a planning kernel decides per batch from the two plans'
  *     estimated times, 0 = never, 1 = whenever the image is sorted and max_dist <= 5
- *   lanes (ISSL_LANES) 1|2: workspaces that the batches of issl_score_device_async alternate between (default 1).  With
+ *   lanes (ISSL_LANES) 1|2|3: workspaces that the batches of issl_score_device_async alternate between (default 1).  With
  *     2 the batches form a software pipeline: scans one after the other, verify / group / replay of a batch on a
- *     high-priority stream beside the next batch's scan (a few per cent more guides/s for back-to-back batches);
- *     outputs of two consecutive batches must then be different buffers
+ *     high-priority stream beside the next batch's scan; with 3 only the BINNING of a batch (its short, latency-bound
+ *     launches) runs beside the batch before it, the scan waits for that batch's replay.  Outputs of two consecutive
+ *     batches must be different buffers with either
  *   scan_stamps (ISSL_SCAN_STAMPS) file for per-wave clocks (diagnostics) */
 int issl_index_set_option(issl_index *idx, const char *key, const char *value);
 /* Current value of an integer knob; also the read-only keys is_sorted, is_compact, cold_on_host, cold_sections (0, 1 =

@@ -496,16 +496,17 @@ def test_one_site_index(tmp_path):
     ix.close()
 
 
-@pytest.mark.parametrize("lanes", [1, 2])
+@pytest.mark.parametrize("lanes", [1, 2, 3])
 def test_async_batches(config0, lanes):
     """issl_score_device_async / issl_score_wait / issl_score_finish: several batches in flight on the internal stream --
-    or, with the lanes option = 2, alternating between two workspaces and streams (the batches then overlap)."""
+    or, with the lanes option = 2 / 3, alternating between two workspaces and streams (the batches then overlap: whole tails
+    beside the next scan / only the binning of a batch beside the batch before it)."""
     import torch
     ix, oracle, sigs, guides = config0
     ix.set_option("lanes", lanes)
     try:
         _async_batches(ix, oracle, guides, torch)
-        if lanes == 2:   # many batches in flight on both lanes, one of them larger than anything before (workspace growth)
+        if lanes >= 2:   # many batches in flight on both lanes, one of them larger than anything before (workspace growth)
             rng = np.random.default_rng(9)
             big = np.concatenate([guides, guides ^ (rng.integers(0, 4, size=len(guides), dtype=np.uint64) << np.uint64(10))])
             batches = [big, guides[:77], guides[100:900], guides[:1], big[::-1].copy(), guides[5:505]] * 3

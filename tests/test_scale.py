@@ -579,7 +579,7 @@ def test_skewed_index_at_scale(tmp_path):
         d_g = torch.from_numpy(guides.view(np.int64)).cuda()
         steps = 6
         out_m = torch.empty(steps, len(guides), dtype=torch.float64, device="cuda:0"); out_c = torch.empty_like(out_m)
-        for lanes in (1, 2):
+        for lanes in (1, 2, 3):
             ix.set_option("lanes", lanes)
             out_m.zero_(); out_c.zero_()
             while True:

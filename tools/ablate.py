@@ -65,7 +65,7 @@ def build():
     src = (CSRC / "issl_kernels.hip").read_text()
     flags = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "--offload-arch=gfx950", f"-I{CSRC}", f"-I{ROOT / 'include'}"]
     objs = []
-    for f in ("issl_extract.hip", "issl_build.hip", "issl_capi.cpp", "issl_node.cpp", "issl_host.cpp"):  # once for all variants
+    for f in ("issl_extract.hip", "issl_build.hip", "issl_capi.cpp", "issl_node.cpp", "issl_host.cpp", "issl_text.cpp"):  # once for all variants
         o = OUT / (f + ".o")
         subprocess.check_call(["/opt/rocm/bin/hipcc"] + flags + ["-c", "-o", str(o), str(CSRC / f)])
         objs.append(str(o))
