@@ -105,6 +105,8 @@ Tuning Tuning::from_env()
 {
     Tuning t;
     t.scan_blocks = kScanGridBlocks;
+    t.scan_threads = 1024;
+    t.scan_prefetch = 0;
     t.item_guides = kItemGuides;
     t.scan_generic = false;
     t.stage_timing = false;
@@ -118,13 +120,14 @@ Tuning Tuning::from_env()
     t.prune = -1;
     t.tail_shapes = 1;
     t.hit_slots = 1;
+    t.lean_tail = 1;
     t.lanes = 1;
     static const char *const keys[][2] = {
-        {"ISSL_SCAN_BLOCKS", "scan_blocks"}, {"ISSL_ITEM_GUIDES", "item_guides"},
+        {"ISSL_SCAN_BLOCKS", "scan_blocks"}, {"ISSL_SCAN_THREADS", "scan_threads"}, {"ISSL_SCAN_PREFETCH", "scan_prefetch"}, {"ISSL_ITEM_GUIDES", "item_guides"},
         {"ISSL_SCAN_GENERIC", "scan_generic"}, {"ISSL_STAGE_TIMING", "stage_timing"}, {"ISSL_RAW_CHUNKS", "raw_chunks"},
         {"ISSL_INLINE_SIGS", "inline_sigs"}, {"ISSL_FORCE_HOST_COLD", "host_cold"}, {"ISSL_SCAN_STAMPS", "scan_stamps"},
         {"ISSL_SORTED_LAYOUT", "sorted_layout"}, {"ISSL_PRUNE", "prune"}, {"ISSL_LANES", "lanes"},
-        {"ISSL_COMPACT", "compact"}, {"ISSL_TAIL_SHAPES", "tail_shapes"}, {"ISSL_HIT_SLOTS", "hit_slots"},
+        {"ISSL_COMPACT", "compact"}, {"ISSL_TAIL_SHAPES", "tail_shapes"}, {"ISSL_HIT_SLOTS", "hit_slots"}, {"ISSL_LEAN_TAIL", "lean_tail"},
         {"ISSL_KEEP_LISTS", "keep_lists"},
     };
     for (const auto &k : keys)
@@ -139,7 +142,9 @@ bool Tuning::set(const char *key, const char *value)
     char *end = nullptr;
     const long long n = std::strtoll(value, &end, 10);
     const bool is_int = end != value && *end == 0;
-    if (k == "scan_blocks") { if (!is_int || n < 1 || n > static_cast<long long>(kScanMaxBlocks)) return false; scan_blocks = static_cast<uint32_t>(n); }
+    if (k == "scan_prefetch") { if (!is_int || n < 0 || n > 1) return false; scan_prefetch = static_cast<int>(n); }
+    else if (k == "scan_threads") { if (!is_int || n < 64 || n > 1024 || n % 64) return false; scan_threads = static_cast<uint32_t>(n); }
+    else if (k == "scan_blocks") { if (!is_int || n < 1 || n > static_cast<long long>(kScanMaxBlocks)) return false; scan_blocks = static_cast<uint32_t>(n); }
     else if (k == "item_guides") { if (!is_int || n < 8 || n > static_cast<long long>(kItemGuides)) return false; item_guides = static_cast<uint32_t>(n) & ~7u; }
     else if (k == "scan_generic") { if (!is_int || (n != 0 && n != 1)) return false; scan_generic = n == 1; }
     else if (k == "stage_timing") { if (!is_int || (n != 0 && n != 1)) return false; stage_timing = n == 1; }
@@ -152,6 +157,7 @@ bool Tuning::set(const char *key, const char *value)
     else if (k == "prune") { if (!is_int || n < -1 || n > 1) return false; prune = static_cast<int>(n); }
     else if (k == "lanes") { if (!is_int || n < 1 || n > 3) return false; lanes = static_cast<int>(n); }
     else if (k == "tail_shapes") { if (!is_int || n < 0 || n > 1) return false; tail_shapes = static_cast<int>(n); }
+    else if (k == "lean_tail") { if (!is_int || n < 0 || n > 1) return false; lean_tail = static_cast<int>(n); }
     else if (k == "hit_slots") { if (!is_int || n < 0 || n > 2) return false; hit_slots = static_cast<int>(n); }
     else if (k == "scan_stamps") stamps_path = value;
     else return false;
@@ -180,6 +186,8 @@ struct Lane {
     bool staged = true;         // the last batch recorded its stage events
     int last_max_dist = 0;
     uint32_t last_prune = 0;
+    bool lean = false;          // the lane's finished batches had no guide beyond its hit slots: the next ones are enqueued
+                                // without the grouping pass and the many-hit replays (Workspace::lean_tail)
 };
 
 struct issl_index {
@@ -839,6 +847,7 @@ static void release_device(issl_index *ix)
             lane.ready = false;
         }
         free_workspace(lane.ws);
+        lane.lean = false;
         lane.last_n = 0;
         lane.pending = 0;
     }
@@ -920,6 +929,7 @@ static int enqueue_batch(issl_index *ix, Lane &lane, hipStream_t stream, const u
     }
     // issl_dump_hits wants every hit of the batch in one array in guide order: no hit slots there
     ws.slot_hits = (!dump && tn.hit_slots && ws.cap_slot_guides >= n) ? ws.slot_width : 0u;
+    ws.lean_tail = (lane.lean && ws.slot_hits >= kSlotHits && tn.lean_tail) ? 1u : 0u;
     ScoreParams p;
     p.max_dist = max_dist;
     p.method = method;
@@ -1032,16 +1042,21 @@ static int finish_batches(issl_index *ix, hipStream_t stream)
                 }
             }
         }
-        if (sticky[0]) {
+        // the lane's next batches go without the grouping pass and the many-hit replays while no batch meets a guide beyond
+        // its hit slots (bit 2: one did; bit 1: and it had been enqueued lean -- once more, with the whole tail)
+        lp->lean = (sticky[0] & 6u) == 0u && lp->ws.slot_hits >= kSlotHits;
+        if (sticky[0] & 2u) retry = true;
+        if (sticky[0] & 1u) {
             // sticky[1] = largest number of chunks any batch asked for
-            HIP_TRY(hipMemset(lp->ws.sticky, 0, 16));
             int rc = ensure_raw_capacity(lp->ws, static_cast<size_t>(sticky[1]) + sticky[1] / 8 + 1024);
             if (rc) return rc;
             retry = true;
         }
+        if (sticky[0]) HIP_TRY(hipMemset(lp->ws.sticky, 0, 16));
     }
     if (retry) {
-        set_error("raw record buffer was too small for a batch; it has been enlarged, score the batch again");
+        set_error("a batch has to be scored again: its raw record buffer was too small (it has been enlarged), or it was enqueued "
+                  "without the many-hit part of the pipeline and met a guide that needs it");
         return ISSL_E_RETRY;
     }
     PlanInfo pl{};
@@ -1315,6 +1330,8 @@ int issl_index_get_option(const issl_index *idx, const char *key, long long *val
     const Tuning &t = idx->tuning;
     const std::string k(key);
     if (k == "scan_blocks") *value = t.scan_blocks;
+    else if (k == "scan_threads") *value = t.scan_threads;
+    else if (k == "scan_prefetch") *value = t.scan_prefetch;
     else if (k == "item_guides") *value = t.item_guides;
     else if (k == "scan_generic") *value = t.scan_generic;
     else if (k == "stage_timing") *value = t.stage_timing;
@@ -1329,6 +1346,7 @@ int issl_index_get_option(const issl_index *idx, const char *key, long long *val
     else if (k == "lanes") *value = t.lanes;
     else if (k == "tail_shapes") *value = t.tail_shapes;
     else if (k == "hit_slots") *value = t.hit_slots;
+    else if (k == "lean_tail") *value = t.lean_tail;
     else if (k == "is_sorted") *value = idx->d_image ? ((idx->hdr.off_srec || idx->hdr.off_sid) ? 1 : 0) : -1; // read-only
     else if (k == "is_compact") *value = idx->d_image ? (idx->hdr.off_sid ? 1 : 0) : -1;                   // read-only
     else if (k == "cold_on_host") *value = idx->d_image ? (idx->hdr.cold_on_host ? 1 : 0) : -1;            // read-only: layout in use

@@ -152,6 +152,10 @@ ImageView make_view(const ImageHeader &h, void *base, void *cold);
 // threads share the process environment), and changed afterwards only through issl_index_set_option().
 struct Tuning {
     uint32_t scan_blocks;   // ISSL_SCAN_BLOCKS   workgroups of the scan launch
+    uint32_t scan_threads;  // ISSL_SCAN_THREADS  threads per scan workgroup (64 .. 1024, a multiple of 64; default 1024 = 16 waves: two workgroups
+                            //                    per CU = 8 waves per SIMD; 768: 6 per SIMD) -- an occupancy experiment, not a tuning knob
+    int scan_prefetch;      // ISSL_SCAN_PREFETCH 1: the pruned scan fetches the next unit's planes into LDS while the current unit is compared
+                            //                    (k_scan_pf: 12-wave workgroups, 6 waves per SIMD); 0: k_scan (8 waves per SIMD, planes straight to registers)
     uint32_t item_guides;   // ISSL_ITEM_GUIDES   guides per scan item (multiple of 8, <= kItemGuides)
     bool scan_generic;      // ISSL_SCAN_GENERIC  force the runtime-threshold build of the scan kernel
     bool stage_timing;      // ISSL_STAGE_TIMING  asynchronous batches record an event at every stage boundary
@@ -170,6 +174,8 @@ struct Tuning {
                             //                    per pass on 16 / 8 candidates per lane; 0: every unit is a full one (A/B)
     int hit_slots;          // ISSL_HIT_SLOTS     1 (default): Workspace::slot_hits = kSlotHits when the arrays fit (kSlotHitsWide once a batch has shown
                             //                    many guides beyond that); 0: never; 2: kSlotHitsWide from the first batch on (A/B, tests)
+    int lean_tail;          // ISSL_LEAN_TAIL     1 (default): a lane whose batches meet no guide beyond its hit slots enqueues the next ones
+                            //                    without the grouping pass and the many-hit replays (Workspace::lean_tail); 0: never (A/B)
     int lanes;              // ISSL_LANES         1|2|3 (default 1; 3: only the binning of a batch beside the batch before it): workspaces + streams that asynchronous batches alternate
                             //                    between (2: the short kernels of one batch fill the wave slots the scan of
                             //                    the next leaves)
@@ -375,7 +381,8 @@ struct Workspace {
     uint32_t span_slot = 0;         // slot of the batch being enqueued
     uint64_t *scan_count = nullptr; // [kScanMaxBlocks] comparisons every scan workgroup actually made (real candidates x real guides)
     unsigned long long *stamps = nullptr; // [kStampsWords] scan wave clocks, then replay phase clocks (ISSL_SCAN_STAMPS diagnostics)
-    uint32_t *sticky = nullptr;  // [4] survives the per-batch resets: [0] raw overflow seen, [1] max chunks asked, [2] plan errors, [3] items a pruned plan wanted beyond cap_fitems
+    uint32_t *sticky = nullptr;  // [4] survives the per-batch resets: [0] bit 0 raw overflow seen, bit 1 a lean tail met a guide beyond its hit slots (run
+                                 // the batch again), bit 2 a guide beyond its hit slots seen at all; [1] max chunks asked, [2] plan errors, [3] items a pruned plan wanted beyond cap_fitems
     uint64_t *sorted = nullptr;  // [hit_cap] keys guide<<37 | slice<<32 | site id or list position, grouped by guide (with hit slots: of the guides that outgrew them)
     uint32_t *gcount = nullptr;  // [G+1] hits per guide
     uint32_t *goff = nullptr;    // [G+1] exclusive prefix
@@ -391,6 +398,12 @@ struct Workspace {
     SlotRec *slots = nullptr;       // [cap_slot_guides * slot_width]
     uint32_t slot_hits = 0;         // of the batch being enqueued: 0 or slot_width
     uint32_t slot_width = kSlotHits; // slots per guide the array was allocated with (kSlotHits / kSlotHitsWide)
+    uint32_t lean_tail = 0;         // of the batch being enqueued: 1 = the grouping pass and the three many-hit replays are NOT
+                                    // launched for it (five dependent launches that find nothing to do on an index where no
+                                    // guide outgrows its hit slots -- 25 us of every batch, a fifth of a 64-guide one).  A
+                                    // prediction from the lane's previous batches; k_replay sets sticky[0] bit 1 when a guide
+                                    // of this batch did outgrow its slots, and the batch is run again with the whole tail
+                                    // (the same ISSL_E_RETRY round an exhausted record buffer takes)
     size_t cap_slot_guides = 0;
     uint32_t *blocksum = nullptr;
     uint64_t *d_guides = nullptr; // staging for the host API

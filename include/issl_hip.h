@@ -34,7 +34,7 @@ enum {
     ISSL_E_DEVICE = -5,   /* HIP error or no device */
     ISSL_E_NOMEM = -6,
     ISSL_E_STATE = -7,    /* call order (e.g. score before upload) */
-    ISSL_E_RETRY = -8     /* issl_score_finish: a batch ran out of scratch space; buffers grown, enqueue it again */
+    ISSL_E_RETRY = -8     /* issl_score_finish: a batch ran out of scratch space (buffers grown) or needs the whole pipeline: enqueue it again */
 };
 
 /* Score methods, isslScoreOfftargets.cpp:44,121-143. */
@@ -239,6 +239,9 @@ int issl_index_attach_image_cold(int device, void *dev_buf, size_t bytes, void *
  *     device short of memory and issl_dump_hits go without; a handle whose batches show many guides beyond 512 hits
  *     widens its slots to 2048 by itself); 0: every hit passes through the grouping pass; 2: slots for 2048 hits per
  *     guide from the first batch on (tests and A/B: the results do not depend on the width)
+ *   lean_tail (ISSL_LEAN_TAIL) 0|1 (default 1): a handle whose finished batches met no guide beyond its hit slots
+ *     enqueues the next ones without the grouping pass and the three many-hit replays (five dependent launches that
+ *     would find nothing to do: 25 us of every batch); a batch that does meet such a guide is run again in full
  *   prune (ISSL_PRUNE) -1|0|1: scan only the successor-byte groups of a bucket that can hold a site within max_dist (13
  *     of 256 for max_dist <= 4, 1 of 256 for <= 2, 67 of 256 for max_dist 5; same hits and scores as the reference's scan
  *     of the whole bucket, isslScoreOfftargets.cpp:344): -1 = a planning kernel decides per batch from the two plans'
@@ -303,8 +306,10 @@ int issl_score_device(issl_index *idx, const uint64_t *d_guides, size_t n, int m
  * NULL means the inputs are ready now.  Results are valid after issl_score_finish(), or, on a stream, behind
  * issl_score_wait(idx, stream), which makes that stream wait for every batch enqueued so far (no host sync).
  * issl_score_finish() synchronises (internal streams and `stream`) and checks the batches: ISSL_E_RETRY means that a
- * batch needed more scratch space than was allocated (first large batch on an index); the buffers have been enlarged
- * and the batches since the previous finish must be enqueued again.  issl_last_stats() then describes the last
+ * batch needed more scratch space than was allocated (first large batch on an index; the buffers have been enlarged), or
+ * that it was enqueued without the many-hit part of the pipeline (lean_tail option: a handle whose batches meet no guide
+ * with more than 512 hits stops launching it) and did meet such a guide: the batches since the previous finish must be
+ * enqueued again.  issl_last_stats() then describes the last
  * batch, with ms_scan averaged over all of them. */
 int issl_score_device_async(issl_index *idx, const uint64_t *d_guides, size_t n, int max_dist,
                             double threshold, int method, double *d_mit, double *d_cfd, void *stream);

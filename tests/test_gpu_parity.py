@@ -1229,3 +1229,52 @@ def test_resident_server_releases_the_least_recently_used_index(tmp_path):
         except subprocess.TimeoutExpired:
             server.kill()
     assert server.returncode == 0
+
+
+def test_lean_tail_prediction_and_its_retry():
+    """A handle whose batches meet no guide with more than 512 hits stops launching the grouping pass and the many-hit replays
+    (Workspace::lean_tail); a batch that then DOES meet such a guide is run again with the whole pipeline -- through issl_score by
+    itself, through the asynchronous entry points as ISSL_E_RETRY.  tests/golden/signedtable: guides with 600 ... 1800 hits beside
+    guides with a handful, reference stdout."""
+    import torch
+    from conftest import Golden
+    g = Golden("signedtable")
+    sigs = ca.encode_guides([s.encode() for s in g.guides])
+    key = next(k for k in g.expected if k.startswith("and|"))
+    method, thr, dist = key.split("|")
+    ix = ca.IsslIndex.open(g.issl).upload(0)
+    try:
+        counts = np.bincount(ix.dump_hits(sigs, int(dist), 0.0, method)[:, 0], minlength=len(sigs))
+        few = np.flatnonzero(counts <= 400)
+        assert len(few) >= 2 and (counts > 512).any()
+        want = g.expected[key].splitlines(keepends=True)
+        for rounds in range(2):
+            for _ in range(2):   # batches without a many-hit guide: the lane turns lean
+                mit, cfd = ix.score(sigs[few], int(dist), float(thr), method)
+                assert ca.format_scores(sigs[few], mit, cfd, method) == "".join(want[i] for i in few)
+            assert ix.stats()["scan_launches"] == 1
+            mit, cfd = ix.score(sigs, int(dist), float(thr), method)   # mispredicted: run again inside the call
+            assert ca.format_scores(sigs, mit, cfd, method) == g.expected[key]
+            assert ix.stats()["scan_launches"] == 2
+            mit, cfd = ix.score(sigs, int(dist), float(thr), method)   # the lane knows now
+            assert ca.format_scores(sigs, mit, cfd, method) == g.expected[key] and ix.stats()["scan_launches"] == 1
+        # asynchronous batches: finish() says "again" once
+        for _ in range(2):
+            ix.score(sigs[few], int(dist), float(thr), method)
+        d_g = torch.from_numpy(sigs.view(np.int64)).cuda()
+        d_m = torch.empty(len(sigs), dtype=torch.float64, device="cuda:0"); d_c = torch.empty_like(d_m)
+        tries = 0
+        while True:
+            ix.score_device_async(d_g, d_m, d_c, int(dist), float(thr), method)
+            tries += 1
+            if ix.finish():
+                break
+        assert tries == 2
+        assert ca.format_scores(sigs, d_m.cpu().numpy(), d_c.cpu().numpy(), method) == g.expected[key]
+        ix.set_option("lean_tail", 0)   # the knob: never lean
+        for _ in range(2):
+            ix.score(sigs[few], int(dist), float(thr), method)
+        ix.score(sigs, int(dist), float(thr), method)
+        assert ix.stats()["scan_launches"] == 1
+    finally:
+        ix.close()
