@@ -106,7 +106,6 @@ Tuning Tuning::from_env()
     Tuning t;
     t.scan_blocks = kScanGridBlocks;
     t.scan_threads = 1024;
-    t.scan_prefetch = 0;
     t.item_guides = kItemGuides;
     t.scan_generic = false;
     t.stage_timing = false;
@@ -123,7 +122,7 @@ Tuning Tuning::from_env()
     t.lean_tail = 1;
     t.lanes = 1;
     static const char *const keys[][2] = {
-        {"ISSL_SCAN_BLOCKS", "scan_blocks"}, {"ISSL_SCAN_THREADS", "scan_threads"}, {"ISSL_SCAN_PREFETCH", "scan_prefetch"}, {"ISSL_ITEM_GUIDES", "item_guides"},
+        {"ISSL_SCAN_BLOCKS", "scan_blocks"}, {"ISSL_SCAN_THREADS", "scan_threads"}, {"ISSL_ITEM_GUIDES", "item_guides"},
         {"ISSL_SCAN_GENERIC", "scan_generic"}, {"ISSL_STAGE_TIMING", "stage_timing"}, {"ISSL_RAW_CHUNKS", "raw_chunks"},
         {"ISSL_INLINE_SIGS", "inline_sigs"}, {"ISSL_FORCE_HOST_COLD", "host_cold"}, {"ISSL_SCAN_STAMPS", "scan_stamps"},
         {"ISSL_SORTED_LAYOUT", "sorted_layout"}, {"ISSL_PRUNE", "prune"}, {"ISSL_LANES", "lanes"},
@@ -142,8 +141,7 @@ bool Tuning::set(const char *key, const char *value)
     char *end = nullptr;
     const long long n = std::strtoll(value, &end, 10);
     const bool is_int = end != value && *end == 0;
-    if (k == "scan_prefetch") { if (!is_int || n < 0 || n > 1) return false; scan_prefetch = static_cast<int>(n); }
-    else if (k == "scan_threads") { if (!is_int || n < 64 || n > 1024 || n % 64) return false; scan_threads = static_cast<uint32_t>(n); }
+    if (k == "scan_threads") { if (!is_int || n < 64 || n > 1024 || n % 64) return false; scan_threads = static_cast<uint32_t>(n); }
     else if (k == "scan_blocks") { if (!is_int || n < 1 || n > static_cast<long long>(kScanMaxBlocks)) return false; scan_blocks = static_cast<uint32_t>(n); }
     else if (k == "item_guides") { if (!is_int || n < 8 || n > static_cast<long long>(kItemGuides)) return false; item_guides = static_cast<uint32_t>(n) & ~7u; }
     else if (k == "scan_generic") { if (!is_int || (n != 0 && n != 1)) return false; scan_generic = n == 1; }
@@ -1331,7 +1329,6 @@ int issl_index_get_option(const issl_index *idx, const char *key, long long *val
     const std::string k(key);
     if (k == "scan_blocks") *value = t.scan_blocks;
     else if (k == "scan_threads") *value = t.scan_threads;
-    else if (k == "scan_prefetch") *value = t.scan_prefetch;
     else if (k == "item_guides") *value = t.item_guides;
     else if (k == "scan_generic") *value = t.scan_generic;
     else if (k == "stage_timing") *value = t.stage_timing;

@@ -154,8 +154,6 @@ struct Tuning {
     uint32_t scan_blocks;   // ISSL_SCAN_BLOCKS   workgroups of the scan launch
     uint32_t scan_threads;  // ISSL_SCAN_THREADS  threads per scan workgroup (64 .. 1024, a multiple of 64; default 1024 = 16 waves: two workgroups
                             //                    per CU = 8 waves per SIMD; 768: 6 per SIMD) -- an occupancy experiment, not a tuning knob
-    int scan_prefetch;      // ISSL_SCAN_PREFETCH 1: the pruned scan fetches the next unit's planes into LDS while the current unit is compared
-                            //                    (k_scan_pf: 12-wave workgroups, 6 waves per SIMD); 0: k_scan (8 waves per SIMD, planes straight to registers)
     uint32_t item_guides;   // ISSL_ITEM_GUIDES   guides per scan item (multiple of 8, <= kItemGuides)
     bool scan_generic;      // ISSL_SCAN_GENERIC  force the runtime-threshold build of the scan kernel
     bool stage_timing;      // ISSL_STAGE_TIMING  asynchronous batches record an event at every stage boundary

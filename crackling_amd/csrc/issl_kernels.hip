@@ -958,14 +958,11 @@ __device__ __forceinline__ uint32_t near_plane_masks(const uint32_t (&c)[kPlanes
 // Masks of up to 8 passes of a short unit (guide slots g0 .. g0 + 8 * per - 1) into the wave's own 1 KiB of LDS: lane
 // (pass i, quarter q) makes the four words 4q .. 4q + 3 of pass i: bit p of each of the pass's `per` guide words, spread
 // over that guide's field of `shape` bits.
-// (PASSES: 8, or 4 where the wave has 512 bytes for its masks -- the prefetching scan; the lanes of the other passes idle)
-template <uint32_t PASSES = 8>
 __device__ __forceinline__ void short_unit_masks(const uint32_t *__restrict__ gword_stream, uint32_t g0, uint32_t shape,
                                                  uint32_t lane, uint4 *lds_masks)
 {
     const uint32_t per = 32u / shape, field = shape == 16u ? 0xFFFFu : 0xFFu;
     const uint32_t i = lane >> 3, q = lane & 7u;
-    if (PASSES < 8u && i >= PASSES) return;
     uint32_t gw[4];
 #pragma unroll
     for (uint32_t j = 0; j < 4; ++j) gw[j] = j < per ? gword_stream[g0 + i * per + j] : 0u;
@@ -1450,255 +1447,6 @@ __device__ __forceinline__ void scan_range(const uint32_t *__restrict__ scan_str
     }
 }
 
-// ---- the pruned scan with the next unit's planes on their way while the current unit is compared ---------------------
-// scan_range<THR, true> asks for a unit's six 16-byte plane loads and cannot start before they are there: ticket -> item ->
-// planes is a chain of three round trips per unit, ~0.2 ms of a 1.3 ms launch that eight waves per SIMD only partly hide.
-// Here the chain runs one to two units ahead: the planes of unit k + 1 are fetched by global_load_lds (no destination
-// registers: the kernel has none to spare) into 6 KiB of LDS of the wave's own while unit k is compared, and unit k + 1 then
-// starts with six ds_read_b128; the ticket and item of unit k + 2 are asked for at the same time.  The LDS that takes --
-// 6.5 KiB per wave with the short units' masks -- fits 24 waves per CU, not 32: 12-wave workgroups, 6 waves per SIMD (80 VGPRs).
-// A wave holds up to two claimed units beyond the one it works on.
-template <int THR>
-__device__ __forceinline__ void scan_range_pf(const uint32_t *__restrict__ scan_stream, const ScanItem *__restrict__ items,
-                                              const RangeStart *__restrict__ range_start, const uint32_t *__restrict__ gword_stream,
-                                              uint4 *wave_masks, uint4 *wave_stage, uint64_t *raw, uint32_t *raw_used,
-                                              uint32_t max_chunks, Counters *counters, uint32_t thr, unsigned long long *stamps,
-                                              uint64_t *__restrict__ scan_count, uint32_t *next_unit_p, uint32_t *waves_done_p,
-                                              unsigned long long *wg_compared_p, unsigned long long t_start,
-                                              unsigned long long *span, uint32_t n_tiles, uint32_t slice_bits)
-{
-    uint32_t &next_unit = *next_unit_p;
-    uint32_t &waves_done = *waves_done_p;
-    unsigned long long &wg_compared = *wg_compared_p;
-    uint32_t units_done = 0;
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave_id = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
-    RawWriter w;
-    const bool no_own_chunk = wave_id >= max_chunks;
-    w.chunk = raw + static_cast<uint64_t>(no_own_chunk ? max_chunks : wave_id) * kChunkRecs;
-    w.fill = 1;
-    w.left = 0;
-    w.reserve = 1;
-    bool own_chunk = false;
-    unsigned long long compared = 0ull;
-
-    const RangeStart first = range_start[blockIdx.x];
-    const RangeStart last = range_start[blockIdx.x + 1];
-    const uint32_t tile_begin = items[first.item].tile0 + first.tile;
-    const uint32_t tile_last = items[last.item].tile0 + last.tile;
-    const uint32_t n_units = tile_last - tile_begin + (last.goff ? 1u : 0u);
-
-    auto take = [&]() {
-        uint32_t t = 0;
-        if (lane == 0) t = atomicAdd(&next_unit, 1u);
-        return static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(t));
-    };
-    // the six plane loads of an item's unit, straight into the wave's LDS: load q lands at wave_stage[q * 64 + lane]
-    auto fetch = [&](const ScanItem &it) {
-        const uint32_t slice_of = it.bucket >> (8u + slice_bits);
-        const uint32_t q0 = fine_order(slice_of, 0u, slice_bits), q1 = fine_order(slice_of, 1u, slice_bits), q2 = fine_order(slice_of, 2u, slice_bits);
-        const uint32_t per = 32u / it.shape; // 1: a full unit
-        // (a wave-uniform base -- the tile of the unit's first lane group -- and a 32-bit offset per lane: one address register
-        // per load instead of two; a lane beyond the end of the stream reads its last lane group, which `keep` hides)
-        const uint32_t tile0 = it.group_abs >> 6;
-        uint32_t glane = it.group_abs + lane / per;
-        const uint32_t g_last = n_tiles * 64u - 1u;
-        glane = glane > g_last ? g_last : glane;
-        const uint32_t rel = glane - tile0 * 64u; // < 128: the unit's window spans at most two tiles
-        const char *base = reinterpret_cast<const char *>(scan_stream + static_cast<uint64_t>(tile0) * kTileCands);
-        const uint32_t off = ((rel >> 6) * (kTileCands / 4u) + (rel & 63u)) * 16u; // bytes: one register serves all six loads
-        const char *b0 = base + q0 * 1024u, *b1 = base + q1 * 1024u, *b2 = base + q2 * 1024u; // (wave-uniform: scalar registers)
-        __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint4 *>(b0 + off), wave_stage + 0 * 64, 16, 0, 0);
-        __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint4 *>(b1 + off), wave_stage + 1 * 64, 16, 0, 0);
-        __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint4 *>(b2 + off), wave_stage + 2 * 64, 16, 0, 0);
-        __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint4 *>(b0 + 4096u + off), wave_stage + 3 * 64, 16, 0, 0);
-        __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint4 *>(b1 + 4096u + off), wave_stage + 4 * 64, 16, 0, 0);
-        __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint4 *>(b2 + 4096u + off), wave_stage + 5 * 64, 16, 0, 0);
-    };
-
-    uint32_t u = take();
-    if (u < n_units) {
-        ScanItem cur = items[tile_begin + u];
-        fetch(cur);
-        uint32_t u_next = take();
-        // (items are fetched whether or not the ticket is still inside the range -- the index is clamped, the load stays a scalar
-        // one; a ticket beyond the range is never worked on)
-        ScanItem nxt = items[tile_begin + (u_next < n_units ? u_next : n_units - 1u)];
-        while (true) {
-            ++units_done;
-            const uint32_t gt = tile_begin + u;
-            const uint32_t g_begin = cur.g0 + (u == 0 ? first.goff : 0u);
-            const uint32_t g_end = (gt == tile_last) ? cur.g0 + last.goff : cur.g1;
-            const uint32_t slice_of = cur.bucket >> (8u + slice_bits);
-            const uint32_t dup_filter = slice_of != 0u ? ~0u : 0u;
-            const uint32_t shape = cur.shape, per = 32u / shape;
-            const uint32_t glane = cur.group_abs + lane / per;
-            uint32_t tile = glane >> 6;
-            const uint32_t grp = glane & 63u;
-            if (tile >= n_tiles) tile = n_tiles - 1u;
-            compared += static_cast<unsigned long long>(cur.last_cands) * (g_end - g_begin);
-            // the unit's planes have been on their way since the unit before was started
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            uint32_t c[24];
-            {
-                const uint4 a0 = wave_stage[0 * 64 + lane], a1 = wave_stage[1 * 64 + lane], a2 = wave_stage[2 * 64 + lane];
-                const uint4 b0 = wave_stage[3 * 64 + lane], b1 = wave_stage[4 * 64 + lane], b2 = wave_stage[5 * 64 + lane];
-                c[0] = a0.x; c[1] = a0.y; c[2] = a0.z; c[3] = a0.w; c[4] = a1.x; c[5] = a1.y; c[6] = a1.z; c[7] = a1.w;
-                c[8] = a2.x; c[9] = a2.y; c[10] = a2.z; c[11] = a2.w;
-                c[12] = b0.x; c[13] = b0.y; c[14] = b0.z; c[15] = b0.w; c[16] = b1.x; c[17] = b1.y; c[18] = b1.z; c[19] = b1.w;
-                c[20] = b2.x; c[21] = b2.y; c[22] = b2.z; c[23] = b2.w;
-            }
-            // (the ticket first: hipcc puts a vmcnt(0) in front of every LDS instruction while an LDS-DMA is on its way -- it cannot
-            // tell the ticket word from the stage --, and behind the fetch that wait would be for the planes just asked for)
-            const bool has_next = u_next < n_units;
-            const uint32_t u_after = has_next ? take() : n_units;
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the planes are in registers: the stage is free for the next unit's
-            if (has_next) fetch(nxt);
-            const ScanItem after = items[tile_begin + (u_after < n_units ? u_after : n_units - 1u)];
-            if (shape != 32u) {
-                // ---- a SHORT unit (see scan_range): 32 / shape guides per pass, masks from the wave's LDS, four passes at a time
-                // (an opaque copy of the lane number: what this path derives from it is made here, per unit, and not kept in
-                // registers across the whole kernel -- at 80 VGPRs that would spill, and a spill's reload is a vector-memory
-                // load whose wait also waits for the planes on their way: no overlap left)
-                uint32_t lane_s = lane;
-                asm volatile("" : "+v"(lane_s));
-                const uint32_t sub = lane_s & (per - 1u);
-                const uint32_t w_log = shape == 16u ? 4u : 3u;
-                const uint32_t sel = shape == 16u ? (sub ? 0x03020302u : 0x01000100u) : sub * 0x01010101u;
-#pragma unroll
-                for (int q = 0; q < 24; ++q) c[q] = __builtin_amdgcn_perm(0u, c[q], sel);
-                const int lo = static_cast<int>(cur.window & 0xFFFFu), hi = static_cast<int>(cur.window >> 16);
-                const int below = lo - static_cast<int>(lane_s * shape), upto = hi - static_cast<int>(lane_s * shape);
-                const uint32_t field = shape == 16u ? 0xFFFFu : 0xFFu;
-                const uint32_t mine = (below <= 0 ? field : below >= static_cast<int>(shape) ? 0u : (field << below) & field) &
-                                      (upto >= static_cast<int>(shape) ? field : upto <= 0 ? 0u : field >> (shape - upto));
-                const uint32_t keep = mine * (shape == 16u ? 0x00010001u : 0x01010101u);
-                const uint32_t off0 = grp * 32u + sub * shape;
-                for (uint32_t gb = g_begin; gb < g_end; gb += 4u * per) {
-                    __builtin_amdgcn_wave_barrier();
-                    short_unit_masks<4>(gword_stream, gb, shape, lane_s, wave_masks);
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    const uint32_t passes = (g_end - gb + per - 1u) / per;
-                    for (uint32_t i = 0; i < (passes < 4u ? passes : 4u); ++i) {
-                        PrevSlice prev;
-                        const uint32_t ok = near_plane12_masks<THR>(c, wave_masks + i * 8u, thr, keep, prev);
-                        if (__ballot(ok != 0u) != 0ull) {
-                            note_candidates(fine_dup(ok, prev, dup_filter), gb + i * per, w_log, tile, off0, lane, w, raw, raw_used, max_chunks, counters);
-                            own_chunk = true;
-                        }
-                    }
-                }
-            } else {
-                const int lo = static_cast<int>(cur.window & 0xFFFFu), hi = static_cast<int>(cur.window >> 16);
-                const int below = lo - static_cast<int>(lane * 32u), upto = hi - static_cast<int>(lane * 32u);
-                const uint32_t keep = (below <= 0 ? ~0u : below >= 32 ? 0u : ~0u << below) &
-                                      (upto >= 32 ? ~0u : upto <= 0 ? 0u : ~0u >> (32 - upto));
-                if constexpr (THR < 0) {
-                    for (uint32_t g = g_begin; g < g_end; g += kGuideGroup) {
-                        const GuideGroup gg = *reinterpret_cast<const GuideGroup *>(gword_stream + g);
-#pragma unroll
-                        for (uint32_t uu = 0; uu < kGuideGroup; ++uu) {
-                            if (g + uu >= g_end) break;
-                            const uint32_t cls = (gg.w[uu] >> 24) & 3u;
-                            if (cls > thr) continue;
-                            PrevSlice prev;
-                            const uint32_t ok = near_plane12<-1>(c, gg.w[uu], thr - cls, keep, prev);
-                            if (__ballot(ok != 0u) != 0ull) {
-                                note_candidates(fine_dup(ok, prev, dup_filter), g + uu, 5u, tile, grp * 32u, lane, w, raw, raw_used, max_chunks, counters);
-                                own_chunk = true;
-                            }
-                        }
-                    }
-                } else {
-                    const uint32_t gmid = cur.gmid < g_begin ? g_begin : cur.gmid > g_end ? g_end : cur.gmid;
-                    if constexpr (THR >= 1) {
-                        for (uint32_t g = g_begin; g < gmid; g += kGuideGroup) {
-                            const GuideGroupAny gg = *reinterpret_cast<const GuideGroupAny *>(gword_stream + g);
-#pragma unroll
-                            for (uint32_t uu = 0; uu < kGuideGroup; ++uu) {
-                                if (g + uu >= gmid) break;
-                                PrevSlice prev;
-                                const uint32_t ok = near_plane12<(THR < 1 ? 0 : THR - 1)>(c, gg.w[uu], thr - 1u, keep, prev);
-                                if (__ballot(ok != 0u) != 0ull) {
-                                    note_candidates(fine_dup(ok, prev, dup_filter), g + uu, 5u, tile, grp * 32u, lane, w, raw, raw_used, max_chunks, counters);
-                                    own_chunk = true;
-                                }
-                            }
-                        }
-                    }
-                    for (uint32_t g = gmid; g < g_end; g += kGuideGroup) {
-                        const GuideGroupAny gg = *reinterpret_cast<const GuideGroupAny *>(gword_stream + g);
-#pragma unroll
-                        for (uint32_t uu = 0; uu < kGuideGroup; ++uu) {
-                            if (g + uu >= g_end) break;
-                            PrevSlice prev;
-                            const uint32_t ok = near_plane12<(THR < 0 ? 0 : THR)>(c, gg.w[uu], thr, keep, prev);
-                            if (__ballot(ok != 0u) != 0ull) {
-                                note_candidates(fine_dup(ok, prev, dup_filter), g + uu, 5u, tile, grp * 32u, lane, w, raw, raw_used, max_chunks, counters);
-                                own_chunk = true;
-                            }
-                        }
-                    }
-                }
-            }
-            if (!has_next) break;
-            cur = nxt; u = u_next;
-            nxt = after; u_next = u_after;
-        }
-    }
-    if (own_chunk) {
-        raw_retire(w, lane, raw, raw_used);
-        if (no_own_chunk && lane == 0) counters->raw_overflow = 1u;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (nothing of this wave stays on its way into the LDS when it ends)
-    if (lane == 0) {
-        atomicAdd(&wg_compared, compared);
-        if (atomicAdd(&waves_done, 1u) == (blockDim.x >> 6) - 1u) {
-            scan_count[blockIdx.x] = atomicAdd(&wg_compared, 0ull);
-            atomicMax(span + 1, static_cast<unsigned long long>(__builtin_amdgcn_s_memrealtime()));
-        }
-    }
-    if (stamps && lane == 0) {
-        stamps[4 * wave_id] = t_start;
-        stamps[4 * wave_id + 1] = __builtin_amdgcn_s_memrealtime();
-        stamps[4 * wave_id + 2] = (static_cast<unsigned long long>(__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11))) << 32) |
-                                  __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
-        stamps[4 * wave_id + 3] = units_done;
-    }
-}
-
-constexpr uint32_t kPfWaves = 10; // waves per workgroup of the prefetching scan: two workgroups per CU = 5 waves per SIMD (96 VGPRs: at 80 the loop spills, and a reload drains the prefetch)
-
-template <int THR>
-__global__ __launch_bounds__(kPfWaves * 64, 5) void k_scan_pf(const uint32_t *__restrict__ scan_stream,
-                                                              const ScanItem *__restrict__ items_fine,
-                                                              const PlanInfo *__restrict__ plan,
-                                                              const RangeStart *__restrict__ range_start,
-                                                              const uint32_t *__restrict__ gword_fine, uint64_t *raw,
-                                                              uint32_t *raw_used, uint32_t max_chunks, Counters *counters, uint32_t thr,
-                                                              unsigned long long *stamps, uint64_t *__restrict__ scan_count,
-                                                              unsigned long long *span, uint32_t n_tiles, uint32_t slice_bits)
-{
-    __shared__ uint32_t next_unit;
-    __shared__ uint32_t waves_done;
-    __shared__ unsigned long long wg_compared;
-    __shared__ uint4 stage[kPfWaves][6 * 64];  // per wave: the planes of its next unit (global_load_lds)
-    __shared__ uint4 tail_masks[kPfWaves][32]; // per wave: the guide masks of 4 passes of a short unit
-    if (plan->fine == 0u) return; // the planner chose whole buckets for this batch: k_scan, launched behind this kernel, works through them
-    const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
-    if (threadIdx.x == 0) { next_unit = 0; waves_done = 0; wg_compared = 0ull; }
-    __syncthreads();
-    if (blockIdx.x >= plan->n_ranges) {
-        if (threadIdx.x == 0) scan_count[blockIdx.x] = 0ull;
-        return;
-    }
-    if (threadIdx.x == 0) atomicMin(span, t_start);
-    const uint32_t wave = threadIdx.x >> 6;
-    scan_range_pf<THR>(scan_stream, items_fine, range_start, gword_fine, tail_masks[wave], stage[wave], raw, raw_used, max_chunks, counters, thr,
-                       stamps, scan_count, &next_unit, &waves_done, &wg_compared, t_start, span, n_tiles, slice_bits);
-}
-
 template <int THR>
 __global__ __launch_bounds__(1024, 8) void k_scan(const uint32_t *__restrict__ scan_stream,
                                                   const ScanItem *__restrict__ items_full,
@@ -1709,13 +1457,12 @@ __global__ __launch_bounds__(1024, 8) void k_scan(const uint32_t *__restrict__ s
                                                   const uint32_t *__restrict__ gword_fine, uint64_t *raw,
                                                   uint32_t *raw_used, uint32_t max_chunks, Counters *counters, uint32_t thr,
                                                   unsigned long long *stamps, uint64_t *__restrict__ scan_count,
-                                                  unsigned long long *span, uint32_t n_tiles, uint32_t slice_bits, uint32_t full_plan_only)
+                                                  unsigned long long *span, uint32_t n_tiles, uint32_t slice_bits)
 {
     __shared__ uint32_t next_unit;
     __shared__ uint32_t waves_done;
     __shared__ unsigned long long wg_compared;
     __shared__ uint4 tail_masks[16][64]; // per wave: the guide masks of 8 passes of a short unit (short_unit_masks)
-    if (full_plan_only && plan->fine != 0u) return; // (k_scan_pf has worked through the pruned plan)
     // stamps (diagnostics, normally null): per wave {start, end} in 100 MHz ticks, {XCC_ID, HW_ID} and the number of
     // tiles it took; nothing else reads them
     const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
@@ -1970,16 +1717,10 @@ static void launch_scan_thr(const ImageView &v, const Workspace &ws, const Tunin
                             hipStream_t stream)
 {
     // pruned scan: the items and guide words grouped by (bucket, successor byte); the plan says which list counts
-    if (prune_mode && tn.scan_prefetch) { // the next unit's planes on their way while the current one is compared (scan_range_pf)
-        hipLaunchKernelGGL(k_scan_pf<THR>, dim3(tn.scan_blocks), dim3(kPfWaves * 64), 0, stream, v.scan, ws.fitems, ws.plan,
-                           ws.range_start, ws.fword, ws.raw, ws.raw_used, static_cast<uint32_t>(ws.cap_chunks), ws.counters, thr,
-                           ws.stamps, ws.scan_count, ws.scan_span + 2u * ws.span_slot, v.n_tiles, v.slice_width);
-    }
-    const uint32_t full_plan_only = (prune_mode && tn.scan_prefetch) ? 1u : 0u; // (... and this launch only the bucket-level plan, if the planner chose it)
     hipLaunchKernelGGL(k_scan<THR>, dim3(tn.scan_blocks), dim3(tn.scan_threads), 0, stream, v.scan, ws.items,
                        prune_mode ? ws.fitems : ws.items, ws.plan, ws.range_start, ws.gword, prune_mode ? ws.fword : ws.gword,
                        ws.raw, ws.raw_used, static_cast<uint32_t>(ws.cap_chunks), ws.counters, thr, ws.stamps, ws.scan_count,
-                       ws.scan_span + 2u * ws.span_slot, v.n_tiles, v.slice_width, full_plan_only);
+                       ws.scan_span + 2u * ws.span_slot, v.n_tiles, v.slice_width);
 }
 
 void launch_scan(const ImageView &v, const Workspace &ws, const Tuning &tn, const uint64_t *d_guides, uint32_t n,
