@@ -73,17 +73,17 @@ def kernels_sha16():
     return hashlib.sha256((ROOT / "crackling_amd" / "csrc" / "issl_kernels.hip").read_bytes()).hexdigest()[:16]
 
 
-def traffic_point(sites, guides, dist, pruned):
-    """(HBM bytes per k_scan launch of this workload from a PMC profile, where it came from), or (None, why not).  A
-    point measured on another build of the kernels (its `kernels_sha16` differs from the source in this tree) is stale
-    and is not used."""
+def traffic_point(sites, guides, dist, pruned, key="hbm_bytes_per_launch"):
+    """(HBM bytes per k_scan launch of this workload from a PMC profile -- or, key="trace_avg_launch_ms", the mean launch
+    duration of the rocprofv3 kernel trace of the same passes --, where it came from), or (None, why not).  A point measured
+    on another build of the kernels (its `kernels_sha16` differs from the source in this tree) is stale and is not used."""
     prof = ROOT / "profiles" / "scan_traffic.json"
     try:
         for rec in json.loads(prof.read_text()).get("points", []):
             if (rec.get("sites"), rec.get("guides"), rec.get("distribution"), rec.get("pruned")) == (sites, guides, dist, pruned):
                 if rec.get("kernels_sha16") != kernels_sha16():
                     return None, f"stale: profiles/scan_traffic.json holds a point of kernel build {rec.get('kernels_sha16')}, this is {kernels_sha16()}"
-                return rec.get("hbm_bytes_per_launch"), rec.get("source")
+                return rec.get(key), rec.get("source")
     except Exception as e:  # noqa: BLE001
         return None, f"{type(e).__name__}: {e}"
     return None, "no PMC point for this workload in profiles/scan_traffic.json"
@@ -644,6 +644,7 @@ def main():
         useful_valu_cycles = cmp_per_launch / 2048.0 * valu_per * VALU_CYCLES_PER_INSTR
         lane_ops = cmp_per_launch * valu_per / 32.0     # 64 lanes x instructions
         traffic, traffic_src = traffic_point(a.sites, n_mine, a.dist, st["pruned"])
+        trace_ms, _trace_src = traffic_point(a.sites, n_mine, a.dist, st["pruned"], key="trace_avg_launch_ms")
         regime = extras.get("north_star_10k_guides") or {}
         out = {
             "metric": "guides/sec (whole node) + achieved HBM GB/s, 20bp/<=4mm ISSL scan",
@@ -678,6 +679,12 @@ def main():
                 "unit": f"TOP/s (32-bit VALU lane-ops; {valu_per:.1f} wave64 instructions per guide and 2048 candidates)",
                 "valu_per_2048_comparisons": valu_per,
                 "frac": useful_valu_cycles / (N_SIMD * PEAK_CLOCK_HZ * t_scan),
+                # the same fraction on the other two clocks of the launch: the HIP event pair around it (measured live, like `frac`)
+                # and the mean duration in the committed rocprofv3 --kernel-trace of this build (profiles/scan_traffic.json; null
+                # when the trace is of another build of the kernels) -- the trace's mean includes the process's first, cold launches
+                "frac_events": useful_valu_cycles / (N_SIMD * PEAK_CLOCK_HZ * st["ms_scan_events"] * 1e-3) if st["ms_scan_events"] else None,
+                "frac_trace": useful_valu_cycles / (N_SIMD * PEAK_CLOCK_HZ * trace_ms * 1e-3) if trace_ms else None,
+                "trace_avg_launch_ms": trace_ms,
                 "traffic": traffic,
                 "traffic_source": traffic_src,
                 "scan_units_per_launch": st["scan_tiles"],

@@ -62,6 +62,10 @@ if len(sys.argv) >= 6 and "scan_hbm_bytes_per_launch" in summary:
                    "hbm_bytes_per_launch": summary["scan_hbm_bytes_per_launch"]["total_bytes"],
                    "fetch_corrected_bytes": summary["scan_hbm_bytes_per_launch"]["fetch_corrected_bytes"],
                    "write_bytes": summary["scan_hbm_bytes_per_launch"]["write_bytes"],
+                   # the same launches in the rocprofv3 --kernel-trace pass (every launch of the process, the first cold ones
+                   # included): bench.py prices roofline.frac_trace on it
+                   "trace_avg_launch_ms": summary.get("scan_avg_launch_ns", 0.0) * 1e-6 or None,
+                   "trace_calls": summary.get("scan_calls"),
                    "source": f"{dst}_pmc.json (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over `python3 bench.py "
                              f"--no-cpu-baseline --no-extras`; FETCH_SIZE x2 per MI355X_MICROARCH.md, KiB->bytes)"})
     path.write_text(json.dumps({"points": points}, indent=1) + "\n")
