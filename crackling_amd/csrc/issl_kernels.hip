@@ -1708,7 +1708,9 @@ __global__ __launch_bounds__(kChunkRecs, 8) void k_verify(ImageView v, Workspace
             }
         }
         if (!in_use) continue;
-        recs[t] = key;
+        // (a lean batch has no grouping pass to read the keys back -- every hit went to its guide's slots, or the batch is run
+        // again in full: 8 bytes per record that need not be written)
+        if (!ws.lean_tail) recs[t] = key;
     }
 }
 
