@@ -106,6 +106,8 @@ Tuning Tuning::from_env()
     Tuning t;
     t.scan_blocks = kScanGridBlocks;
     t.scan_threads = 1024;
+    t.upload_chunk_kib = 16384;
+    t.upload_ring_min_kib = 65536;
     t.item_guides = kItemGuides;
     t.scan_generic = false;
     t.stage_timing = false;
@@ -122,7 +124,7 @@ Tuning Tuning::from_env()
     t.lean_tail = 1;
     t.lanes = 1;
     static const char *const keys[][2] = {
-        {"ISSL_SCAN_BLOCKS", "scan_blocks"}, {"ISSL_SCAN_THREADS", "scan_threads"}, {"ISSL_ITEM_GUIDES", "item_guides"},
+        {"ISSL_SCAN_BLOCKS", "scan_blocks"}, {"ISSL_SCAN_THREADS", "scan_threads"}, {"ISSL_UPLOAD_CHUNK_KIB", "upload_chunk_kib"}, {"ISSL_UPLOAD_RING_MIN_KIB", "upload_ring_min_kib"}, {"ISSL_ITEM_GUIDES", "item_guides"},
         {"ISSL_SCAN_GENERIC", "scan_generic"}, {"ISSL_STAGE_TIMING", "stage_timing"}, {"ISSL_RAW_CHUNKS", "raw_chunks"},
         {"ISSL_INLINE_SIGS", "inline_sigs"}, {"ISSL_FORCE_HOST_COLD", "host_cold"}, {"ISSL_SCAN_STAMPS", "scan_stamps"},
         {"ISSL_SORTED_LAYOUT", "sorted_layout"}, {"ISSL_PRUNE", "prune"}, {"ISSL_LANES", "lanes"},
@@ -141,7 +143,9 @@ bool Tuning::set(const char *key, const char *value)
     char *end = nullptr;
     const long long n = std::strtoll(value, &end, 10);
     const bool is_int = end != value && *end == 0;
-    if (k == "scan_threads") { if (!is_int || n < 64 || n > 1024 || n % 64) return false; scan_threads = static_cast<uint32_t>(n); }
+    if (k == "upload_chunk_kib") { if (!is_int || n < 4 || n > (1 << 20)) return false; upload_chunk_kib = static_cast<size_t>(n); }
+    else if (k == "upload_ring_min_kib") { if (!is_int || n < 0) return false; upload_ring_min_kib = static_cast<size_t>(n); }
+    else if (k == "scan_threads") { if (!is_int || n < 64 || n > 1024 || n % 64) return false; scan_threads = static_cast<uint32_t>(n); }
     else if (k == "scan_blocks") { if (!is_int || n < 1 || n > static_cast<long long>(kScanMaxBlocks)) return false; scan_blocks = static_cast<uint32_t>(n); }
     else if (k == "item_guides") { if (!is_int || n < 8 || n > static_cast<long long>(kItemGuides)) return false; item_guides = static_cast<uint32_t>(n) & ~7u; }
     else if (k == "scan_generic") { if (!is_int || (n != 0 && n != 1)) return false; scan_generic = n == 1; }
@@ -475,15 +479,19 @@ struct DevTemp { // device allocation freed on every path out of a function
 // profiles/r05_ubench_h2d.txt).  Anything that is not file-backed, or small, takes the plain copy.
 class FileUploader {
   public:
+    // chunk_kib: bytes per pinned slot (default 16 MiB); min_kib: sections smaller than this take the plain copy (default 64 MiB).
+    // Both from the upload_chunk_kib / upload_ring_min_kib knobs: tests send a 10 MB golden index through a ring of 64 KiB slots.
+    FileUploader(size_t chunk_kib, size_t min_kib) : chunk_(std::max<size_t>(chunk_kib, 4) << 10), min_bytes_(min_kib << 10) {}
     ~FileUploader() { release(); }
     int copy(const HostIndex &h, void *dst, const void *src, size_t bytes)
     {
         int fd = -1;
         uint64_t off = 0;
-        if (bytes < (size_t(64) << 20) || !h.file_range(src, bytes, &fd, &off) || !ensure()) {
+        if (bytes < std::max<size_t>(min_bytes_, 1) || !h.file_range(src, bytes, &fd, &off) || !ensure()) {
             HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
             return ISSL_OK;
         }
+        const size_t kChunk = chunk_;
         const size_t n_chunks = (bytes + kChunk - 1) / kChunk;
         std::atomic<size_t> next{0};
         std::atomic<int> failed{0};
@@ -534,13 +542,15 @@ class FileUploader {
 
   private:
     static constexpr uint32_t kThreads = 8;
-    static constexpr size_t kChunk = size_t(16) << 20; // 16 slots: 256 MiB of pinned memory while an upload lasts (pinning costs ~0.2 ms per MiB)
+    const size_t chunk_;     // 16 slots of 16 MiB by default: 256 MiB of pinned memory while an upload lasts (pinning costs ~0.2 ms per MiB)
+    const size_t min_bytes_;
     bool ensure()
     {
         if (ready_) return true;
         if (tried_) return false;
         tried_ = true;
         if (hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); stream_ = nullptr; return false; }
+        const size_t kChunk = chunk_;
         if (hipHostMalloc(&block_, 2 * kThreads * kChunk, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); block_ = nullptr; release(); return false; }
         for (uint32_t i = 0; i < 2 * kThreads; ++i) {
             pin_[i] = static_cast<char *>(block_) + i * kChunk;
@@ -612,7 +622,7 @@ static int finish_upload(issl_index *ix, const DeviceBuildInput *dbi = nullptr)
         seen = static_cast<uint32_t *>(seen_mem.p);
     }
     double t0 = wall_ms();
-    FileUploader from_file;
+    FileUploader from_file(ix->tuning.upload_chunk_kib, ix->tuning.upload_ring_min_kib);
     if (ix->hdr.off_sub_start) {
         // Sorted layouts.  Site table and counts into the image, then one slice at a time: the slice's list (in the
         // image, or -- lists in pinned host memory -- in a temporary 8 B/site device copy), the successor-byte order
@@ -1329,6 +1339,8 @@ int issl_index_get_option(const issl_index *idx, const char *key, long long *val
     const std::string k(key);
     if (k == "scan_blocks") *value = t.scan_blocks;
     else if (k == "scan_threads") *value = t.scan_threads;
+    else if (k == "upload_chunk_kib") *value = static_cast<long long>(t.upload_chunk_kib);
+    else if (k == "upload_ring_min_kib") *value = static_cast<long long>(t.upload_ring_min_kib);
     else if (k == "item_guides") *value = t.item_guides;
     else if (k == "scan_generic") *value = t.scan_generic;
     else if (k == "stage_timing") *value = t.stage_timing;

@@ -77,6 +77,7 @@ struct BufPool {
     std::mutex mu;
     std::vector<char *> idle; // base pointers (header included)
     size_t bytes = 0;
+    ~BufPool() { for (char *b : idle) std::free(b); }
 } g_pool;
 size_t buf_cap(const char *base) { size_t c; std::memcpy(&c, base, sizeof c); return c; }
 char *buf_take(size_t cap) // returns the text pointer (base + header) of a buffer that holds at least `cap` bytes, or null

@@ -274,7 +274,9 @@ int issl_read_query_file(const char *path, size_t seq_len, uint64_t **out, size_
  * comes in *n_spans consecutive pieces (formatted by up to `threads` threads, 0 = automatic; a million lines are
  * otherwise as long as their scoring): write them out one after the other, release with issl_free_spans.  The "%f" is
  * the library's own exact formatter (the binary value rounded to six decimals, ties to even: digit for digit glibc's
- * output), snprintf for negative, huge and non-finite values.  Host arithmetic only.  (ABI 6) */
+ * output), snprintf for negative, huge and non-finite values.  Host arithmetic only.  issl_free_spans hands the buffers
+ * back to the library, which keeps up to 512 MB of them for the next call (a resident scorer formats page after page of the
+ * same size, and a fresh buffer costs a page fault per 4 KiB when it is first written).  (ABI 6) */
 typedef struct issl_span {
     char *data;
     size_t len;

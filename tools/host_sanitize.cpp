@@ -1,7 +1,7 @@
 // Host-side parser / builder under AddressSanitizer + UndefinedBehaviorSanitizer (CPU build only: GPU sanitizers are
 // not available on the pool).  Built and run by tests/test_host_sanitizers.py:
 //   g++ -std=c++17 -O1 -g -fsanitize=address,undefined -fno-sanitize-recover=undefined tools/host_sanitize.cpp \
-//       crackling_amd/csrc/issl_host.cpp -lpthread -o <tmp>/host_sanitize && <tmp>/host_sanitize <index.issl> <sites.txt>
+//       crackling_amd/csrc/issl_host.cpp crackling_amd/csrc/issl_text.cpp -lpthread -o <tmp>/host_sanitize && <tmp>/host_sanitize <index.issl> <sites.txt>
 // The .issl reader is the one piece of the product that parses untrusted bytes (isslScoreOfftargets.cpp:152-243 trusts
 // its file; this reader validates sizes, truncation and overflow): every truncation of the file, and a few thousand
 // random single-field and single-byte corruptions, must come back as a clean error or a consistent index -- never as
@@ -15,6 +15,8 @@
 #include <vector>
 
 #include "../crackling_amd/csrc/issl_host.hpp"
+
+extern "C" void issl_free(void *p) { std::free(p); } // (lives in issl_capi.cpp, which needs the HIP runtime)
 
 static std::vector<uint8_t> slurp(const char *path)
 {
@@ -103,6 +105,68 @@ int main(int argc, char **argv)
         char dec[40];
         issl::decode_guide(sink, 20, dec);
         issl::decode_guide(sink, 32, dec);
+    }
+    // the scorer's text (issl_text.cpp): the library's own "%f" against snprintf on doubles of every exponent and on the exact
+    // ties k/128, through issl_format_scores on several threads (buffers taken from and given back to its pool), and the
+    // threaded query-file reader on a file of odd length
+    {
+        const size_t n = 70000;
+        std::vector<uint64_t> g(n);
+        std::vector<double> a(n), b(n);
+        for (size_t i = 0; i < n; ++i) {
+            g[i] = rng() & ((1ull << 40) - 1);
+            uint64_t bits = rng() >> (i % 3 ? 1 : 0); // (two thirds with the sign bit clear)
+            std::memcpy(&a[i], &bits, 8);
+            b[i] = (i % 5 == 0) ? static_cast<double>(2 * (rng() % 4000) + 1) / 128.0 : 10000.0 / (100.0 + static_cast<double>(rng() % 1000000) / 97.0);
+        }
+        for (int round = 0; round < 3; ++round) {
+            issl_span *spans = nullptr;
+            size_t n_spans = 0;
+            if (issl_format_scores(g.data(), a.data(), b.data(), n, 20, ISSL_METHOD_AND, round == 0 ? 1 : 4, &spans, &n_spans)) { std::fprintf(stderr, "format failed\n"); return 1; }
+            size_t i = 0;
+            for (size_t sp = 0; sp < n_spans; ++sp) {
+                const char *q = spans[sp].data, *end = q + spans[sp].len;
+                while (q < end) {
+                    char want[1024], seq[40];
+                    issl::decode_guide(g[i], 20, seq);
+                    const int k = std::snprintf(want, sizeof want, "%s\t%f\t%f\n", seq, a[i], b[i]);
+                    if (static_cast<size_t>(end - q) < static_cast<size_t>(k) || std::memcmp(q, want, static_cast<size_t>(k)) != 0) {
+                        std::fprintf(stderr, "line %zu differs from printf's: %s", i, want);
+                        return 1;
+                    }
+                    q += k;
+                    ++i;
+                }
+            }
+            if (i != n) { std::fprintf(stderr, "formatted %zu of %zu lines\n", i, n); return 1; }
+            sink += n_spans;
+            issl_free_spans(spans, n_spans);
+        }
+        const std::string qpath = std::string(argv[1]) + ".query.tmp";
+        FILE *qf = std::fopen(qpath.c_str(), "wb");
+        const size_t n_lines = 200003;
+        for (size_t i = 0; i < n_lines; ++i) {
+            char seq[40];
+            issl::decode_guide(g[i % n], 20, seq);
+            seq[20] = '\n';
+            std::fwrite(seq, 1, 21, qf);
+        }
+        std::fclose(qf);
+        uint64_t *out = nullptr;
+        size_t got = 0;
+        if (issl_read_query_file(qpath.c_str(), 20, &out, &got) || got != n_lines) { std::fprintf(stderr, "query reader failed: %s\n", issl::get_error()); return 1; }
+        for (size_t i = 0; i < n_lines; ++i)
+            if (out[i] != g[i % n]) { std::fprintf(stderr, "query reader: guide %zu differs\n", i); return 1; }
+        issl_free(out);
+        std::remove(qpath.c_str());
+        // an index opened from its file keeps the descriptor for the upload's pread path: ranges inside and outside the mapping
+        issl::HostIndex h;
+        if (h.open_file(argv[1])) { std::fprintf(stderr, "open_file: %s\n", issl::get_error()); return 1; }
+        int fd = -1;
+        uint64_t off = 0;
+        if (!h.file_range(h.sites, 8 * h.geo.n_sites, &fd, &off) || fd < 0 || off < 48) { std::fprintf(stderr, "file_range: site table not found in the mapping\n"); return 1; }
+        if (h.file_range(g.data(), 8, &fd, &off)) { std::fprintf(stderr, "file_range: a foreign pointer accepted\n"); return 1; }
+        sink += off;
     }
     std::printf("ok: %zu corrupted or truncated images rejected, %zu accepted as consistent (checksum %llu)\n", rejected, accepted,
                 static_cast<unsigned long long>(sink));
