@@ -1243,6 +1243,9 @@ def test_lean_tail_prediction_and_its_retry():
     key = next(k for k in g.expected if k.startswith("and|"))
     method, thr, dist = key.split("|")
     ix = ca.IsslIndex.open(g.issl).upload(0)
+    if ix.get_option("lean_tail") != 1 or ix.get_option("hit_slots") == 0:   # (a whole-suite run with ISSL_LEAN_TAIL=0 / ISSL_HIT_SLOTS=0 in the environment)
+        ix.close()
+        pytest.skip("the environment switches the lean tail off")
     try:
         counts = np.bincount(ix.dump_hits(sigs, int(dist), 0.0, method)[:, 0], minlength=len(sigs))
         few = np.flatnonzero(counts <= 400)
