@@ -44,6 +44,14 @@ VARIANTS = {
     # VERDICT r04 item 1(b), scan side only: one 16-byte record per lane with its whole result plane (k_verify switched off)
     "scan_wide_record": [("    uint64_t who = __ballot(ok != 0u);\n    if (who == 0ull) return;\n    // One round per candidate of the lane that has most -- almost always ONE: the loop is laid out with its first round as the\n    // straight path (a taken branch drains the wave's instruction buffer, and more than half of the passes come through\n    // here: k_scan<4> -3 % same-box, profiles/r05_ab_scan_peel_lanes3.log).\n    do {\n        const uint32_t n = static_cast<uint32_t>(__builtin_popcountll(who));\n        if (__builtin_expect(w.fill + n > kChunkRecs, 0)) {\n            raw_retire(w, lane, raw, raw_used);\n            raw_acquire(w, raw, max_chunks, counters, lane);\n        }\n        if (ok != 0u) {\n            const uint32_t q = static_cast<uint32_t>(__builtin_ctz(ok));\n            ok &= ok - 1u;\n            const uint32_t rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(who >> 32),\n                                                            __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(who), 0u));\n            w.chunk[w.fill + rank] = raw_record(gslot + (q >> w_log), tile, off0 + (q & ((1u << w_log) - 1u)));\n        }\n        w.fill += n;\n        who = __ballot(ok != 0u);\n    } while (__builtin_expect(who != 0ull, 0));\n}\n", '    // TIMING ONLY (tools/ablate.py: scan_wide_record): one 16-byte record per lane with its whole result plane instead of one\n    // 8-byte record per candidate -- no bit scan, no second round; k_verify of this build does nothing.\n    const uint64_t who = __ballot(ok != 0u);\n    if (who == 0ull) return;\n    const uint32_t n = 2u * static_cast<uint32_t>(__builtin_popcountll(who)); // in 8-byte slots\n    if (__builtin_expect(((w.fill + 1u) & ~1u) + n > kChunkRecs, 0)) {\n        raw_retire(w, lane, raw, raw_used);\n        raw_acquire(w, raw, max_chunks, counters, lane);\n    }\n    if (ok != 0u) {\n        const uint32_t rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(who >> 32),\n                                                        __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(who), 0u));\n        uint4 rec;\n        rec.x = ok; rec.y = gslot | (w_log << 27); rec.z = tile; rec.w = off0;\n        *reinterpret_cast<uint4 *>(w.chunk + ((w.fill + 1u) & ~1u) + 2u * rank) = rec;\n    }\n    w.fill = ((w.fill + 1u) & ~1u) + n;\n}\n'), ('    short_kernel_priority();\n    const int max_dist = p.max_dist;\n    const bool calc_mit = p.method == ISSL_METHOD_MIT || p.method == ISSL_METHOD_AND || p.method == ISSL_METHOD_OR ||\n                          p.method == ISSL_METHOD_AVG;\n    const bool calc_cfd = p.method == ISSL_METHOD_CFD || p.method == ISSL_METHOD_AND || p.method == ISSL_METHOD_OR ||\n                          p.method == ISSL_METHOD_AVG;\n    const uint32_t prune_mode = ws.plan->fine; // what the scan of this batch worked through', "    short_kernel_priority();\n    if (p.max_dist >= -100) return; // TIMING ONLY (scan_wide_record): the records of this build are not k_verify's\n    const int max_dist = p.max_dist;\n    const bool calc_mit = p.method == ISSL_METHOD_MIT || p.method == ISSL_METHOD_AND || p.method == ISSL_METHOD_OR ||\n                          p.method == ISSL_METHOD_AVG;\n    const bool calc_cfd = p.method == ISSL_METHOD_CFD || p.method == ISSL_METHOD_AND || p.method == ISSL_METHOD_OR ||\n                          p.method == ISSL_METHOD_AVG;\n    const uint32_t prune_mode = ws.plan->fine; // what the scan of this batch worked through")],
     "scan_wide_record12": [("    uint64_t who = __ballot(ok != 0u);\n    if (who == 0ull) return;\n    // One round per candidate of the lane that has most -- almost always ONE: the loop is laid out with its first round as the\n    // straight path (a taken branch drains the wave's instruction buffer, and more than half of the passes come through\n    // here: k_scan<4> -3 % same-box, profiles/r05_ab_scan_peel_lanes3.log).\n    do {\n        const uint32_t n = static_cast<uint32_t>(__builtin_popcountll(who));\n        if (__builtin_expect(w.fill + n > kChunkRecs, 0)) {\n            raw_retire(w, lane, raw, raw_used);\n            raw_acquire(w, raw, max_chunks, counters, lane);\n        }\n        if (ok != 0u) {\n            const uint32_t q = static_cast<uint32_t>(__builtin_ctz(ok));\n            ok &= ok - 1u;\n            const uint32_t rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(who >> 32),\n                                                            __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(who), 0u));\n            w.chunk[w.fill + rank] = raw_record(gslot + (q >> w_log), tile, off0 + (q & ((1u << w_log) - 1u)));\n        }\n        w.fill += n;\n        who = __ballot(ok != 0u);\n    } while (__builtin_expect(who != 0ull, 0));\n}\n", '    // TIMING ONLY (tools/ablate.py: scan_wide_record): one 16-byte record per lane with its whole result plane instead of one\n    // 8-byte record per candidate -- no bit scan, no second round; k_verify of this build does nothing.\n    const uint64_t who = __ballot(ok != 0u);\n    if (who == 0ull) return;\n    const uint32_t n = 2u * static_cast<uint32_t>(__builtin_popcountll(who)); // in 8-byte slots\n    if (__builtin_expect(((w.fill + 1u) & ~1u) + n > kChunkRecs, 0)) {\n        raw_retire(w, lane, raw, raw_used);\n        raw_acquire(w, raw, max_chunks, counters, lane);\n    }\n    if (ok != 0u) {\n        const uint32_t rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(who >> 32),\n                                                        __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(who), 0u));\n        uint3 rec;\n        rec.x = ok; rec.y = gslot | (w_log << 27) | ((off0 & 24u) << 27); rec.z = (tile << 6) | (off0 >> 5);\n        *reinterpret_cast<uint3 *>(reinterpret_cast<uint32_t *>(w.chunk + ((w.fill + 1u) & ~1u)) + 3u * rank) = rec;\n    }\n    w.fill = ((w.fill + 1u) & ~1u) + n;\n}\n'), ('    short_kernel_priority();\n    const int max_dist = p.max_dist;\n    const bool calc_mit = p.method == ISSL_METHOD_MIT || p.method == ISSL_METHOD_AND || p.method == ISSL_METHOD_OR ||\n                          p.method == ISSL_METHOD_AVG;\n    const bool calc_cfd = p.method == ISSL_METHOD_CFD || p.method == ISSL_METHOD_AND || p.method == ISSL_METHOD_OR ||\n                          p.method == ISSL_METHOD_AVG;\n    const uint32_t prune_mode = ws.plan->fine; // what the scan of this batch worked through', "    short_kernel_priority();\n    if (p.max_dist >= -100) return; // TIMING ONLY (scan_wide_record): the records of this build are not k_verify's\n    const int max_dist = p.max_dist;\n    const bool calc_mit = p.method == ISSL_METHOD_MIT || p.method == ISSL_METHOD_AND || p.method == ISSL_METHOD_OR ||\n                          p.method == ISSL_METHOD_AVG;\n    const bool calc_cfd = p.method == ISSL_METHOD_CFD || p.method == ISSL_METHOD_AND || p.method == ISSL_METHOD_OR ||\n                          p.method == ISSL_METHOD_AVG;\n    const uint32_t prune_mode = ws.plan->fine; // what the scan of this batch worked through")],
+    # an alternative (results stay right): 8 bytes per guide slot {guide, group} instead of 16 {guide, group, signature} -- k_fine_scatter
+    # writes 40 % fewer bytes, k_verify fetches the guide's signature from the batch (one more dependent load)
+    "fmeta8": [("        for (uint32_t k2 = c; k2 < static_cast<uint32_t>(slots); ++k2) { fmeta[slot_at + k2] = FineMeta{kNoGuide, 0u, 0ull}; fword[slot_at + k2] = kPadGuideWord; }",
+                "        for (uint32_t k2 = c; k2 < static_cast<uint32_t>(slots); ++k2) { reinterpret_cast<uint2 *>(fmeta)[slot_at + k2] = make_uint2(kNoGuide, 0u); fword[slot_at + k2] = kPadGuideWord; }"),
+               ("            fmeta[slot] = FineMeta{guide, (b << 8) | ww, gsig};",
+                "            reinterpret_cast<uint2 *>(fmeta)[slot] = make_uint2(guide, (b << 8) | ww);"),
+               ("            if (prune_mode) { const FineMeta m = ws.fmeta[gslot]; guide = m.guide; where = m.where; gsig = m.gsig; }",
+                "            if (prune_mode) { const uint2 m = reinterpret_cast<const uint2 *>(ws.fmeta)[gslot]; guide = m.x; where = m.y; if (guide != kNoGuide) gsig = guides[guide]; }")],
     # k_verify
     "verify_no_atomic": [("            if (live) rank = atomicAdd(&ws.gcount[guide], 1u);", "            if (live) rank = lane;"),
                          ("if (live && !continues) base = atomicAdd(&ws.gcount[guide], next - lane);", "if (live && !continues) base = next - lane;")],
