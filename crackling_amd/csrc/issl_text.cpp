@@ -125,7 +125,7 @@ void buf_give(char *text)
 
 static size_t worker_count(size_t n, size_t per_thread, int threads)
 {
-    size_t t = threads > 0 ? static_cast<size_t>(threads) : std::min<size_t>(16, std::max(1u, std::thread::hardware_concurrency()));
+    size_t t = threads > 0 ? std::min<size_t>(static_cast<size_t>(threads), 64) : std::min<size_t>(16, std::max(1u, std::thread::hardware_concurrency()));
     return std::max<size_t>(1, std::min(t, n / per_thread));
 }
 
