@@ -286,3 +286,31 @@ def test_query_file_reader_threads_and_rules(tmp_path):
         assert _lib.lib.issl_read_query_file(os.fsencode(path), 20, C.byref(out), C.byref(n)) != 0
         assert code in _lib.lib.issl_last_error().decode()
     assert _lib.lib.issl_read_query_file(os.fsencode(tmp_path / "absent"), 20, C.byref(out), C.byref(n)) != 0
+
+
+def test_cli_without_its_library_fails_loudly(golden, tmp_path):
+    """bin/isslScoreOfftargets is host code that loads libissl_hip.so on demand (never when a resident server answers).  Away from
+    the library -- a copy of the executable alone -- it says what it tried and exits 1 with nothing on stdout; ISSL_LIBRARY
+    points it at the library again (and then it fails for want of a GPU, here)."""
+    import shutil
+    exe = tmp_path / "isslScoreOfftargets"
+    shutil.copy(ROOT / "bin" / "isslScoreOfftargets", exe)
+    args = [str(exe), str(golden.issl), str(golden.guides_txt), "4", "75", "and"]
+    env = {k: v for k, v in os.environ.items() if k not in ("LD_LIBRARY_PATH", "ISSL_LIBRARY", "ISSL_SERVER")}
+    r = subprocess.run(args, capture_output=True, env=env, cwd=str(tmp_path))
+    assert r.returncode == 1 and r.stdout == b"" and b"cannot load libissl_hip.so" in r.stderr and b"ISSL_LIBRARY" in r.stderr
+    r = subprocess.run(args, capture_output=True, env=dict(env, ISSL_LIBRARY=_lib.LIB_PATH), cwd=str(tmp_path))
+    assert r.stdout == b"" and b"cannot load" not in r.stderr
+    if not _has_gpu():
+        assert r.returncode == 1 and b"no HIP device" in r.stderr
+    # usage errors need no library at all
+    r = subprocess.run([str(exe), str(golden.issl)], capture_output=True, env=env)
+    assert r.returncode == 1 and b"Usage:" in r.stderr
+
+
+def _has_gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:  # noqa: BLE001
+        return False
