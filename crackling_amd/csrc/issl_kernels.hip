@@ -335,11 +335,22 @@ __device__ __forceinline__ RangeStart range_start_of(const ScanItem *__restrict_
     return out;
 }
 
+// Scan workgroups that get a range of the plan: all of the launch's for a plan of any size, fewer for a small one -- a workgroup
+// with less than a few units per wave is no faster, and every scan wave owns a record chunk that k_verify then has to visit
+// (a 64-guide batch of 12 k units: 1024 workgroups = 16 384 nearly empty chunks were 25 us of its 130).  The record chunks
+// [0, 16 x ranges) are the scan waves' own; what is handed out later comes behind them (Counters::raw_chunks).
+__device__ __forceinline__ uint32_t ranges_for(uint64_t units, uint32_t scan_blocks)
+{
+    const uint64_t want = units / 64u + 1u; // ~4 units per wave
+    const uint32_t floor_ = scan_blocks < 64u ? scan_blocks : 64u;
+    return want >= scan_blocks ? scan_blocks : want < floor_ ? floor_ : static_cast<uint32_t>(want);
+}
+
 // One block: lay out the bucket-sorted guide arrays and the list of scan items.
 __global__ __launch_bounds__(256) void k_plan(ImageView v, uint32_t *__restrict__ ng, uint32_t *__restrict__ gfill,
                                               uint32_t *__restrict__ gstart, ScanItem *__restrict__ items,
                                               uint32_t cap_items, PlanInfo *__restrict__ plan, uint32_t item_guides,
-                                              uint32_t scan_blocks)
+                                              uint32_t scan_blocks, Counters *__restrict__ counters)
 {
     short_kernel_priority();
     __shared__ uint64_t lds[256];
@@ -413,7 +424,8 @@ __global__ __launch_bounds__(256) void k_plan(ImageView v, uint32_t *__restrict_
         plan->fine = 0;
         plan->tiles = tot_tiles;
         // one equal-cost range per scan workgroup; inside a workgroup the waves share the tiles dynamically
-        plan->n_ranges = (overflow || tot_tiles == 0) ? 0u : scan_blocks;
+        plan->n_ranges = (overflow || tot_tiles == 0) ? 0u : ranges_for(tot_tiles, scan_blocks);
+        counters->raw_chunks = (plan->n_ranges ? plan->n_ranges : 1u) * 16u; // (k_guide_hist has reset the counters; k_fine_plan may choose again)
         plan->error = overflow ? 2u : 0u;
     }
 }
@@ -631,7 +643,7 @@ __global__ __launch_bounds__(256) void k_fine_count(ImageView v, const uint64_t 
 __global__ __launch_bounds__(256) void k_fine_plan(FineSum *__restrict__ fsum, uint32_t nb, ScanItem *__restrict__ fitems,
                                                    uint32_t cap_items, uint32_t cap_slots, PlanInfo *__restrict__ plan,
                                                    uint32_t scan_blocks, uint32_t prune_mode, uint32_t always,
-                                                   uint32_t *__restrict__ sticky)
+                                                   uint32_t *__restrict__ sticky, Counters *__restrict__ counters)
 {
     short_kernel_priority();
     __shared__ uint64_t lds[256];
@@ -681,7 +693,8 @@ __global__ __launch_bounds__(256) void k_fine_plan(FineSum *__restrict__ fsum, u
             plan->total_cost = t_cost;
             plan->candidates = t_cand; // reference_candidates stays what the bucket-level plan counted
             plan->tiles = t_units;
-            plan->n_ranges = t_units == 0 ? 0u : scan_blocks;
+            plan->n_ranges = t_units == 0 ? 0u : ranges_for(t_units, scan_blocks);
+            counters->raw_chunks = (plan->n_ranges ? plan->n_ranges : 1u) * 16u;
             plan->fine = prune_mode;
             plan->fine_slots = static_cast<uint32_t>(t_slots);
         }
@@ -813,7 +826,7 @@ void launch_bin_guides(const ImageView &v, const Workspace &ws, const Tuning &tn
     hipLaunchKernelGGL(k_guide_hist, dim3(std::max(blocks, reset_blocks)), dim3(256), 0, stream, ws, d_guides, n,
                        v.slice_width, v.n_slices, nb, n_slots, tn.scan_blocks * 16u);
     hipLaunchKernelGGL(k_plan, dim3(1), dim3(256), 0, stream, v, ws.ng, ws.gfill, ws.gstart, ws.items,
-                       static_cast<uint32_t>(ws.cap_items), ws.plan, tn.item_guides, tn.scan_blocks);
+                       static_cast<uint32_t>(ws.cap_items), ws.plan, tn.item_guides, tn.scan_blocks, ws.counters);
     const uint32_t range_blocks = (tn.scan_blocks + 1u + 255u) / 256u;
     hipLaunchKernelGGL(k_guide_scatter, dim3(blocks + range_blocks), dim3(256), 0, stream, d_guides, n, v.slice_width,
                        v.n_slices, (v.srec || v.sid) ? 1u : 0u, nb, ws.gstart, ws.gfill, ws.gword, ws.gidx, ws.gbucket, blocks, ws.plan, ws.items,
@@ -828,7 +841,7 @@ void launch_bin_guides(const ImageView &v, const Workspace &ws, const Tuning &tn
                                ws.fcount0, ws.fsum, tn.item_guides, tail_shapes);
             hipLaunchKernelGGL(k_fine_plan, dim3(1), dim3(256), 0, stream, ws.fsum, nb, ws.fitems,
                                static_cast<uint32_t>(ws.cap_fitems), static_cast<uint32_t>(ws.cap_fslots), ws.plan, tn.scan_blocks,
-                               prune_mode, tn.prune == 1 ? 1u : 0u, ws.sticky);
+                               prune_mode, tn.prune == 1 ? 1u : 0u, ws.sticky, ws.counters);
             hipLaunchKernelGGL(k_fine_scatter<W>, dim3(nb), dim3(256), 0, stream, v, d_guides, ws.gstart, ws.gfill, ws.gword, ws.gidx,
                                ws.fcount, ws.fcount0, ws.fsum, ws.plan, ws.fword, ws.fmeta, ws.fitems, tn.item_guides, tail_shapes);
         };
