@@ -6,6 +6,7 @@
 #include <atomic>
 #include <cctype>
 #include <chrono>
+#include <condition_variable>
 #include <cmath>
 #include <cerrno>
 #include <cstdio>
@@ -108,6 +109,7 @@ Tuning Tuning::from_env()
     t.scan_threads = 1024;
     t.upload_chunk_kib = 16384;
     t.upload_ring_min_kib = 65536;
+    t.upload_threads = 8;
     t.item_guides = kItemGuides;
     t.scan_generic = false;
     t.stage_timing = false;
@@ -124,7 +126,7 @@ Tuning Tuning::from_env()
     t.lean_tail = 1;
     t.lanes = 1;
     static const char *const keys[][2] = {
-        {"ISSL_SCAN_BLOCKS", "scan_blocks"}, {"ISSL_SCAN_THREADS", "scan_threads"}, {"ISSL_UPLOAD_CHUNK_KIB", "upload_chunk_kib"}, {"ISSL_UPLOAD_RING_MIN_KIB", "upload_ring_min_kib"}, {"ISSL_ITEM_GUIDES", "item_guides"},
+        {"ISSL_SCAN_BLOCKS", "scan_blocks"}, {"ISSL_SCAN_THREADS", "scan_threads"}, {"ISSL_UPLOAD_CHUNK_KIB", "upload_chunk_kib"}, {"ISSL_UPLOAD_RING_MIN_KIB", "upload_ring_min_kib"}, {"ISSL_UPLOAD_THREADS", "upload_threads"}, {"ISSL_ITEM_GUIDES", "item_guides"},
         {"ISSL_SCAN_GENERIC", "scan_generic"}, {"ISSL_STAGE_TIMING", "stage_timing"}, {"ISSL_RAW_CHUNKS", "raw_chunks"},
         {"ISSL_INLINE_SIGS", "inline_sigs"}, {"ISSL_FORCE_HOST_COLD", "host_cold"}, {"ISSL_SCAN_STAMPS", "scan_stamps"},
         {"ISSL_SORTED_LAYOUT", "sorted_layout"}, {"ISSL_PRUNE", "prune"}, {"ISSL_LANES", "lanes"},
@@ -145,6 +147,7 @@ bool Tuning::set(const char *key, const char *value)
     const bool is_int = end != value && *end == 0;
     if (k == "upload_chunk_kib") { if (!is_int || n < 4 || n > (1 << 20)) return false; upload_chunk_kib = static_cast<size_t>(n); }
     else if (k == "upload_ring_min_kib") { if (!is_int || n < 0) return false; upload_ring_min_kib = static_cast<size_t>(n); }
+    else if (k == "upload_threads") { if (!is_int || n < 1 || n > 32) return false; upload_threads = static_cast<int>(n); }
     else if (k == "scan_threads") { if (!is_int || n < 64 || n > 1024 || n % 64) return false; scan_threads = static_cast<uint32_t>(n); }
     else if (k == "scan_blocks") { if (!is_int || n < 1 || n > static_cast<long long>(kScanMaxBlocks)) return false; scan_blocks = static_cast<uint32_t>(n); }
     else if (k == "item_guides") { if (!is_int || n < 8 || n > static_cast<long long>(kItemGuides)) return false; item_guides = static_cast<uint32_t>(n) & ~7u; }
@@ -472,135 +475,275 @@ struct DevTemp { // device allocation freed on every path out of a function
     ~DevTemp() { if (p) (void)hipFree(p); }
 };
 
-// A section of a file-mapped index into device memory.  hipMemcpy from a FRESH private file mapping moves 11 GB/s on an
+// Sections of a file-mapped index into device memory.  hipMemcpy from a FRESH private file mapping moves 11 GB/s on an
 // MI355X host (every page of the mapping is faulted in on the way; 56 GB/s once they are), so the 14 GB of a human-scale
 // .issl took 0.6 - 0.8 s of a one-shot scorer's second.  Here a few threads pread() the file into a ring of pinned chunks
 // and every chunk goes out with its own asynchronous copy: 48 - 53 GB/s, the link's rate (tools/ubench_h2d.cpp,
 // profiles/r05_ubench_h2d.txt).  Anything that is not file-backed, or small, takes the plain copy.
+// Sections are QUEUED (begin) and waited for one by one (wait): the readers go from the last chunk of one section
+// straight to the first of the next while the caller launches the kernels that consume the section that has landed.
+// Every reader pins its own two slots when it first needs them (pinning costs ~0.3 ms per MiB: 80 ms for the whole ring
+// in one go, before the first byte moved), and the ring is given back on a thread of its own (release_async: another
+// 40 ms nobody has to wait for).
 class FileUploader {
   public:
     // chunk_kib: bytes per pinned slot (default 16 MiB); min_kib: sections smaller than this take the plain copy (default 64 MiB).
     // Both from the upload_chunk_kib / upload_ring_min_kib knobs: tests send a 10 MB golden index through a ring of 64 KiB slots.
-    FileUploader(size_t chunk_kib, size_t min_kib) : chunk_(std::max<size_t>(chunk_kib, 4) << 10), min_bytes_(min_kib << 10) {}
-    ~FileUploader() { release(); }
-    int copy(const HostIndex &h, void *dst, const void *src, size_t bytes)
+    FileUploader(size_t chunk_kib, size_t min_kib, int threads)
+        : chunk_(std::max<size_t>(chunk_kib, 4) << 10), min_bytes_(min_kib << 10), n_threads_(static_cast<uint32_t>(std::min(std::max(threads, 1), static_cast<int>(kMaxThreads)))) {}
+    ~FileUploader() { abandon_ = true; release(); } // (an upload that failed half way: what is still queued is dropped)
+    FileUploader(const FileUploader &) = delete;
+    FileUploader &operator=(const FileUploader &) = delete;
+
+    // Queue a section; *ticket names it for wait().  Plain copies are done before this returns.
+    int begin(const HostIndex &h, void *dst, const void *src, size_t bytes, int *ticket)
     {
         int fd = -1;
         uint64_t off = 0;
+        std::unique_ptr<Job> job(new (std::nothrow) Job());
+        if (!job) { set_error("out of memory"); return ISSL_E_NOMEM; }
         if (bytes < std::max<size_t>(min_bytes_, 1) || !h.file_range(src, bytes, &fd, &off) || !ensure()) {
             HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+            job->recorded = true; // (nothing to wait for)
+            std::lock_guard<std::mutex> lock(mu_);
+            jobs_.push_back(std::move(job));
+            *ticket = static_cast<int>(jobs_.size() - 1);
             return ISSL_OK;
         }
-        const size_t kChunk = chunk_;
-        const size_t n_chunks = (bytes + kChunk - 1) / kChunk;
-        std::atomic<size_t> next{0};
-        std::atomic<int> failed{0};
-        int device = 0;
-        (void)hipGetDevice(&device);
-        auto work = [&](uint32_t w) {
-            (void)hipSetDevice(device);
-            for (uint32_t turn = 0;; ++turn) {
-                const size_t c = next.fetch_add(1);
-                if (c >= n_chunks || failed.load()) break;
-                const uint32_t slot = w + (turn & 1u) * kThreads; // every thread alternates between its two slots
-                if (hipEventSynchronize(ev_[slot]) != hipSuccess) { failed = 1; break; } // the slot's previous copy has left it
-                const size_t len = std::min(kChunk, bytes - c * kChunk);
-                size_t got = 0;
-                while (got < len) {
-                    const ssize_t k = ::pread(fd, static_cast<char *>(pin_[slot]) + got, len - got, static_cast<off_t>(off + c * kChunk + got));
-                    if (k < 0 && errno == EINTR) continue;
-                    if (k <= 0) { failed = 2; break; }
-                    got += static_cast<size_t>(k);
-                }
-                if (got < len) break;
-                std::lock_guard<std::mutex> lock(mu_);
-                if (hipMemcpyAsync(static_cast<char *>(dst) + c * kChunk, pin_[slot], len, hipMemcpyHostToDevice, stream_) != hipSuccess ||
-                    hipEventRecord(ev_[slot], stream_) != hipSuccess) { failed = 1; break; }
-            }
-        };
-        {
-            std::vector<std::thread> pool;
-            for (uint32_t w = 1; w < kThreads; ++w) pool.emplace_back(work, w);
-            work(0);
-            for (auto &th : pool) th.join();
+        job->fd = fd;
+        job->off = off;
+        job->dst = static_cast<char *>(dst);
+        job->src = static_cast<const char *>(src);
+        job->bytes = bytes;
+        job->n_chunks = (bytes + chunk_ - 1) / chunk_;
+        if (hipEventCreateWithFlags(&job->landed, hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            set_error("HIP error: cannot create an event for a section of the index");
+            return ISSL_E_DEVICE;
         }
-        HIP_TRY(hipStreamSynchronize(stream_));
-        if (failed.load() == 2) { set_error("Error reading index: the file shrank or could not be read while it was uploaded"); return ISSL_E_IO; }
-        if (failed.load()) { (void)hipGetLastError(); set_error("HIP error while a section of the index was uploaded"); return ISSL_E_DEVICE; }
+        {
+            std::lock_guard<std::mutex> lock(mu_);
+            jobs_.push_back(std::move(job));
+            *ticket = static_cast<int>(jobs_.size() - 1);
+            if (pool_.empty()) {
+                (void)hipGetDevice(&device_);
+                for (uint32_t w = 0; w < n_threads_; ++w) pool_.emplace_back([this, w] { work(w); });
+            }
+        }
+        cv_work_.notify_all();
         return ISSL_OK;
     }
+    // Returns when the section has landed in device memory (or could not be read).
+    int wait(int ticket)
+    {
+        Job *j = nullptr;
+        {
+            std::unique_lock<std::mutex> lock(mu_);
+            if (ticket < 0 || static_cast<size_t>(ticket) >= jobs_.size()) { set_error("internal: no such upload section"); return ISSL_E_STATE; }
+            j = jobs_[static_cast<size_t>(ticket)].get();
+            cv_done_.wait(lock, [&] { return j->recorded; });
+        }
+        if (j->landed && !j->failed.load()) HIP_TRY(hipEventSynchronize(j->landed));
+        if (j->failed.load() == 2) { set_error("Error reading index: the file shrank or could not be read while it was uploaded"); return ISSL_E_IO; }
+        if (j->failed.load()) { (void)hipGetLastError(); set_error("HIP error while a section of the index was uploaded"); return ISSL_E_DEVICE; }
+        return ISSL_OK;
+    }
+    int copy(const HostIndex &h, void *dst, const void *src, size_t bytes)
+    {
+        int t = -1;
+        if (int rc = begin(h, dst, src, bytes, &t)) return rc;
+        return wait(t);
+    }
+    // Stops the readers (they finish what is queued) and frees everything.
     void release()
     {
-        if (block_) (void)hipHostFree(block_);
-        block_ = nullptr;
-        for (void *&p : pin_) p = nullptr;
-        for (hipEvent_t &e : ev_) { if (e) (void)hipEventDestroy(e); e = nullptr; }
-        if (stream_) (void)hipStreamDestroy(stream_);
-        stream_ = nullptr;
-        ready_ = false;
+        std::vector<void *> pins = stop();
+        for (void *p : pins) (void)hipHostFree(p);
     }
+    double pin_ms() const { return pin_us_.load() * 1e-3; } // summed over the readers (they pin side by side)
 
   private:
-    static constexpr uint32_t kThreads = 8;
-    const size_t chunk_;     // 16 slots of 16 MiB by default: 256 MiB of pinned memory while an upload lasts (pinning costs ~0.2 ms per MiB)
+    static constexpr uint32_t kMaxThreads = 32;
+    struct Job {
+        int fd = -1;
+        uint64_t off = 0;
+        char *dst = nullptr;
+        const char *src = nullptr;
+        size_t bytes = 0, n_chunks = 0;
+        size_t next = 0, issued = 0; // under mu_
+        std::atomic<int> failed{0};
+        hipEvent_t landed = nullptr; // recorded behind the section's last copy
+        bool recorded = false;       // under mu_: every chunk has been issued (or given up)
+    };
+    const size_t chunk_; // 16 slots of 16 MiB by default: 256 MiB of pinned memory while an upload lasts
     const size_t min_bytes_;
-    bool ensure()
+    const uint32_t n_threads_; // readers (upload_threads knob, default 8)
+
+    bool ensure() // the copy stream; false: plain copies from here on
     {
-        if (ready_) return true;
+        if (stream_) return true;
         if (tried_) return false;
         tried_ = true;
         if (hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); stream_ = nullptr; return false; }
-        const size_t kChunk = chunk_;
-        if (hipHostMalloc(&block_, 2 * kThreads * kChunk, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); block_ = nullptr; release(); return false; }
-        for (uint32_t i = 0; i < 2 * kThreads; ++i) {
-            pin_[i] = static_cast<char *>(block_) + i * kChunk;
-            if (hipEventCreateWithFlags(&ev_[i], hipEventDisableTiming) != hipSuccess) {
-                (void)hipGetLastError();
-                release();
-                return false;
-            }
-        }
-        ready_ = true;
         return true;
     }
-    void *block_ = nullptr; // one pinned allocation, cut into the slots
-    void *pin_[2 * kThreads] = {};
-    hipEvent_t ev_[2 * kThreads] = {};
+    void work(uint32_t w)
+    {
+        (void)hipSetDevice(device_);
+        for (uint32_t turn = 0;; ++turn) {
+            Job *j = nullptr;
+            size_t c = 0;
+            {
+                std::unique_lock<std::mutex> lock(mu_);
+                for (;;) {
+                    while (head_ < jobs_.size() && jobs_[head_]->next >= jobs_[head_]->n_chunks) ++head_;
+                    if (head_ < jobs_.size()) break;
+                    if (stop_) return;
+                    cv_work_.wait(lock);
+                }
+                j = jobs_[head_].get();
+                c = j->next++;
+            }
+            const uint32_t slot = w + (turn & 1u) * kMaxThreads; // every reader alternates between its two slots
+            const size_t len = std::min(chunk_, j->bytes - c * chunk_);
+            bool issued_here = false;
+            if (!j->failed.load() && !abandon_.load()) {
+                if (!pin_[slot] && !no_pin_[slot]) { // first use: pin it (side by side with the other readers)
+                    const double t0 = wall_ms();
+                    if (hipHostMalloc(&pin_[slot], chunk_, hipHostMallocDefault) != hipSuccess ||
+                        hipEventCreateWithFlags(&ev_[slot], hipEventDisableTiming) != hipSuccess) {
+                        (void)hipGetLastError();
+                        if (pin_[slot]) (void)hipHostFree(pin_[slot]);
+                        pin_[slot] = nullptr;
+                        no_pin_[slot] = true;
+                    }
+                    pin_us_ += static_cast<long long>((wall_ms() - t0) * 1e3);
+                }
+                if (!pin_[slot]) { // no pinned memory to be had: this chunk straight from the mapping
+                    if (hipMemcpy(j->dst + c * chunk_, j->src + c * chunk_, len, hipMemcpyHostToDevice) != hipSuccess) j->failed = 1;
+                } else if (hipEventSynchronize(ev_[slot]) != hipSuccess) { // the slot's previous copy has left it
+                    j->failed = 1;
+                } else {
+                    size_t got = 0;
+                    while (got < len) {
+                        const ssize_t k = ::pread(j->fd, static_cast<char *>(pin_[slot]) + got, len - got, static_cast<off_t>(j->off + c * chunk_ + got));
+                        if (k < 0 && errno == EINTR) continue;
+                        if (k <= 0) { j->failed = 2; break; }
+                        got += static_cast<size_t>(k);
+                    }
+                    if (got == len) {
+                        std::lock_guard<std::mutex> lock(mu_); // one thread at a time talks to the stream
+                        if (hipMemcpyAsync(j->dst + c * chunk_, pin_[slot], len, hipMemcpyHostToDevice, stream_) != hipSuccess ||
+                            hipEventRecord(ev_[slot], stream_) != hipSuccess) j->failed = 1;
+                        finish_chunk(j);
+                        issued_here = true;
+                    }
+                }
+            }
+            if (!issued_here) {
+                std::lock_guard<std::mutex> lock(mu_);
+                finish_chunk(j);
+            }
+        }
+    }
+    void finish_chunk(Job *j) // under mu_
+    {
+        if (++j->issued < j->n_chunks) return;
+        if (!j->failed.load() && hipEventRecord(j->landed, stream_) != hipSuccess) j->failed = 1;
+        j->recorded = true;
+        cv_done_.notify_all();
+    }
+    std::vector<void *> stop()
+    {
+        {
+            std::lock_guard<std::mutex> lock(mu_);
+            stop_ = true;
+        }
+        cv_work_.notify_all();
+        for (auto &th : pool_) th.join();
+        pool_.clear();
+        if (stream_) (void)hipStreamSynchronize(stream_);
+        std::vector<void *> pins;
+        for (uint32_t i = 0; i < 2 * kMaxThreads; ++i) {
+            if (pin_[i]) pins.push_back(pin_[i]);
+            pin_[i] = nullptr;
+            if (ev_[i]) (void)hipEventDestroy(ev_[i]);
+            ev_[i] = nullptr;
+            no_pin_[i] = false;
+        }
+        for (auto &j : jobs_) if (j->landed) { (void)hipEventDestroy(j->landed); j->landed = nullptr; }
+        jobs_.clear();
+        head_ = 0;
+        if (stream_) (void)hipStreamDestroy(stream_);
+        stream_ = nullptr;
+        stop_ = false;
+        tried_ = false;
+        return pins;
+    }
+    void *pin_[2 * kMaxThreads] = {};   // slot w and w + kMaxThreads belong to reader w alone
+    hipEvent_t ev_[2 * kMaxThreads] = {};
+    bool no_pin_[2 * kMaxThreads] = {};
     hipStream_t stream_ = nullptr;
-    std::mutex mu_; // one thread at a time talks to the stream
-    bool ready_ = false, tried_ = false;
+    int device_ = 0;
+    std::mutex mu_; // the queue, the sections' counts, the stream
+    std::condition_variable cv_work_, cv_done_;
+    std::vector<std::unique_ptr<Job>> jobs_;
+    size_t head_ = 0; // first section that still has chunks to hand out
+    std::vector<std::thread> pool_;
+    bool stop_ = false, tried_ = false;
+    std::atomic<bool> abandon_{false};
+    std::atomic<long long> pin_us_{0};
 };
 
 static int finish_upload(issl_index *ix, const DeviceBuildInput *dbi = nullptr)
 {
-    // sections that are plain copies
     const HostIndex &h = *ix->host;
     const Geometry &g = h.geo;
     const uint64_t nb = g.n_buckets();
+    const double t_tables = wall_ms();
     const hipMemcpyKind dbi_kind = (dbi && dbi->on_device) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
     uint8_t *base = static_cast<uint8_t *>(ix->d_image);
-    std::vector<uint64_t> bstart(nb + 1);
-    std::vector<uint32_t> tfirst(nb + 1);
-    bstart[0] = 0;
-    tfirst[0] = 0;
-    for (uint64_t b = 0; b < nb; ++b) {
-        bstart[b + 1] = bstart[b] + h.sizes[b];
-        tfirst[b + 1] = tfirst[b] + static_cast<uint32_t>((h.sizes[b] + kTileCands - 1) / kTileCands);
-    }
+    // The big sections of a file-mapped index are queued first: the readers pin their slots and fill them while this
+    // thread makes the tables below (the process's first copy also loads the runtime's copy kernels: 40 ms).
+    FileUploader from_file(ix->tuning.upload_chunk_kib, ix->tuning.upload_ring_min_kib, ix->tuning.upload_threads);
+    const bool lists_to_image = !dbi && !ix->hdr.lists_absent && !(ix->hdr.cold_on_host & 1u); // slice lists: file -> image, slice by slice
+    const bool sites_to_image = !dbi && !(ix->hdr.cold_on_host & 2u);
+    int t_sites = -1;
+    std::vector<int> t_list(g.n_slices, -1);
+    uint64_t *const img_entries = reinterpret_cast<uint64_t *>(base + ix->hdr.off_entries);
+    auto begin_list = [&](uint64_t sl) -> int { // (two sections at most are queued ahead of the one waited for)
+        if (!lists_to_image || sl >= g.n_slices || t_list[sl] >= 0) return ISSL_OK;
+        return from_file.begin(h, img_entries + sl * g.n_sites, h.entries + sl * g.n_sites, 8 * g.n_sites, &t_list[sl]);
+    };
+    if (sites_to_image)
+        if (int crc = from_file.begin(h, base + ix->hdr.off_sites, h.sites, 8 * g.n_sites, &t_sites)) return crc;
+    if (int crc = begin_list(0)) return crc;
+    // the head of the image -- header, bucket tables, score tables: contiguous -- as ONE copy
     std::vector<uint64_t> masks;
     std::vector<double> vals;
     h.unique_scores(masks, vals);
-    HIP_TRY(hipMemcpy(base, &ix->hdr, sizeof(ImageHeader), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(base + ix->hdr.off_bucket_start, bstart.data(), 8 * (nb + 1), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(base + ix->hdr.off_tile_first, tfirst.data(), 4 * (nb + 1), hipMemcpyHostToDevice));
-    if (!masks.empty()) {
-        HIP_TRY(hipMemcpy(base + ix->hdr.off_score_mask, masks.data(), 8 * masks.size(), hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(base + ix->hdr.off_score_val, vals.data(), 8 * vals.size(), hipMemcpyHostToDevice));
-    }
-    if (ix->hdr.off_mit_dense) {
-        std::vector<double> dense(size_t(1) << 20, 0.0);
-        for (size_t i = 0; i < masks.size(); ++i) dense[dense_index(masks[i])] = vals[i];
-        HIP_TRY(hipMemcpy(base + ix->hdr.off_mit_dense, dense.data(), 8 * dense.size(), hipMemcpyHostToDevice));
+    std::vector<uint32_t> tfirst(nb + 1);
+    {
+        const uint64_t head_end = ix->hdr.off_mit_dense ? ix->hdr.off_mit_dense + 8ull * (1u << 20) : ix->hdr.off_score_val + 8 * masks.size();
+        std::vector<uint8_t> head(head_end, 0);
+        std::memcpy(head.data(), &ix->hdr, sizeof(ImageHeader));
+        uint64_t *bstart = reinterpret_cast<uint64_t *>(head.data() + ix->hdr.off_bucket_start);
+        bstart[0] = 0;
+        tfirst[0] = 0;
+        for (uint64_t b = 0; b < nb; ++b) {
+            bstart[b + 1] = bstart[b] + h.sizes[b];
+            tfirst[b + 1] = tfirst[b] + static_cast<uint32_t>((h.sizes[b] + kTileCands - 1) / kTileCands);
+        }
+        std::memcpy(head.data() + ix->hdr.off_tile_first, tfirst.data(), 4 * (nb + 1));
+        if (!masks.empty()) {
+            std::memcpy(head.data() + ix->hdr.off_score_mask, masks.data(), 8 * masks.size());
+            std::memcpy(head.data() + ix->hdr.off_score_val, vals.data(), 8 * vals.size());
+        }
+        if (ix->hdr.off_mit_dense) {
+            double *dense = reinterpret_cast<double *>(head.data() + ix->hdr.off_mit_dense);
+            for (size_t i = 0; i < masks.size(); ++i) dense[dense_index(masks[i])] = vals[i];
+        }
+        HIP_TRY(hipMemcpy(base, head.data(), head_end, hipMemcpyHostToDevice));
     }
     ix->view = make_view(ix->hdr, ix->d_image, ix->d_cold);
     DevTemp flag_mem, occ_mem;
@@ -621,8 +764,8 @@ static int finish_upload(issl_index *ix, const DeviceBuildInput *dbi = nullptr)
         HIP_TRY(hipMemset(seen_mem.p, 0, 4 * words));
         seen = static_cast<uint32_t *>(seen_mem.p);
     }
+    upload_note(ix, "bucket tables, score table (the file's sections are on their way)", t_tables);
     double t0 = wall_ms();
-    FileUploader from_file(ix->tuning.upload_chunk_kib, ix->tuning.upload_ring_min_kib);
     if (ix->hdr.off_sub_start) {
         // Sorted layouts.  Site table and counts into the image, then one slice at a time: the slice's list (in the
         // image, or -- lists in pinned host memory -- in a temporary 8 B/site device copy), the successor-byte order
@@ -631,7 +774,7 @@ static int finish_upload(issl_index *ix, const DeviceBuildInput *dbi = nullptr)
         uint64_t *d_sites = reinterpret_cast<uint64_t *>(base + ix->hdr.off_sites);
         uint32_t *d_site_occ = reinterpret_cast<uint32_t *>(base + ix->hdr.off_site_occ);
         if (dbi) HIP_TRY(hipMemcpy(d_sites, dbi->sigs, 8 * n, dbi_kind));
-        else if (int crc = from_file.copy(h, d_sites, h.sites, 8 * n)) return crc;
+        else if (int crc = from_file.wait(t_sites)) return crc;
         if (dbi) HIP_TRY(hipMemcpy(d_site_occ, dbi->occ, 4 * n, dbi_kind)); // (k_fill_maps writes the same again)
         upload_note(ix, "sites", t0);
         t0 = wall_ms();
@@ -667,8 +810,10 @@ static int finish_upload(issl_index *ix, const DeviceBuildInput *dbi = nullptr)
         for (uint64_t sl = 0; sl < g.n_slices; ++sl) {
             uint64_t *const t_list_mem = lent_list ? lent_list : static_cast<uint64_t *>(list_mem.p);
             const uint64_t *d_list = lists_cold ? t_list_mem : d_entries + sl * n;
-            if (stream_lists)
-                if (int crc = from_file.copy(h, d_entries + sl * n, h.entries + sl * n, 8 * n)) return crc;
+            if (stream_lists) {
+                if (int crc = begin_list(sl + 1)) return crc;
+                if (int crc = from_file.wait(t_list[sl])) return crc;
+            }
             if (lists_cold) {
                 uint64_t *t_list = t_list_mem;
                 if (dbi) {
@@ -705,7 +850,7 @@ static int finish_upload(issl_index *ix, const DeviceBuildInput *dbi = nullptr)
     } else if (!ix->hdr.cold_on_host) {
         // (file-mapped host arrays go through FileUploader's pinned ring, everything else through plain copies)
         if (dbi) HIP_TRY(hipMemcpy(base + ix->hdr.off_sites, dbi->sigs, 8 * g.n_sites, dbi_kind));
-        else if (int crc = from_file.copy(h, base + ix->hdr.off_sites, h.sites, 8 * g.n_sites)) return crc;
+        else if (int crc = from_file.wait(t_sites)) return crc;
         upload_note(ix, "sites", t0);
         t0 = wall_ms();
         if (dbi) { // isslCreateIndex.cpp:218-234 on the device
@@ -722,9 +867,9 @@ static int finish_upload(issl_index *ix, const DeviceBuildInput *dbi = nullptr)
         } else {
             // scan stream: built on the device from sites + entries, one slice at a time: the kernel that packs slice s runs
             // while the list of slice s + 1 is on its way (a slice's buckets own a contiguous run of tiles)
-            uint64_t *d_entries = reinterpret_cast<uint64_t *>(base + ix->hdr.off_entries);
             for (uint64_t sl = 0; sl < g.n_slices; ++sl) {
-                if (int crc = from_file.copy(h, d_entries + sl * g.n_sites, h.entries + sl * g.n_sites, 8 * g.n_sites)) return crc;
+                if (int crc = begin_list(sl + 1)) return crc;
+                if (int crc = from_file.wait(t_list[sl])) return crc;
                 launch_pack_scan_range(ix->view, scan_out, ix->hdr.off_esig ? reinterpret_cast<uint64_t *>(base + ix->hdr.off_esig) : nullptr,
                                        nullptr, flag, seen, tfirst[sl << g.slice_width], tfirst[(sl + 1) << g.slice_width], nullptr);
                 HIP_TRY(hipGetLastError());
@@ -773,6 +918,10 @@ static int finish_upload(issl_index *ix, const DeviceBuildInput *dbi = nullptr)
     uint32_t err = 0;
     HIP_TRY(hipMemcpy(&err, flag, 4, hipMemcpyDeviceToHost));
     upload_note(ix, "scan stream", t0);
+    if (ix->tuning.upload_timing) std::fprintf(stderr, "[issl upload] (pinning the ring: %.1f ms, summed over the readers)\n", from_file.pin_ms());
+    const double t_ring = wall_ms();
+    from_file.release();
+    upload_note(ix, "pinned ring given back", t_ring);
     if (err & 1u) {
         set_error("Error reading index: a slice entry refers to an off-target id beyond the site table");
         return ISSL_E_FORMAT;
@@ -1341,6 +1490,7 @@ int issl_index_get_option(const issl_index *idx, const char *key, long long *val
     else if (k == "scan_threads") *value = t.scan_threads;
     else if (k == "upload_chunk_kib") *value = static_cast<long long>(t.upload_chunk_kib);
     else if (k == "upload_ring_min_kib") *value = static_cast<long long>(t.upload_ring_min_kib);
+    else if (k == "upload_threads") *value = t.upload_threads;
     else if (k == "item_guides") *value = t.item_guides;
     else if (k == "scan_generic") *value = t.scan_generic;
     else if (k == "stage_timing") *value = t.stage_timing;

@@ -154,6 +154,7 @@ struct Tuning {
     uint32_t scan_blocks;   // ISSL_SCAN_BLOCKS   workgroups of the scan launch
     uint32_t scan_threads;  // ISSL_SCAN_THREADS  threads per scan workgroup (64 .. 1024, a multiple of 64; default 1024 = 16 waves: two workgroups
                             //                    per CU = 8 waves per SIMD; 768: 6 per SIMD) -- an occupancy experiment, not a tuning knob
+    int upload_threads; // ISSL_UPLOAD_THREADS: readers of the ring below (1..32, default 8)
     size_t upload_chunk_kib, upload_ring_min_kib; // ISSL_UPLOAD_CHUNK_KIB / ISSL_UPLOAD_RING_MIN_KIB: the pinned ring a file-mapped index is uploaded through (FileUploader,
                             //                    issl_capi.cpp): KiB per slot (default 16384) and the section size from which it is used (default 65536); tests
     uint32_t item_guides;   // ISSL_ITEM_GUIDES   guides per scan item (multiple of 8, <= kItemGuides)

@@ -242,10 +242,13 @@ int issl_index_attach_image_cold(int device, void *dev_buf, size_t bytes, void *
  *   lean_tail (ISSL_LEAN_TAIL) 0|1 (default 1): a handle whose finished batches met no guide beyond its hit slots
  *     enqueues the next ones without the grouping pass and the three many-hit replays (five dependent launches that
  *     would find nothing to do: 25 us of every batch); a batch that does meet such a guide is run again in full
- *   upload_chunk_kib, upload_ring_min_kib (ISSL_UPLOAD_CHUNK_KIB, ISSL_UPLOAD_RING_MIN_KIB): the ring of pinned chunks a
- *     file-mapped index is uploaded through (eight threads pread the file into sixteen slots, every slot leaves with its
- *     own asynchronous copy: the PCIe link's rate, where hipMemcpy from the fresh mapping moves a fifth of it): KiB per
- *     slot (default 16384) and the section size from which the ring is used (default 65536)
+ *   upload_chunk_kib, upload_ring_min_kib, upload_threads (ISSL_UPLOAD_CHUNK_KIB, ISSL_UPLOAD_RING_MIN_KIB,
+ *     ISSL_UPLOAD_THREADS): the ring of pinned chunks a file-mapped index is uploaded through (eight threads pread the
+ *     file into two slots each, every slot leaves with its own asynchronous copy: the PCIe link's rate, where hipMemcpy
+ *     from the fresh mapping moves a fifth of it; the sections are queued one behind the other, every reader pins its
+ *     slots when it first needs them, and the ring goes back on a thread of its own after the handle's first scoring
+ *     call -- or at issl_index_close): KiB per slot (default 16384), the section size from which the ring is used
+ *     (default 65536), readers (1..32, default 8)
  *   scan_threads (ISSL_SCAN_THREADS) 64..1024: threads per scan workgroup (default 1024 = 8 waves per SIMD; an occupancy
  *     experiment)
  *   prune (ISSL_PRUNE) -1|0|1: scan only the successor-byte groups of a bucket that can hold a site within max_dist (13

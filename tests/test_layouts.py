@@ -340,18 +340,19 @@ def test_a_site_in_a_foreign_bucket_or_listed_twice_is_a_format_error(golden_uni
 @pytest.mark.parametrize("layout", [None, "compact", "compact_bare", "compact_cold", "list_esig", "host_cold"])
 def test_upload_through_the_pinned_ring(name, layout):
     """A file-mapped index reaches the device through a ring of pinned chunks filled by pread (FileUploader: the link's rate
-    instead of a fifth of it), its slice lists one slice at a time beside the kernels that order / pack them.  Sections below 64
+    instead of a fifth of it), its sections queued one behind the other and waited for one by one: the slice lists land beside the
+    kernels that order / pack the slice before.  Sections below 64
     MiB take the plain copy, so the golden indexes never see the ring by themselves: here they do -- slots of 64 KiB (and of 4
     KiB: a chunk then ends inside every few hundred entries), no minimum size, the 9.7 MB index in ~150 (~2400) chunks that end
     inside sections -- and every reference stdout and hit list must come out as through the plain copy."""
     g = Golden(name)
     sigs = ca.encode_guides([s.encode() for s in g.guides])
-    for chunk_kib in (64, 4):
+    for chunk_kib, readers in ((64, 8), (4, 3)):
         ix = ca.IsslIndex.open(g.issl)
         if layout:
             for key, value in LAYOUTS[layout].items():
                 ix.set_option(key, value)
-        ix.set_option("upload_chunk_kib", chunk_kib).set_option("upload_ring_min_kib", 0)
+        ix.set_option("upload_chunk_kib", chunk_kib).set_option("upload_ring_min_kib", 0).set_option("upload_threads", readers)
         ix.upload(0)
         try:
             if layout:
