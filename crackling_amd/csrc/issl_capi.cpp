@@ -124,13 +124,15 @@ Tuning Tuning::from_env()
     t.tail_shapes = 1;
     t.hit_slots = 1;
     t.lean_tail = 1;
+    t.small_bin = 1;
+    t.fine_items = 0;
     t.lanes = 1;
     static const char *const keys[][2] = {
         {"ISSL_SCAN_BLOCKS", "scan_blocks"}, {"ISSL_SCAN_THREADS", "scan_threads"}, {"ISSL_UPLOAD_CHUNK_KIB", "upload_chunk_kib"}, {"ISSL_UPLOAD_RING_MIN_KIB", "upload_ring_min_kib"}, {"ISSL_UPLOAD_THREADS", "upload_threads"}, {"ISSL_ITEM_GUIDES", "item_guides"},
         {"ISSL_SCAN_GENERIC", "scan_generic"}, {"ISSL_STAGE_TIMING", "stage_timing"}, {"ISSL_RAW_CHUNKS", "raw_chunks"},
         {"ISSL_INLINE_SIGS", "inline_sigs"}, {"ISSL_FORCE_HOST_COLD", "host_cold"}, {"ISSL_SCAN_STAMPS", "scan_stamps"},
         {"ISSL_SORTED_LAYOUT", "sorted_layout"}, {"ISSL_PRUNE", "prune"}, {"ISSL_LANES", "lanes"},
-        {"ISSL_COMPACT", "compact"}, {"ISSL_TAIL_SHAPES", "tail_shapes"}, {"ISSL_HIT_SLOTS", "hit_slots"}, {"ISSL_LEAN_TAIL", "lean_tail"},
+        {"ISSL_COMPACT", "compact"}, {"ISSL_TAIL_SHAPES", "tail_shapes"}, {"ISSL_HIT_SLOTS", "hit_slots"}, {"ISSL_LEAN_TAIL", "lean_tail"}, {"ISSL_SMALL_BIN", "small_bin"}, {"ISSL_FINE_ITEMS", "fine_items"},
         {"ISSL_KEEP_LISTS", "keep_lists"},
     };
     for (const auto &k : keys)
@@ -163,6 +165,8 @@ bool Tuning::set(const char *key, const char *value)
     else if (k == "lanes") { if (!is_int || n < 1 || n > 3) return false; lanes = static_cast<int>(n); }
     else if (k == "tail_shapes") { if (!is_int || n < 0 || n > 1) return false; tail_shapes = static_cast<int>(n); }
     else if (k == "lean_tail") { if (!is_int || n < 0 || n > 1) return false; lean_tail = static_cast<int>(n); }
+    else if (k == "small_bin") { if (!is_int || n < 0 || n > 1) return false; small_bin = static_cast<int>(n); }
+    else if (k == "fine_items") { if (!is_int || n < 0) return false; fine_items = static_cast<size_t>(n); }
     else if (k == "hit_slots") { if (!is_int || n < 0 || n > 2) return false; hit_slots = static_cast<int>(n); }
     else if (k == "scan_stamps") stamps_path = value;
     else return false;
@@ -393,7 +397,8 @@ static int ensure_workspace(issl_index *ix, size_t n, Lane &lane, uint32_t fine_
         // sites / 65536 candidates per group -- sites / 4096 with 4-bit slices --, +1.2 tiles for the ends); a batch that needs more scans whole buckets
         // and reports it (sticky[3]), finish_batches() then enlarges the list for the next one
         const size_t tiles_per_group = static_cast<size_t>(ix->hdr.n_sites * ix->hdr.n_slices / (static_cast<uint64_t>(nb) * 256ull * kTileCands)) + 4;
-        const size_t fitems = std::max<size_t>(tiles_per_group * (groups + places / 64) + 2, w.cap_fitems);
+        // (fine_items knob: start with a short list -- tests of the two ways out of a list that is too short)
+        const size_t fitems = std::max<size_t>(tn.fine_items ? tn.fine_items : tiles_per_group * (groups + places / 64) + 2, w.cap_fitems);
         if ((rc = dev_alloc(w.fword, fslots + 64))) return rc; // (+ slack: short_unit_masks reads whole groups of 32 slots)
         if ((rc = dev_alloc(w.fmeta, fslots))) return rc;
         if ((rc = dev_alloc(w.fitems, fitems + 1))) return rc;
@@ -1112,7 +1117,7 @@ static int enqueue_batch(issl_index *ix, Lane &lane, hipStream_t stream, const u
         HIP_TRY(hipStreamWaitEvent(tail, ix->ring[2 * slot + 1], 0));
         ix->prev_scan_end = ix->ring[2 * slot + 1];
     }
-    launch_verify(ix->view, ws, d_guides, p, tail);
+    launch_verify(ix->view, ws, d_guides, static_cast<uint32_t>(n), p, tail);
     if (staged) HIP_TRY(hipEventRecord(lane.ev[3], tail));
     launch_group_hits(ws, n32, tail);
     if (staged) HIP_TRY(hipEventRecord(lane.ev[4], tail));
@@ -1506,6 +1511,8 @@ int issl_index_get_option(const issl_index *idx, const char *key, long long *val
     else if (k == "tail_shapes") *value = t.tail_shapes;
     else if (k == "hit_slots") *value = t.hit_slots;
     else if (k == "lean_tail") *value = t.lean_tail;
+    else if (k == "small_bin") *value = t.small_bin;
+    else if (k == "fine_items") *value = static_cast<long long>(t.fine_items);
     else if (k == "is_sorted") *value = idx->d_image ? ((idx->hdr.off_srec || idx->hdr.off_sid) ? 1 : 0) : -1; // read-only
     else if (k == "is_compact") *value = idx->d_image ? (idx->hdr.off_sid ? 1 : 0) : -1;                   // read-only
     else if (k == "cold_on_host") *value = idx->d_image ? (idx->hdr.cold_on_host ? 1 : 0) : -1;            // read-only: layout in use

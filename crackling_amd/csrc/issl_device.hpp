@@ -175,6 +175,9 @@ struct Tuning {
                             //                    per pass on 16 / 8 candidates per lane; 0: every unit is a full one (A/B)
     int hit_slots;          // ISSL_HIT_SLOTS     1 (default): Workspace::slot_hits = kSlotHits when the arrays fit (kSlotHitsWide once a batch has shown
                             //                    many guides beyond that); 0: never; 2: kSlotHitsWide from the first batch on (A/B, tests)
+    size_t fine_items;      // ISSL_FINE_ITEMS    0 (default): the pruned plan's item list is sized from the index; n: it starts with room for n items
+    int small_bin;          // ISSL_SMALL_BIN     1 (default): batches of up to 8192 placements (102 guides of five slices) are binned by ONE workgroup
+                            // in one launch instead of seven (k_bin_small); 0: always the general kernels
     int lean_tail;          // ISSL_LEAN_TAIL     1 (default): a lane whose batches meet no guide beyond its hit slots enqueues the next ones
                             //                    without the grouping pass and the many-hit replays (Workspace::lean_tail); 0: never (A/B)
     int lanes;              // ISSL_LANES         1|2|3 (default 1; 3: only the binning of a batch beside the batch before it): workspaces + streams that asynchronous batches alternate
@@ -444,7 +447,7 @@ void launch_bin_guides(const ImageView &v, const Workspace &ws, const Tuning &tn
                        uint32_t prune_mode, void *stream);
 void launch_scan(const ImageView &v, const Workspace &ws, const Tuning &tn, const uint64_t *d_guides, uint32_t n,
                  int max_dist, uint32_t prune_mode, void *stream);
-void launch_verify(const ImageView &v, const Workspace &ws, const uint64_t *d_guides, const ScoreParams &p, void *stream);
+void launch_verify(const ImageView &v, const Workspace &ws, const uint64_t *d_guides, uint32_t n, const ScoreParams &p, void *stream);
 void launch_group_hits(const Workspace &ws, uint32_t n, void *stream);
 void launch_replay(const ImageView &v, const Workspace &ws, const uint64_t *d_guides, uint32_t n,
                    const ScoreParams &p, double *d_mit, double *d_cfd, uint32_t *d_kept, issl_hit *d_hitrec,

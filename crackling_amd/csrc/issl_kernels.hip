@@ -298,6 +298,7 @@ __device__ inline uint64_t block_exclusive_scan(uint64_t v, uint64_t *lds /*[256
 }
 
 // Start of cost range r of n_ranges (r == n_ranges: the end marker).
+template <bool COOP = false>
 __device__ __forceinline__ RangeStart range_start_of(const ScanItem *__restrict__ items, uint32_t n_items, uint64_t total,
                                                      uint32_t n_ranges, uint32_t r)
 {
@@ -310,6 +311,20 @@ __device__ __forceinline__ RangeStart range_start_of(const ScanItem *__restrict_
         // no 128-bit intermediate: costs < 2^50 and range counts <= 2^15
         const uint64_t lo = total / n_ranges * r + (total % n_ranges) * r / n_ranges;
         uint32_t a = 0, z = n_items; // last item with cost0 <= lo
+        if (COOP) {
+            // the whole wave looks for ONE range's start: 64 probes per round trip instead of one (a list of a million items: four
+            // dependent loads instead of twenty -- the chain was most of k_fine_ranges' 7 - 12 us)
+            const uint32_t lane = threadIdx.x & 63u;
+            while (z - a > 1) {
+                const uint32_t step = (z - a + 63u) / 64u;
+                const uint64_t pos = static_cast<uint64_t>(a) + static_cast<uint64_t>(lane + 1u) * step;
+                const bool le = pos < z && items[pos].cost0 <= lo;
+                const uint32_t k = static_cast<uint32_t>(__popcll(__ballot(le))); // (costs ascend: the lanes that say yes are the first k)
+                const uint64_t na = static_cast<uint64_t>(a) + static_cast<uint64_t>(k) * step, nz = na + step;
+                a = static_cast<uint32_t>(na);
+                if (nz < z) z = static_cast<uint32_t>(nz);
+            }
+        } else
         while (z - a > 1) {
             const uint32_t mid = (a + z) >> 1;
             if (items[mid].cost0 <= lo) a = mid; else z = mid;
@@ -797,8 +812,172 @@ __global__ __launch_bounds__(256) void k_fine_ranges(const PlanInfo *__restrict_
     short_kernel_priority();
     if (!plan->fine) return;
     const uint32_t n_ranges = plan->n_ranges;
-    const uint32_t r = blockIdx.x * 256 + threadIdx.x;
-    if (r <= n_ranges && n_ranges != 0) starts[r] = range_start_of(fitems, plan->n_items, plan->total_cost, n_ranges, r);
+    const uint32_t r = blockIdx.x * 4u + (threadIdx.x >> 6); // one wave per range start
+    if (r <= n_ranges && n_ranges != 0) {
+        const RangeStart st = range_start_of<true>(fitems, plan->n_items, plan->total_cost, n_ranges, r);
+        if ((threadIdx.x & 63u) == 0u) starts[r] = st;
+    }
+}
+
+// ---- a small batch: the whole binning in ONE launch -------------------------------------------------------------------
+// Seven dependent launches bin a batch (histogram, plan, scatter, group counts, group plan, group scatter, ranges); for a
+// page of a few dozen guides they are 48 us of a 110 us step, and nearly all of that is launch boundaries and the chains of
+// dependent loads behind each.  A batch of up to kSmallPairs (guide, slice) pairs (102 guides of five slices) is planned here
+// without any grouping: EVERY (guide, slice, way) placement becomes a group of its own -- eight slots, the guide in the
+// first --, so there is nothing to count, sort or scatter: one thread per (guide, slice) pair looks its 13 (or 1) groups up, a
+// prefix sum over the pairs lays out slots, items and costs.  One workgroup PER WAY: each of them makes the whole prefix
+// (loads that hit the L2) and writes the slots and items of its own way -- the stores of 4160 placements from one CU alone
+// took 40 us.  Two guides that would have shared a group fetch its units twice; at this size that is nothing.  Same slots /
+// items / plan as k_fine_* leave behind (k_fine_ranges follows); the bucket-level plan is not made (the host takes this path
+// only where the pruned plan wins anyway: small_bin_ok).
+constexpr uint32_t kSmallPairs = 512;
+
+__device__ inline uint64_t block512_exclusive_scan(uint64_t v, uint64_t *lds /*[8]*/, uint64_t *total)
+{
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint64_t incl = wave_inclusive_scan_u64(v);
+    if (lane == 63) lds[wave] = incl;
+    __syncthreads();
+    uint64_t before = 0, all = 0;
+    for (uint32_t w = 0; w < kSmallPairs / 64u; ++w) {
+        const uint64_t x = lds[w];
+        if (w < wave) before += x;
+        all += x;
+    }
+    if (total) *total = all;
+    __syncthreads();
+    return before + incl - v;
+}
+
+template <uint32_t WAYS>
+__global__ __launch_bounds__(kSmallPairs) void k_bin_small(ImageView v, Workspace ws, const uint64_t *__restrict__ guides, uint32_t n,
+                                                           uint32_t prune_mode, uint32_t tail_shapes, uint32_t scan_blocks,
+                                                           uint32_t sorted_layout)
+{
+    short_kernel_priority();
+    __shared__ uint64_t lds[kSmallPairs / 64u];
+    const uint32_t t = threadIdx.x, my_way = blockIdx.x; // gridDim.x == WAYS
+    // what k_guide_hist resets (shared out among the workgroups)
+    for (uint32_t k = my_way * kSmallPairs + t; k <= n; k += WAYS * kSmallPairs) ws.gcount[k] = 0;
+    for (uint32_t k = my_way * kSmallPairs + t; k <= ws.cap_chunks; k += WAYS * kSmallPairs) ws.raw_used[k] = 0;
+    if (t == 0 && my_way == 0) {
+        ws.scan_span[2u * ws.span_slot] = ~0ull;
+        ws.scan_span[2u * ws.span_slot + 1u] = 0ull;
+    }
+    const uint32_t pairs = n * v.n_slices;
+    const uint32_t low = (1u << v.slice_width) - 1u;
+    const bool mine = t < pairs;
+    const uint32_t g = mine ? t / v.n_slices : 0u, sl = mine ? t - g * v.n_slices : 0u;
+    // the pair's bucket, its 13 (1) groups and what they add; pairs in thread order, ways in order = the order of slots and items
+    uint64_t sig = 0, blen = 0, units = 0, cost = 0, cand = 0, ref = 0, valid = 0;
+    uint64_t cost_before = 0;               // ... of the pair's ways in front of this workgroup's
+    uint32_t units_before = 0, valid_before = 0;
+    uint32_t b = 0, gj = 0, tf = 0, my_s0 = 0, my_s1 = 0;
+    if (mine) {
+        sig = guides[g];
+        b = (sl << v.slice_width) + (static_cast<uint32_t>(sig >> (v.slice_width * sl)) & low);
+        gj = succ_byte(sig, sl, v.slice_width);
+        const uint32_t *ss = v.sub_start + static_cast<uint64_t>(b) * 257u;
+        uint32_t s0[WAYS], s1[WAYS];
+#pragma unroll
+        for (uint32_t way = 0; way < WAYS; ++way) { // (all in flight together)
+            const uint32_t ww = fine_way(gj, way);
+            s0[way] = ss[ww];
+            s1[way] = ss[ww + 1];
+        }
+        blen = v.bucket_start[b + 1] - v.bucket_start[b];
+        tf = v.tile_first[b];
+        ref = blen;
+#pragma unroll
+        for (uint32_t way = 0; way < WAYS; ++way) {
+            if (way == my_way) { my_s0 = s0[way]; my_s1 = s1[way]; units_before = static_cast<uint32_t>(units); cost_before = cost; valid_before = static_cast<uint32_t>(valid); }
+            if (s1[way] > s0[way]) {
+                const GroupUnits gu = group_units(s0[way], s1[way], tail_shapes);
+                units += gu.units;
+                cost += group_cost(gu, 1u);
+                cand += s1[way] - s0[way];
+                ++valid;
+            }
+        }
+    }
+    uint64_t t_units, t_cost, t_cand, t_ref, t_valid;
+    uint32_t item_at = static_cast<uint32_t>(block512_exclusive_scan(units, lds, &t_units)) + units_before;
+    uint64_t cost_at = block512_exclusive_scan(cost, lds, &t_cost) + cost_before;
+    (void)block512_exclusive_scan(cand, lds, &t_cand);
+    (void)block512_exclusive_scan(ref, lds, &t_ref);
+    const uint32_t slot_at = (static_cast<uint32_t>(block512_exclusive_scan(valid, lds, &t_valid)) + valid_before) * kGuideGroup;
+    const uint64_t t_slots = t_valid * kGuideGroup;
+    const bool overflow = t_units > ws.cap_fitems || t_slots > ws.cap_fslots;
+    // slots and items of this workgroup's way of every pair
+    if (mine && !overflow && my_s1 > my_s0) {
+        const uint32_t way = my_way, s0 = my_s0, s1 = my_s1;
+        const uint32_t word12 = fine_word(image_word(sig, sl, v.slice_width, sorted_layout != 0u), sl, v.slice_width);
+        const uint32_t ww = fine_way(gj, way);
+        const uint32_t c1 = way ? 1u : 0u; // a group's class-1 guides come first, its class-0 guides from gmid on: here ONE guide
+        uint4 *fw = reinterpret_cast<uint4 *>(ws.fword + slot_at); // (slot_at is a multiple of 8: 32-byte aligned)
+        fw[0] = make_uint4(word12 | (fine_class(way) << 24), kPadGuideWord, kPadGuideWord, kPadGuideWord);
+        fw[1] = make_uint4(kPadGuideWord, kPadGuideWord, kPadGuideWord, kPadGuideWord);
+        ws.fmeta[slot_at] = FineMeta{g, (b << 8) | ww, sig};
+#pragma unroll
+        for (uint32_t k2 = 1; k2 < kGuideGroup; ++k2) ws.fmeta[slot_at + k2] = FineMeta{kNoGuide, 0u, 0ull};
+        const GroupUnits gu = group_units(s0, s1, tail_shapes);
+        for (uint32_t u = 0; u < gu.units; ++u) { // as k_fine_scatter lays a group's units out, for one guide
+            const bool full = u < gu.n_full;
+            const uint32_t shape = full ? 32u : gu.shape, cap = 64u * shape;
+            const uint32_t wstart = gu.s0a + u * kTileCands;
+            const uint64_t after = blen - wstart;
+            ScanItem it;
+            it.bucket = (b << 8) | ww;
+            it.g0 = slot_at;
+            it.g1 = slot_at + 1u;
+            it.n_tiles = 1;
+            it.cost0 = cost_at;
+            it.tile0 = item_at;
+            it.last_cands = after < cap ? static_cast<uint32_t>(after) : cap;
+            it.group_abs = tf * 64u + (wstart >> 5);
+            it.window = (u == 0 ? s0 - gu.s0a : 0u) | ((s1 - wstart < cap ? s1 - wstart : cap) << 16);
+            it.shape = shape; it.gmid = slot_at + c1;
+            ws.fitems[item_at++] = it;
+            cost_at += static_cast<uint64_t>(shape >> 3) + kTileFixedCost;
+        }
+    }
+    if (t == 0 && my_way == 0) {
+        const uint32_t n_items = overflow ? 0u : static_cast<uint32_t>(t_units);
+        ScanItem end;
+        end.bucket = 0; end.g0 = 0; end.g1 = 0; end.n_tiles = 0; end.cost0 = overflow ? 0ull : t_cost;
+        end.tile0 = n_items; end.last_cands = 0; end.group_abs = 0; end.window = 0; end.shape = 32; end.gmid = 0;
+        ws.fitems[n_items] = end;
+        PlanInfo pl{};
+        pl.n_items = n_items;
+        pl.error = 0;
+        pl.n_ranges = n_items == 0 ? 0u : ranges_for(t_units, scan_blocks);
+        pl.fine = prune_mode;
+        pl.total_cost = overflow ? 0ull : t_cost;
+        pl.candidates = overflow ? 0ull : t_cand;
+        pl.reference_candidates = t_ref;
+        pl.tiles = n_items;
+        pl.fine_slots = overflow ? 0u : static_cast<uint32_t>(t_slots);
+        *ws.plan = pl;
+        Counters c{};
+        c.raw_chunks = (pl.n_ranges ? pl.n_ranges : 1u) * 16u;
+        *ws.counters = c;
+        if (overflow) { // room for the next try (finish_batches enlarges the item list), and this batch once more
+            atomicMax(&ws.sticky[3], static_cast<uint32_t>(t_units < 0xFFFFFFFFull ? t_units : 0xFFFFFFFFull));
+            atomicOr(&ws.sticky[0], 2u);
+        }
+    }
+}
+
+// The one-launch binning where it is safe and pays: a sorted image (the pruned plan exists), at most kSmallPairs
+// (guide, slice) pairs, 13 ways or 1 (max_dist <= 4), and an index on which the pruned plan beats the bucket-level one for a lone
+// guide anyway -- its buckets hold more units than the 13 groups a guide visits (k_fine_plan's estimate, taken for the mean
+// bucket) -- or a caller who asked for the pruned plan always (prune = 1).
+static bool small_bin_ok(const ImageView &v, const Workspace &ws, const Tuning &tn, uint32_t n, uint32_t prune_mode)
+{
+    if (!tn.small_bin || (prune_mode != 1u && prune_mode != 2u) || !ws.fitems || !v.sub_start) return false;
+    if (n == 0 || static_cast<uint64_t>(n) * v.n_slices > kSmallPairs) return false;
+    const uint64_t buckets_per_slice = 1ull << v.slice_width;
+    return tn.prune == 1 || v.n_sites / buckets_per_slice >= 16ull * kTileCands;
 }
 
 uint32_t prune_mode_for(const ImageView &v, const Tuning &tn, uint32_t n_guides, int max_dist)
@@ -817,6 +996,17 @@ void launch_bin_guides(const ImageView &v, const Workspace &ws, const Tuning &tn
 {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const uint32_t nb = v.n_buckets;
+    if (small_bin_ok(v, ws, tn, n, prune_mode)) { // two launches instead of seven
+        const uint32_t sorted = (v.srec || v.sid) ? 1u : 0u;
+        if (fine_ways_of(prune_mode) == 1u)
+            hipLaunchKernelGGL(k_bin_small<1u>, dim3(1), dim3(kSmallPairs), 0, stream, v, ws, d_guides, n, prune_mode,
+                               static_cast<uint32_t>(tn.tail_shapes), tn.scan_blocks, sorted);
+        else
+            hipLaunchKernelGGL(k_bin_small<kFineWays>, dim3(kFineWays), dim3(kSmallPairs), 0, stream, v, ws, d_guides, n, prune_mode,
+                               static_cast<uint32_t>(tn.tail_shapes), tn.scan_blocks, sorted);
+        hipLaunchKernelGGL(k_fine_ranges, dim3((tn.scan_blocks + 1u + 3u) / 4u), dim3(256), 0, stream, ws.plan, ws.fitems, ws.range_start);
+        return;
+    }
     // slots in use: 8-padded guides per bucket, at most n * slices + 8 * buckets
     const uint32_t n_slots = static_cast<uint32_t>(
         std::min<size_t>(ws.cap_gslots, static_cast<size_t>(n) * v.n_slices + static_cast<size_t>(kGuideGroup) * nb));
@@ -848,7 +1038,7 @@ void launch_bin_guides(const ImageView &v, const Workspace &ws, const Tuning &tn
         if (ways == 1u) launch_fine(std::integral_constant<uint32_t, 1u>{});
         else if (ways == kFineWays) launch_fine(std::integral_constant<uint32_t, kFineWays>{});
         else launch_fine(std::integral_constant<uint32_t, kFineWays2>{});
-        hipLaunchKernelGGL(k_fine_ranges, dim3(range_blocks), dim3(256), 0, stream, ws.plan, ws.fitems, ws.range_start);
+        hipLaunchKernelGGL(k_fine_ranges, dim3((tn.scan_blocks + 1u + 3u) / 4u), dim3(256), 0, stream, ws.plan, ws.fitems, ws.range_start);
     }
 }
 
@@ -1758,10 +1948,12 @@ void launch_scan(const ImageView &v, const Workspace &ws, const Tuning &tn, cons
     else launch_scan_thr<4>(v, ws, tn, thr, prune_mode, stream);
 }
 
-void launch_verify(const ImageView &v, const Workspace &ws, const uint64_t *d_guides, const ScoreParams &p, void *stream)
+void launch_verify(const ImageView &v, const Workspace &ws, const uint64_t *d_guides, uint32_t n, const ScoreParams &p, void *stream)
 {
     if (p.max_dist < 0) return;
-    hipLaunchKernelGGL(k_verify, dim3(kTailGrid), dim3(kChunkRecs), 0, static_cast<hipStream_t>(stream), v, ws, d_guides, p);
+    // (the kernel strides over the chunks the scan used: a small batch's few thousand need no 16 384 workgroups to start and leave)
+    const uint32_t grid = n < 256u ? std::max<uint32_t>(2048u, 64u * n) : kTailGrid;
+    hipLaunchKernelGGL(k_verify, dim3(std::min(grid, kTailGrid)), dim3(kChunkRecs), 0, static_cast<hipStream_t>(stream), v, ws, d_guides, p);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -1281,3 +1281,88 @@ def test_lean_tail_prediction_and_its_retry():
         assert ix.stats()["scan_launches"] == 1
     finally:
         ix.close()
+
+
+def test_one_workgroup_binning_of_small_batches(tmp_path):
+    """A batch of up to 512 (guide, slice) pairs is binned by ONE workgroup in one launch (k_bin_small: every placement a group
+    of its own) where the general path takes seven.  On the index of the many-windows test -- groups several units long that
+    start inside tiles, guides that SHARE groups (the small path then scans those twice) -- batches of 1 ... 103 guides (the
+    103rd no longer fits: general path) must give the oracle's hit lists and scores bit for bit with the path on and off,
+    for max_dist 0 ... 4 (13 ways, 1 way) and the runtime-threshold kernel; then the same with an item list that is too short
+    for the plan: the small path asks for the batch again (the ISSL_E_RETRY round inside issl_score), the general path scans
+    whole buckets that once; both have the room afterwards."""
+    rng = np.random.default_rng(78)
+    a, b = 0x5A, 0xC3
+    centres = rng.integers(0, 1 << 24, size=200, dtype=np.uint64)
+
+    def rest(n):
+        r = centres[rng.integers(0, len(centres), size=n)]
+        for _ in range(3):
+            r = r ^ (rng.integers(0, 4, size=n, dtype=np.uint64) << (np.uint64(2) * rng.integers(0, 12, size=n).astype(np.uint64)))
+        return r << np.uint64(16)
+
+    sites = np.concatenate([
+        rest(30_000) | np.uint64(a) | (np.uint64(b) << np.uint64(8)),
+        rest(15_000) | np.uint64(a) | (np.uint64(b ^ 1) << np.uint64(8)),
+        rest(7_000) | np.uint64(a) | (np.uint64(b ^ 0x10) << np.uint64(8)),
+        rng.integers(0, 1 << 40, size=13_000, dtype=np.uint64)])
+    sig = np.unique(sites)
+    sig = sig[np.argsort(text_order_key(sig), kind="stable")]
+    occ = rng.integers(1, 4, size=len(sig)).astype(np.uint32)
+    ix = ca.IsslIndex.build_from_sites(sig, occ)
+    path = tmp_path / "small.issl"
+    ix.write(path)
+    ix.close()
+    oracle = ou.OracleIndex(path)
+    picks = sig[rng.integers(0, len(sig), size=103)]
+    guides = picks.copy()
+    for k in range(len(guides)):
+        for pos in rng.choice(20, size=int(rng.integers(0, 5)), replace=False):
+            guides[k] ^= np.uint64(int(rng.integers(1, 4)) << (2 * int(pos)))
+    guides[5] = guides[4]          # the same guide twice, and
+    guides[7] = guides[6] ^ np.uint64(1 << 38)  # two that share every group of four slices
+    want = {}
+    try:
+        for small in (1, 0):
+            ix = ca.IsslIndex.open(path)
+            ix.set_option("prune", 1).set_option("small_bin", small)
+            ix.upload(0)
+            assert ix.get_option("is_sorted") == 1
+            for n in (1, 2, 8, 64, 102, 103):
+                for dist, thr, method in ((4, 0.0, "and"), (4, 75.0, "and"), (3, 0.0, "or"), (2, 0.0, "mit"), (0, 0.0, "avg")):
+                    key = (n, dist, thr, method)
+                    if key not in want:
+                        want[key] = oracle.score(guides[:n], dist, thr, method, want_hits=True)
+                    omit, ocfd, ohits = want[key]
+                    hits = ix.dump_hits(guides[:n], dist, thr, method)
+                    assert np.array_equal(hits, ohits), (small, key)
+                    mit, cfd = ix.score(guides[:n], dist, thr, method)
+                    st = ix.stats()
+                    assert np.array_equal(mit.view(np.uint64), omit.view(np.uint64)), (small, key)
+                    assert np.array_equal(cfd.view(np.uint64), ocfd.view(np.uint64)), (small, key)
+                    assert st["pruned"] == (1 if dist <= 2 else 2) and st["scan_launches"] == 1
+                    assert st["reference_comparisons"] == ix.count_candidates(guides[:n])
+            ix.set_option("scan_generic", 1)   # the runtime-threshold build of the scan
+            mit, cfd = ix.score(guides[:64], 4, 0.0, "and")
+            assert np.array_equal(mit.view(np.uint64), want[(64, 4, 0.0, "and")][0].view(np.uint64))
+            ix.close()
+        # an item list too short for the plan
+        for small in (1, 0):
+            ix = ca.IsslIndex.open(path)
+            ix.set_option("prune", 1).set_option("small_bin", small).set_option("fine_items", 16)
+            ix.upload(0)
+            omit, ocfd, _ = want[(64, 4, 0.0, "and")]
+            mit, cfd = ix.score(guides[:64], 4, 0.0, "and")
+            st = ix.stats()
+            assert np.array_equal(mit.view(np.uint64), omit.view(np.uint64)) and np.array_equal(cfd.view(np.uint64), ocfd.view(np.uint64))
+            if small:
+                assert st["scan_launches"] == 2 and st["pruned"] == 2     # asked for again, with room
+            else:
+                assert st["scan_launches"] == 1 and st["pruned"] == 0     # whole buckets that once
+            mit, cfd = ix.score(guides[:64], 4, 0.0, "and")
+            st = ix.stats()
+            assert np.array_equal(mit.view(np.uint64), omit.view(np.uint64)) and np.array_equal(cfd.view(np.uint64), ocfd.view(np.uint64))
+            assert st["scan_launches"] == 1 and st["pruned"] == 2
+            ix.close()
+    finally:
+        oracle.close()
