@@ -1366,3 +1366,63 @@ def test_one_workgroup_binning_of_small_batches(tmp_path):
             ix.close()
     finally:
         oracle.close()
+
+
+def test_cli_writes_a_large_page_where_its_stdout_points(golden_uniform, tmp_path):
+    """A page whose text is several megabytes (the library formats it in pieces, on several threads), wherever the caller's
+    stdout points: a fresh file, a file with something in front (the text starts at the descriptor's position, which ends behind
+    the text), a descriptor in append mode, a pipe -- the same bytes as the in-process scores formatted by the library, and the
+    same through the resident server, which writes to the client's descriptor itself.  (Writing the pieces with pwrite from
+    several threads was measured and dropped: 12.6 ms against 7.1 for the 41 MB of a 1 M-guide page -- writers of one file
+    wait for each other; profiles/r05_cli_ab_pwrite.log.)"""
+    import sys
+    sys.path.insert(0, str(ROOT / "tools"))
+    import cli_end_to_end as e2e
+    exe = ROOT / "bin" / "isslScoreOfftargets"
+    g = golden_uniform
+    rng = np.random.default_rng(5)
+    base = ca.encode_guides([s.encode() for s in g.guides if set(s) <= set("ACGT")])
+    guides = np.concatenate([base, rng.integers(0, 1 << 40, size=130_000, dtype=np.uint64)])
+    query = tmp_path / "big.q"
+    e2e.write_query(query, guides)
+    with ca.IsslIndex.open(g.issl) as ix:
+        ix.upload(0)
+        mit, cfd = ix.score(guides, 4, 75.0, "and")
+        want = ca.format_scores(guides, mit, cfd, "and").encode()
+    assert len(want) > (4 << 20)
+    args = [str(exe), str(g.issl), str(query), "4", "75", "and"]
+
+    def run(env=None):
+        fresh = tmp_path / "fresh.out"
+        with open(fresh, "wb") as fh:
+            assert subprocess.run(args, stdout=fh, env=env).returncode == 0
+        assert fresh.read_bytes() == want
+        behind = tmp_path / "behind.out"
+        with open(behind, "wb") as fh:
+            fh.write(b"# header\n")
+            fh.flush()
+            assert subprocess.run(args, stdout=fh, env=env).returncode == 0
+            fh.write(b"# trailer\n")   # (our own position is shared with the child's: it must sit behind the text)
+        assert behind.read_bytes() == b"# header\n" + want + b"# trailer\n"
+        appended = tmp_path / "appended.out"
+        appended.write_bytes(b"# first\n")
+        with open(appended, "ab") as fh:
+            assert subprocess.run(args, stdout=fh, env=env).returncode == 0
+        assert appended.read_bytes() == b"# first\n" + want
+        r = subprocess.run(args, stdout=subprocess.PIPE, env=env)
+        assert r.returncode == 0 and r.stdout == want
+
+    run()
+    sock = str(tmp_path / "srv.sock")
+    import time
+    srv = subprocess.Popen([str(exe), "--serve", sock], stderr=subprocess.PIPE)
+    try:
+        for _ in range(100):
+            if os.path.exists(sock):
+                break
+            time.sleep(0.1)
+        assert os.path.exists(sock)
+        run(dict(os.environ, ISSL_SERVER=sock))
+    finally:
+        srv.terminate()
+        srv.wait(timeout=30)
