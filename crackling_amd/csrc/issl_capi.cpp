@@ -113,6 +113,7 @@ Tuning Tuning::from_env()
     t.item_guides = kItemGuides;
     t.scan_generic = false;
     t.stage_timing = false;
+    t.scan_events = 2;
     t.upload_timing = env_flag("ISSL_UPLOAD_TIMING");
     t.raw_chunks = 0;
     t.inline_sigs = -1;
@@ -129,7 +130,7 @@ Tuning Tuning::from_env()
     t.lanes = 1;
     static const char *const keys[][2] = {
         {"ISSL_SCAN_BLOCKS", "scan_blocks"}, {"ISSL_SCAN_THREADS", "scan_threads"}, {"ISSL_UPLOAD_CHUNK_KIB", "upload_chunk_kib"}, {"ISSL_UPLOAD_RING_MIN_KIB", "upload_ring_min_kib"}, {"ISSL_UPLOAD_THREADS", "upload_threads"}, {"ISSL_ITEM_GUIDES", "item_guides"},
-        {"ISSL_SCAN_GENERIC", "scan_generic"}, {"ISSL_STAGE_TIMING", "stage_timing"}, {"ISSL_RAW_CHUNKS", "raw_chunks"},
+        {"ISSL_SCAN_GENERIC", "scan_generic"}, {"ISSL_STAGE_TIMING", "stage_timing"}, {"ISSL_SCAN_EVENTS", "scan_events"}, {"ISSL_RAW_CHUNKS", "raw_chunks"},
         {"ISSL_INLINE_SIGS", "inline_sigs"}, {"ISSL_FORCE_HOST_COLD", "host_cold"}, {"ISSL_SCAN_STAMPS", "scan_stamps"},
         {"ISSL_SORTED_LAYOUT", "sorted_layout"}, {"ISSL_PRUNE", "prune"}, {"ISSL_LANES", "lanes"},
         {"ISSL_COMPACT", "compact"}, {"ISSL_TAIL_SHAPES", "tail_shapes"}, {"ISSL_HIT_SLOTS", "hit_slots"}, {"ISSL_LEAN_TAIL", "lean_tail"}, {"ISSL_SMALL_BIN", "small_bin"}, {"ISSL_FINE_ITEMS", "fine_items"},
@@ -155,6 +156,7 @@ bool Tuning::set(const char *key, const char *value)
     else if (k == "item_guides") { if (!is_int || n < 8 || n > static_cast<long long>(kItemGuides)) return false; item_guides = static_cast<uint32_t>(n) & ~7u; }
     else if (k == "scan_generic") { if (!is_int || (n != 0 && n != 1)) return false; scan_generic = n == 1; }
     else if (k == "stage_timing") { if (!is_int || (n != 0 && n != 1)) return false; stage_timing = n == 1; }
+    else if (k == "scan_events") { if (!is_int || n < 0 || n > 2) return false; scan_events = static_cast<int>(n); }
     else if (k == "raw_chunks") { if (!is_int || n < 0) return false; raw_chunks = static_cast<size_t>(n); }
     else if (k == "inline_sigs") { if (!is_int || n < -1 || n > 1) return false; inline_sigs = static_cast<int>(n); }
     else if (k == "host_cold") { if (!is_int || n < -1 || n > 1) return false; host_cold = static_cast<int>(n); }
@@ -218,7 +220,8 @@ struct issl_index {
     Lane lane2;               // ... and of the batches in between (lanes option = 2)
     uint32_t n_async = 0;     // asynchronous batches enqueued so far: picks the lane
     Lane *last_lane = nullptr; // lane of the most recent batch (whose counters issl_last_stats reports)
-    hipEvent_t ring[2 * kRing] = {}; // scan begin/end of the batches enqueued since the last finish
+    hipEvent_t ring[2 * kRing] = {}; // scan begin/end of the batches enqueued since the last finish (of those that recorded them: n_ring)
+    uint32_t n_ring = 0;
     bool have_events = false;
     issl_stats stats{};
     uint32_t n_pending = 0;  // batches enqueued and not yet finished
@@ -1019,6 +1022,7 @@ static void release_device(issl_index *ix)
         ix->have_events = false;
     }
     ix->n_pending = 0;
+    ix->n_ring = 0;
     ix->prev_scan_end = nullptr;
     ix->prev_batch_end = nullptr;
     if (ix->d_image && ix->owns_image) (void)hipFree(ix->d_image);
@@ -1097,7 +1101,12 @@ static int enqueue_batch(issl_index *ix, Lane &lane, hipStream_t stream, const u
     p.method = method;
     p.maximum_sum = (10000.0 - threshold * 100) / threshold; // isslScoreOfftargets.cpp:326
     const uint32_t n32 = static_cast<uint32_t>(n);
-    const uint32_t slot = ix->n_pending % kRing;
+    // The event pair around the scan (issl_stats::ms_scan_events): around every batch's (scan_events = 1; always where the stage
+    // events are recorded too), around the first batch's after a finish (2, the default: the kernel's own clock stamps time
+    // every launch anyway, ms_scan) or never (0) -- an event record is ~5 us of stream time, two of them a seventh of a
+    // 64-guide batch.  Pipelined lanes chain their scans by these events: there, always.
+    const bool scan_pair = staged || pipelined || tn.scan_events == 1 || (tn.scan_events == 2 && ix->n_ring == 0);
+    const uint32_t slot = ix->n_ring % kRing;
     lane.staged = staged;
     if (pipelined && lane.pending) HIP_TRY(hipStreamWaitEvent(stream, lane.done, 0)); // the workspace's previous batch (tail stream)
     // (bin_ahead: the workspace's previous batch ran on this very stream)
@@ -1107,9 +1116,10 @@ static int enqueue_batch(issl_index *ix, Lane &lane, hipStream_t stream, const u
     if (staged) HIP_TRY(hipEventRecord(lane.ev[1], stream));
     if (pipelined && ix->prev_scan_end) HIP_TRY(hipStreamWaitEvent(stream, ix->prev_scan_end, 0)); // one scan at a time
     if (bin_ahead && ix->prev_batch_end) HIP_TRY(hipStreamWaitEvent(stream, ix->prev_batch_end, 0)); // the batch before is through
-    HIP_TRY(hipEventRecord(ix->ring[2 * slot], stream));
+    if (scan_pair) HIP_TRY(hipEventRecord(ix->ring[2 * slot], stream));
     launch_scan(ix->view, ws, tn, d_guides, n32, max_dist, prune_mode, stream);
-    HIP_TRY(hipEventRecord(ix->ring[2 * slot + 1], stream));
+    if (scan_pair) HIP_TRY(hipEventRecord(ix->ring[2 * slot + 1], stream));
+    if (scan_pair) ix->n_ring += 1;
     if (staged) HIP_TRY(hipEventRecord(lane.ev[2], stream));
     hipStream_t tail = stream;
     if (pipelined) {
@@ -1124,7 +1134,7 @@ static int enqueue_batch(issl_index *ix, Lane &lane, hipStream_t stream, const u
     launch_replay(ix->view, ws, d_guides, n32, p, d_mit, d_cfd, dump ? ws.d_kept : nullptr,
                   dump ? ws.d_hitrec : nullptr, tail);
     if (staged) HIP_TRY(hipEventRecord(lane.ev[5], tail));
-    HIP_TRY(hipEventRecord(lane.done, tail));
+    if (pipelined || bin_ahead) HIP_TRY(hipEventRecord(lane.done, tail)); // (what the other lane's batches wait for)
     if (bin_ahead) ix->prev_batch_end = lane.done;
     ix->n_pending += 1;
     lane.pending += 1;
@@ -1152,7 +1162,9 @@ static int finish_batches(issl_index *ix, hipStream_t stream)
     ix->prev_batch_end = nullptr;
     HIP_TRY(hipGetLastError());
     const uint32_t batches = ix->n_pending;
+    const uint32_t ring_pairs = ix->n_ring; // scan event pairs recorded since the last finish (scan_events)
     ix->n_pending = 0;
+    ix->n_ring = 0;
     bool retry = false;
     uint32_t max_chunks = 0; // of the lane whose counters are reported
     Lane &lane = ix->last_lane ? *ix->last_lane : ix->lane;
@@ -1238,7 +1250,7 @@ static int finish_batches(issl_index *ix, hipStream_t stream)
     if (lane.staged)
         for (int i = 0; i < 5; ++i) (void)hipEventElapsedTime(&ms[i], lane.ev[i], lane.ev[i + 1]);
     double scan_sum = 0.0;
-    const uint32_t have = batches < kRing ? batches : kRing;
+    const uint32_t have = ring_pairs < kRing ? ring_pairs : kRing;
     for (uint32_t i = 0; i < have; ++i) {
         float t = 0;
         (void)hipEventElapsedTime(&t, ix->ring[2 * i], ix->ring[2 * i + 1]);
@@ -1499,6 +1511,7 @@ int issl_index_get_option(const issl_index *idx, const char *key, long long *val
     else if (k == "item_guides") *value = t.item_guides;
     else if (k == "scan_generic") *value = t.scan_generic;
     else if (k == "stage_timing") *value = t.stage_timing;
+    else if (k == "scan_events") *value = t.scan_events;
     else if (k == "raw_chunks") *value = static_cast<long long>(t.raw_chunks);
     else if (k == "inline_sigs") *value = t.inline_sigs;
     else if (k == "host_cold") *value = t.host_cold;

@@ -159,6 +159,7 @@ struct Tuning {
                             //                    issl_capi.cpp): KiB per slot (default 16384) and the section size from which it is used (default 65536); tests
     uint32_t item_guides;   // ISSL_ITEM_GUIDES   guides per scan item (multiple of 8, <= kItemGuides)
     bool scan_generic;      // ISSL_SCAN_GENERIC  force the runtime-threshold build of the scan kernel
+    int scan_events;        // ISSL_SCAN_EVENTS   HIP event pair around the scan: 1 every batch, 2 (default) the first batch after a finish, 0 never
     bool stage_timing;      // ISSL_STAGE_TIMING  asynchronous batches record an event at every stage boundary
     bool upload_timing;     // ISSL_UPLOAD_TIMING one stderr line per upload stage
     size_t raw_chunks;      // ISSL_RAW_CHUNKS    initial raw-record buffer in chunks (0: sized from the launch)

@@ -98,9 +98,9 @@ typedef struct {
                                        loop :344 without early exit (host equivalent: issl_count_candidates) */
     uint64_t pruned;              /* 0: full scan; 1 / 2 / 3: pruned scan over the successor-byte groups equal to / within
                                      one / within two mismatches of the guide's own (max_dist <= 2 / <= 4 / = 5, sorted image) */
-    double ms_scan_events;        /* the scan launches by the HIP event pair recorded around them on their stream; equals
-                                     ms_scan for batches on one lane, includes the wait for wave slots when a second
-                                     lane shares the device (lanes option) */
+    double ms_scan_events;        /* the scan launches by the HIP event pair recorded around them on their stream (mean over
+                                     the batches that recorded one: scan_events option); equals ms_scan for batches on one
+                                     lane, includes the wait for wave slots when a second lane shares the device (lanes) */
 } issl_stats;
 
 const char *issl_last_error(void);
@@ -226,6 +226,9 @@ int issl_index_attach_image_cold(int device, void *dev_buf, size_t bytes, void *
  * attach), never inside a scoring call; afterwards this call changes it (no batches may be in flight).  Keys (env):
  *   scan_blocks (ISSL_SCAN_BLOCKS) workgroups of the scan launch      item_guides (ISSL_ITEM_GUIDES) guides per scan item
  *   scan_generic (ISSL_SCAN_GENERIC) 0|1 runtime-threshold scan       stage_timing (ISSL_STAGE_TIMING) 0|1 events at every stage
+ *   scan_events (ISSL_SCAN_EVENTS) 0|1|2: the HIP event pair around the scan of an asynchronous batch (issl_stats::ms_scan_events):
+ *     1 every batch, 2 (default) the first batch after a finish, 0 never -- an event record is ~5 us of stream time, and
+ *     ms_scan (the kernel's own clock stamps) times every launch without them
  *   raw_chunks (ISSL_RAW_CHUNKS) initial raw-record buffer
  *   sorted_layout (ISSL_SORTED_LAYOUT), compact (ISSL_COMPACT), inline_sigs (ISSL_INLINE_SIGS), host_cold
  *     (ISSL_FORCE_HOST_COLD), keep_lists (ISSL_KEEP_LISTS), each -1|0|1: image layout, read at upload (see above; -1 =
