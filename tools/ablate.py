@@ -52,6 +52,20 @@ VARIANTS = {
                 "            reinterpret_cast<uint2 *>(fmeta)[slot] = make_uint2(guide, (b << 8) | ww);"),
                ("            if (prune_mode) { const FineMeta m = ws.fmeta[gslot]; guide = m.guide; where = m.where; gsig = m.gsig; }",
                 "            if (prune_mode) { const uint2 m = reinterpret_cast<const uint2 *>(ws.fmeta)[gslot]; guide = m.x; where = m.y; if (guide != kNoGuide) gsig = guides[guide]; }")],
+    # alternatives (results stay right): wave priorities for the two workgroups a CU starts the scan with -- the arbiter favours one of
+    # them (it ends after 500 us where the other takes 910, DESIGN 3.1 "what the 13 % are")
+    "scan_prio_second": [("    if (threadIdx.x == 0) atomicMin(span, t_start); // the launch's own span: first workgroup in, last one out",
+                          "    if (threadIdx.x == 0) atomicMin(span, t_start); // the launch's own span: first workgroup in, last one out\n    if ((blockIdx.x >> 8) & 1u) __builtin_amdgcn_s_setprio(1);")],
+    "scan_prio_first": [("    if (threadIdx.x == 0) atomicMin(span, t_start); // the launch's own span: first workgroup in, last one out",
+                         "    if (threadIdx.x == 0) atomicMin(span, t_start); // the launch's own span: first workgroup in, last one out\n    if (!((blockIdx.x >> 8) & 1u)) __builtin_amdgcn_s_setprio(1);")],
+    "scan_prio_late": [("    if (threadIdx.x == 0) atomicMin(span, t_start); // the launch's own span: first workgroup in, last one out",
+                        "    if (threadIdx.x == 0) atomicMin(span, t_start); // the launch's own span: first workgroup in, last one out\n    if (blockIdx.x >= 512u) __builtin_amdgcn_s_setprio(1);")],
+    "scan_prio_ramp": [("    if (threadIdx.x == 0) atomicMin(span, t_start); // the launch's own span: first workgroup in, last one out",
+                       "    if (threadIdx.x == 0) atomicMin(span, t_start); // the launch's own span: first workgroup in, last one out\n    { const uint32_t q = blockIdx.x >> 8; if (q == 1u) __builtin_amdgcn_s_setprio(1); else if (q == 2u) __builtin_amdgcn_s_setprio(2); else if (q >= 3u) __builtin_amdgcn_s_setprio(3); }")],
+    "scan_prio_late3": [("    if (threadIdx.x == 0) atomicMin(span, t_start); // the launch's own span: first workgroup in, last one out",
+                       "    if (threadIdx.x == 0) atomicMin(span, t_start); // the launch's own span: first workgroup in, last one out\n    if (blockIdx.x >= 512u) __builtin_amdgcn_s_setprio(3);")],
+    "scan_prio_last": [("    if (threadIdx.x == 0) atomicMin(span, t_start); // the launch's own span: first workgroup in, last one out",
+                       "    if (threadIdx.x == 0) atomicMin(span, t_start); // the launch's own span: first workgroup in, last one out\n    if (blockIdx.x >= 768u) __builtin_amdgcn_s_setprio(2); else if (blockIdx.x >= 512u) __builtin_amdgcn_s_setprio(1);")],
     # k_verify
     "verify_no_atomic": [("            if (live) rank = atomicAdd(&ws.gcount[guide], 1u);", "            if (live) rank = lane;"),
                          ("if (live && !continues) base = atomicAdd(&ws.gcount[guide], next - lane);", "if (live && !continues) base = next - lane;")],
