@@ -1345,6 +1345,16 @@ def test_one_workgroup_binning_of_small_batches(tmp_path):
             ix.set_option("scan_generic", 1)   # the runtime-threshold build of the scan
             mit, cfd = ix.score(guides[:64], 4, 0.0, "and")
             assert np.array_equal(mit.view(np.uint64), want[(64, 4, 0.0, "and")][0].view(np.uint64))
+            ix.set_option("scan_generic", 0)
+            # other launch shapes of the scan: ranges, record chunks and the range search follow the knobs
+            for knobs in ({"scan_blocks": 4096}, {"scan_blocks": 64}, {"scan_blocks": 1024, "scan_threads": 768}, {"scan_threads": 256}):
+                for k, val in knobs.items():
+                    ix.set_option(k, val)
+                for n in (1, 64, 102):
+                    mit, cfd = ix.score(guides[:n], 4, 0.0, "and")
+                    assert np.array_equal(mit.view(np.uint64), want[(n, 4, 0.0, "and")][0].view(np.uint64)), (small, knobs, n)
+                    assert np.array_equal(cfd.view(np.uint64), want[(n, 4, 0.0, "and")][1].view(np.uint64)), (small, knobs, n)
+                    assert np.array_equal(ix.dump_hits(guides[:n], 4, 0.0, "and"), want[(n, 4, 0.0, "and")][2]), (small, knobs, n)
             ix.close()
         # an item list too short for the plan
         for small in (1, 0):
