@@ -469,15 +469,20 @@ def test_large_batch_paths(config0, monkeypatch):
     assert ix.stats()["pruned"] == 2
     assert np.array_equal(mit, np.tile(base[0], 300)) and np.array_equal(cfd, np.tile(base[1], 300))
     ix.set_option("prune", -1)
-    huge = np.tile(guides, 4300)  # 4.3M guides: pieces of 2^20 guides while the pruned scan may be chosen, else of 2^22
+    huge = np.tile(guides, 4300)  # 4.3M guides: equal pieces of at most 512 k guides (what gets hit slots) ...
+    mit, cfd = ix.score(huge, 4, 75.0, "and")
+    assert np.array_equal(mit, np.tile(base[0], 4300)) and np.array_equal(cfd, np.tile(base[1], 4300))
+    assert ix.stats()["n_batches"] == 9 and ix.stats()["n_guides"] == len(huge)
+    assert ix.stats()["reference_comparisons"] == 4300 * ix.count_candidates(guides)
+    ix.set_option("hit_slots", 0)  # ... without them: of 2^20 guides while the pruned scan may be chosen, else of 2^22
     mit, cfd = ix.score(huge, 4, 75.0, "and")
     assert np.array_equal(mit, np.tile(base[0], 4300)) and np.array_equal(cfd, np.tile(base[1], 4300))
     assert ix.stats()["n_batches"] == 5 and ix.stats()["n_guides"] == len(huge)
-    assert ix.stats()["reference_comparisons"] == 4300 * ix.count_candidates(guides)
     ix.set_option("prune", 0)
     mit, cfd = ix.score(huge, 4, 75.0, "and")
     assert np.array_equal(mit, np.tile(base[0], 4300)) and np.array_equal(cfd, np.tile(base[1], 4300))
     assert ix.stats()["n_batches"] == 2 and ix.stats()["n_guides"] == len(huge)
+    ix.set_option("hit_slots", 1)
 
 
 def test_one_site_index(tmp_path):
