@@ -228,6 +228,10 @@ struct issl_index {
     hipEvent_t prev_scan_end = nullptr; // lanes = 2: end of the previous batch's scan (scans run one after the other)
     hipEvent_t prev_batch_end = nullptr; // lanes = 3: end of the previous batch (its scan starts when that batch is through)
     bool list_order_only = false; // the lists of this index cannot be re-ordered (kSortNeedsListOrder)
+    // issl_score: the largest piece that went through at once (no grow-and-rerun round) with record buffers of at least
+    // proven_chunks chunks at a max_dist of at least proven_dist: pieces within that skip the per-guide estimate (0.9 ms per 500 k guides)
+    size_t proven_guides = 0, proven_chunks = 0;
+    int proven_dist = -1;
 };
 
 #define HIP_TRY(expr)                                                                              \
@@ -1023,6 +1027,9 @@ static void release_device(issl_index *ix)
     }
     ix->n_pending = 0;
     ix->n_ring = 0;
+    ix->proven_guides = 0;
+    ix->proven_chunks = 0;
+    ix->proven_dist = -1;
     ix->prev_scan_end = nullptr;
     ix->prev_batch_end = nullptr;
     if (ix->d_image && ix->owns_image) (void)hipFree(ix->d_image);
@@ -1951,7 +1958,8 @@ int issl_score(issl_index *idx, const uint64_t *guides, size_t n, int max_dist, 
         const size_t cap_chunks = idx->lane.ws.cap_chunks;
         const double have_slots = static_cast<double>(cap_chunks > wave_chunks ? cap_chunks - wave_chunks : 0) * (kChunkRecs - 1);
         // (an index of even buckets on a handle that has grown its buffers: the bound alone says the piece fits)
-        const bool covered = static_cast<double>(most) * static_cast<double>(idx->worst_per_guide) * records_per_comparison <= have_slots;
+        const bool covered = static_cast<double>(most) * static_cast<double>(idx->worst_per_guide) * records_per_comparison <= have_slots ||
+                             (most <= idx->proven_guides && cap_chunks >= idx->proven_chunks && idx->proven_chunks > 0 && max_dist <= idx->proven_dist);
         if (!estimate || covered) cnt = most;
         while (estimate && !covered && at + cnt < n && cnt < piece) {
             uint64_t c = 0;
@@ -2000,6 +2008,13 @@ int issl_score(issl_index *idx, const uint64_t *guides, size_t n, int max_dist, 
             HIP_TRY(hipMemcpy(cfd + at, ws.d_cfd, 8 * cnt, hipMemcpyDeviceToHost));
         }
         const issl_stats &s = idx->stats;
+        // (a piece that went through at once: the next ones within its size and distance need no estimate; denser guides than
+        // these still take the grow-and-rerun round)
+        if (s.scan_launches == 1 && (max_dist > idx->proven_dist || (max_dist == idx->proven_dist && cnt > idx->proven_guides))) {
+            idx->proven_dist = max_dist;
+            idx->proven_guides = cnt;
+            idx->proven_chunks = ws.cap_chunks;
+        }
         total.n_guides += s.n_guides; total.candidates += s.candidates; total.hits += s.hits;
         total.planned_comparisons += s.planned_comparisons; total.reference_comparisons += s.reference_comparisons;
         total.pruned = std::max(total.pruned, s.pruned);
