@@ -604,6 +604,32 @@ def main():
             dt = (time.perf_counter() - t1) / reps
             extras["host_pointer_entry"] = {"ms_per_step": dt * 1e3, "guides_per_s": n_mine / dt,
                                             "note": "issl_score(): guides in and scores out over PCIe, one synchronisation per call"}
+            # Batches of half a million guides -- the pieces `issl_score` cuts a page of Crackling's into (the most that get hit slots):
+            # a unit the scan fetches serves five times the guides, and a step costs less per guide than the line's own 100 000
+            try:
+                n_big = 500_000
+                if a.sites >= 50_000_000 and n_mine <= n_big // 2:
+                    gb = torch.from_numpy(random_guides_fast(sigs, n_big, seed=778).view(np.int64)).to(dev)
+                    mb = torch.empty(n_big, dtype=torch.float64, device=dev)
+                    cb = torch.empty_like(mb)
+                    for _ in range(3):
+                        step(gb, mb, cb)
+                        index.finish(stream)
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    reps = 6
+                    for _ in range(reps):
+                        step(gb, mb, cb)
+                    if index.finish(stream):
+                        dt = time.perf_counter() - t1
+                        s2 = index.stats()
+                        extras["batch_500k_guides"] = {"guides_per_step": n_big, "steps": reps, "ms_per_step": dt * 1e3 / reps,
+                                                       "ms_per_100k_guides": dt * 1e3 / reps / (n_big / 1e5), "guides_per_s": n_big * reps / dt,
+                                                       "scan_ms": s2["ms_scan"], "note": "not the line's workload (BASELINE configs[2] is 100 000 guides per step): the same "
+                                                       "index scored in batches of 500 000 guides"}
+                    del gb, mb, cb
+            except Exception as e:  # noqa: BLE001
+                extras["batch_500k_guides"] = {"error": f"{type(e).__name__}: {e}"}
             # the same line on a SKEWED index of the same size (`--dist markov` run by itself gives the full record): an
             # AT-rich order-3 Markov chain, seven times the hits, most guides leave through the early exit -- the tail's
             # kernels carry the step there
