@@ -195,6 +195,9 @@ bool upload_index(const DeviceChoice &dc, Resident &r, std::string &err, long lo
 {
     if (one_shot_guides >= 0 && one_shot_guides < kSortedLayoutPaysFromGuides && !std::getenv("ISSL_SORTED_LAYOUT"))
         (void)api.issl_index_set_option(r.idx, "sorted_layout", "0");
+    // (the page is known: its scoring workspace is set up beside the upload)
+    if (one_shot_guides > 0 && !std::getenv("ISSL_EXPECT_GUIDES"))
+        (void)api.issl_index_set_option(r.idx, "expect_guides", std::to_string(one_shot_guides).c_str());
     const bool all = dc.all;
     const double t1 = now_ms();
     if (all || dc.list.size() > 1) {

@@ -126,6 +126,7 @@ Tuning Tuning::from_env()
     t.hit_slots = 1;
     t.lean_tail = 1;
     t.small_bin = 1;
+    t.expect_guides = 0;
     t.fine_items = 0;
     t.lanes = 1;
     static const char *const keys[][2] = {
@@ -133,7 +134,7 @@ Tuning Tuning::from_env()
         {"ISSL_SCAN_GENERIC", "scan_generic"}, {"ISSL_STAGE_TIMING", "stage_timing"}, {"ISSL_SCAN_EVENTS", "scan_events"}, {"ISSL_RAW_CHUNKS", "raw_chunks"},
         {"ISSL_INLINE_SIGS", "inline_sigs"}, {"ISSL_FORCE_HOST_COLD", "host_cold"}, {"ISSL_SCAN_STAMPS", "scan_stamps"},
         {"ISSL_SORTED_LAYOUT", "sorted_layout"}, {"ISSL_PRUNE", "prune"}, {"ISSL_LANES", "lanes"},
-        {"ISSL_COMPACT", "compact"}, {"ISSL_TAIL_SHAPES", "tail_shapes"}, {"ISSL_HIT_SLOTS", "hit_slots"}, {"ISSL_LEAN_TAIL", "lean_tail"}, {"ISSL_SMALL_BIN", "small_bin"}, {"ISSL_FINE_ITEMS", "fine_items"},
+        {"ISSL_COMPACT", "compact"}, {"ISSL_TAIL_SHAPES", "tail_shapes"}, {"ISSL_HIT_SLOTS", "hit_slots"}, {"ISSL_LEAN_TAIL", "lean_tail"}, {"ISSL_SMALL_BIN", "small_bin"}, {"ISSL_EXPECT_GUIDES", "expect_guides"}, {"ISSL_FINE_ITEMS", "fine_items"},
         {"ISSL_KEEP_LISTS", "keep_lists"},
     };
     for (const auto &k : keys)
@@ -168,6 +169,7 @@ bool Tuning::set(const char *key, const char *value)
     else if (k == "tail_shapes") { if (!is_int || n < 0 || n > 1) return false; tail_shapes = static_cast<int>(n); }
     else if (k == "lean_tail") { if (!is_int || n < 0 || n > 1) return false; lean_tail = static_cast<int>(n); }
     else if (k == "small_bin") { if (!is_int || n < 0 || n > 1) return false; small_bin = static_cast<int>(n); }
+    else if (k == "expect_guides") { if (!is_int || n < 0) return false; expect_guides = static_cast<size_t>(n); }
     else if (k == "fine_items") { if (!is_int || n < 0) return false; fine_items = static_cast<size_t>(n); }
     else if (k == "hit_slots") { if (!is_int || n < 0 || n > 2) return false; hit_slots = static_cast<int>(n); }
     else if (k == "scan_stamps") stamps_path = value;
@@ -195,6 +197,8 @@ struct Lane {
     uint32_t last_n = 0;
     uint32_t pending = 0;       // batches enqueued since the last finish
     bool staged = true;         // the last batch recorded its stage events
+    bool done_recorded = false; // `done` stands behind the lane's last batch
+    hipStream_t last_tail = nullptr; // the stream that batch's last kernels went to
     int last_max_dist = 0;
     uint32_t last_prune = 0;
     bool lean = false;          // the lane's finished batches had no guide beyond its hit slots: the next ones are enqueued
@@ -1142,6 +1146,8 @@ static int enqueue_batch(issl_index *ix, Lane &lane, hipStream_t stream, const u
                   dump ? ws.d_hitrec : nullptr, tail);
     if (staged) HIP_TRY(hipEventRecord(lane.ev[5], tail));
     if (pipelined || bin_ahead) HIP_TRY(hipEventRecord(lane.done, tail)); // (what the other lane's batches wait for)
+    lane.done_recorded = pipelined || bin_ahead; // (one lane: issl_score_wait records it when somebody asks)
+    lane.last_tail = tail;
     if (bin_ahead) ix->prev_batch_end = lane.done;
     ix->n_pending += 1;
     lane.pending += 1;
@@ -1532,6 +1538,7 @@ int issl_index_get_option(const issl_index *idx, const char *key, long long *val
     else if (k == "hit_slots") *value = t.hit_slots;
     else if (k == "lean_tail") *value = t.lean_tail;
     else if (k == "small_bin") *value = t.small_bin;
+    else if (k == "expect_guides") *value = static_cast<long long>(t.expect_guides);
     else if (k == "fine_items") *value = static_cast<long long>(t.fine_items);
     else if (k == "is_sorted") *value = idx->d_image ? ((idx->hdr.off_srec || idx->hdr.off_sid) ? 1 : 0) : -1; // read-only
     else if (k == "is_compact") *value = idx->d_image ? (idx->hdr.off_sid ? 1 : 0) : -1;                   // read-only
@@ -1626,7 +1633,28 @@ static int upload_common(issl_index *idx, int device, void *buf, size_t bytes, c
             }
         }
         upload_note(idx, c.cold ? "layout + allocation (cold sections in pinned host memory)" : "layout + allocation", t0);
+        // expect_guides: the caller will score a batch of about this many guides right after the upload (the one-shot scorer
+        // knows its page).  The scoring workspace -- streams, events, the buffers of a small batch -- is set up on a thread of
+        // its own while the file's sections are on their way (the upload is bound by the PCIe link): 20 ms less in front of a
+        // one-shot process's first kernel.  Only where image and temporaries leave the device half empty; a failure here is
+        // the first scoring call's to report.
+        std::thread prep;
+        if (tn.expect_guides && !buf) {
+            size_t free_now = 0, total_now = 0;
+            if (hipMemGetInfo(&free_now, &total_now) == hipSuccess && free_now > temp + (size_t(24) << 30) + total_now / 2)
+                prep = std::thread([idx] { // (reads the header the layout has just made; the view is finish_upload's)
+                    (void)hipSetDevice(idx->device);
+                    // (for at most 32 k guides: the streams, the events, the small buffers -- the first call's fixed 20 ms.  The
+                    // gigabytes a page of a million guides needs are allocated by the scoring call itself: beside the upload they
+                    // held its copies up for as long as they took, 27 ms moved from one stage to the other)
+                    const size_t n = std::min<size_t>(idx->tuning.expect_guides, size_t(1) << 15);
+                    if (ensure_workspace(idx, n, idx->lane) != ISSL_OK) (void)hipGetLastError();
+                });
+            else
+                (void)hipGetLastError();
+        }
         rc = finish_upload(idx, dbi);
+        if (prep.joinable()) prep.join();
         if (rc == ISSL_OK) return ISSL_OK;
         release_device(idx);
         if (rc == kSortNoRoom) { // the temporaries of the sort did not fit after all: the next, smaller layout
@@ -1904,7 +1932,13 @@ int issl_score_wait(issl_index *idx, void *stream)
     if (!idx) { set_error("null argument"); return ISSL_E_ARG; }
     if (idx->device >= 0) HIP_TRY(hipSetDevice(idx->device));
     for (Lane *lp : {&idx->lane, &idx->lane2})
-        if (lp->ready && lp->pending) HIP_TRY(hipStreamWaitEvent(static_cast<hipStream_t>(stream), lp->done, 0));
+        if (lp->ready && lp->pending) {
+            if (!lp->done_recorded) { // the end of the lane's last batch, recorded now: everything enqueued on its stream so far
+                HIP_TRY(hipEventRecord(lp->done, lp->last_tail));
+                lp->done_recorded = true;
+            }
+            HIP_TRY(hipStreamWaitEvent(static_cast<hipStream_t>(stream), lp->done, 0));
+        }
     return ISSL_OK;
 }
 

@@ -177,6 +177,7 @@ struct Tuning {
     int hit_slots;          // ISSL_HIT_SLOTS     1 (default): Workspace::slot_hits = kSlotHits when the arrays fit (kSlotHitsWide once a batch has shown
                             //                    many guides beyond that); 0: never; 2: kSlotHitsWide from the first batch on (A/B, tests)
     size_t fine_items;      // ISSL_FINE_ITEMS    0 (default): the pruned plan's item list is sized from the index; n: it starts with room for n items
+    size_t expect_guides;   // ISSL_EXPECT_GUIDES 0 (default); n: a batch of about n guides follows the upload at once: its workspace is set up beside the upload
     int small_bin;          // ISSL_SMALL_BIN     1 (default): batches of up to 8192 placements (102 guides of five slices) are binned by ONE workgroup
                             // in one launch instead of seven (k_bin_small); 0: always the general kernels
     int lean_tail;          // ISSL_LEAN_TAIL     1 (default): a lane whose batches meet no guide beyond its hit slots enqueues the next ones

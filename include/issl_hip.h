@@ -249,6 +249,9 @@ int issl_index_attach_image_cold(int device, void *dev_buf, size_t bytes, void *
  *     <= 4, sorted image, are binned in two launches instead of seven -- every placement a group of its own (a matter of
  *     latency only: 64 guides against 300 M sites 0.110 -> 0.079 ms); fine_items (ISSL_FINE_ITEMS): initial capacity of the
  *     pruned plan's item list instead of the size derived from the index (tests of the list's two overflow paths)
+ *   expect_guides (ISSL_EXPECT_GUIDES) n: a batch of about n guides follows the upload at once (the one-shot scorer knows its
+ *     page): the scoring workspace's streams, events and small buffers are set up on a thread of their own beside the upload --
+ *     20 ms less in front of the first kernel; 0 (default): nothing is prepared
  *   upload_chunk_kib, upload_ring_min_kib, upload_threads (ISSL_UPLOAD_CHUNK_KIB, ISSL_UPLOAD_RING_MIN_KIB,
  *     ISSL_UPLOAD_THREADS): the ring of pinned chunks a file-mapped index is uploaded through (eight threads pread the
  *     file into two slots each, every slot leaves with its own asynchronous copy: the PCIe link's rate, where hipMemcpy

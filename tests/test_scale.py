@@ -400,7 +400,10 @@ def test_config3_shape_on_one_gpu(scale):
     node = ca.IsslNode(scale.ix, devices=[0, 0, 0])
     try:
         assert node.info()["n_devices"] == 3
-        node.score(guides[:50_000], 4, 75.0, "and")           # sizes the replicas' scratch buffers
+        node.score(guides, 4, 75.0, "and")                    # sizes the replicas' scratch buffers for chunks of THIS size (the
+                                                              # queue's chunk grows with the batch) and lets every handle see a
+                                                              # piece go through at once: replica 0 is the warm handle above,
+                                                              # the other two are new
         t = time.time(); mit, cfd = node.score(guides, 4, 75.0, "and"); wall = time.time() - t
         busy, done = node.shard_times()
     finally:
