@@ -562,6 +562,16 @@ def _async_batches(ix, oracle, guides, torch):
     mit = np.concatenate([o[1].cpu().numpy() for o in outs]); cfd = np.concatenate([o[2].cpu().numpy() for o in outs])
     omit, ocfd = oracle.score(guides, 4, 75.0, "and")
     assert np.array_equal(mit.view(np.uint64), omit.view(np.uint64)) and np.array_equal(cfd.view(np.uint64), ocfd.view(np.uint64))
+    # a batch that keeps the device busy for milliseconds: what the consumer stream copies behind issl_score_wait must be the
+    # scores, not what the buffers held before (on one lane the end of a batch is recorded by the wait itself)
+    long_g = torch.from_numpy(np.tile(guides, 200).view(np.int64)).cuda()
+    d_m = torch.zeros(len(long_g), dtype=torch.float64, device="cuda:0"); d_c = torch.zeros_like(d_m)
+    ix.score_device_async(long_g, d_m, d_c, 4, 75.0, "and", stream=None)
+    ix.wait(stream)
+    m1, c1 = d_m.clone(), d_c.clone()
+    assert ix.finish(stream)
+    assert torch.equal(m1, d_m) and torch.equal(c1, d_c)
+    assert np.array_equal(m1.cpu().numpy().view(np.uint64), np.tile(omit, 200).view(np.uint64))
 
 
 def test_guides_with_thousands_of_hits(tmp_path):
