@@ -314,3 +314,33 @@ def _has_gpu():
         return torch.cuda.is_available()
     except Exception:  # noqa: BLE001
         return False
+
+
+def test_every_documented_option_can_be_set_and_read_back(golden_uniform):
+    """The options `include/issl_hip.h` lists for issl_index_set_option (their environment names in brackets there): each
+    takes a value of its range and gives it back through issl_index_get_option; a value outside the range is refused and
+    leaves the option as it was.  No device needed: options live on the handle."""
+    import re
+    header = (ROOT / "include" / "issl_hip.h").read_text()
+    named = {n for n in re.findall(r"\b([a-z][a-z_0-9]+)\b", header) if ("ISSL_" + n.upper()) in header}  # name and environment name both there
+    # (name, a value inside its range, a value outside it or None)
+    cases = {"prune": (1, 2), "lanes": (3, 4), "hit_slots": (2, 3), "lean_tail": (0, 2), "small_bin": (0, 2), "scan_events": (1, 3),
+             "scan_threads": (768, 63), "scan_blocks": (512, None), "upload_threads": (3, 33), "upload_chunk_kib": (64, 3),
+             "upload_ring_min_kib": (0, None), "fine_items": (16, None), "expect_guides": (1000, None), "scan_generic": (1, 2),
+             "stage_timing": (1, 2), "tail_shapes": (0, None), "item_guides": (64, None), "raw_chunks": (1000, None)}
+    missing = sorted(n for n in ("small_bin", "scan_events", "upload_threads", "fine_items", "expect_guides", "lean_tail", "lanes", "hit_slots")
+                     if n not in named)
+    assert not missing, f"options this round added or changed are not in the header's list: {missing}"
+    ix = ca.IsslIndex.open(golden_uniform.issl)
+    try:
+        for name, (good, bad) in cases.items():
+            before = ix.get_option(name)
+            ix.set_option(name, good)
+            assert ix.get_option(name) == good, name
+            if bad is not None:
+                with pytest.raises(ca.IsslError):
+                    ix.set_option(name, bad)
+                assert ix.get_option(name) == good, name
+            ix.set_option(name, before)
+    finally:
+        ix.close()
