@@ -756,35 +756,68 @@ __global__ __launch_bounds__(256) void k_fine_scatter(ImageView v, const uint64_
     slot0_of[w] = slot_at + c1;
     cursor[w] = 0;
     cursor0[w] = 0;
-    if (c) {
-        const uint64_t blen = v.bucket_start[b + 1] - v.bucket_start[b];
-        for (uint32_t done = 0; done < c; done += item_guides) {
-            const uint32_t len = (c - done < item_guides) ? c - done : item_guides;
-            for (uint32_t t = 0; t < gu.units; ++t) { // single-unit items: item index == unit number
-                const bool full = t < gu.n_full;
-                const uint32_t shape = full ? 32u : gu.shape, cap = 64u * shape;  // candidates the unit covers
-                const uint32_t wstart = gu.s0a + t * kTileCands;               // position in the bucket (a lane group)
-                const uint64_t after = blen - wstart;                           // candidates of the bucket from there on
-                ScanItem it;
-                it.bucket = (b << 8) | w;
-                it.g0 = slot_at + done; // item_guides is a multiple of 8
-                it.g1 = it.g0 + len;
-                it.n_tiles = 1;
-                it.cost0 = cost_at;
-                it.tile0 = item_at;
-                it.last_cands = after < cap ? static_cast<uint32_t>(after) : cap;
-                it.group_abs = v.tile_first[b] * 64u + (wstart >> 5);
-                it.window = (t == 0 ? s0 - gu.s0a : 0u) | ((s1 - wstart < cap ? s1 - wstart : cap) << 16);
-                it.shape = shape; it.gmid = slot_at + c1;
-                fitems[item_at++] = it;
-                cost_at += static_cast<uint64_t>(len) * (shape >> 3) + kTileFixedCost;
-            }
-        }
-        // padding slots behind the group's guides
+    // The bucket's items -- one per unit and chunk of guides, ~770 of 48 bytes -- are written by the whole workgroup, item i by
+    // thread i % 256 into a staging row in LDS and from there in 16-byte pieces that consecutive lanes put side by side: every
+    // group's thread writing its own three items one after the other touched each 64-byte line of the list three times from
+    // different lanes (four times the requests of the bytes moved; the kernel is the largest part of the binning).
+    __shared__ uint32_t item0_of[257], c_of[256];
+    __shared__ uint64_t cost0_of[256];
+    __shared__ __attribute__((aligned(16))) ScanItem stage[256];
+    item0_of[w] = item_at - base.items;
+    if (w == 255u) item0_of[256] = item_at - base.items + static_cast<uint32_t>(items);
+    c_of[w] = c;
+    cost0_of[w] = cost_at;
+    if (c) // padding slots behind the group's guides
         for (uint32_t k2 = c; k2 < static_cast<uint32_t>(slots); ++k2) { fmeta[slot_at + k2] = FineMeta{kNoGuide, 0u, 0ull}; fword[slot_at + k2] = kPadGuideWord; }
-    }
     has_cands[w] = s1 > s0 ? 1u : 0u;
     __syncthreads();
+    {
+        const uint32_t total = item0_of[256];
+        const uint64_t blen = v.bucket_start[b + 1] - v.bucket_start[b];
+        const uint32_t tile_first_b = v.tile_first[b];
+        for (uint32_t i0 = 0; i0 < total; i0 += 256u) {
+            const uint32_t i = i0 + w;
+            if (i < total) {
+                uint32_t lo = 0, hi = 256; // the group of item i: the last one whose first item is <= i (groups without items share a start)
+                while (hi - lo > 1u) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (item0_of[mid] <= i) lo = mid; else hi = mid;
+                }
+                const uint32_t gw = lo, gc = c_of[gw];
+                const uint32_t gs0 = ss[gw], gs1 = ss[gw + 1];
+                const GroupUnits g2 = group_units(gs0, gs1, tail_shapes);
+                const uint32_t j = i - item0_of[gw];
+                const uint32_t chunk = j / g2.units, t = j - chunk * g2.units; // single-unit items: chunk after chunk, unit after unit
+                const uint32_t done = chunk * item_guides;
+                const uint32_t len = (gc - done < item_guides) ? gc - done : item_guides;
+                const bool full = t < g2.n_full;
+                const uint32_t shape = full ? 32u : g2.shape, cap = 64u * shape;  // candidates the unit covers
+                const uint32_t wstart = g2.s0a + t * kTileCands;               // position in the bucket (a lane group)
+                const uint64_t after = blen - wstart;                           // candidates of the bucket from there on
+                const uint32_t gslot = slot_of[gw];
+                ScanItem it;
+                it.bucket = (b << 8) | gw;
+                it.g0 = gslot + done; // item_guides is a multiple of 8
+                it.g1 = it.g0 + len;
+                it.n_tiles = 1;
+                // the chunks in front of this one are full ones; the units in front of this one inside its chunk are full units
+                it.cost0 = cost0_of[gw] + static_cast<uint64_t>(chunk) * group_cost(g2, item_guides) +
+                           static_cast<uint64_t>(t) * (static_cast<uint64_t>(len) * kGuideCost + kTileFixedCost);
+                it.tile0 = base.items + i;
+                it.last_cands = after < cap ? static_cast<uint32_t>(after) : cap;
+                it.group_abs = tile_first_b * 64u + (wstart >> 5);
+                it.window = (t == 0 ? gs0 - g2.s0a : 0u) | ((gs1 - wstart < cap ? gs1 - wstart : cap) << 16);
+                it.shape = shape; it.gmid = slot0_of[gw];
+                stage[w] = it;
+            }
+            __syncthreads();
+            const uint32_t n_here = total - i0 < 256u ? total - i0 : 256u;
+            const uint4 *src4 = reinterpret_cast<const uint4 *>(stage);
+            uint4 *dst4 = reinterpret_cast<uint4 *>(fitems + base.items + i0);
+            for (uint32_t q = w; q < n_here * 3u; q += 256u) dst4[q] = src4[q];
+            __syncthreads();
+        }
+    }
     // One guide per thread and step: its index, scan word and signature are loaded once (a chain of two round trips),
     // its 13 (or 1) places come from registers and LDS.  (One (guide, way) pair per thread and step repeated that chain
     // 13 times over: 0.18 ms at 100 k guides, two thirds of the binning.)
