@@ -2019,7 +2019,15 @@ int issl_score(issl_index *idx, const uint64_t *guides, size_t n, int max_dist, 
         if (estimate && !covered) {
             double slots = static_cast<double>(cand) * records_per_comparison;
             if (budget_slots >= 0.0) slots = std::min(slots, budget_slots);
-            rc = ensure_raw_capacity(ws, static_cast<size_t>(slots / (kChunkRecs - 1)) + wave_chunks);
+            // (a buffer that has to grow grows by a quarter at least: the pieces of a page have estimates a few per cent apart, and
+            // every step up is a free and an allocation of gigabytes -- the record buffer and the four arrays sized by it)
+            size_t want_chunks = static_cast<size_t>(slots / (kChunkRecs - 1)) + wave_chunks;
+            if (want_chunks > ws.cap_chunks && ws.cap_chunks > 0) {
+                const size_t roomy = ws.cap_chunks + ws.cap_chunks / 4;
+                const size_t most_chunks = budget_slots >= 0.0 ? static_cast<size_t>(budget_slots / (kChunkRecs - 1)) + wave_chunks : roomy;
+                want_chunks = std::max(want_chunks, std::min(roomy, std::max(most_chunks, want_chunks)));
+            }
+            rc = ensure_raw_capacity(ws, want_chunks);
             if (rc) return rc;
         }
         if (ensure_stage(ws, 24 * cnt)) { // guides in, scores out through pinned memory: one DMA each, one synchronisation
