@@ -33,7 +33,7 @@ def write_query(path, guides):
 def _run(issl, query, out, env, args=("4", "75", "and"), exe=EXE):
     t = time.perf_counter()
     with open(out, "wb") as fh:
-        r = subprocess.run([exe, str(issl), str(query), *args], stdout=fh, stderr=subprocess.PIPE, env=env)
+        r = subprocess.run([exe, str(issl), str(query), *args], stdout=fh, stderr=subprocess.PIPE, env=env, timeout=180)  # (a hung child must not hang the bench line)
     wall = time.perf_counter() - t
     if r.returncode != 0:
         raise RuntimeError(f"{exe} exited {r.returncode}: {r.stderr.decode(errors='replace')[-400:]}")
@@ -107,7 +107,10 @@ def measure(issl, pages, tmp, expected=None, server=True, exe=EXE, log=None, one
                             res[label]["resident"].append(rec)
                         say(f"[cli] {label} through the server, request {i}: {wall*1e3:.1f} ms wall  {json.dumps(timing)}")
             finally:
-                subprocess.run([exe, "--stop", sock], capture_output=True)
+                try:
+                    subprocess.run([exe, "--stop", sock], capture_output=True, timeout=60)
+                except Exception:  # noqa: BLE001  (the server is waited for, and killed, below either way)
+                    pass
                 try:
                     srv.wait(timeout=60)
                 except subprocess.TimeoutExpired:
