@@ -566,6 +566,12 @@ def _async_batches(ix, oracle, guides, torch):
     # scores, not what the buffers held before (on one lane the end of a batch is recorded by the wait itself)
     long_g = torch.from_numpy(np.tile(guides, 200).view(np.int64)).cuda()
     d_m = torch.zeros(len(long_g), dtype=torch.float64, device="cuda:0"); d_c = torch.zeros_like(d_m)
+    while True:   # (once through first: a batch of this size may have to grow the record buffers)
+        ix.score_device_async(long_g, d_m, d_c, 4, 75.0, "and", stream=None)
+        if ix.finish(stream):
+            break
+    d_m.zero_(); d_c.zero_()
+    torch.cuda.synchronize()
     ix.score_device_async(long_g, d_m, d_c, 4, 75.0, "and", stream=None)
     ix.wait(stream)
     m1, c1 = d_m.clone(), d_c.clone()
