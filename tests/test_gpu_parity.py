@@ -570,12 +570,16 @@ def _async_batches(ix, oracle, guides, torch):
         ix.score_device_async(long_g, d_m, d_c, 4, 75.0, "and", stream=None)
         if ix.finish(stream):
             break
-    d_m.zero_(); d_c.zero_()
-    torch.cuda.synchronize()
-    ix.score_device_async(long_g, d_m, d_c, 4, 75.0, "and", stream=None)
-    ix.wait(stream)
-    m1, c1 = d_m.clone(), d_c.clone()
-    assert ix.finish(stream)
+    for _ in range(4):   # (two lanes: the other workspace may still have to grow)
+        d_m.zero_(); d_c.zero_()
+        torch.cuda.synchronize()
+        ix.score_device_async(long_g, d_m, d_c, 4, 75.0, "and", stream=None)
+        ix.wait(stream)
+        m1, c1 = d_m.clone(), d_c.clone()
+        if ix.finish(stream):
+            break
+    else:
+        raise AssertionError("the batch kept asking for larger buffers")
     assert torch.equal(m1, d_m) and torch.equal(c1, d_c)
     assert np.array_equal(m1.cpu().numpy().view(np.uint64), np.tile(omit, 200).view(np.uint64))
 
